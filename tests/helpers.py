@@ -1,0 +1,52 @@
+"""Shared test helpers (config construction mirrors tools/refsim/make_goldens.py)."""
+import numpy as np
+
+from handheld_super_resolution.config import default_config
+from handheld_super_resolution import synthetic as synth
+import oracle
+
+ALPHA, BETA = synth.ALPHA_ISO100, synth.BETA_ISO100
+
+
+def base_config(ts=16, scale=2, snr=30.0, metrics=("L2", "L2", "L2", "L2"), **kw):
+    cfg = default_config()
+    cfg.scale = scale
+    cfg.verbose = 0
+    cfg.block_matching.tuning.tile_size = ts
+    cfg.block_matching.tuning.metrics = list(metrics)
+    cfg.noise_model.alpha = ALPHA
+    cfg.noise_model.beta = BETA
+    oracle.update_snr_config(cfg, snr)
+    std, diff = synth.noise_curves(ALPHA, BETA)
+    cfg.noise_model.update({"std_curve": std.tolist(), "diff_curve": diff.tolist()})
+    cfg.exif = {"cfa_pattern": [[0, 1], [1, 2]], "iso": 100, "white_balance": [1.0, 1.0, 1.0]}
+    cfg.accumulated_robustness_denoiser.enabled = False
+    for k, v in kw.items():
+        cfg[k] = v
+    return cfg
+
+
+def acc_pattern(oh, ow, phase):
+    """Same deterministic accumulator content the golden generator used."""
+    i = np.arange(oh)[:, None, None]
+    j = np.arange(ow)[None, :, None]
+    c = np.arange(3)[None, None, :]
+    return (((i * 7 + j * 13 + c * 3 + phase) % 17) / 17.0 + 0.25).astype(np.float32)
+
+
+def assert_close(a, b, rtol, atol, what="", max_bad_frac=0.0):
+    """allclose with NaN == NaN and inf == inf; optionally tolerate a fraction of outliers."""
+    a = np.asarray(a, dtype=np.float64)
+    b = np.asarray(b, dtype=np.float64)
+    assert a.shape == b.shape, f"{what}: shape {a.shape} vs {b.shape}"
+    both_nan = np.isnan(a) & np.isnan(b)
+    same_inf = np.isinf(a) & np.isinf(b) & (np.sign(a) == np.sign(b))
+    with np.errstate(all="ignore"):
+        ok = np.abs(a - b) <= atol + rtol * np.abs(b)
+    ok = ok | both_nan | same_inf
+    bad = (~ok).sum()
+    if bad > max_bad_frac * ok.size:
+        with np.errstate(all="ignore"):
+            err = np.where(ok, 0, np.abs(a - b))
+        k = np.unravel_index(np.nanargmax(err), err.shape)
+        raise AssertionError(f"{what}: {bad}/{ok.size} mismatches; worst at {k}: {a[k]} vs {b[k]}")

@@ -1,0 +1,178 @@
+"""Pin the CPU oracle against vectors captured from the reference's own code (tests/golden/*.npz,
+produced by tools/refsim/make_goldens.py in the build container).  CPU only."""
+import numpy as np
+import pytest
+
+import oracle
+from helpers import base_config, acc_pattern, assert_close
+
+F32 = np.float32
+
+
+def test_params(golden):
+    from handheld_super_resolution.config import default_config
+
+    for row in golden("params")["table"]:
+        cfg = default_config()
+        oracle.update_snr_config(cfg, row[0])
+        t = cfg.merging.tuning
+        got = [cfg.block_matching.tuning.tile_size, *cfg.block_matching.tuning.tile_sizes,
+               t.k_detail, t.k_denoise, t.D_th, t.D_tr]
+        np.testing.assert_allclose(got, row[1:], rtol=0, atol=1e-15)
+
+
+def test_grey(golden):
+    g = golden("grey")
+    for tag in "abc":
+        assert_close(oracle.grey_fft(g["in_" + tag]), g["out_" + tag], 0, 2e-6, "grey " + tag)
+    assert_close(oracle.decimate_to_grey(g["dec_in"]), g["dec_out"], 0, 1e-7, "decimate")
+
+
+def test_downsample(golden):
+    g = golden("downsample")
+    assert_close(oracle.downsample(g["img"], 2), g["f2"], 0, 1e-6, "f2")
+    assert_close(oracle.downsample(g["img"], 4), g["f4"], 0, 1e-6, "f4")
+    pyr = oracle.build_gaussian_pyramid(g["img2"], [1, 2, 4, 2])
+    for i in range(4):
+        assert_close(pyr[3 - i], g[f"pyr{i}"], 0, 1e-6, f"pyr{i}")
+
+
+def test_hessian(golden):
+    g = golden("hessian")
+    for ts in (8, 16, 32, 64):
+        gx, gy, H = oracle.init_ica(g["lvl"], ts)
+        assert_close(gx, g["gx"], 0, 0, "gx")
+        assert_close(gy, g["gy"], 0, 0, "gy")
+        assert_close(H, g[f"H{ts}"], 1e-5, 1e-7, f"H{ts}")
+
+
+def test_bm_l2(golden):
+    g = golden("bm_l2")
+    for tag in ("t16", "t8", "t32"):
+        ts, r = (int(v) for v in g[tag + "_ts_r"])
+        flow, cost = oracle.bm_l2(g[tag + "_ref"], g[tag + "_mov"], g[tag + "_flow_in"], ts, r, return_cost=True)
+        want = g[tag + "_flow_out"]
+        diff = np.abs(flow - want).max(-1) > 0
+        # any disagreement must be a near-tie of the two best costs (FFT float32 vs exact sums)
+        for ty, tx in zip(*np.nonzero(diff)):
+            c = np.sort(cost[ty, tx].ravel())
+            assert (c[1] - c[0]) <= 1e-4 * max(1.0, abs(c[0])), (tag, ty, tx, c[:3])
+        assert diff.mean() <= 0.05, (tag, diff.mean())
+
+
+def test_ica(golden):
+    g = golden("ica")
+    for ts in (8, 16, 32, 64):
+        ref, mov = g[f"t{ts}_ref"], g[f"t{ts}_mov"]
+        gx, gy, H = oracle.init_ica(ref, ts)
+        assert_close(H, g[f"t{ts}_H"], 1e-5, 1e-7, f"H ts={ts}")
+        flow = oracle.ica(ref, gx, gy, g[f"t{ts}_H"], mov, g[f"t{ts}_flow_in"], ts, 3)
+        assert_close(flow, g[f"t{ts}_flow_out"], 1e-4, 2e-5, f"ica ts={ts}")
+
+
+def test_upscale(golden):
+    g = golden("upscale")
+    for mode in ("nearest", "bilinear", "bicubic"):
+        cfg = base_config(ts=16)
+        cfg.block_matching.tuning.flow_upscale_mode = mode
+        assert_close(oracle.upscale_lvl(g["flow"], (11, 15), 2, cfg), g[mode + "_l2"], 1e-6, 1e-6, mode + " l2")
+        assert_close(oracle.upscale_lvl(g["flow"], (21, 29), 1, cfg), g[mode + "_l1"], 1e-6, 1e-6, mode + " l1")
+
+
+def test_kernels(golden):
+    g = golden("kernels")
+    for law in ("linear", "hard_threshold"):
+        cfg = base_config()
+        cfg.merging.selection_law = law
+        covs = oracle.estimate_kernels(g["raw"], cfg)
+        if law == "linear":
+            assert np.isnan(g["cov_" + law][:3, :3]).all()  # the constant block (D10)
+        else:
+            assert np.isfinite(g["cov_" + law]).all()  # NaN anisotropy falls into the k1 = k2 = 1 branch
+        assert_close(covs, g["cov_" + law], 2e-5, 1e-7, "cov " + law)
+    cfg = base_config()
+    cfg.merging.tuning.update({"k_detail": "SNR_based", "k_denoise": "SNR_based", "D_th": "SNR_based", "D_tr": "SNR_based"})
+    oracle.update_snr_config(cfg, 10.0)
+    assert_close(oracle.estimate_kernels(g["raw"], cfg), g["cov_snr10"], 2e-5, 1e-7, "cov snr10")
+
+
+def test_robustness(golden):
+    g = golden("robustness")
+    cfa, wb = g["cfa"], g["wb"]
+    guide = oracle.guide_image(g["ref"], cfa, wb)
+    assert_close(guide, g["guide"], 1e-7, 0, "guide")
+    m, v = oracle.local_stats(guide)
+    assert_close(m, g["gmeans"], 1e-6, 1e-8, "means")
+    assert_close(v, g["gvars"], 1e-5, 1e-9, "vars")
+    cfg = base_config(ts=16)
+    rm, rv = oracle.init_robustness(g["ref"], cfa, wb, cfg)
+    assert np.isinf(g["ref_means"][:, 0, :]).all() and np.isinf(g["ref_means"][:, :, 0]).all()  # D6
+    assert_close(rm, g["ref_means"], 1e-6, 1e-8, "ref means")
+    assert_close(rv, g["ref_vars"], 1e-5, 1e-9, "ref vars")
+    dbg = {}
+    r = oracle.compute_robustness(g["comp"], g["ref_means"], g["ref_vars"], g["flow"], cfa, wb,
+                                  (g["std_curve"], g["diff_curve"]), cfg, debug=dbg)
+    assert_close(dbg["comp_means_up"], g["comp_means_up"], 1e-6, 1e-8, "warped means")
+    assert_close(dbg["S"], g["S"], 0, 0, "S")
+    assert_close(dbg["sigma_sq"], g["sigma_sq"], 1e-5, 0, "sigma_sq")
+    assert_close(dbg["d_sq"], g["d_sq"], 1e-4, 1e-12, "d_sq")
+    assert_close(dbg["R"], g["R"], 1e-4, 1e-5, "R")
+    assert_close(r, g["r"], 1e-4, 1e-5, "r")
+    assert (g["r"][:3] == 0).all() and (g["r"][:, :3] == 0).all()  # D6: first 3 rows / columns
+
+
+@pytest.mark.parametrize("tag,scale,kern,do_ref", [("s2", 2, "steerable", True), ("s15", 1.5, "steerable", True),
+                                                   ("s1", 1, "steerable", True), ("s3", 3, "steerable", False),
+                                                   ("s2iso", 2, "iso", True)])
+def test_merge(golden, tag, scale, kern, do_ref):
+    g = golden("merge")
+    H, W = g["comp"].shape
+    cfg = base_config(ts=16, scale=scale)
+    cfg.merging.kernel = kern
+    oh, ow = round(scale * H), round(scale * W)
+    num, den = acc_pattern(oh, ow, 0), acc_pattern(oh, ow, 5)
+    oracle.merge(g["comp"], g["flow"], g["covs"], g["r"], num, den, g["cfa"], cfg)
+    assert_close(num, g[tag + "_num"], 2e-6, 1e-7, tag + " num")
+    assert_close(den, g[tag + "_den"], 2e-6, 1e-7, tag + " den")
+    if do_ref:
+        num, den = acc_pattern(oh, ow, 0), acc_pattern(oh, ow, 5)
+        oracle.merge_ref(g["ref"], g["covs_ref"], num, den, g["cfa"], cfg)
+        assert_close(num, g[tag + "_numref"], 1e-5, 1e-7, tag + " numref")
+        assert_close(den, g[tag + "_denref"], 1e-5, 1e-7, tag + " denref")
+
+
+def test_merge_ref_denoiser(golden):
+    g = golden("merge")
+    H, W = g["ref"].shape
+    cfg = base_config(ts=16, scale=2)
+    cfg.accumulated_robustness_denoiser.enabled = True
+    cfg.accumulated_robustness_denoiser.merge.enabled = True
+    num, den = acc_pattern(2 * H, 2 * W, 0), acc_pattern(2 * H, 2 * W, 5)
+    oracle.merge_ref(g["ref"], g["covs_ref"], num, den, g["cfa"], cfg, g["acc_rob"].astype(np.float64))
+    assert_close(num, g["den_numref"], 1e-5, 1e-7, "denoiser numref")
+    assert_close(den, g["den_denref"], 1e-5, 1e-7, "denoiser denref")
+
+
+def test_e2e_128(golden):
+    """main() on the 128x128 x3 burst the reference itself processed (x2, Ts=16, all-L2)."""
+    from handheld_super_resolution import synthetic as synth
+
+    g = golden("e2e_128")
+    ref, comp, shifts = synth.make_burst(128, 128, 3, seed=int(g["seed"]), max_shift=2.0, occluder=True)
+    np.testing.assert_array_equal(shifts, g["shifts"])
+    cfg = base_config(ts=16, scale=2)
+    cfg.block_matching.tuning.factors = [1, 2, 2, 2]
+    cfg.robustness.save_mask = True
+    cap = {}
+    out, dbg = oracle.main(ref, comp, cfg, capture=cap)
+    assert_close(cap["grey_ref"], g["grey_ref"], 0, 2e-6, "grey ref")
+    flow = np.stack(cap["flow"])
+    assert_close(flow, g["flow"], 0, 2e-3, "flow", max_bad_frac=0.02)
+    assert_close(np.stack(cap["r"]), g["r"], 0, 1e-3, "r", max_bad_frac=0.01)
+    assert_close(cap["covs"][-1], g["covs_last"], 1e-4, 1e-6, "ref covs")
+    assert_close(dbg["accumulated robustness"], g["acc_r"], 0, 2e-3, "acc r", max_bad_frac=0.01)
+    assert_close(out, g["out"], 0, 1e-3, "output", max_bad_frac=0.005)
+    # and the bulk is much tighter than the outlier allowance
+    with np.errstate(all="ignore"):
+        d = np.abs(out - g["out"])
+    assert np.nanpercentile(d, 99) < 1e-4

@@ -1,0 +1,404 @@
+"""Capture golden vectors by executing the reference's own code on CPU.
+
+TEST INFRASTRUCTURE ONLY.  Run in the build container (where /root/reference
+exists):
+
+    python -m tools.refsim.make_goldens [stage ...]      # default: all stages
+
+It imports the reference through ``tools.refsim.loader`` (fake numba, torch on
+CPU), feeds it small seeded inputs and writes ``tests/golden/<stage>.npz``
+holding inputs and the reference's outputs.  The reference's sources never
+leave /root/reference; only these data files are committed.
+
+The default level-0 metric (L1) is undefined behaviour upstream (SURVEY.md
+App. A D1) and cannot be captured; every golden uses L2.
+"""
+from __future__ import annotations
+
+import copy
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+from . import loader
+
+OUT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "..", "tests", "golden")
+OUT = os.path.abspath(OUT)
+
+cfgmod = loader.install()
+from numba import cuda  # noqa: E402  (the fake one)
+
+
+def _load_synth():
+    import importlib.util
+
+    p = os.path.join(os.path.dirname(OUT), "..", "handheld-multi-frame-super-resolution_amd",
+                     "handheld_super_resolution", "synthetic.py")
+    spec = importlib.util.spec_from_file_location("_refsim_synth", os.path.abspath(p))
+    m = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(m)
+    return m
+
+
+synth = _load_synth()
+ALPHA, BETA = synth.ALPHA_ISO100, synth.BETA_ISO100
+
+
+def smooth_field(rng, h, w, sigma=2.0, amp=1.0):
+    """Band-limited random image in [0,1] (textured enough for LK / matching)."""
+    from scipy.ndimage import gaussian_filter
+
+    f = gaussian_filter(rng.standard_normal((h + 16, w + 16)), sigma)
+    f = (f - f.min()) / (f.max() - f.min())
+    return (amp * f).astype(np.float32)
+
+
+def base_config(ts=16, scale=2, **kw):
+    cfg = cfgmod.default_config()
+    cfg.scale = scale
+    cfg.verbose = 0
+    cfg.block_matching.tuning.tile_size = ts
+    cfg.block_matching.tuning.metrics = ["L2", "L2", "L2", "L2"]
+    cfg.noise_model.alpha = ALPHA
+    cfg.noise_model.beta = BETA
+    params = loader.ref("params")
+    params.update_snr_config(cfg, 30.0)
+    std, diff = synth.noise_curves(ALPHA, BETA)
+    cfg.noise_model.update({"std_curve": std.tolist(), "diff_curve": diff.tolist()})
+    cfg.exif = {"cfa_pattern": [[0, 1], [1, 2]], "iso": 100, "white_balance": [1.0, 1.0, 1.0]}
+    cfg.accumulated_robustness_denoiser.enabled = False
+    for k, v in kw.items():
+        cfg[k] = v
+    return cfg
+
+
+def save(name, **arrs):
+    os.makedirs(OUT, exist_ok=True)
+    p = os.path.join(OUT, name + ".npz")
+    np.savez_compressed(p, **{k: np.asarray(v) for k, v in arrs.items()})
+    print(f"  wrote {p} ({os.path.getsize(p) / 1024:.1f} KiB)")
+
+
+def npy(a):
+    if isinstance(a, torch.Tensor):
+        return a.detach().contiguous().numpy().copy()
+    return np.array(a)
+
+
+# --------------------------------------------------------------------------- stages
+def stage_grey():
+    ui = loader.ref("utils_image")
+    rng = np.random.default_rng(10)
+    out = {}
+    for tag, (h, w) in {"a": (48, 40), "b": (50, 42), "c": (31, 45)}.items():
+        img = rng.random((h, w), dtype=np.float32)
+        out["in_" + tag] = img
+        out["out_" + tag] = npy(ui.compute_grey_images(cuda.to_device(img), "FFT"))
+    img = rng.random((20, 26), dtype=np.float32)
+    out["dec_in"] = img
+    out["dec_out"] = npy(ui.compute_grey_images(cuda.to_device(img), "decimating"))
+    save("grey", **out)
+
+
+def stage_downsample():
+    ui = loader.ref("utils_image")
+    rng = np.random.default_rng(11)
+    img = rng.random((70, 83), dtype=np.float32)
+    t = torch.as_tensor(img)[None, None]
+    o2 = ui.cuda_downsample(t, "gaussian", 2)
+    o4 = ui.cuda_downsample(t, "gaussian", 4)
+    # a 4-level pyramid (coarse first in the reference's list)
+    al = loader.ref("alignment")
+    img2 = rng.random((200, 220), dtype=np.float32)
+    pyr = al.build_gaussian_pyramid(torch.as_tensor(img2)[None, None], [1, 2, 4, 2])
+    save("downsample", img=img, f2=npy(o2.squeeze()), f4=npy(o4.squeeze()), img2=img2,
+         pyr0=npy(pyr[3]), pyr1=npy(pyr[2]), pyr2=npy(pyr[1]), pyr3=npy(pyr[0]))
+
+
+def stage_hessian():
+    ica = loader.ref("ICA")
+    rng = np.random.default_rng(12)
+    lvl = smooth_field(rng, 64, 80)[:64, :80]
+    out = {"lvl": lvl}
+    for ts in (8, 16, 32, 64):
+        gx, gy, H = ica.init_ica(torch.as_tensor(lvl), ts, None)
+        out[f"gx"] = npy(gx)
+        out[f"gy"] = npy(gy)
+        out[f"H{ts}"] = npy(H)
+    save("hessian", **out)
+
+
+def _bm_case(rng, h, w, ts, r, shift, cfg_l, noise=0.01):
+    """ref level [h,w] (multiple of ts), moving level slightly smaller (D16)."""
+    big = smooth_field(rng, h + 32, w + 32, sigma=1.5)
+    ref = big[16 : 16 + h, 16 : 16 + w].copy()
+    sy, sx = shift
+    mov = big[16 + sy : 16 + sy + h - 3, 16 + sx : 16 + sx + w - 5].copy()
+    mov += noise * rng.standard_normal(mov.shape).astype(np.float32)
+    return ref, mov
+
+
+def stage_bm_l2():
+    al = loader.ref("alignment")
+    bm = loader.ref("block_matching")
+    rng = np.random.default_rng(13)
+    out = {}
+    for tag, ts, r, shift in (("t16", 16, 4, (2, -3)), ("t8", 8, 4, (-1, 2)), ("t32", 32, 2, (1, 1))):
+        h, w = 4 * ts, 5 * ts
+        ref, mov = _bm_case(rng, h, w, ts, r, shift, None)
+        cfg = base_config(ts=16)
+        cfg.block_matching.tuning.tile_sizes = [ts, ts, ts, ts]
+        cfg.block_matching.tuning.search_radii = [r, r, r, r]
+        tiled = torch.as_tensor(ref).unfold(0, ts, ts).unfold(1, ts, ts)
+        tiled = torch.nn.functional.pad(tiled, (r, r, r, r), mode="constant", value=0)
+        fft = torch.fft.rfft2(tiled, dim=(-2, -1))
+        ny, nx = tiled.shape[:2]
+        flow0 = (rng.uniform(-1.6, 1.6, (ny, nx, 2))).astype(np.float32)
+        flow0[0, 0] = (0.5, -0.5)  # round-half-even probes
+        flow0[0, 1] = (1.5, 2.5)
+        flow0[1, 0] = (-1.5, -2.5)
+        flow0[-1, -1] = (6.0, 5.0)  # pushes the window over the border (clamp-to-edge)
+        flow0[0, -1] = (-7.0, -6.0)
+        flow = torch.as_tensor(flow0.copy())
+        bm.align_lvl_block_matching_L2(tiled, fft, torch.as_tensor(mov), flow, 0, cfg)
+        out.update({f"{tag}_ref": ref, f"{tag}_mov": mov, f"{tag}_flow_in": flow0, f"{tag}_flow_out": npy(flow),
+                    f"{tag}_ts_r": np.array([ts, r])})
+    save("bm_l2", **out)
+
+
+def stage_ica():
+    ica = loader.ref("ICA")
+    rng = np.random.default_rng(14)
+    out = {}
+    for ts in (8, 16, 32, 64):
+        ny, nx = (3, 4) if ts <= 16 else (2, 2)
+        h, w = ny * ts, nx * ts
+        from scipy.ndimage import shift as nd_shift
+
+        big = smooth_field(rng, h + 32, w + 32, sigma=2.5)
+        ref = big[16 : 16 + h, 16 : 16 + w].copy()
+        movbig = nd_shift(big.astype(np.float64), (0.3, -0.45), order=3, mode="nearest").astype(np.float32)
+        mov = movbig[16 : 16 + h - 2, 16 : 16 + w - 3].copy()  # moving level a bit smaller (D16)
+        cfg = base_config(ts=16)
+        cfg.block_matching.tuning.tile_sizes = [ts, ts, ts, ts]
+        gx, gy, H = ica.init_ica(torch.as_tensor(ref), ts, cfg)
+        flow0 = rng.uniform(-0.6, 0.6, (ny, nx, 2)).astype(np.float32)
+        flow0[0, 0] = (-1.3, -0.7)   # negative: truncation + signed fraction (D11)
+        flow0[-1, -1] = (2.4, 1.8)   # samples beyond the moving image
+        flow0[0, -1] = (0.0, 0.0)
+        flow = torch.as_tensor(flow0.copy())
+        t0 = time.time()
+        ica.align_lvl_ica(torch.as_tensor(ref), gx, gy, H, torch.as_tensor(mov), flow, 0, cfg)
+        print(f"    ica ts={ts}: {time.time() - t0:.1f}s")
+        out.update({f"t{ts}_ref": ref, f"t{ts}_mov": mov, f"t{ts}_flow_in": flow0, f"t{ts}_flow_out": npy(flow),
+                    f"t{ts}_H": npy(H)})
+    save("ica", **out)
+
+
+def stage_upscale():
+    al = loader.ref("alignment")
+    rng = np.random.default_rng(15)
+    out = {}
+    flow = rng.uniform(-3, 3, (5, 7, 2)).astype(np.float32)
+    out["flow"] = flow
+    for mode in ("nearest", "bilinear", "bicubic"):
+        cfg = base_config(ts=16)
+        cfg.block_matching.tuning.flow_upscale_mode = mode
+        # level 3 -> 2 (ts 8 -> 16, factor 4: repeat 2), level 2 -> 1 (16 -> 16, factor 4: repeat 4)
+        o32 = al.upscale_lvl(torch.as_tensor(flow.copy()), (11, 15), 2, cfg)
+        o21 = al.upscale_lvl(torch.as_tensor(flow.copy()), (21, 29), 1, cfg)
+        out[f"{mode}_l2"] = npy(o32)
+        out[f"{mode}_l1"] = npy(o21)
+    save("upscale", **out)
+
+
+def stage_kernels():
+    k = loader.ref("kernels")
+    rng = np.random.default_rng(16)
+    raw = smooth_field(rng, 40, 48, sigma=1.2)[:40, :48]
+    raw = np.clip(raw + 0.02 * rng.standard_normal(raw.shape), 0, 1).astype(np.float32)
+    raw[:8, :8] = 0.25  # constant block -> zero structure tensor -> NaN covariances (D10)
+    out = {"raw": raw}
+    for law in ("linear", "hard_threshold"):
+        cfg = base_config()
+        cfg.merging.selection_law = law
+        out["cov_" + law] = npy(k.estimate_kernels(cuda.to_device(raw), cfg))
+    cfg = base_config()
+    params = loader.ref("params")
+    cfg.merging.tuning.update({"k_detail": "SNR_based", "k_denoise": "SNR_based", "D_th": "SNR_based", "D_tr": "SNR_based"})
+    params.update_snr_config(cfg, 10.0)
+    out["snr10_params"] = np.array([cfg.merging.tuning.k_detail, cfg.merging.tuning.k_denoise,
+                                    cfg.merging.tuning.D_th, cfg.merging.tuning.D_tr])
+    out["cov_snr10"] = npy(k.estimate_kernels(cuda.to_device(raw), cfg))
+    save("kernels", **out)
+
+
+def _flows(rng, ny, nx, amp=2.0):
+    f = rng.uniform(-amp, amp, (ny, nx, 2)).astype(np.float32)
+    f[0, 0] = (-3.2, -2.7)
+    f[-1, -1] = (4.6, 3.9)
+    return f
+
+
+def stage_robustness():
+    rb = loader.ref("robustness")
+    rng = np.random.default_rng(17)
+    H, W, ts = 64, 80, 16
+    wb = [2.0, 1.0, 1.5]
+    ref, comp, _ = synth.make_burst(H, W, 2, seed=77, wb=wb, occluder=True, max_shift=1.0)
+    comp = comp[0]
+    cfa = np.array([[0, 1], [1, 2]])
+    out = {"ref": ref, "comp": comp, "wb": np.array(wb), "cfa": cfa}
+    cfg = base_config(ts=ts)
+    d_cfa, d_wb = cuda.to_device(cfa), cuda.to_device(np.array(wb))
+    guide = rb.compute_guide_image(cuda.to_device(ref), d_cfa, d_wb)
+    m, v = rb.compute_local_stats(guide)
+    out.update(guide=npy(guide), gmeans=npy(m), gvars=npy(v))
+    means, stds = rb.init_robustness(cuda.to_device(ref), d_cfa, d_wb, cfg)
+    out.update(ref_means=npy(means), ref_vars=npy(stds))
+    flow = rng.uniform(-0.4, 0.4, (H // ts, W // ts, 2)).astype(np.float32)
+    flow[1, 2] = (1.7, -1.2)   # flow discontinuity -> s1 around it
+    flow[-1, -1] = (3.5, 2.5)  # warps beyond the frame -> +inf -> R = 0
+    flow[0, 0] = (-2.5, -1.5)
+    out["flow"] = flow
+    std, diff = synth.noise_curves(ALPHA, BETA)
+    out.update(std_curve=std, diff_curve=diff)
+    r = rb.compute_robustness(cuda.to_device(comp), means, stds, cuda.to_device(flow), d_cfa, d_wb,
+                              (cuda.to_device(std), cuda.to_device(diff)), cfg)
+    out["r"] = npy(r)
+    # intermediate maps (same calls compute_robustness makes)
+    gcomp = rb.compute_guide_image(cuda.to_device(comp), d_cfa, d_wb)
+    cm, _ = rb.compute_local_stats(gcomp)
+    cmu = rb.upscale_warp_stats(cm, ts, cuda.to_device(flow))
+    d_p = rb.compute_dist(means, cmu)
+    d_sq, s_sq = rb.apply_noise_model(d_p, means, stds, cuda.to_device(std), cuda.to_device(diff))
+    t = cfg.robustness.tuning
+    S = rb.compute_s(cuda.to_device(flow), t.Mt, t.s1, t.s2)
+    R = rb.robustness_threshold(d_sq, s_sq, S, t.t, ts, True)
+    out.update(comp_means_up=npy(cmu), d_sq=npy(d_sq), sigma_sq=npy(s_sq), S=npy(S), R=npy(R))
+    save("robustness", **out)
+
+
+def acc_pattern(oh, ow, phase):
+    """Deterministic non-zero initial accumulator content (recomputed by the tests, not stored)."""
+    i = np.arange(oh)[:, None, None]
+    j = np.arange(ow)[None, :, None]
+    c = np.arange(3)[None, None, :]
+    return (((i * 7 + j * 13 + c * 3 + phase) % 17) / 17.0 + 0.25).astype(np.float32)
+
+
+def stage_merge():
+    mg = loader.ref("merge")
+    k = loader.ref("kernels")
+    rng = np.random.default_rng(18)
+    H, W, ts = 32, 48, 16
+    ref, comp, _ = synth.make_burst(H, W, 2, seed=99, max_shift=1.0)
+    comp = comp[0]
+    cfa = np.array([[0, 1], [1, 2]])
+    out = {"ref": ref, "comp": comp, "cfa": cfa}
+    cfg = base_config(ts=ts)
+    covs = npy(k.estimate_kernels(cuda.to_device(comp), cfg))
+    covs_ref = npy(k.estimate_kernels(cuda.to_device(ref), cfg))
+    covs[3, 5] = np.nan  # NaN covariance -> box weights (D10)
+    covs_ref[2, 4] = np.nan
+    flow = _flows(rng, H // ts, W // ts, amp=1.5)
+    r = rng.random((H, W), dtype=np.float32)
+    out.update(covs=covs, covs_ref=covs_ref, flow=flow, r=r)
+    for tag, scale, kern, do_ref in (("s2", 2, "steerable", True), ("s15", 1.5, "steerable", True),
+                                     ("s1", 1, "steerable", True), ("s3", 3, "steerable", False),
+                                     ("s2iso", 2, "iso", True)):
+        cfg = base_config(ts=ts, scale=scale)
+        cfg.merging.kernel = kern
+        oh, ow = round(scale * H), round(scale * W)
+        num0, den0 = acc_pattern(oh, ow, 0), acc_pattern(oh, ow, 5)
+        num, den = cuda.to_device(num0), cuda.to_device(den0)
+        t0 = time.time()
+        mg.merge(cuda.to_device(comp), cuda.to_device(flow), cuda.to_device(covs), cuda.to_device(r),
+                 num, den, cuda.to_device(cfa), cfg)
+        out.update({f"{tag}_num": npy(num), f"{tag}_den": npy(den)})
+        if do_ref:
+            numr, denr = cuda.to_device(num0), cuda.to_device(den0)
+            mg.merge_ref(cuda.to_device(ref), cuda.to_device(covs_ref), numr, denr, cuda.to_device(cfa), cfg)
+            out.update({f"{tag}_numref": npy(numr), f"{tag}_denref": npy(denr)})
+        print(f"    merge {tag}: {time.time() - t0:.1f}s")
+    # accumulated-robustness denoiser variant of merge_ref (Alg. 11 widening + overwrite)
+    cfg = base_config(ts=ts, scale=2)
+    cfg.accumulated_robustness_denoiser.enabled = True
+    cfg.accumulated_robustness_denoiser.merge.enabled = True
+    acc_rob = (rng.random((H, W)) * 4).astype(np.float32).astype(np.float64)
+    oh, ow = 2 * H, 2 * W
+    num0, den0 = acc_pattern(oh, ow, 0), acc_pattern(oh, ow, 5)
+    numr, denr = cuda.to_device(num0), cuda.to_device(den0)
+    mg.merge_ref(cuda.to_device(ref), cuda.to_device(covs_ref), numr, denr, cuda.to_device(cfa), cfg,
+                 cuda.to_device(acc_rob))
+    out.update(acc_rob=acc_rob.astype(np.float32), den_numref=npy(numr), den_denref=npy(denr))
+    save("merge", **out)
+
+
+def stage_params():
+    params = loader.ref("params")
+    rows = []
+    for snr in (3.0, 6.0, 10.0, 14.0, 14.5, 22.0, 22.5, 27.3, 30.0, 45.0):
+        cfg = cfgmod.default_config()
+        params.update_snr_config(cfg, snr)
+        t = cfg.merging.tuning
+        rows.append([snr, cfg.block_matching.tuning.tile_size, *cfg.block_matching.tuning.tile_sizes,
+                     t.k_detail, t.k_denoise, t.D_th, t.D_tr])
+    save("params", table=np.array(rows, dtype=np.float64))
+
+
+def stage_e2e():
+    """main() end to end: 128x128, 3 frames, x2, Ts=16, factors [1,2,2,2], all-L2."""
+    sr = loader.ref("super_resolution")
+    H = W = 128
+    ref, comp, shifts = synth.make_burst(H, W, 3, seed=1234, max_shift=2.0, occluder=True)
+    cfg = base_config(ts=16, scale=2)
+    cfg.block_matching.tuning.factors = [1, 2, 2, 2]
+    cfg.robustness.save_mask = True
+    cap = {"flow": [], "r": [], "covs": [], "grey": []}
+
+    def wrap(name, key):
+        f = getattr(sr, name)
+
+        def g(*a, **k):
+            o = f(*a, **k)
+            cap[key].append(npy(o))
+            return o
+
+        setattr(sr, name, g)
+
+    wrap("align", "flow")
+    wrap("compute_robustness", "r")
+    wrap("estimate_kernels", "covs")
+    wrap("compute_grey_images", "grey")
+    t0 = time.time()
+    with np.errstate(all="ignore"):
+        out, dbg = sr.main(ref, comp, cfg)
+    print(f"    main(): {time.time() - t0:.1f}s")
+    save("e2e_128", shifts=shifts, seed=np.array(1234), grey_ref=cap["grey"][0],
+         flow=np.stack(cap["flow"]), r=np.stack(cap["r"]), covs_last=cap["covs"][-1],
+         out=npy(out), acc_r=np.asarray(dbg["accumulated robustness"], dtype=np.float32))
+
+
+STAGES = {
+    "grey": stage_grey, "downsample": stage_downsample, "hessian": stage_hessian, "bm_l2": stage_bm_l2,
+    "ica": stage_ica, "upscale": stage_upscale, "kernels": stage_kernels, "robustness": stage_robustness,
+    "merge": stage_merge, "params": stage_params, "e2e": stage_e2e,
+}
+
+
+def main(argv):
+    names = argv or list(STAGES)
+    for n in names:
+        print(f"[refsim] {n}")
+        t0 = time.time()
+        with np.errstate(all="ignore"):
+            STAGES[n]()
+        print(f"  done in {time.time() - t0:.1f}s")
+
+
+if __name__ == "__main__":
+    main(sys.argv[1:])
