@@ -1,0 +1,60 @@
+"""Build libhhsr_hip.so (gfx950) in-tree with hipcc.  Usage: python build.py [--force]"""
+import os
+import subprocess
+import sys
+from concurrent.futures import ThreadPoolExecutor
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+OUT = os.path.join(HERE, "handheld_super_resolution", "libhhsr_hip.so")
+OBJ = os.path.join(HERE, "build")
+HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+ARCH = "gfx950"
+
+# IEEE maths everywhere (no -ffast-math).  FMA contraction is disabled for the stages that take
+# discrete decisions on float32 sums (argmin, rounding) so they associate exactly like the oracle;
+# the merge keeps hipcc's default contraction (its weights are float64 / tolerance-checked).
+COMMON = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
+SOURCES = {
+    "hhsr_api.hip": ["-ffp-contract=off"],
+    "hhsr_pyramid.hip": ["-ffp-contract=off"],
+    "hhsr_align.hip": ["-ffp-contract=off"],
+    "hhsr_kernels.hip": ["-ffp-contract=off"],
+    "hhsr_robustness.hip": ["-ffp-contract=off"],
+    "hhsr_merge.hip": [],
+}
+
+
+def _stale(target, deps):
+    if not os.path.exists(target):
+        return True
+    t = os.path.getmtime(target)
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def build(force=False, verbose=True):
+    os.makedirs(OBJ, exist_ok=True)
+    headers = [os.path.join(CSRC, "hhsr_common.h"), os.path.join(HERE, "..", "include", "hhsr.h"), __file__]
+    jobs = []
+    objs = []
+    for src, extra in SOURCES.items():
+        s = os.path.join(CSRC, src)
+        o = os.path.join(OBJ, src.replace(".hip", ".o"))
+        objs.append(o)
+        if force or _stale(o, [s] + headers):
+            jobs.append([HIPCC, *COMMON, *extra, "-c", s, "-o", o])
+
+    def run(cmd):
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        subprocess.run(cmd, check=True)
+
+    with ThreadPoolExecutor(max_workers=max(1, min(len(jobs), os.cpu_count() or 1))) as ex:
+        list(ex.map(run, jobs))
+    if jobs or force or _stale(OUT, objs):
+        run([HIPCC, "--offload-arch=" + ARCH, "-shared", "-fPIC", "-o", OUT, *objs])
+    return OUT
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv))

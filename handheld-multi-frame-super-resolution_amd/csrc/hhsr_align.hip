@@ -1,0 +1,319 @@
+// Per-level alignment kernels: Lucas-Kanade precompute, block matching, ICA, flow upscaling
+// (reference ICA.py, block_matching.py, alignment.py:150-172).
+//
+// One 256-thread workgroup (4 wave64) per tile.  The moving search window and the reference tile are
+// staged in LDS once and reused by all (2r+1)^2 candidate shifts; per-tile sums use wave64 shuffles
+// plus a 4-entry LDS exchange.  These levels are small (sum of level sizes = 1.33 P) and latency bound,
+// not MFMA shaped: 81 shifts x ts^2 MACs per tile is ~0.1 GFLOP for a 12 MP level.
+#include "hhsr_common.h"
+
+// ---- gradients + per-tile Hessian (ICA.py:15-76) ------------------------------------------------
+__global__ void __launch_bounds__(256) k_grad_hessian(const float* __restrict__ I, int H, int W, int pitch, int ts,
+                                                       float* __restrict__ gx, float* __restrict__ gy,
+                                                       float* __restrict__ hess, int ny, int nx) {
+    __shared__ float sm[12];
+    const int tx = blockIdx.x, ty = blockIdx.y;
+    float a = 0.f, b = 0.f, c = 0.f;
+    for (int p = threadIdx.x; p < ts * ts; p += 256) {
+        const int i = p / ts, j = p - i * ts;
+        const int y = ty * ts + i, x = tx * ts + j;
+        if (y < H && x < W) {
+            const float l = x > 0 ? I[(size_t)y * pitch + x - 1] : 0.f;
+            const float r = x + 1 < W ? I[(size_t)y * pitch + x + 1] : 0.f;
+            const float u = y > 0 ? I[(size_t)(y - 1) * pitch + x] : 0.f;
+            const float d = y + 1 < H ? I[(size_t)(y + 1) * pitch + x] : 0.f;
+            const float vx = r - l, vy = d - u;
+            gx[(size_t)y * pitch + x] = vx;
+            gy[(size_t)y * pitch + x] = vy;
+            a += vx * vx;
+            b += vx * vy;
+            c += vy * vy;
+        }
+    }
+    float c2 = 0.f;
+    block_sum2<4>(a, b, sm);
+    block_sum2<4>(c, c2, sm);
+    if (threadIdx.x == 0 && ty < ny && tx < nx) {
+        float* h = hess + ((size_t)ty * nx + tx) * 4;
+        h[0] = a;
+        h[1] = b;
+        h[2] = b;
+        h[3] = c;
+    }
+}
+
+extern "C" int hhsr_grad_hessian(const float* lvl, int H, int W, int pitch, int ts, float* gx, float* gy,
+                                 float* hess, void* stream) {
+    HHSR_ARG(lvl && gx && gy && hess && H > 0 && W > 0 && pitch >= W);
+    HHSR_ARG(ts == 8 || ts == 16 || ts == 32 || ts == 64);
+    const int ny = H / ts, nx = W / ts;
+    hipLaunchKernelGGL(k_grad_hessian, dim3(hhsr_cdiv(W, ts), hhsr_cdiv(H, ts)), dim3(256), 0, (hipStream_t)stream,
+                       lvl, H, W, pitch, ts, gx, gy, hess, ny, nx);
+    HHSR_LAUNCHED();
+}
+
+// ---- block matching -----------------------------------------------------------------------------
+// LDS layout: s_ref[ts*ts] | s_win[P*Pp] (P = ts+2r, Pp = P|1) | s_part[256] | s_cost[n] ...
+// Thread t handles candidate c = t % n for the pixel subset g = t / n (g < G = 256 / n), so that the
+// lanes of a wave read consecutive window addresses (conflict-free) and one broadcast ref address.
+template <bool L1>
+__global__ void __launch_bounds__(256) k_block_match(const float* __restrict__ ref, int ref_pitch,
+                                                      const float* __restrict__ mov, int mh, int mw, int mov_pitch,
+                                                      float* __restrict__ flow, int nx, int ts, int r, int mode) {
+    extern __shared__ float lds[];
+    const int tx = blockIdx.x, ty = blockIdx.y;
+    float* fl = flow + ((size_t)ty * nx + tx) * 2;
+    const float f0 = fl[0], f1 = fl[1];
+    const float r0 = rintf(f0), r1 = rintf(f1);  // round-half-even (torch.round / Python round)
+    if (L1 && mode == 1) {                        // "L1_ref_effective": flow <- round(flow)
+        if (threadIdx.x == 0) {
+            fl[0] = r0;
+            fl[1] = r1;
+        }
+        return;
+    }
+    const int P = ts + 2 * r, Pp = P | 1, n1 = 2 * r + 1, n = n1 * n1;
+    float* s_ref = lds;
+    float* s_win = s_ref + ts * ts;
+    float* s_part = s_win + P * Pp;
+    const int tid = threadIdx.x;
+    const int y0 = ty * ts + (int)r1 - r, x0 = tx * ts + (int)r0 - r;
+    for (int p = tid; p < ts * ts; p += 256) {
+        const int i = p / ts, j = p - i * ts;
+        s_ref[p] = ref[(size_t)(ty * ts + i) * ref_pitch + tx * ts + j];
+    }
+    for (int p = tid; p < P * P; p += 256) {
+        const int i = p / P, j = p - i * P;
+        const int y = y0 + i, x = x0 + j;
+        float v;
+        if (L1) {  // zero outside the moving level (block_matching.py:131-139)
+            v = (y >= 0 && y < mh && x >= 0 && x < mw) ? mov[(size_t)y * mov_pitch + x] : 0.f;
+        } else {   // clamp-to-edge (block_matching.py:369-371)
+            v = mov[(size_t)clampi(y, 0, mh - 1) * mov_pitch + clampi(x, 0, mw - 1)];
+        }
+        s_win[i * Pp + j] = v;
+    }
+    __syncthreads();
+    const int G = max(1, min(256 / n, 16));
+    float best = INFINITY;
+    int besti = 0;
+    // candidates in rounds of `n_per_round` (n can exceed 256 for large radii)
+    for (int cbase = 0; cbase < n; cbase += 256) {
+        const int nc = min(n - cbase, 256);
+        const int Gr = (nc == n) ? G : 1;
+        const int c = cbase + tid % nc, g = tid / nc;
+        float acc = 0.f;
+        if (g < Gr) {
+            const int dy = c / n1, dx = c - dy * n1;
+            for (int i = g; i < ts; i += Gr) {
+                const float* wrow = s_win + (i + dy) * Pp + dx;
+                const float* rrow = s_ref + i * ts;
+                for (int j = 0; j < ts; ++j) {
+                    const float d = rrow[j] - wrow[j];
+                    acc += L1 ? fabsf(d) : d * d;
+                }
+            }
+        }
+        __syncthreads();
+        s_part[tid] = acc;
+        __syncthreads();
+        // candidate totals (fixed order over g), then this thread keeps a running first-minimum
+        if (tid < nc) {
+            float tot = s_part[tid];
+            for (int k = 1; k < Gr; ++k) tot += s_part[k * nc + tid];
+            if (tot < best) {  // strict: earlier candidate wins ties within this thread's sequence
+                best = tot;
+                besti = cbase + tid;
+            }
+        }
+    }
+    // first minimum in row-major candidate order == torch.argmin on the flattened map
+    __syncthreads();
+    float* s_cost = s_part;
+    int* s_idx = reinterpret_cast<int*>(s_part + 256);
+    s_cost[tid] = best;
+    s_idx[tid] = besti;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if (tid < s) {
+            const float oc = s_cost[tid + s];
+            const int oi = s_idx[tid + s];
+            if (oc < s_cost[tid] || (oc == s_cost[tid] && oi < s_idx[tid])) {
+                s_cost[tid] = oc;
+                s_idx[tid] = oi;
+            }
+        }
+        __syncthreads();
+    }
+    if (tid == 0) {
+        const int bi = s_idx[0];
+        const int dy = bi / n1 - r, dx = bi % n1 - r;
+        if (L1) {  // flow <- round(flow) + shift (block_matching.py:119-120,179-180)
+            fl[0] = r0 + (float)dx;
+            fl[1] = r1 + (float)dy;
+        } else {   // shift added to the UN-rounded flow (block_matching.py:75-76)
+            fl[0] = f0 + (float)dx;
+            fl[1] = f1 + (float)dy;
+        }
+    }
+}
+
+static size_t bm_lds(int ts, int r) {
+    const int P = ts + 2 * r, Pp = P | 1;
+    return (size_t)(ts * ts + P * Pp + 512) * sizeof(float);
+}
+
+extern "C" int hhsr_bm_l2(const float* ref, int ref_pitch, const float* mov, int mh, int mw, int mov_pitch,
+                          float* flow, int ny, int nx, int ts, int r, void* stream) {
+    HHSR_ARG(ref && mov && flow && mh > 0 && mw > 0 && ny > 0 && nx > 0 && r >= 0);
+    HHSR_ARG(ts == 8 || ts == 16 || ts == 32 || ts == 64);  // the reference's box filters (block_matching.py:47-57)
+    HHSR_ARG(bm_lds(ts, r) <= 64 * 1024);
+    hipLaunchKernelGGL(k_block_match<false>, dim3(nx, ny), dim3(256), bm_lds(ts, r), (hipStream_t)stream, ref,
+                       ref_pitch, mov, mh, mw, mov_pitch, flow, nx, ts, r, 0);
+    HHSR_LAUNCHED();
+}
+
+extern "C" int hhsr_bm_l1(const float* ref, int ref_pitch, const float* mov, int mh, int mw, int mov_pitch,
+                          float* flow, int ny, int nx, int ts, int r, int mode, void* stream) {
+    HHSR_ARG(ref && mov && flow && mh > 0 && mw > 0 && ny > 0 && nx > 0 && r >= 0);
+    HHSR_ARG(ts == 16 || ts == 32 || ts == 64);  // ts = 8 raises NotImplementedError upstream (block_matching.py:87)
+    HHSR_ARG(mode == 0 || mode == 1);
+    HHSR_ARG(bm_lds(ts, r) <= 64 * 1024);
+    hipLaunchKernelGGL(k_block_match<true>, dim3(nx, ny), dim3(256), bm_lds(ts, r), (hipStream_t)stream, ref,
+                       ref_pitch, mov, mh, mw, mov_pitch, flow, nx, ts, r, mode);
+    HHSR_LAUNCHED();
+}
+
+// ---- ICA ------------------------------------------------------------------------------------------
+// TS*TS/NT pixels per thread; reference value and both gradients stay in registers across iterations.
+template <int TS, int NT>
+__global__ void __launch_bounds__(NT) k_ica(const float* __restrict__ ref, const float* __restrict__ gx,
+                                            const float* __restrict__ gy, int ref_pitch,
+                                            const float* __restrict__ hess, const float* __restrict__ mov, int mh,
+                                            int mw, int mov_pitch, float* __restrict__ flow, int nx, int n_iter,
+                                            int row_bug) {
+    constexpr int PPT = TS * TS / NT;  // pixels per thread
+    constexpr int NW = NT / HHSR_WAVE;
+    __shared__ float sm[2 * (NW > 0 ? NW : 1)];
+    __shared__ float s_flow[2];
+    const int tx = blockIdx.x, ty = blockIdx.y, tid = threadIdx.x;
+    const float* h = hess + ((size_t)ty * nx + tx) * 4;
+    const float A00 = h[0], A01 = h[1], A10 = h[2], A11 = h[3];
+    const float det = A00 * A11 - A01 * A10;
+    if (fabsf(det) < 1e-10f) return;  // not solvable: tile untouched (ICA.py:124-125)
+    const float det_inv = 1.0f / det;
+    float* fl = flow + ((size_t)ty * nx + tx) * 2;
+    if (tid == 0) {
+        s_flow[0] = fl[0];
+        s_flow[1] = fl[1];
+    }
+    float rc[PPT], lgx[PPT], lgy[PPT];
+    int py[PPT], px[PPT];
+#pragma unroll
+    for (int k = 0; k < PPT; ++k) {
+        const int p = tid + k * NT;
+        const int i = p / TS, j = p % TS;
+        py[k] = ty * TS + i;
+        px[k] = tx * TS + j;
+        const size_t o = (size_t)py[k] * ref_pitch + px[k];
+        rc[k] = ref[o];
+        lgx[k] = gx[o];
+        lgy[k] = gy[o];
+    }
+    for (int it = 0; it < n_iter; ++it) {
+        __syncthreads();
+        const float fxv = s_flow[0], fyv = s_flow[1];
+        const float tx_ = truncf(fxv), ty_ = truncf(fyv);
+        const float frx = fxv - tx_, fry = fyv - ty_;  // signed fraction of modf (D11)
+        const int ix = (int)tx_, iy = (int)ty_;
+        float B0 = 0.f, B1 = 0.f;
+#pragma unroll
+        for (int k = 0; k < PPT; ++k) {
+            int x0 = px[k] + ix, y0 = py[k] + iy;
+            float m00, m01, m10, m11;
+            if (TS == 8) {  // clamp-to-edge sampling (ICA.py:152-156)
+                x0 = clampi(x0, 0, mw - 1);
+                y0 = clampi(y0, 0, mh - 1);
+                const int x1 = clampi(x0 + 1, 0, mw - 1), y1 = clampi(y0 + 1, 0, mh - 1);
+                m00 = mov[(size_t)y0 * mov_pitch + x0];
+                m01 = mov[(size_t)y0 * mov_pitch + x1];
+                m10 = mov[(size_t)y1 * mov_pitch + x0];
+                m11 = mov[(size_t)y1 * mov_pitch + x1];
+            } else {  // zero outside (ICA.py:240-243)
+                int yt = y0, yb = y0 + 1;
+                if (TS == 64 && row_bug) {  // ICA.py:437-449 (D2): thread rows (4q .. 4q+3)
+                    const int q = (py[k] - ty * TS) & 3;
+                    yt = q == 0 ? y0 : y0 + 1;
+                    yb = y0 + 2;
+                }
+                const bool xa = x0 >= 0 && x0 < mw, xb = x0 + 1 >= 0 && x0 + 1 < mw;
+                const bool ya = yt >= 0 && yt < mh, yb_ = yb >= 0 && yb < mh;
+                m00 = (ya && xa) ? mov[(size_t)yt * mov_pitch + x0] : 0.f;
+                m01 = (ya && xb) ? mov[(size_t)yt * mov_pitch + x0 + 1] : 0.f;
+                m10 = (yb_ && xa) ? mov[(size_t)yb * mov_pitch + x0] : 0.f;
+                m11 = (yb_ && xb) ? mov[(size_t)yb * mov_pitch + x0 + 1] : 0.f;
+            }
+            const float top = m00 + (m01 - m00) * frx;
+            const float bot = m10 + (m11 - m10) * frx;
+            const float gradt = (top + (bot - top) * fry) - rc[k];
+            B0 += -lgx[k] * gradt;
+            B1 += -lgy[k] * gradt;
+        }
+        block_sum2<NW>(B0, B1, sm);
+        if (tid == 0) {
+            s_flow[0] = fxv + det_inv * (A11 * B0 - A01 * B1);
+            s_flow[1] = fyv + det_inv * (-A10 * B0 + A00 * B1);
+        }
+    }
+    __syncthreads();
+    if (tid == 0) {
+        fl[0] = s_flow[0];
+        fl[1] = s_flow[1];
+    }
+}
+
+extern "C" int hhsr_ica(const float* ref, const float* gx, const float* gy, int ref_pitch, const float* hess,
+                        const float* mov, int mh, int mw, int mov_pitch, float* flow, int ny, int nx, int ts,
+                        int n_iter, int flags, void* stream) {
+    HHSR_ARG(ref && gx && gy && hess && mov && flow && mh > 0 && mw > 0 && ny > 0 && nx > 0 && n_iter > 0);
+    const dim3 grid(nx, ny);
+    hipStream_t s = (hipStream_t)stream;
+    const int bug = flags & 1;
+#define ICA_ARGS ref, gx, gy, ref_pitch, hess, mov, mh, mw, mov_pitch, flow, nx, n_iter, bug
+    switch (ts) {
+        case 8: hipLaunchKernelGGL((k_ica<8, 64>), grid, dim3(64), 0, s, ICA_ARGS); break;
+        case 16: hipLaunchKernelGGL((k_ica<16, 256>), grid, dim3(256), 0, s, ICA_ARGS); break;
+        case 32: hipLaunchKernelGGL((k_ica<32, 256>), grid, dim3(256), 0, s, ICA_ARGS); break;
+        case 64: hipLaunchKernelGGL((k_ica<64, 256>), grid, dim3(256), 0, s, ICA_ARGS); break;
+        default:
+            hhsr_set_error("hhsr_ica: ICA kernel for tile size %d not implemented", ts);  // ICA.py:100
+            return -2;
+    }
+#undef ICA_ARGS
+    HHSR_LAUNCHED();
+}
+
+// ---- flow upscaling (nearest) ---------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_flow_upscale(const float2* __restrict__ src, int sny, int snx,
+                                                       float2* __restrict__ dst, int dny, int dnx, int rep,
+                                                       float mult) {
+    const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
+    if (x >= dnx) return;
+    const int sy = y / rep, sx = x / rep;
+    float2 v = make_float2(0.f, 0.f);
+    if (sy < sny && sx < snx) {
+        v = src[(size_t)sy * snx + sx];
+        v.x *= mult;
+        v.y *= mult;
+    }
+    dst[(size_t)y * dnx + x] = v;
+}
+
+extern "C" int hhsr_flow_upscale_nearest(const float* src, int sny, int snx, float* dst, int dny, int dnx, int rep,
+                                         float mult, void* stream) {
+    HHSR_ARG(src && dst && sny > 0 && snx > 0 && dny > 0 && dnx > 0 && rep >= 1);
+    hipLaunchKernelGGL(k_flow_upscale, dim3(hhsr_cdiv(dnx, 256), dny), dim3(256), 0, (hipStream_t)stream,
+                       reinterpret_cast<const float2*>(src), sny, snx, reinterpret_cast<float2*>(dst), dny, dnx, rep,
+                       mult);
+    HHSR_LAUNCHED();
+}

@@ -1,0 +1,348 @@
+// Alg. 4 / Alg. 11 anisotropic kernel-regression merge (reference merge.py:22-434, linalg.py:38-200).
+//
+// One thread per high-resolution output pixel, 64x4 pixel workgroups (a wave64 covers 64 consecutive
+// pixels of one output row, so the [sH][sW][3] accumulators are read/written as contiguous 768-byte
+// runs).  Two entry shapes:
+//   hhsr_accumulate / hhsr_accumulate_ref   per-frame read-modify-write of num/den, the reference's
+//                                           operator API (2 x 12 S P bytes of accumulator traffic per frame)
+//   hhsr_merge_burst                        loops over all resident frames with the accumulators in
+//                                           registers and writes the output once: the accumulator
+//                                           traffic drops from 48 S P bytes per frame to 12-24 S P per burst.
+// Arithmetic follows the reference's Numba typing: coordinates, covariance
+// interpolation and weights are float64, the per-pixel val/acc sums are float32 rounded after every
+// tap.  `WT` selects the type of the weight chain (double = reference typing, float = fast path).
+#include "hhsr_common.h"
+
+struct Cfa4 {
+    uint8_t c[4];
+};
+
+struct Geo {
+    int H, W, pitch;    // raw frame
+    int gh, gw;         // covariance grid (H/2, W/2)
+    int ny, nx, ts;     // flow tile grid
+    int sH, sW;         // output
+    double scale;
+};
+
+struct FramePtr {
+    const float* raw;
+    const float2* flow;
+    const float4* cov;
+    const float* r;
+};
+
+// ---- one comp frame's contribution to HR pixel (hi, hj)  (merge.py:291-434) -----------------------
+template <typename WT, bool ISO>
+__device__ __forceinline__ void comp_contrib(const FramePtr f, const Geo& g, const Cfa4 cfa, int hi, int hj,
+                                             float val[3], float acc[3]) {
+    const double lr_x = ((double)hj + 0.5) / g.scale;
+    const double lr_y = ((double)hi + 0.5) / g.scale;
+    const int px = (int)lr_x / g.ts, py = (int)lr_y / g.ts;  // == int(lr // tile_size) for lr >= 0
+    const float2 fl = f.flow[(size_t)py * g.nx + px];
+    const int i_r = min((int)lr_y, g.H - 1), j_r = min((int)lr_x, g.W - 1);
+    const double mx = lr_x + (double)fl.x, my = lr_y + (double)fl.y;
+    if (!(mx >= 0.0 && mx < (double)g.W && my >= 0.0 && my < (double)g.H)) return;
+    const WT local_r = (WT)f.r[(size_t)i_r * g.W + j_r];
+    WT ixx = 0, ixy = 0, iyy = 0;
+    if (!ISO) {
+        const double kj = mx / 2.0 - 0.5, ki = my / 2.0 - 0.5;
+        const double tkj = trunc(kj), tki = trunc(ki);
+        const WT fx = (WT)(kj - tkj), fy = (WT)(ki - tki);  // signed modf fraction (D11)
+        const int x0 = max((int)tkj, 0), y0 = max((int)tki, 0);
+        const int x1 = min(x0 + 1, g.gw - 1), y1 = min(y0 + 1, g.gh - 1);
+        const float4 c00 = f.cov[(size_t)y0 * g.gw + x0], c01 = f.cov[(size_t)y0 * g.gw + x1];
+        const float4 c10 = f.cov[(size_t)y1 * g.gw + x0], c11 = f.cov[(size_t)y1 * g.gw + x1];
+        // float32 differences, then lerp in the weight type (merge.py:378-390)
+        const WT txx = (WT)c00.x + fx * (WT)(c01.x - c00.x), bxx = (WT)c10.x + fx * (WT)(c11.x - c10.x);
+        const WT txy = (WT)c00.y + fx * (WT)(c01.y - c00.y), bxy = (WT)c10.y + fx * (WT)(c11.y - c10.y);
+        const WT tyy = (WT)c00.w + fx * (WT)(c01.w - c00.w), byy = (WT)c10.w + fx * (WT)(c11.w - c10.w);
+        const WT cxx = txx + fy * (bxx - txx), cxy = txy + fy * (bxy - txy), cyy = tyy + fy * (byy - tyy);
+        const WT det = cxx * cyy - cxy * cxy;
+        const WT inv_det = (WT)1.0 / det;
+        ixx = inv_det * cyy;
+        ixy = -inv_det * cxy;
+        iyy = inv_det * cxx;
+    }
+    const int cj = (int)mx, ci = (int)my;
+    const double mj = mx - 0.5, mi = my - 0.5;
+#pragma unroll
+    for (int di = -1; di <= 1; ++di) {
+        const int i = ci + di;
+        const WT dy = (WT)((double)i - mi);
+#pragma unroll
+        for (int dj = -1; dj <= 1; ++dj) {
+            const int j = cj + dj;
+            if (j < 0 || j >= g.W || i < 0 || i >= g.H) continue;
+            const int ch = cfa.c[(i & 1) * 2 + (j & 1)];
+            const WT c = (WT)f.raw[(size_t)i * g.pitch + j];
+            const WT dx = (WT)((double)j - mj);
+            WT z;
+            if (ISO) z = (WT)2.0 * (dx * dx + dy * dy);
+            else z = ixx * dx * dx + (WT)2.0 * ixy * dx * dy + iyy * dy * dy;
+            z = z > (WT)0 ? z : (WT)0;  // Python max(0, z): NaN -> 0 -> w = 1 (D10)
+            const WT w = exp((WT)-0.5 * z);
+            const WT wr = w * local_r;
+#pragma unroll
+            for (int k = 0; k < 3; ++k)
+                if (ch == k) {
+                    val[k] = (float)((WT)val[k] + wr * c);
+                    acc[k] = (float)((WT)acc[k] + wr);
+                }
+        }
+    }
+}
+
+// ---- the reference frame's contribution (merge.py:83-233) -------------------------------------------
+// Returns true when the accumulated-robustness rule says "overwrite" (merge.py:223-228).
+template <bool ISO>
+__device__ __forceinline__ bool ref_contrib(const float* __restrict__ raw, const float4* __restrict__ cov,
+                                            const Geo& g, const Cfa4 cfa, int oi, int oj,
+                                            const float* __restrict__ acc_rob, int rad_max, double max_mult,
+                                            double max_fc, float val[3], float acc[3]) {
+    const float pyf = (float)((double)oi / g.scale);  // coarse_ref_sub_pos is a float32 local array
+    const float pxf = (float)((double)oj / g.scale);
+    float i00 = 1.f, i01 = 0.f, i10 = 0.f, i11 = 1.f;
+    if (!ISO) {
+        const float gy = (float)(((double)pyf - 0.5) / 2.0), gx = (float)(((double)pxf - 0.5) / 2.0);
+        const int x0 = (int)fmaxf(floorf(gx), 0.f), y0 = (int)fmaxf(floorf(gy), 0.f);
+        const int x1 = min(x0 + 1, g.gw - 1), y1 = min(y0 + 1, g.gh - 1);
+        const double rx = (double)(gx - truncf(gx)), ry = (double)(gy - truncf(gy));  // modf (signed)
+        const float4 c00 = cov[(size_t)y0 * g.gw + x0], c01 = cov[(size_t)y0 * g.gw + x1];
+        const float4 c10 = cov[(size_t)y1 * g.gw + x0], c11 = cov[(size_t)y1 * g.gw + x1];
+#define HHSR_ICOV(m) \
+    (float)((double)c00.m * (1.0 - rx) * (1.0 - ry) + (double)c01.m * rx * (1.0 - ry) + \
+            (double)c10.m * (1.0 - rx) * ry + (double)c11.m * rx * ry)
+        const float m00 = HHSR_ICOV(x), m01 = HHSR_ICOV(y), m10 = HHSR_ICOV(z), m11 = HHSR_ICOV(w);
+#undef HHSR_ICOV
+        const float det = m00 * m11 - m01 * m10;  // float32 (linalg.py:53)
+        if (fabsf(det) > 1e-10f) {                // NaN fails the test -> identity (D10)
+            const double det_i = 1.0 / (double)det;
+            i00 = (float)((double)m11 * det_i);
+            i01 = (float)(-(double)m01 * det_i);
+            i10 = (float)(-(double)m10 * det_i);
+            i11 = (float)((double)m00 * det_i);
+        }
+    }
+    double power = 1.0;
+    int rad = 1;
+    bool overwrite = false;
+    if (acc_rob) {
+        const int ry_i = min((int)rintf(pyf), g.H - 1), rx_i = min((int)rintf(pxf), g.W - 1);
+        const float la = acc_rob[(size_t)ry_i * g.W + rx_i];
+        if ((double)la <= max_fc) {  // utils_image.py:311-325
+            power = max_mult;
+            rad = rad_max;
+        }
+        overwrite = (double)la < max_fc;
+    }
+    const int cx = (int)rintf(pxf), cy = (int)rintf(pyf);  // round-half-even
+    for (int i = -rad; i <= rad; ++i) {
+        const int pi = cy + i;
+        const double dy = (double)pi - (double)pyf;
+        for (int j = -rad; j <= rad; ++j) {
+            const int pj = cx + j;
+            if (pj < 0 || pj >= g.W || pi < 0 || pi >= g.H) continue;
+            const int ch = cfa.c[(pi & 1) * 2 + (pj & 1)];
+            const double c = (double)raw[(size_t)pi * g.pitch + pj];
+            const double dx = (double)pj - (double)pxf;
+            double y;
+            if (ISO) y = 2.0 * (dx * dx + dy * dy);
+            else y = (double)i00 * dx * dx + dx * dy * (double)(i01 + i10) + (double)i11 * dy * dy;
+            y = pymax0(y);
+            y = y / power;
+            const double w = exp(-0.5 * y);
+#pragma unroll
+            for (int k = 0; k < 3; ++k)
+                if (ch == k) {
+                    val[k] = (float)((double)val[k] + c * w);
+                    acc[k] = (float)((double)acc[k] + w);
+                }
+        }
+    }
+    return overwrite;
+}
+
+// ---- per-frame kernels (operator API) ----------------------------------------------------------------
+template <typename WT, bool ISO>
+__global__ void __launch_bounds__(256) k_accumulate(FramePtr f, Geo g, Cfa4 cfa, float* __restrict__ num,
+                                                     float* __restrict__ den) {
+    const int hj = blockIdx.x * 64 + (threadIdx.x & 63), hi = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (hj >= g.sW || hi >= g.sH) return;
+    float val[3] = {0.f, 0.f, 0.f}, acc[3] = {0.f, 0.f, 0.f};
+    comp_contrib<WT, ISO>(f, g, cfa, hi, hj, val, acc);
+    const size_t o = ((size_t)hi * g.sW + hj) * 3;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        num[o + k] += val[k];
+        den[o + k] += acc[k];
+    }
+}
+
+template <bool ISO>
+__global__ void __launch_bounds__(256) k_accumulate_ref(const float* __restrict__ raw,
+                                                         const float4* __restrict__ cov, Geo g, Cfa4 cfa,
+                                                         const float* __restrict__ acc_rob, int rad_max,
+                                                         double max_mult, double max_fc, float* __restrict__ num,
+                                                         float* __restrict__ den) {
+    const int oj = blockIdx.x * 64 + (threadIdx.x & 63), oi = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (oj >= g.sW || oi >= g.sH) return;
+    float val[3] = {0.f, 0.f, 0.f}, acc[3] = {0.f, 0.f, 0.f};
+    const bool over = ref_contrib<ISO>(raw, cov, g, cfa, oi, oj, acc_rob, rad_max, max_mult, max_fc, val, acc);
+    const size_t o = ((size_t)oi * g.sW + oj) * 3;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        if (over) {
+            num[o + k] = val[k];
+            den[o + k] = acc[k];
+        } else {
+            num[o + k] += val[k];
+            den[o + k] += acc[k];
+        }
+    }
+}
+
+// ---- fused burst kernel -------------------------------------------------------------------------------
+struct BurstArgs {
+    FramePtr f[HHSR_MAX_FRAMES];
+    int n;
+    const float* ref_raw;
+    const float4* ref_cov;
+    int flags;
+};
+
+template <typename WT, bool ISO>
+__global__ void __launch_bounds__(256) k_merge_burst(BurstArgs a, Geo g, Cfa4 cfa, float* __restrict__ num,
+                                                      float* __restrict__ den) {
+    const int hj = blockIdx.x * 64 + (threadIdx.x & 63), hi = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (hj >= g.sW || hi >= g.sH) return;
+    const size_t o = ((size_t)hi * g.sW + hj) * 3;
+    float n3[3] = {0.f, 0.f, 0.f}, d3[3] = {0.f, 0.f, 0.f};
+    if (a.flags & HHSR_MERGE_LOAD_ACC) {
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            n3[k] = num[o + k];
+            d3[k] = den[o + k];
+        }
+    }
+    for (int n = 0; n < a.n; ++n) {
+        float val[3] = {0.f, 0.f, 0.f}, acc[3] = {0.f, 0.f, 0.f};
+        comp_contrib<WT, ISO>(a.f[n], g, cfa, hi, hj, val, acc);
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {  // same float32 order as successive `num += val`
+            n3[k] += val[k];
+            d3[k] += acc[k];
+        }
+    }
+    if (a.flags & HHSR_MERGE_DO_REF) {
+        float val[3] = {0.f, 0.f, 0.f}, acc[3] = {0.f, 0.f, 0.f};
+        ref_contrib<ISO>(a.ref_raw, a.ref_cov, g, cfa, hi, hj, nullptr, 0, 0.0, 0.0, val, acc);
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            n3[k] += val[k];
+            d3[k] += acc[k];
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        num[o + k] = (a.flags & HHSR_MERGE_DIVIDE) ? n3[k] / d3[k] : n3[k];
+        if (a.flags & HHSR_MERGE_STORE_DEN) den[o + k] = d3[k];
+    }
+}
+
+// ---- host entry points ----------------------------------------------------------------------------------
+static int fill_geo(Geo& g, int H, int W, int pitch, int ny, int nx, int ts, double scale, int sH, int sW) {
+    g.H = H; g.W = W; g.pitch = pitch; g.gh = H / 2; g.gw = W / 2;
+    g.ny = ny; g.nx = nx; g.ts = ts; g.sH = sH; g.sW = sW; g.scale = scale;
+    return 0;
+}
+
+static inline bool weight_f32() {
+    // HHSR_WEIGHT_F32=1 selects the float32 weight chain (faster, ~1e-6 relative differences)
+    static const int v = [] {
+        const char* e = getenv("HHSR_WEIGHT_F32");
+        return (e && e[0] == '1') ? 1 : 0;
+    }();
+    return v != 0;
+}
+
+extern "C" int hhsr_accumulate(const float* raw, int H, int W, int pitch, const float* flow, int ny, int nx, int ts,
+                               const float* covs, const float* r, const uint8_t cfa[4], double scale, int iso,
+                               float* num, float* den, int sH, int sW, void* stream) {
+    HHSR_ARG(raw && flow && r && cfa && num && den && (iso || covs));
+    HHSR_ARG(H >= 2 && W >= 2 && pitch >= W && ts > 0 && scale >= 1.0 && sH > 0 && sW > 0);
+    HHSR_ARG((int64_t)ny * ts >= H && (int64_t)nx * ts >= W);  // every LR position has a flow tile
+    HHSR_ARG((double)sH <= scale * H + 0.5 && (double)sW <= scale * W + 0.5);
+    for (int k = 0; k < 4; ++k) HHSR_ARG(cfa[k] <= 2);
+    Geo g;
+    fill_geo(g, H, W, pitch, ny, nx, ts, scale, sH, sW);
+    Cfa4 c;
+    for (int k = 0; k < 4; ++k) c.c[k] = cfa[k];
+    FramePtr f{raw, reinterpret_cast<const float2*>(flow), reinterpret_cast<const float4*>(covs), r};
+    const dim3 grid(hhsr_cdiv(sW, 64), hhsr_cdiv(sH, 4)), block(256);
+    hipStream_t s = (hipStream_t)stream;
+    if (iso) hipLaunchKernelGGL((k_accumulate<double, true>), grid, block, 0, s, f, g, c, num, den);
+    else if (weight_f32()) hipLaunchKernelGGL((k_accumulate<float, false>), grid, block, 0, s, f, g, c, num, den);
+    else hipLaunchKernelGGL((k_accumulate<double, false>), grid, block, 0, s, f, g, c, num, den);
+    HHSR_LAUNCHED();
+}
+
+extern "C" int hhsr_accumulate_ref(const float* raw, int H, int W, int pitch, const float* covs,
+                                   const uint8_t cfa[4], double scale, int iso, const float* acc_rob, int rad_max,
+                                   double max_multiplier, double max_frame_count, float* num, float* den, int sH,
+                                   int sW, void* stream) {
+    HHSR_ARG(raw && cfa && num && den && (iso || covs));
+    HHSR_ARG(H >= 2 && W >= 2 && pitch >= W && scale >= 1.0 && sH > 0 && sW > 0);
+    HHSR_ARG(!acc_rob || (rad_max >= 0 && rad_max <= 8 && max_multiplier > 0.0));
+    for (int k = 0; k < 4; ++k) HHSR_ARG(cfa[k] <= 2);
+    Geo g;
+    fill_geo(g, H, W, pitch, 0, 0, 1, scale, sH, sW);
+    Cfa4 c;
+    for (int k = 0; k < 4; ++k) c.c[k] = cfa[k];
+    const dim3 grid(hhsr_cdiv(sW, 64), hhsr_cdiv(sH, 4)), block(256);
+    hipStream_t s = (hipStream_t)stream;
+    const float4* cv = reinterpret_cast<const float4*>(covs);
+    if (iso)
+        hipLaunchKernelGGL((k_accumulate_ref<true>), grid, block, 0, s, raw, cv, g, c, acc_rob, rad_max,
+                           max_multiplier, max_frame_count, num, den);
+    else
+        hipLaunchKernelGGL((k_accumulate_ref<false>), grid, block, 0, s, raw, cv, g, c, acc_rob, rad_max,
+                           max_multiplier, max_frame_count, num, den);
+    HHSR_LAUNCHED();
+}
+
+extern "C" int hhsr_merge_burst(const float* const* raws, const float* const* flows, const float* const* covs,
+                                const float* const* rs, int n_frames, int H, int W, int pitch, int ny, int nx,
+                                int ts, const float* ref_raw, const float* ref_covs, const uint8_t cfa[4],
+                                double scale, int iso, int flags, float* num, float* den, int sH, int sW,
+                                void* stream) {
+    HHSR_ARG(n_frames >= 0 && n_frames <= HHSR_MAX_FRAMES && cfa && num);
+    HHSR_ARG(n_frames == 0 || (raws && flows && rs && (iso || covs)));
+    HHSR_ARG(H >= 2 && W >= 2 && pitch >= W && ts > 0 && scale >= 1.0 && sH > 0 && sW > 0);
+    HHSR_ARG(n_frames == 0 || ((int64_t)ny * ts >= H && (int64_t)nx * ts >= W));
+    HHSR_ARG((double)sH <= scale * H + 0.5 && (double)sW <= scale * W + 0.5);
+    HHSR_ARG(!(flags & HHSR_MERGE_DO_REF) || (ref_raw && (iso || ref_covs)));
+    HHSR_ARG(!(flags & (HHSR_MERGE_LOAD_ACC | HHSR_MERGE_STORE_DEN)) || den);
+    for (int k = 0; k < 4; ++k) HHSR_ARG(cfa[k] <= 2);
+    BurstArgs a;
+    for (int n = 0; n < n_frames; ++n) {
+        HHSR_ARG(raws[n] && flows[n] && rs[n] && (iso || covs[n]));
+        a.f[n] = FramePtr{raws[n], reinterpret_cast<const float2*>(flows[n]),
+                          iso ? nullptr : reinterpret_cast<const float4*>(covs[n]), rs[n]};
+    }
+    for (int n = n_frames; n < HHSR_MAX_FRAMES; ++n) a.f[n] = FramePtr{nullptr, nullptr, nullptr, nullptr};
+    a.n = n_frames;
+    a.ref_raw = ref_raw;
+    a.ref_cov = reinterpret_cast<const float4*>(ref_covs);
+    a.flags = flags;
+    Geo g;
+    fill_geo(g, H, W, pitch, ny, nx, ts, scale, sH, sW);
+    Cfa4 c;
+    for (int k = 0; k < 4; ++k) c.c[k] = cfa[k];
+    const dim3 grid(hhsr_cdiv(sW, 64), hhsr_cdiv(sH, 4)), block(256);
+    hipStream_t s = (hipStream_t)stream;
+    if (iso) hipLaunchKernelGGL((k_merge_burst<double, true>), grid, block, 0, s, a, g, c, num, den);
+    else if (weight_f32()) hipLaunchKernelGGL((k_merge_burst<float, false>), grid, block, 0, s, a, g, c, num, den);
+    else hipLaunchKernelGGL((k_merge_burst<double, false>), grid, block, 0, s, a, g, c, num, den);
+    HHSR_LAUNCHED();
+}

@@ -1,0 +1,134 @@
+// Grey-image low-pass masks and the Gaussian pyramid (reference utils_image.py:82-100, 360-391;
+// alignment.py:27-37, 74-82).  HBM-bound streaming kernels; the decimating filter stages its input
+// tile in LDS so every source pixel is fetched from L2/HBM ~1.4x instead of (4f+1)^2/f^2 times.
+#include "hhsr_common.h"
+
+// ---- low-pass masks --------------------------------------------------------------------------
+// kept(u): un-shifted bin u survives the reference's zeroing of the fftshift-ed spectrum
+// (rows [:n//4] and [-ceil(n/4):] removed; shifted index i = (u + n//2) mod n).
+__device__ __forceinline__ bool lp_kept(int u, int n) {
+    int i = u + n / 2;
+    if (i >= n) i -= n;
+    return i >= n / 4 && i < n - (n + 3) / 4;
+}
+
+// The spectrum may have any element strides (rocFFT's real transform returns a transposed layout
+// through torch); `xfast` says which dimension is contiguous so that a wave reads consecutive bins.
+__global__ void __launch_bounds__(256) k_lowpass_c2c(float2* __restrict__ spec, int H, int W, int64_t sy,
+                                                      int64_t sx, int xfast) {
+    const int a = blockIdx.x * blockDim.x + threadIdx.x, b = blockIdx.y;
+    const int x = xfast ? a : b, y = xfast ? b : a;
+    if (x >= W || y >= H) return;
+    if (!(lp_kept(y, H) && lp_kept(x, W))) spec[y * sy + x * sx] = make_float2(0.f, 0.f);
+}
+
+__global__ void __launch_bounds__(256) k_lowpass_r2c(float2* __restrict__ spec, int H, int W, int Wh, int64_t sy,
+                                                      int64_t sx, int xfast) {
+    const int a = blockIdx.x * blockDim.x + threadIdx.x, b = blockIdx.y;
+    const int x = xfast ? a : b, y = xfast ? b : a;
+    if (x >= Wh || y >= H) return;
+    const int ny = y == 0 ? 0 : H - y, nx = x == 0 ? 0 : W - x;
+    const int m = (int)(lp_kept(y, H) && lp_kept(x, W)) + (int)(lp_kept(ny, H) && lp_kept(nx, W));
+    if (m == 2) return;
+    float2 v = spec[y * sy + x * sx];
+    const float s = 0.5f * (float)m;
+    v.x *= s;
+    v.y *= s;
+    spec[y * sy + x * sx] = v;
+}
+
+extern "C" int hhsr_lowpass_mask_c2c(float* spec, int H, int W, int64_t stride_y, int64_t stride_x, void* stream) {
+    HHSR_ARG(spec && H > 0 && W > 0 && stride_y > 0 && stride_x > 0);
+    const int xfast = stride_x <= stride_y;
+    const dim3 grid = xfast ? dim3(hhsr_cdiv(W, 256), H) : dim3(hhsr_cdiv(H, 256), W);
+    hipLaunchKernelGGL(k_lowpass_c2c, grid, dim3(256), 0, (hipStream_t)stream, reinterpret_cast<float2*>(spec), H, W,
+                       stride_y, stride_x, xfast);
+    HHSR_LAUNCHED();
+}
+
+extern "C" int hhsr_lowpass_mask_r2c(float* spec, int H, int W, int64_t stride_y, int64_t stride_x, void* stream) {
+    HHSR_ARG(spec && H > 0 && W > 0 && stride_y > 0 && stride_x > 0);
+    const int Wh = W / 2 + 1;
+    const int xfast = stride_x <= stride_y;
+    const dim3 grid = xfast ? dim3(hhsr_cdiv(Wh, 256), H) : dim3(hhsr_cdiv(H, 256), Wh);
+    hipLaunchKernelGGL(k_lowpass_r2c, grid, dim3(256), 0, (hipStream_t)stream, reinterpret_cast<float2*>(spec), H, W,
+                       Wh, stride_y, stride_x, xfast);
+    HHSR_LAUNCHED();
+}
+
+// ---- circular padding ---------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_pad_circular(const float* __restrict__ src, int H, int W, int sp,
+                                                       float* __restrict__ dst, int Hp, int Wp, int dp) {
+    const int x = blockIdx.x * blockDim.x + threadIdx.x;
+    const int y = blockIdx.y;
+    if (x >= Wp) return;
+    dst[(size_t)y * dp + x] = src[(size_t)(y % H) * sp + (x % W)];
+}
+
+extern "C" int hhsr_pad_circular(const float* src, int H, int W, int src_pitch, float* dst, int Hp, int Wp,
+                                 int dst_pitch, void* stream) {
+    HHSR_ARG(src && dst && H > 0 && W > 0 && Hp >= H && Wp >= W && src_pitch >= W && dst_pitch >= Wp);
+    hipLaunchKernelGGL(k_pad_circular, dim3(hhsr_cdiv(Wp, 256), Hp), dim3(256), 0, (hipStream_t)stream, src, H, W,
+                       src_pitch, dst, Hp, Wp, dst_pitch);
+    HHSR_LAUNCHED();
+}
+
+// ---- separable Gaussian + decimation ------------------------------------------------------------
+struct Taps {
+    float g[HHSR_MAX_TAPS];
+};
+
+constexpr int GD_TX = 32, GD_TY = 16;  // output tile per 256-thread workgroup
+
+// out[y][x] = sum_j g[j] * (sum_i g[i] * src[f*y+i][f*x+j]): rows first, then columns, both in float32 in
+// tap order — the association of the reference's two chained valid conv2d calls.
+__global__ void __launch_bounds__(256) k_gauss_decimate(const float* __restrict__ src, int H, int W, int sp,
+                                                         float* __restrict__ dst, int h2, int w2, int dp, int f,
+                                                         int nt, Taps taps) {
+    extern __shared__ float lds[];
+    const int IH = (GD_TY - 1) * f + nt, IW = (GD_TX - 1) * f + nt;
+    const int IWp = IW | 1;  // odd pitch: the strided column reads below stay <= 2-way conflicted
+    float* s_in = lds;                  // [IH][IWp]
+    float* s_tmp = lds + IH * IWp;      // [GD_TY][IWp]
+    const int ox0 = blockIdx.x * GD_TX, oy0 = blockIdx.y * GD_TY;
+    const int ix0 = ox0 * f, iy0 = oy0 * f;
+    const int tid = threadIdx.x;
+    for (int p = tid; p < IH * IW; p += 256) {
+        const int r = p / IW, c = p - r * IW;
+        const int y = min(iy0 + r, H - 1), x = min(ix0 + c, W - 1);
+        s_in[r * IWp + c] = src[(size_t)y * sp + x];
+    }
+    __syncthreads();
+    for (int p = tid; p < GD_TY * IW; p += 256) {
+        const int r = p / IW, c = p - r * IW;
+        float acc = 0.f;
+        for (int i = 0; i < nt; ++i) acc += taps.g[i] * s_in[(r * f + i) * IWp + c];
+        s_tmp[r * IWp + c] = acc;
+    }
+    __syncthreads();
+    for (int p = tid; p < GD_TY * GD_TX; p += 256) {
+        const int r = p / GD_TX, c = p - r * GD_TX;
+        const int oy = oy0 + r, ox = ox0 + c;
+        if (oy < h2 && ox < w2) {
+            float acc = 0.f;
+            for (int j = 0; j < nt; ++j) acc += taps.g[j] * s_tmp[r * IWp + c * f + j];
+            dst[(size_t)oy * dp + ox] = acc;
+        }
+    }
+}
+
+extern "C" int hhsr_gauss_decimate(const float* src, int H, int W, int src_pitch, float* dst, int dst_pitch,
+                                   int factor, const float* taps, int ntaps, void* stream) {
+    HHSR_ARG(src && dst && taps && H > 0 && W > 0 && src_pitch >= W);
+    HHSR_ARG(factor >= 2 && factor <= 4 && ntaps >= 1 && ntaps <= HHSR_MAX_TAPS && (ntaps & 1));
+    const int r = (ntaps - 1) / 2;
+    const int h2 = (H - 2 * r) / factor, w2 = (W - 2 * r) / factor;
+    HHSR_ARG(h2 > 0 && w2 > 0 && dst_pitch >= w2);
+    Taps t;
+    for (int i = 0; i < HHSR_MAX_TAPS; ++i) t.g[i] = i < ntaps ? taps[i] : 0.f;
+    const int IH = (GD_TY - 1) * factor + ntaps, IWp = ((GD_TX - 1) * factor + ntaps) | 1;
+    const size_t lds = (size_t)(IH + GD_TY) * IWp * sizeof(float);
+    hipLaunchKernelGGL(k_gauss_decimate, dim3(hhsr_cdiv(w2, GD_TX), hhsr_cdiv(h2, GD_TY)), dim3(256), lds,
+                       (hipStream_t)stream, src, H, W, src_pitch, dst, h2, w2, dst_pitch, factor, ntaps, t);
+    HHSR_LAUNCHED();
+}

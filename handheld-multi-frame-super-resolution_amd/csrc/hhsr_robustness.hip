@@ -1,0 +1,278 @@
+// Alg. 6-9 robustness (reference robustness.py; Dodgson kernel utils_image.py:395-406).
+//
+// The reference runs 8 launches and ~600 MB of raw-resolution temporaries per frame.  Here:
+//   k_rob_stats   raw -> guide (LDS tile) -> 3x3 mean/variance at guide resolution        (1 read of raw)
+//   k_rob_frame   fused: Dodgson warp-upsample of the frame's means, |d mu|, noise-model shrink,
+//                 S lookup, threshold -> R at raw resolution                               (no temporaries)
+//   k_local_min5  5x5 minimum through an LDS tile
+// Arithmetic follows the reference's Numba typing: float64 weights and noise-model
+// maths, float32 storage and float32 running sums that are rounded after every tap.
+#include "hhsr_common.h"
+
+// ---- guide image + local statistics -----------------------------------------------------------
+constexpr int RS_TX = 32, RS_TY = 8;
+
+struct Cfa {
+    uint8_t c[4];
+};
+struct Wb {
+    double w[3];
+};
+
+__global__ void __launch_bounds__(256) k_rob_stats(const float* __restrict__ raw, int pitch, Cfa cfa, Wb wb,
+                                                    float* __restrict__ means, float* __restrict__ vars, int gh,
+                                                    int gw) {
+    __shared__ float s_g[3][RS_TY + 2][RS_TX + 2 + 1];
+    const int gx0 = blockIdx.x * RS_TX, gy0 = blockIdx.y * RS_TY;
+    for (int p = threadIdx.x; p < (RS_TY + 2) * (RS_TX + 2); p += 256) {
+        const int i = p / (RS_TX + 2), j = p - i * (RS_TX + 2);
+        // clamp-border neighbourhood (robustness.py:284-286)
+        const int gy = clampi(gy0 + i - 1, 0, gh - 1), gx = clampi(gx0 + j - 1, 0, gw - 1);
+        const float2 a = *reinterpret_cast<const float2*>(raw + (size_t)(2 * gy) * pitch + 2 * gx);
+        const float2 b = *reinterpret_cast<const float2*>(raw + (size_t)(2 * gy + 1) * pitch + 2 * gx);
+        const float v[4] = {a.x, a.y, b.x, b.y};
+        double g = 0.0;
+        float ch[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {  // robustness.py:215-225: raw / wb[c] in float64
+            const int c = cfa.c[k];
+            const double x = (double)v[k] / wb.w[c];
+            if (c == 1) g += x;
+            else ch[c] = (float)x;
+        }
+        ch[1] = (float)(g / 2.0);
+        s_g[0][i][j] = ch[0];
+        s_g[1][i][j] = ch[1];
+        s_g[2][i][j] = ch[2];
+    }
+    __syncthreads();
+    const int lx = threadIdx.x % RS_TX, ly = threadIdx.x / RS_TX;
+    const int gx = gx0 + lx, gy = gy0 + ly;
+    if (gx >= gw || gy >= gh) return;
+    const size_t plane = (size_t)gh * gw, o = (size_t)gy * gw + gx;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        float s0 = 0.f, s1 = 0.f;  // float32 running sums in (i, j) order (robustness.py:280-288)
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+#pragma unroll
+            for (int j = 0; j < 3; ++j) {
+                const float v = s_g[c][ly + i][lx + j];
+                s0 += v;
+                s1 += v * v;
+            }
+        const double m = (double)s0 / 9.0;
+        means[c * plane + o] = (float)m;
+        vars[c * plane + o] = (float)((double)s1 / 9.0 - m * m);
+    }
+}
+
+extern "C" int hhsr_rob_stats(const float* raw, int H, int W, int pitch, const uint8_t cfa[4], const double* wb,
+                              float* means, float* vars, void* stream) {
+    HHSR_ARG(raw && cfa && wb && means && vars && H >= 2 && W >= 2 && pitch >= W);
+    HHSR_ARG((pitch & 1) == 0 && ((uintptr_t)raw & 7) == 0);
+    for (int k = 0; k < 4; ++k) HHSR_ARG(cfa[k] <= 2);
+    Cfa c;
+    Wb w;
+    for (int k = 0; k < 4; ++k) c.c[k] = cfa[k];
+    for (int k = 0; k < 3; ++k) w.w[k] = wb[k];
+    const int gh = H / 2, gw = W / 2;
+    hipLaunchKernelGGL(k_rob_stats, dim3(hhsr_cdiv(gw, RS_TX), hhsr_cdiv(gh, RS_TY)), dim3(256), 0,
+                       (hipStream_t)stream, raw, pitch, c, w, means, vars, gh, gw);
+    HHSR_LAUNCHED();
+}
+
+// ---- Dodgson quadratic warp-upsample ------------------------------------------------------------
+__device__ __forceinline__ double dodgson(double x) {  // utils_image.py:399-406
+    const double a = fabs(x);
+    if (a <= 0.5) return -2.0 * a * a + 1.0;
+    if (a <= 1.5) return a * a - 5.0 / 2.0 * a + 1.5;
+    return 0.0;
+}
+
+// Interpolates the three channels of a [3][lh][lw] map at raw pixel (y, x) displaced by (fx, fy).
+// Returns false (outside the guide image -> +inf, robustness.py:386-391) or true with out[3].
+__device__ __forceinline__ bool dodgson_sample(const float* __restrict__ LR, int lh, int lw, int y, int x, double fx,
+                                               double fy, float out[3]) {
+    const double ly = ((double)y + fy + 0.5) / 2.0 - 0.5;
+    const double lx = ((double)x + fx + 0.5) / 2.0 - 0.5;
+    if (!(ly >= 0.0 && ly < (double)lh && lx >= 0.0 && lx < (double)lw)) return false;
+    const int cy = (int)rint(ly), cx = (int)rint(lx);  // round-half-even
+    const size_t plane = (size_t)lh * lw;
+    float b0 = 0.f, b1 = 0.f, b2 = 0.f;
+    double wacc = 0.0;
+#pragma unroll
+    for (int i = -1; i <= 1; ++i) {
+        const int y_ = clampi(cy + i, 0, lh - 1);
+        const double wy = dodgson((double)y_ - ly);
+#pragma unroll
+        for (int j = -1; j <= 1; ++j) {
+            const int x_ = clampi(cx + j, 0, lw - 1);
+            const double w = wy * dodgson((double)x_ - lx);
+            const size_t o = (size_t)y_ * lw + x_;
+            // float32 buffer += float32 * float64, rounded after every tap (robustness.py:414-415)
+            b0 = (float)((double)b0 + (double)LR[o] * w);
+            b1 = (float)((double)b1 + (double)LR[plane + o] * w);
+            b2 = (float)((double)b2 + (double)LR[2 * plane + o] * w);
+            wacc += w;
+        }
+    }
+    out[0] = (float)((double)b0 / wacc);
+    out[1] = (float)((double)b1 / wacc);
+    out[2] = (float)((double)b2 / wacc);
+    return true;
+}
+
+__global__ void __launch_bounds__(256) k_rob_upscale(const float* __restrict__ LR, int lh, int lw,
+                                                      const float2* __restrict__ flow, int nx, int ts,
+                                                      float* __restrict__ HR, int H, int W) {
+    const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (x >= W || y >= H) return;
+    double fx = 0.0, fy = 0.0;
+    if (flow) {
+        const float2 f = flow[(size_t)(y / ts) * nx + x / ts];
+        fx = (double)f.x;
+        fy = (double)f.y;
+    }
+    float v[3];
+    const size_t plane = (size_t)H * W, o = (size_t)y * W + x;
+    if (!dodgson_sample(LR, lh, lw, y, x, fx, fy, v)) v[0] = v[1] = v[2] = INFINITY;
+    HR[o] = v[0];
+    HR[plane + o] = v[1];
+    HR[2 * plane + o] = v[2];
+}
+
+extern "C" int hhsr_rob_upscale(const float* stats, int lh, int lw, const float* flow, int ny, int nx, int ts,
+                                float* out, void* stream) {
+    HHSR_ARG(stats && out && lh > 0 && lw > 0);
+    const int H = 2 * lh, W = 2 * lw;
+    if (flow) HHSR_ARG(ts > 0 && ny * ts >= H && nx * ts >= W);
+    hipLaunchKernelGGL(k_rob_upscale, dim3(hhsr_cdiv(W, 64), hhsr_cdiv(H, 4)), dim3(256), 0, (hipStream_t)stream,
+                       stats, lh, lw, reinterpret_cast<const float2*>(flow), nx, ts > 0 ? ts : 1, out, H, W);
+    HHSR_LAUNCHED();
+}
+
+// ---- flow irregularity S (robustness.py:570-612) ------------------------------------------------
+__global__ void __launch_bounds__(256) k_rob_s(const float2* __restrict__ flow, int ny, int nx, double Mt2, float s1,
+                                                float s2, float* __restrict__ S) {
+    const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
+    if (x >= nx) return;
+    float mnx = INFINITY, mny = INFINITY, mxx = -INFINITY, mxy = -INFINITY;
+    for (int i = -1; i <= 1; ++i)
+        for (int j = -1; j <= 1; ++j) {
+            const int yy = y + i, xx = x + j;
+            if (yy >= 0 && yy < ny && xx >= 0 && xx < nx) {
+                const float2 f = flow[(size_t)yy * nx + xx];
+                mxx = fmaxf(mxx, f.x); mxy = fmaxf(mxy, f.y);
+                mnx = fminf(mnx, f.x); mny = fminf(mny, f.y);
+            }
+        }
+    const float d0 = mxx - mnx, d1 = mxy - mny;
+    const float m = d0 * d0 + d1 * d1;
+    S[(size_t)y * nx + x] = ((double)m > Mt2) ? s1 : s2;
+}
+
+extern "C" int hhsr_rob_s(const float* flow, int ny, int nx, float Mt, float s1, float s2, float* S, void* stream) {
+    HHSR_ARG(flow && S && ny > 0 && nx > 0);
+    hipLaunchKernelGGL(k_rob_s, dim3(hhsr_cdiv(nx, 256), ny), dim3(256), 0, (hipStream_t)stream,
+                       reinterpret_cast<const float2*>(flow), ny, nx, (double)Mt * (double)Mt, s1, s2, S);
+    HHSR_LAUNCHED();
+}
+
+// ---- fused per-frame robustness -> R ----------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_rob_frame(const float* __restrict__ cm, int lh, int lw,
+                                                    const float* __restrict__ rmean, const float* __restrict__ rvar,
+                                                    const float2* __restrict__ flow, int nx, int ts,
+                                                    const float* __restrict__ S, const double* __restrict__ stdc,
+                                                    const double* __restrict__ difc, int ncurve, double t,
+                                                    float* __restrict__ R, int H, int W) {
+    const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (x >= W || y >= H) return;
+    const int tix = x / ts, tiy = y / ts;
+    const float2 f = flow[(size_t)tiy * nx + tix];
+    float cmu[3];
+    const bool inb = dodgson_sample(cm, lh, lw, y, x, (double)f.x, (double)f.y, cmu);
+    if (!inb) cmu[0] = cmu[1] = cmu[2] = INFINITY;
+    const size_t plane = (size_t)H * W, o = (size_t)y * W + x;
+    double d_sq = 0.0, s_sq = 0.0;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        const float b = rmean[c * plane + o];
+        const float dp = fabsf(b - cmu[c]);  // robustness.py:453-461
+        // noise-model lookup at round(1000 * brightness) (robustness.py:517-520).  Non-finite brightness
+        // (the +inf border of the reference map, D6) reads index 0: the reference reads out of bounds
+        // there and the value never survives the NaN -> 0 clamp below.
+        int id = 0;
+        const double bb = 1000.0 * (double)b;
+        if (isfinite(bb)) id = clampi((int)rint(bb), 0, ncurve - 1);
+        const double d_t = difc[id], s_t = stdc[id];
+        const double sp = (double)rvar[c * plane + o];
+        const double st2 = s_t * s_t;
+        s_sq += (st2 > sp) ? st2 : sp;  // Python max(sigma_p_sq, sigma_t^2)
+        const float dp2f = dp * dp;
+        const double dp2 = (double)dp2f;
+        const double shrink = dp2 / (dp2 + d_t * d_t);
+        d_sq += dp2 * shrink * shrink;
+    }
+    const float dsf = (float)d_sq, ssf = (float)s_sq;
+    // R = clamp(S * exp(-d^2/sigma^2) - t, 0, 1), float32 up to the subtraction (robustness.py:636-639)
+    const float e = expf(-dsf / ssf);
+    double v = (double)(S[(size_t)tiy * nx + tix] * e) - t;
+    v = v > 0.0 ? v : 0.0;  // NaN -> 0
+    v = v < 1.0 ? v : 1.0;
+    R[o] = (float)v;
+}
+
+extern "C" int hhsr_rob_frame(const float* comp_means, int lh, int lw, const float* ref_means,
+                              const float* ref_vars, const float* flow, int ny, int nx, int ts, const float* S,
+                              const double* std_curve, const double* diff_curve, int ncurve, double t, float* R,
+                              void* stream) {
+    HHSR_ARG(comp_means && ref_means && ref_vars && flow && S && std_curve && diff_curve && R);
+    HHSR_ARG(lh > 0 && lw > 0 && ts > 0 && ncurve > 0);
+    const int H = 2 * lh, W = 2 * lw;
+    HHSR_ARG(ny * ts >= H && nx * ts >= W);
+    hipLaunchKernelGGL(k_rob_frame, dim3(hhsr_cdiv(W, 64), hhsr_cdiv(H, 4)), dim3(256), 0, (hipStream_t)stream,
+                       comp_means, lh, lw, ref_means, ref_vars, reinterpret_cast<const float2*>(flow), nx, ts, S,
+                       std_curve, diff_curve, ncurve, t, R, H, W);
+    HHSR_LAUNCHED();
+}
+
+// ---- 5x5 local minimum (robustness.py:670-686) ------------------------------------------------------
+constexpr int LM_TX = 64, LM_TY = 16;
+
+__global__ void __launch_bounds__(256) k_local_min5(const float* __restrict__ R, int H, int W,
+                                                     float* __restrict__ r) {
+    __shared__ float s[LM_TY + 4][LM_TX + 4 + 1];
+    __shared__ float s_row[LM_TY + 4][LM_TX + 1];
+    const int x0 = blockIdx.x * LM_TX, y0 = blockIdx.y * LM_TY;
+    for (int p = threadIdx.x; p < (LM_TY + 4) * (LM_TX + 4); p += 256) {
+        const int i = p / (LM_TX + 4), j = p - i * (LM_TX + 4);
+        s[i][j] = R[(size_t)clampi(y0 + i - 2, 0, H - 1) * W + clampi(x0 + j - 2, 0, W - 1)];
+    }
+    __syncthreads();
+    for (int p = threadIdx.x; p < (LM_TY + 4) * LM_TX; p += 256) {
+        const int i = p / LM_TX, j = p - i * LM_TX;
+        float m = s[i][j];
+#pragma unroll
+        for (int k = 1; k < 5; ++k) m = fminf(m, s[i][j + k]);
+        s_row[i][j] = m;
+    }
+    __syncthreads();
+    for (int p = threadIdx.x; p < LM_TY * LM_TX; p += 256) {
+        const int i = p / LM_TX, j = p - i * LM_TX;
+        const int y = y0 + i, x = x0 + j;
+        if (y < H && x < W) {
+            float m = s_row[i][j];
+#pragma unroll
+            for (int k = 1; k < 5; ++k) m = fminf(m, s_row[i + k][j]);
+            r[(size_t)y * W + x] = m;
+        }
+    }
+}
+
+extern "C" int hhsr_local_min5(const float* R, int H, int W, float* r, void* stream) {
+    HHSR_ARG(R && r && H > 0 && W > 0 && R != r);
+    hipLaunchKernelGGL(k_local_min5, dim3(hhsr_cdiv(W, LM_TX), hhsr_cdiv(H, LM_TY)), dim3(256), 0,
+                       (hipStream_t)stream, R, H, W, r);
+    HHSR_LAUNCHED();
+}

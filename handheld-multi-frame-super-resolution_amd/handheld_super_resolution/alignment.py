@@ -1,0 +1,112 @@
+"""Coarse-to-fine alignment driver (reference alignment.py).
+
+Flow convention: alignments[ty, tx] = (dx, dy), moving(p + flow) ~= ref(p).  Pyramids are COARSE FIRST
+like the reference's lists."""
+import torch
+import torch.nn.functional as F
+
+from . import _lib
+from .ICA import init_ica, align_lvl_ica
+from .block_matching import align_lvl_block_matching_L2, align_lvl_block_matching_L1
+from .utils_image import cuda_downsample
+
+
+def build_gaussian_pyramid(image, factors=[1, 2, 4, 4], kernel="gaussian"):
+    """alignment.py:74-82: compact contiguous levels, coarse first."""
+    pyramid = [cuda_downsample(image, kernel, factors[0])]
+    for factor in factors[1:]:
+        pyramid.append(cuda_downsample(pyramid[-1], kernel, factor))
+    pyramid = [lvl.reshape(lvl.shape[-2:]) for lvl in pyramid]
+    return pyramid[::-1]
+
+
+def init_alignment(ref_img, config):
+    """Reference-side precompute (alignment.py:20-72): circular pad to a multiple of the tile size,
+    pyramid, per-level gradients + Hessian.
+
+    Returns the reference's 6-tuple (pyramid, tiled_pyr, tiled_fft, gradx, grady, hessian), coarse first.
+    The tiled / FFT'd copies of the reference tiles exist upstream only to feed the FFT correlation; the
+    LDS block-matching kernel reads the level directly, so those two lists hold None."""
+    ref_img = _lib.f32c(ref_img)
+    h, w = ref_img.shape
+    bm = config.block_matching.tuning
+    Ts, tss, factors = bm.tile_size, bm.tile_sizes, bm.factors
+    pb = (Ts - h % Ts) * (h % Ts != 0)
+    pr = (Ts - w % Ts) * (w % Ts != 0)
+    if pb or pr:
+        padded = torch.empty((h + pb, w + pr), dtype=torch.float32, device=ref_img.device)
+        _lib.call("hhsr_pad_circular", _lib.ptr(ref_img), h, w, w, _lib.ptr(padded), h + pb, w + pr, w + pr,
+                  _lib.stream())
+    else:
+        padded = ref_img
+    pyramid = build_gaussian_pyramid(padded, factors)
+    gxs, gys, hs = [], [], []
+    for i, lvl in enumerate(pyramid):
+        ts = tss[len(factors) - i - 1]
+        if lvl.shape[0] // ts < 1 or lvl.shape[1] // ts < 1:
+            raise ValueError(f"pyramid level of shape {tuple(lvl.shape)} cannot be divided into tiles of size {ts}")
+        gx, gy, hess = init_ica(lvl, ts, config)
+        gxs.append(gx)
+        gys.append(gy)
+        hs.append(hess)
+    none = [None] * len(pyramid)
+    return pyramid, list(none), list(none), gxs, gys, hs
+
+
+def upscale_lvl(alignments, npatchs, l, config):
+    """Re-tile and scale the flow for the next finer level (alignment.py:150-172)."""
+    bm = config.block_matching.tuning
+    new_ts, prev_ts = bm.tile_sizes[l], bm.tile_sizes[l + 1]
+    up = bm.factors[l + 1]
+    rep = up // (new_ts // prev_ts)
+    mode = bm.flow_upscale_mode
+    sny, snx, _ = alignments.shape
+    if mode == "nearest":
+        out = torch.empty((npatchs[0], npatchs[1], 2), dtype=torch.float32, device=alignments.device)
+        _lib.call("hhsr_flow_upscale_nearest", _lib.ptr(alignments), sny, snx, _lib.ptr(out), npatchs[0], npatchs[1],
+                  rep, float(up), _lib.stream())
+        return out
+    # bilinear / bicubic: the reference itself delegates to F.interpolate on this <= 188x250x2 field
+    ups = F.interpolate(alignments.permute(2, 0, 1)[None], scale_factor=rep, mode=mode)[0].permute(1, 2, 0)
+    ups = ups * up
+    py, px = npatchs[0] - ups.shape[0], npatchs[1] - ups.shape[1]
+    if py > 0 or px > 0:
+        ups = F.pad(ups, (0, 0, 0, max(px, 0), 0, max(py, 0)), mode="constant", value=0)
+    return ups[: npatchs[0], : npatchs[1]].contiguous()
+
+
+def align_lvl(ref_lvl, tyled_pyr_lvl, ref_fft_lvl, ref_gradx_lvl, ref_grady_lvl, ref_hessian_lvl, moving_lvl,
+              alignments, l, config):
+    """Block matching then ICA on one level (alignment.py:125-147)."""
+    metric = config.block_matching.tuning.metrics[l]
+    if metric == "L2":
+        align_lvl_block_matching_L2(ref_lvl, ref_fft_lvl, moving_lvl, alignments, l, config)
+    elif metric == "L1":
+        align_lvl_block_matching_L1(ref_lvl, moving_lvl, alignments, l, config)
+    elif metric == "L1_ref_effective":
+        align_lvl_block_matching_L1(ref_lvl, moving_lvl, alignments, l, config, effective=True)
+    else:
+        raise ValueError("Unknown block matching metric {}".format(metric))
+    align_lvl_ica(ref_lvl, ref_gradx_lvl, ref_grady_lvl, ref_hessian_lvl, moving_lvl, alignments, l, config)
+
+
+def align(ref_pyramid, tyled_pyr, ref_tiled_fft, ref_gradx, ref_grady, ref_hessian, img, config):
+    """Coarse-to-fine alignment of one grey frame (alignment.py:84-123).  Everything is enqueued on
+    torch's current stream: no host synchronisation between levels (the reference needs a
+    cuda.synchronize() per level to order its torch and Numba streams)."""
+    img = _lib.f32c(img)
+    factors = config.block_matching.tuning.factors
+    moving_pyramid = build_gaussian_pyramid(img, factors)
+    alignments = None
+    n = len(ref_pyramid)
+    for i in range(n):
+        l = n - i - 1
+        ts = config.block_matching.tuning.tile_sizes[l]
+        grid = (ref_pyramid[i].shape[0] // ts, ref_pyramid[i].shape[1] // ts)
+        if alignments is None:
+            alignments = torch.zeros((*grid, 2), dtype=torch.float32, device=img.device)
+        else:
+            alignments = upscale_lvl(alignments, grid, l, config)
+        align_lvl(ref_pyramid[i], tyled_pyr[i], ref_tiled_fft[i], ref_gradx[i], ref_grady[i], ref_hessian[i],
+                  moving_pyramid[i], alignments, l, config)
+    return alignments

@@ -1,0 +1,33 @@
+"""Alg. 5 kernel covariances (reference kernels.py)."""
+import torch
+
+from . import _lib
+
+SEL_HARD_THRESHOLD = 0
+SEL_LINEAR = 1
+
+
+def estimate_kernels(img, config):
+    """covs float32[H/2, W/2, 2, 2] sampled at the centre of every Bayer quad (kernels.py:29-137).
+    GAT, 2x2 decimation, the two gradient convolutions and the per-quad kernel are ONE HIP kernel."""
+    if config.mode != "bayer":
+        raise NotImplementedError("grey mode is outside the MI355X hot path (bayer only)")
+    law = config.merging.selection_law
+    if law == "hard_threshold":
+        sel = SEL_HARD_THRESHOLD
+    elif law == "linear":
+        sel = SEL_LINEAR
+    else:
+        raise ValueError(f"Unknown selection law: {law}")
+    t = config.merging.tuning
+    alpha, beta = config.noise_model.alpha, config.noise_model.beta
+    assert alpha > 0, f"alpha should be positive, got {alpha} (VST is ill defined and kernels would be wrong)"
+    img = _lib.f32c(img)
+    H, W = img.shape
+    if H % 2 or W % 2:
+        raise ValueError(f"bayer frames need even dimensions, got {(H, W)}")
+    covs = torch.empty((H // 2, W // 2, 2, 2), dtype=torch.float32, device=img.device)
+    _lib.call("hhsr_cov_from_raw", _lib.ptr(img), H, W, W, _lib.ptr(covs), float(alpha), float(beta),
+              float(t.k_detail), float(t.k_denoise), float(t.D_th), float(t.D_tr), float(t.k_stretch),
+              float(t.k_shrink), sel, _lib.stream())
+    return covs

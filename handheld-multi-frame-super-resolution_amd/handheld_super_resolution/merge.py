@@ -1,0 +1,75 @@
+"""Alg. 4 / Alg. 11 accumulation (reference merge.py) plus the fused burst merge."""
+import torch
+
+from . import _lib
+
+
+def _common(config):
+    if config.mode != "bayer":
+        raise NotImplementedError("grey mode is outside the MI355X hot path (bayer only)")
+    return float(config.scale), 1 if config.merging.kernel == "iso" else 0
+
+
+def merge(comp_img, alignments, covs, r, num, den, cfa_pattern, config):
+    """Accumulate one non-reference frame into num / den in place (merge.py:236-288)."""
+    scale, iso = _common(config)
+    ts = config.block_matching.tuning.tile_size
+    H, W = comp_img.shape
+    ny, nx, _ = alignments.shape
+    sH, sW, _ = num.shape
+    _lib.call("hhsr_accumulate", _lib.ptr(comp_img), H, W, W, _lib.ptr(alignments), ny, nx, int(ts),
+              _lib.ptr(covs), _lib.ptr(r), _lib.cfa_bytes(cfa_pattern), scale, iso, _lib.ptr(num), _lib.ptr(den),
+              sH, sW, _lib.stream())
+
+
+def merge_ref(ref_img, kernels, num, den, cfa_pattern, config, acc_rob=None):
+    """Accumulate the reference frame (merge.py:22-80); with the accumulated-robustness denoiser enabled
+    the window widens / the pixel is overwritten where few frames were merged."""
+    scale, iso = _common(config)
+    H, W = ref_img.shape
+    sH, sW, _ = num.shape
+    den_cfg = config.accumulated_robustness_denoiser
+    if den_cfg.enabled:
+        if acc_rob is None:
+            raise ValueError("accumulated robustness denoiser enabled but no accumulated robustness given")
+        acc = _lib.f32c(acc_rob)
+        rad_max, mult, mfc = int(den_cfg.merge.rad_max), float(den_cfg.merge.max_multiplier), float(den_cfg.merge.max_frame_count)
+    else:
+        acc, rad_max, mult, mfc = None, 0, 0.0, 0.0
+    _lib.call("hhsr_accumulate_ref", _lib.ptr(ref_img), H, W, W, _lib.ptr(kernels), _lib.cfa_bytes(cfa_pattern),
+              scale, iso, _lib.ptr(acc), rad_max, mult, mfc, _lib.ptr(num), _lib.ptr(den), sH, sW, _lib.stream())
+
+
+def merge_burst(frames, ref_img, ref_kernels, num, den, cfa_pattern, config, load_acc=False, do_ref=True,
+                divide=True, store_den=False):
+    """Fused merge of a whole (shard of a) burst: `frames` is a list of (raw, flow, covs, r).  Per output
+    pixel the frames are summed in list order with the accumulators in registers — the same float32
+    order as successive merge() calls — then the reference frame is added and the result normalised,
+    writing `num` once.  Not usable with the accumulated-robustness denoiser (its
+    overwrite rule needs the sequential merge_ref)."""
+    scale, iso = _common(config)
+    if do_ref and config.accumulated_robustness_denoiser.enabled:
+        raise ValueError("merge_burst cannot apply the accumulated robustness denoiser; use merge_ref")
+    ts = config.block_matching.tuning.tile_size
+    sH, sW, _ = num.shape
+    flags = (1 if load_acc else 0) | (2 if do_ref else 0) | (4 if divide else 0) | (8 if store_den else 0)
+    if frames:
+        H, W = frames[0][0].shape
+        ny, nx, _ = frames[0][1].shape
+    else:
+        H, W = ref_img.shape
+        ny = nx = 0
+    cfa = _lib.cfa_bytes(cfa_pattern)
+    chunks = [frames[i:i + _lib.MAX_FRAMES] for i in range(0, len(frames), _lib.MAX_FRAMES)] or [[]]
+    for ci, chunk in enumerate(chunks):
+        last = ci == len(chunks) - 1
+        f = flags
+        if ci > 0:
+            f |= 1
+        if not last:  # intermediate chunk: keep raw sums
+            f = (f & ~(2 | 4)) | 8
+        _lib.call("hhsr_merge_burst", _lib.ptr_array([c[0] for c in chunk]), _lib.ptr_array([c[1] for c in chunk]),
+                  _lib.ptr_array([c[2] for c in chunk]), _lib.ptr_array([c[3] for c in chunk]), len(chunk),
+                  H, W, W, ny, nx, int(ts), _lib.ptr(ref_img if (f & 2) else None),
+                  _lib.ptr(ref_kernels if (f & 2) else None), cfa, scale, iso, f, _lib.ptr(num), _lib.ptr(den),
+                  sH, sW, _lib.stream())

@@ -1,0 +1,100 @@
+"""Alg. 6-9 robustness (reference robustness.py)."""
+import numpy as np
+import torch
+
+from . import _lib
+
+
+def _wb3(white_balance):
+    wb = [float(v) for v in (white_balance.tolist() if hasattr(white_balance, "tolist") else white_balance)]
+    if len(wb) < 3:
+        raise ValueError("white balance needs at least 3 gains")
+    return wb[:3]
+
+
+def compute_local_stats_from_raw(raw_img, cfa_pattern, white_balance):
+    """Guide image (Alg. 7, robustness.py:207-225) and its 3x3 local mean / variance (Alg. 8,
+    :269-294) at guide resolution in one pass over the raw frame.  Returns (means, vars) [3, H/2, W/2]."""
+    raw_img = _lib.f32c(raw_img)
+    H, W = raw_img.shape
+    if H % 2 or W % 2:
+        raise ValueError(f"bayer frames need even dimensions, got {(H, W)}")
+    means = torch.empty((3, H // 2, W // 2), dtype=torch.float32, device=raw_img.device)
+    vars_ = torch.empty_like(means)
+    _lib.call("hhsr_rob_stats", _lib.ptr(raw_img), H, W, W, _lib.cfa_bytes(cfa_pattern), _lib.doubles(_wb3(white_balance)),
+              _lib.ptr(means), _lib.ptr(vars_), _lib.stream())
+    return means, vars_
+
+
+def upscale_warp_stats(local_stats, tile_size=None, flow=None):
+    """Dodgson-quadratic x2 upsampling of a [3, h, w] map, optionally warped by the per-tile flow
+    (robustness.py:296-421).  +inf where the guide position falls outside the map."""
+    local_stats = _lib.f32c(local_stats)
+    nc, lh, lw = local_stats.shape
+    if nc != 3:
+        raise ValueError("Incoherent number of channel : {}".format(nc))
+    out = torch.empty((3, 2 * lh, 2 * lw), dtype=torch.float32, device=local_stats.device)
+    if flow is None:
+        _lib.call("hhsr_rob_upscale", _lib.ptr(local_stats), lh, lw, _lib.ptr(None), 0, 0, 0, _lib.ptr(out), _lib.stream())
+    else:
+        ny, nx, _ = flow.shape
+        _lib.call("hhsr_rob_upscale", _lib.ptr(local_stats), lh, lw, _lib.ptr(flow), ny, nx, int(tile_size),
+                  _lib.ptr(out), _lib.stream())
+    return out
+
+
+def init_robustness(ref_img, cfa_pattern, white_balance, config):
+    """Reference-frame local means / variances at raw resolution (robustness.py:23-76)."""
+    if not config.robustness.enabled:
+        return None, None
+    if config.mode != "bayer":
+        raise NotImplementedError("grey mode is outside the MI355X hot path (bayer only)")
+    m, v = compute_local_stats_from_raw(ref_img, cfa_pattern, white_balance)
+    return upscale_warp_stats(m), upscale_warp_stats(v)
+
+
+def compute_s(flows, M_th, s1, s2):
+    """Per-tile flow-irregularity weight (robustness.py:530-612)."""
+    ny, nx, _ = flows.shape
+    S = torch.empty((ny, nx), dtype=torch.float32, device=flows.device)
+    _lib.call("hhsr_rob_s", _lib.ptr(flows), ny, nx, float(M_th), float(s1), float(s2), _lib.ptr(S), _lib.stream())
+    return S
+
+
+def local_min(R):
+    """Alg. 9: 5x5 clamp-border minimum (robustness.py:641-686)."""
+    r = torch.empty_like(R)
+    _lib.call("hhsr_local_min5", _lib.ptr(R), R.shape[0], R.shape[1], _lib.ptr(r), _lib.stream())
+    return r
+
+
+def noise_curves_to_device(std_curve, diff_curve, device):
+    """float64 device copies of the two noise curves (super_resolution.py:98-99)."""
+    s = torch.as_tensor(np.asarray(std_curve, dtype=np.float64), device=device)
+    d = torch.as_tensor(np.asarray(diff_curve, dtype=np.float64), device=device)
+    return s.contiguous(), d.contiguous()
+
+
+def compute_robustness(comp_img, ref_local_means, ref_local_stds, flows, cfa_pattern, white_balance, noise_model,
+                       config, return_R=False):
+    """Alg. 6 (robustness.py:79-170): r float32 [H, W].  3 kernels instead of the reference's 8:
+    guide + local stats; fused warp-upsample / colour distance / noise model / threshold; 5x5 min."""
+    comp_img = _lib.f32c(comp_img)
+    if not config.robustness.enabled:
+        return torch.ones_like(comp_img)
+    if config.mode != "bayer":
+        raise NotImplementedError("grey mode is outside the MI355X hot path (bayer only)")
+    ts = config.block_matching.tuning.tile_size
+    t = config.robustness.tuning
+    std_curve, diff_curve = noise_model
+    assert std_curve.dtype == torch.float64 and diff_curve.dtype == torch.float64 and std_curve.is_cuda
+    H, W = comp_img.shape
+    ny, nx, _ = flows.shape
+    cm, _ = compute_local_stats_from_raw(comp_img, cfa_pattern, white_balance)
+    S = compute_s(flows, t.Mt, t.s1, t.s2)
+    R = torch.empty((H, W), dtype=torch.float32, device=comp_img.device)
+    _lib.call("hhsr_rob_frame", _lib.ptr(cm), H // 2, W // 2, _lib.ptr(ref_local_means), _lib.ptr(ref_local_stds),
+              _lib.ptr(flows), ny, nx, int(ts), _lib.ptr(S), _lib.ptr(std_curve), _lib.ptr(diff_curve),
+              int(std_curve.numel()), float(t.t), _lib.ptr(R), _lib.stream())
+    r = local_min(R)
+    return (r, R) if return_R else r

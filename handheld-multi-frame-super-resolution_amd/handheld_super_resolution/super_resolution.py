@@ -1,0 +1,224 @@
+"""Alg. 1 driver: main() and the process() facade (reference super_resolution.py:41-360).
+
+MI355X design notes (vs the reference's per-frame Python loop):
+  * everything is enqueued on ONE HIP stream (torch's current stream): no host synchronisation inside
+    the hot path, no torch<->Numba stream fences;
+  * each frame is uploaded once (the reference uploads it twice);
+  * a frame's (raw, flow, covariances, robustness) stay resident in HBM (144 MB per 12 MP frame; a
+    20-frame burst is <3 GB of the 288 GB) and the merge of the whole burst is ONE kernel with the
+    accumulators in registers (merge.merge_burst), instead of a read-modify-write of the 2x576 MB
+    accumulators per frame;
+  * frames shard across GPUs with one RCCL sum-reduce of num/den (distributed.py).
+"""
+import time
+
+import numpy as np
+import torch
+
+from . import _lib
+from .utils_image import compute_grey_images
+from .utils import divide, add, getTime
+from .alignment import align, init_alignment
+from .params import sanitize_config, update_snr_config
+from .robustness import init_robustness, compute_robustness, noise_curves_to_device
+from .kernels import estimate_kernels
+from .merge import merge, merge_ref, merge_burst
+
+
+def denoiser_enabled(config):
+    """config.accumulated_robustness_denoiser.enabled is derived by process() upstream
+    (super_resolution.py:291-296); derive it here too when main() is called directly."""
+    den = config.accumulated_robustness_denoiser
+    if "enabled" in den:
+        return bool(den.enabled)
+    den.enabled = bool(den.median.enabled or den.gauss.enabled or den.merge.enabled)
+    return den.enabled
+
+
+def _device():
+    if not torch.cuda.is_available():
+        raise RuntimeError("handheld_super_resolution (MI355X build): no HIP device is visible; this package has no "
+                           "CPU path (the NumPy oracle under oracle/ is test infrastructure only)")
+    return torch.device("cuda", torch.cuda.current_device())
+
+
+class BurstPipeline:
+    """Device-resident state of one burst: reference-frame precompute + per-frame stage chain."""
+
+    def __init__(self, config, device=None):
+        self.config = config
+        self.device = device or _device()
+        if config.mode != "bayer":
+            raise NotImplementedError("grey mode is outside the MI355X hot path (bayer only)")
+        self.cfa = [[int(v) for v in row] for row in config.exif.cfa_pattern]
+        self.wb = [float(v) for v in config.exif.white_balance]
+        self.curves = noise_curves_to_device(config.noise_model.std_curve, config.noise_model.diff_curve, self.device)
+        self.grey_method = config.grey_method
+        self.ref = None
+
+    def init_ref(self, ref_img):
+        cfg = self.config
+        self.ref = _lib.f32c(ref_img, self.device)
+        sanitize_config(cfg, tuple(self.ref.shape))
+        grey = compute_grey_images(self.ref, self.grey_method)
+        self.align_state = init_alignment(grey, cfg)
+        self.ref_means, self.ref_vars = init_robustness(self.ref, self.cfa, self.wb, cfg)
+        self.grey_ref = grey
+        return self
+
+    def process_frame(self, img):
+        """grey -> align -> robustness -> kernels for one comp frame; returns (raw, flow, covs, r)."""
+        cfg = self.config
+        raw = _lib.f32c(img, self.device)
+        grey = compute_grey_images(raw, self.grey_method)
+        flow = align(*self.align_state, grey, cfg)
+        r = compute_robustness(raw, self.ref_means, self.ref_vars, flow, self.cfa, self.wb, self.curves, cfg)
+        covs = estimate_kernels(raw, cfg)
+        return raw, flow, covs, r
+
+    def output_size(self):
+        s = self.config.scale
+        H, W = self.ref.shape
+        return round(s * H), round(s * W)
+
+
+def main(ref_img, comp_imgs, config):
+    """Alg. 1 (reference super_resolution.py:41-200).
+
+    ref_img [H, W], comp_imgs [N-1, H, W]: float32 NumPy arrays (as in the reference) or torch tensors
+    (host or already device-resident).  Returns (num, debug_dict): num is the normalised RGB image,
+    a float32 GPU tensor [sH, sW, 3] WITHOUT post-processing; debug_dict has 'flow' / 'robustness' lists
+    (NumPy, only if config.debug) and 'accumulated robustness' (GPU tensor) when the mask is requested."""
+    verbose = config.verbose >= 1
+    debug_mode = bool(config.debug)
+    debug_dict = {"robustness": [], "flow": []}
+    denoiser_on = denoiser_enabled(config)
+    accumulate_r = denoiser_on or bool(config.robustness.save_mask)
+    hip_cfg = config.get("hip", None) if hasattr(config, "get") else None
+    fused = True if hip_cfg is None else bool(hip_cfg.get("fused_merge", True))
+    fused = fused and not denoiser_on
+
+    if verbose:
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        print("\nProcessing reference image ---------\n")
+    pipe = BurstPipeline(config).init_ref(ref_img)
+    dev = pipe.device
+    H, W = pipe.ref.shape
+    sH, sW = pipe.output_size()
+    accumulated_r = torch.zeros((H, W), dtype=torch.float32, device=dev) if accumulate_r else None
+    num = torch.empty((sH, sW, 3), dtype=torch.float32, device=dev)
+    den = None
+    if not fused:
+        num.zero_()
+        den = torch.zeros_like(num)
+    if verbose:
+        torch.cuda.synchronize()
+        getTime(t1, "\nRef Img processed (Total)")
+
+    frames = []
+    n_images = len(comp_imgs)
+    for im_id in range(n_images):
+        if verbose:
+            torch.cuda.synchronize()
+            print("\nProcessing image {} ---------\n".format(im_id + 1))
+            im_time = time.perf_counter()
+        raw, flow, covs, r = pipe.process_frame(comp_imgs[im_id])
+        if accumulate_r:
+            add(accumulated_r, r)
+        if fused:
+            frames.append((raw, flow, covs, r))
+        else:
+            merge(raw, flow, covs, r, num, den, pipe.cfa, config)
+        if debug_mode:  # the reference crashes here at HEAD (Tensor.copy_to_host)
+            debug_dict["flow"].append(flow.cpu().numpy())
+            debug_dict["robustness"].append(r.cpu().numpy())
+        if verbose:
+            torch.cuda.synchronize()
+            getTime(im_time, "\nImage processed (Total)")
+
+    ref_covs = estimate_kernels(pipe.ref, config)
+    if fused:
+        merge_burst(frames, pipe.ref, ref_covs, num, None, pipe.cfa, config, do_ref=True, divide=True)
+    else:
+        merge_ref(pipe.ref, ref_covs, num, den, pipe.cfa, config, accumulated_r if denoiser_on else None)
+        divide(num, den)
+    if verbose:
+        torch.cuda.synchronize()
+        s = "\nTotal ellapsed time : "
+        print(s, " " * (50 - len(s)), ": ", round((time.perf_counter() - t1), 2), "seconds")
+    if accumulate_r:
+        debug_dict["accumulated robustness"] = accumulated_r
+    return num, debug_dict
+
+
+def prepare_config(config, ref_raw, alpha=None, beta=None, cfa_pattern=None, white_balance=None, iso=100,
+                   std_curve=None, diff_curve=None):
+    """The parameter derivation process() performs between loading the burst and calling main()
+    (reference super_resolution.py:227-296): noise model, SNR -> tile size / merge tunings, sanity
+    checks, exif block, denoiser switch.  Mutates `config` in place like the reference."""
+    from .synthetic import noise_curves
+
+    if config.noise_model.get("alpha", None) is not None:
+        alpha, beta = config.noise_model.alpha, config.noise_model.beta
+    if alpha is None or beta is None:
+        raise ValueError("noise model (alpha, beta) missing: give it in config.noise_model or in the burst")
+    config.noise_model.update({"alpha": float(alpha), "beta": float(beta)})
+    if std_curve is None or diff_curve is None:
+        # the reference draws these by an unseeded Monte-Carlo (fast_monte_carlo.py); here: its analytic
+        # un-clipped limit (synthetic.noise_curves) unless the caller supplies curves
+        std_curve, diff_curve = noise_curves(float(alpha), float(beta))
+    brightness = float(np.mean(ref_raw))
+    id_noise = min(max(round(1000 * brightness), 0), len(std_curve) - 1)
+    SNR = brightness / float(std_curve[id_noise])
+    if config.verbose >= 1:
+        print(" ", 10 * "-")
+        print("|ISO : {}".format(iso))
+        print("|Image brightness : {:.2f}".format(brightness))
+        print("|expected noise std : {:.2e}".format(float(std_curve[id_noise])))
+        print("|Estimated SNR : {:.2f}".format(SNR))
+    update_snr_config(config, SNR)
+    sanitize_config(config, tuple(ref_raw.shape))
+    config.exif = {"cfa_pattern": np.asarray(cfa_pattern).tolist(), "iso": iso,
+                   "white_balance": [float(v) for v in white_balance]}
+    config.noise_model.update({"std_curve": np.asarray(std_curve).tolist(), "diff_curve": np.asarray(diff_curve).tolist()})
+    den = config.accumulated_robustness_denoiser
+    den.enabled = bool(den.median.enabled or den.gauss.enabled or den.merge.enabled)
+    return config
+
+
+def process(burst_path, config):
+    """process(burst_path, config) -> (float32 ndarray [sH, sW, 3], debug_dict)   (reference :203-360).
+
+    `burst_path` is either a burst held in memory / in an .npz file — a mapping with keys ``ref`` [H,W],
+    ``comp`` [N-1,H,W] (normalised, white-balanced RAW), ``cfa_pattern`` [2,2], ``white_balance`` [>=3],
+    ``alpha``, ``beta`` and optionally ``iso``, ``std_curve``, ``diff_curve`` — or a folder of .dng files,
+    which needs rawpy + exifread like the reference (absent from this image: ImportError).  The CPU-side
+    ISP after the hot path (colour matrix, gamma, sharpening, orientation; raw2rgb.py) is out of scope:
+    the un-post-processed linear RGB image is returned, as with ``postprocessing.enabled: false``."""
+    import os
+
+    if isinstance(burst_path, (str, os.PathLike)) and str(burst_path).endswith(".npz"):
+        burst = dict(np.load(burst_path))
+    elif isinstance(burst_path, (str, os.PathLike)):
+        try:
+            import rawpy  # noqa: F401
+            import exifread  # noqa: F401
+        except ImportError as e:
+            raise ImportError("reading .dng bursts needs rawpy and exifread (not installed); pass an in-memory burst "
+                              "or an .npz file instead") from e
+        raise NotImplementedError("DNG decoding is outside the MI355X hot path (SURVEY.md §8f-3)")
+    else:
+        burst = burst_path
+    ref_raw = np.asarray(burst["ref"], dtype=np.float32)
+    raw_comp = np.asarray(burst["comp"], dtype=np.float32)
+    prepare_config(config, ref_raw, burst.get("alpha"), burst.get("beta"), burst["cfa_pattern"],
+                   burst["white_balance"], int(burst.get("iso", 100)), burst.get("std_curve"), burst.get("diff_curve"))
+    den = config.accumulated_robustness_denoiser
+    if den.median.enabled or den.gauss.enabled:
+        raise NotImplementedError("post-hoc median / gauss frame-count denoisers are out of scope (SURVEY.md §2a)")
+    out, debug_dict = main(ref_raw, raw_comp, config)
+    output_image = out.cpu().numpy()
+    if "accumulated robustness" in debug_dict:
+        debug_dict["accumulated robustness"] = debug_dict["accumulated robustness"].cpu().numpy()
+    return output_image, debug_dict

@@ -1,0 +1,151 @@
+/*
+ * hhsr.h — C ABI of libhhsr_hip.so: the MI355X (gfx950) kernels of the handheld burst
+ * super-resolution hot path.
+ *
+ * The reference (Jamy-L/Handheld-Multi-Frame-Super-Resolution) has no native layer: its hot path
+ * is 25 Numba-CUDA kernels plus torch ops launched from Python.  Each entry point below replaces
+ * one of those launch sites (cited as file:line relative to the reference's
+ * handheld_super_resolution/ package).  INTEGRATION.md shows the ctypes binding a maintainer of
+ * the reference would add.
+ *
+ * Conventions
+ *  - every pointer is a DEVICE pointer owned by the caller unless the parameter is documented as
+ *    "host"; functions never allocate, free or synchronise: they only enqueue work on `stream`
+ *    (a hipStream_t passed as void*; NULL = the null stream);
+ *  - images are row-major float32; `pitch` arguments are in ELEMENTS;
+ *  - flow fields are float32 [ny][nx][2] = (dx, dy) per tile, moving(p + flow) ~ ref(p);
+ *  - covariances are float32 [H/2][W/2][2][2]; accumulators float32 [sH][sW][3];
+ *  - the CFA is 4 bytes {c00, c01, c10, c11} with 0=R, 1=G, 2=B;
+ *  - return value: 0 = OK, >0 = hipError_t of the launch, <0 = invalid argument; the message is
+ *    available from hhsr_last_error() (thread local).  No C++ exception crosses the boundary.
+ *  - no global mutable state: re-entrant across host threads and streams.
+ */
+#ifndef HHSR_H
+#define HHSR_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define HHSR_VERSION_MAJOR 0
+#define HHSR_VERSION_MINOR 1
+
+#define HHSR_MAX_TAPS 33      /* Gaussian taps: 4*factor+1, factor <= 8 */
+#define HHSR_MAX_FRAMES 64    /* frames per hhsr_merge_burst launch */
+
+const char* hhsr_version(void);
+const char* hhsr_last_error(void);
+
+/* ---- grey image: mask of the ideal half-band low-pass (utils_image.py:82-100) -----------------
+ * The reference zeroes the outer quarter bands of the fftshift-ed full complex spectrum and keeps
+ * the real part of the inverse.  hhsr_lowpass_mask_c2c zeroes the same bins of an UN-shifted
+ * complex64 spectrum [H][W] in place.  hhsr_lowpass_mask_r2c applies the equivalent Hermitian
+ * mask m'(k) = (m(k) + m(-k))/2 in {0, 1/2, 1} to a half spectrum [H][W/2+1] (rfft2 layout), so
+ * that irfft2 returns exactly Re(ifft2(mask * fft2(x))). `spec` = interleaved (re, im) float32.
+ * stride_y / stride_x: element (complex) strides of the two spectrum dimensions — rocFFT hands torch a
+ * transposed half spectrum, which is masked in place as it lies. */
+int hhsr_lowpass_mask_c2c(float* spec, int H, int W, int64_t stride_y, int64_t stride_x, void* stream);
+int hhsr_lowpass_mask_r2c(float* spec, int H, int W, int64_t stride_y, int64_t stride_x, void* stream);
+
+/* ---- pyramid (alignment.py:27-37, 74-82; utils_image.py:360-391) ------------------------------ */
+/* dst[y][x] = src[y mod H][x mod W], dst is Hp x Wp (F.pad 'circular', bottom/right). */
+int hhsr_pad_circular(const float* src, int H, int W, int src_pitch,
+                      float* dst, int Hp, int Wp, int dst_pitch, void* stream);
+/* Valid separable Gaussian (rows then columns) + decimation by `factor`:
+ * dst is floor((H-2r)/f) x floor((W-2r)/f), r = (ntaps-1)/2, 2 <= factor <= 4.  `taps` is a HOST array. */
+int hhsr_gauss_decimate(const float* src, int H, int W, int src_pitch,
+                        float* dst, int dst_pitch, int factor,
+                        const float* taps, int ntaps, void* stream);
+
+/* ---- Lucas-Kanade precompute (ICA.py:15-76) ---------------------------------------------------
+ * gx = I[x+1]-I[x-1], gy likewise (zero border, no 1/2 factor); hess[ty][tx] = sum over the tile of
+ * [gx^2, gx gy; gx gy, gy^2] for the floor(H/ts) x floor(W/ts) tile grid. */
+int hhsr_grad_hessian(const float* lvl, int H, int W, int pitch, int ts,
+                      float* gx, float* gy, float* hess, void* stream);
+
+/* ---- block matching (block_matching.py:20-76, 348-377 and 78-345) -----------------------------
+ * L2: argmin over (2r+1)^2 integer shifts of the tile SSD (== the reference's
+ * sum(win^2) - 2 corr(ref, win) up to a per-tile constant), window origin
+ * tile*ts + round_half_even(flow) - r with clamp-to-edge addressing of the moving level, first
+ * minimum in row-major order; the shift is ADDED to the un-rounded flow.
+ * L1 (mode 0): the INTENDED semantics of the reference's undefined-behaviour kernels — SAD, zero
+ * outside the moving level, flow <- round(flow) + shift.  mode 1: flow <- round_half_even(flow). */
+int hhsr_bm_l2(const float* ref, int ref_pitch, const float* mov, int mh, int mw, int mov_pitch,
+               float* flow, int ny, int nx, int ts, int r, void* stream);
+int hhsr_bm_l1(const float* ref, int ref_pitch, const float* mov, int mh, int mw, int mov_pitch,
+               float* flow, int ny, int nx, int ts, int r, int mode, void* stream);
+
+/* ---- ICA (ICA.py:78-482): n_iter Gauss-Newton steps per tile, in place on `flow`.
+ * flags bit 0: reproduce the ts=64 row off-by-one of ica_kernel_64 (ICA.py:437-449). */
+int hhsr_ica(const float* ref, const float* gx, const float* gy, int ref_pitch, const float* hess,
+             const float* mov, int mh, int mw, int mov_pitch,
+             float* flow, int ny, int nx, int ts, int n_iter, int flags, void* stream);
+
+/* ---- flow upscaling, nearest mode (alignment.py:150-172): dst[y][x] = mult*src[y/rep][x/rep],
+ * zero where y/rep >= sny or x/rep >= snx. */
+int hhsr_flow_upscale_nearest(const float* src, int sny, int snx, float* dst, int dny, int dnx,
+                              int rep, float mult, void* stream);
+
+/* ---- kernel covariances, Alg. 5 (kernels.py:29-243; utils_image.py:117-170, 346-357;
+ * linalg.py:87-185), bayer mode: GAT -> 2x2 mean -> gradients -> structure tensor -> eigen ->
+ * (k1, k2) -> covariance per Bayer quad.  law: 0 = hard_threshold, 1 = linear. */
+int hhsr_cov_from_raw(const float* raw, int H, int W, int pitch, float* covs,
+                      double alpha, double beta, double k_detail, double k_denoise,
+                      double D_th, double D_tr, double k_stretch, double k_shrink, int law,
+                      void* stream);
+
+/* ---- robustness, Alg. 6-9 (robustness.py) -----------------------------------------------------*/
+/* Guide image + 3x3 local mean / variance at guide resolution [3][H/2][W/2]
+ * (robustness.py:207-225, 269-294).  wb: HOST double[3]. */
+int hhsr_rob_stats(const float* raw, int H, int W, int pitch, const uint8_t cfa[4],
+                   const double* wb, float* means, float* vars, void* stream);
+/* Dodgson-quadratic x2 upsampling of a [3][lh][lw] map to [3][2lh][2lw], optionally warped by the
+ * per-tile flow (NULL = reference frame; robustness.py:359-421).  +inf outside. */
+int hhsr_rob_upscale(const float* stats, int lh, int lw, const float* flow, int ny, int nx, int ts,
+                     float* out, void* stream);
+/* Per-tile flow-irregularity map S (robustness.py:570-612). */
+int hhsr_rob_s(const float* flow, int ny, int nx, float Mt, float s1, float s2, float* S, void* stream);
+/* Fused warp-upsample of the frame's guide means + colour distance + noise model + threshold
+ * (robustness.py:359-421, 453-461, 505-528, 627-639) -> R float32 [2lh][2lw].
+ * std_curve / diff_curve: device double[ncurve]. */
+int hhsr_rob_frame(const float* comp_means, int lh, int lw, const float* ref_means, const float* ref_vars,
+                   const float* flow, int ny, int nx, int ts, const float* S,
+                   const double* std_curve, const double* diff_curve, int ncurve,
+                   double t, float* R, void* stream);
+/* 5x5 clamp-border minimum (robustness.py:670-686). */
+int hhsr_local_min5(const float* R, int H, int W, float* r, void* stream);
+
+/* ---- merge, Alg. 4 / Alg. 11 (merge.py; utils.py:62-120) --------------------------------------
+ * hhsr_accumulate: one comp frame, num/den += (merge.py:291-434).
+ * hhsr_accumulate_ref: the reference frame (merge.py:83-233); acc_rob = NULL disables the
+ * accumulated-robustness widening (rad_max / max_multiplier / max_frame_count ignored). */
+int hhsr_accumulate(const float* raw, int H, int W, int pitch, const float* flow, int ny, int nx, int ts,
+                    const float* covs, const float* r, const uint8_t cfa[4], double scale, int iso,
+                    float* num, float* den, int sH, int sW, void* stream);
+int hhsr_accumulate_ref(const float* raw, int H, int W, int pitch, const float* covs,
+                        const uint8_t cfa[4], double scale, int iso,
+                        const float* acc_rob, int rad_max, double max_multiplier, double max_frame_count,
+                        float* num, float* den, int sH, int sW, void* stream);
+int hhsr_divide(float* num, const float* den, int64_t n, void* stream);   /* num /= den */
+int hhsr_add(float* A, const float* B, int64_t n, void* stream);          /* A += B */
+
+/* Fused burst merge: for every HR pixel, sum the contributions of `n_frames` comp frames with the
+ * accumulators held in registers (same left-to-right float32 order as n calls of hhsr_accumulate),
+ * then optionally add the reference frame and normalise.  HOST arrays of device pointers.
+ * flags: */
+#define HHSR_MERGE_LOAD_ACC 1   /* start from the existing num/den instead of zero          */
+#define HHSR_MERGE_DO_REF 2     /* add the reference frame (ref_raw/ref_covs) after the comps */
+#define HHSR_MERGE_DIVIDE 4     /* write num/den into num                                    */
+#define HHSR_MERGE_STORE_DEN 8  /* also store den                                            */
+int hhsr_merge_burst(const float* const* raws, const float* const* flows, const float* const* covs,
+                     const float* const* rs, int n_frames, int H, int W, int pitch,
+                     int ny, int nx, int ts, const float* ref_raw, const float* ref_covs,
+                     const uint8_t cfa[4], double scale, int iso, int flags,
+                     float* num, float* den, int sH, int sW, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* HHSR_H */
