@@ -10,7 +10,8 @@
 //                                           traffic drops from 48 S P bytes per frame to 12-24 S P per burst.
 // Arithmetic follows the reference's Numba typing: coordinates, covariance
 // interpolation and weights are float64, the per-pixel val/acc sums are float32 rounded after every
-// tap.  `WT` selects the type of the weight chain (double = reference typing, float = fast path).
+// tap.  `WT` selects the type of the weight chain: double = the reference's typing (validation mode,
+// HHSR_WEIGHT_F64), float = the default fast path (comp_accum_fast).
 #include "hhsr_common.h"
 
 struct Cfa4 {
@@ -93,6 +94,155 @@ __device__ __forceinline__ void comp_contrib(const FramePtr f, const Geo& g, con
     }
 }
 
+// ---- float32 fast path of the same contribution ------------------------------------------------------
+// The discrete decisions (which LR pixel is the window centre, which covariance cell, in/out of frame)
+// are taken exactly as the reference's float64 code takes them; everything continuous — covariance
+// interpolation / inversion, the quadratic form, exp — runs in float32:
+//   * z = (ixx*dx + 2 ixy*dy)*dx + iyy*dy*dy: two FMAs per tap with the per-row terms hoisted;
+//   * w = exp(-z/2) = v_exp_f32(z * -0.5*log2(e))  (abs error < 1e-7 on weights in [0, 1]);
+//   * the CFA channel of a tap depends only on the parity of its raw coordinates, so the 9 taps are
+//     summed into 4 parity-class accumulators with compile-time indices and the classes are mapped to
+//     R/G/B once per OUTPUT PIXEL (the CFA is wave-uniform) instead of a 3-way select per tap;
+//   * frames whose robustness is exactly 0 at this pixel add +0 to both sums and are skipped.
+// Two geometry front ends:
+//   GEOM_P2   scale in {1, 2, 4, ...}: (hj + 0.5)/scale and its split into integer + fraction are exact
+//             in float32, and floor(lr + flow) is decided by ONE exact float comparison
+//             flow >= floor(flow) + (1 - frac(lr)) — no float64 instruction in the frame loop;
+//   GEOM_F64  any scale: positions in float64 exactly like the reference (merge.py:319-345, 396-399).
+// Differences to the float64 weight chain are O(1e-6) relative on num/den (tests: rel 2e-5).
+enum { GEOM_F64 = 0, GEOM_P2 = 1 };
+
+struct Pix {
+    // frame-independent per-output-pixel state
+    double lr_x, lr_y;   // GEOM_F64
+    int lix, liy;        // GEOM_P2: integer part of the LR position ...
+    float lfx, lfy;      // ... and its exact fraction
+    int tile;            // flow tile index
+    int ridx;            // robustness pixel index
+};
+
+__device__ __forceinline__ Pix make_pix(const Geo& g, int hi, int hj) {
+    Pix p;
+    p.lr_x = ((double)hj + 0.5) / g.scale;
+    p.lr_y = ((double)hi + 0.5) / g.scale;
+    p.lix = (int)p.lr_x;
+    p.liy = (int)p.lr_y;
+    p.lfx = (float)(p.lr_x - (double)p.lix);
+    p.lfy = (float)(p.lr_y - (double)p.liy);
+    p.tile = (p.liy / g.ts) * g.nx + p.lix / g.ts;
+    p.ridx = min(p.liy, g.H - 1) * g.W + min(p.lix, g.W - 1);
+    return p;
+}
+
+// Adds one comp frame's taps into the absolute-parity accumulators n4/d4[row parity][col parity].
+template <int GEOM, bool ISO>
+__device__ __forceinline__ void comp_accum_fast(const FramePtr f, const Geo& g, const Pix& p, float n4[2][2],
+                                                float d4[2][2]) {
+    const float2 fl = f.flow[p.tile];
+    int ci, cj, x0 = 0, y0 = 0;
+    float frx, fry, fx = 0.f, fy = 0.f;
+    if (GEOM == GEOM_P2) {
+        const float fix = floorf(fl.x), fiy = floorf(fl.y);
+        const int cx = fl.x >= fix + (1.f - p.lfx), cy = fl.y >= fiy + (1.f - p.lfy);  // exact
+        cj = p.lix + (int)fix + cx;
+        ci = p.liy + (int)fiy + cy;
+        if (cj < 0 || cj >= g.W || ci < 0 || ci >= g.H) return;
+        frx = (fl.x - fix) + (p.lfx - (float)cx);
+        fry = (fl.y - fiy) + (p.lfy - (float)cy);
+        if (!ISO) {  // kmap = lr_mov/2 - 0.5, trunc toward zero + signed fraction (merge.py:349-361)
+            if (cj >= 1) { x0 = (cj - 1) >> 1; fx = 0.5f * ((float)((cj - 1) & 1) + frx); }
+            else         { x0 = 0;             fx = 0.5f * (frx - 1.f); }
+            if (ci >= 1) { y0 = (ci - 1) >> 1; fy = 0.5f * ((float)((ci - 1) & 1) + fry); }
+            else         { y0 = 0;             fy = 0.5f * (fry - 1.f); }
+        }
+    } else {
+        const double mx = p.lr_x + (double)fl.x, my = p.lr_y + (double)fl.y;
+        if (!(mx >= 0.0 && mx < (double)g.W && my >= 0.0 && my < (double)g.H)) return;
+        cj = (int)mx;
+        ci = (int)my;
+        frx = (float)(mx - (double)cj);
+        fry = (float)(my - (double)ci);
+        if (!ISO) {
+            const double kj = mx / 2.0 - 0.5, ki = my / 2.0 - 0.5;
+            const double tkj = trunc(kj), tki = trunc(ki);
+            fx = (float)(kj - tkj);
+            fy = (float)(ki - tki);
+            x0 = max((int)tkj, 0);
+            y0 = max((int)tki, 0);
+        }
+    }
+    const float local_r = f.r[p.ridx];
+    if (local_r == 0.f) return;
+    float ixx = 2.f, ixy = 0.f, iyy = 2.f;  // iso kernel: z = 2 (dx^2 + dy^2)
+    if (!ISO) {
+        const int x1 = min(x0 + 1, g.gw - 1), y1 = min(y0 + 1, g.gh - 1);
+        const float4* __restrict__ r0 = f.cov + (size_t)y0 * g.gw;
+        const float4* __restrict__ r1 = f.cov + (size_t)y1 * g.gw;
+        const float4 c00 = r0[x0], c01 = r0[x1], c10 = r1[x0], c11 = r1[x1];
+        const float txx = c00.x + fx * (c01.x - c00.x), bxx = c10.x + fx * (c11.x - c10.x);
+        const float txy = c00.y + fx * (c01.y - c00.y), bxy = c10.y + fx * (c11.y - c10.y);
+        const float tyy = c00.w + fx * (c01.w - c00.w), byy = c10.w + fx * (c11.w - c10.w);
+        const float cxx = txx + fy * (bxx - txx), cxy = txy + fy * (bxy - txy), cyy = tyy + fy * (byy - tyy);
+        const float inv_det = __builtin_amdgcn_rcpf(cxx * cyy - cxy * cxy);
+        ixx = inv_det * cyy;
+        ixy = -inv_det * cxy;
+        iyy = inv_det * cxx;
+    }
+    const float dx0 = 0.5f - frx, dy0 = 0.5f - fry;  // tap - (lr_mov - 0.5) for the centre tap
+    const float* __restrict__ rawc = f.raw + (size_t)ci * g.pitch + cj;
+    const float kexp = -0.72134752044448170368f;  // -0.5 * log2(e)
+    float sv[2][2] = {{0.f, 0.f}, {0.f, 0.f}}, sa[2][2] = {{0.f, 0.f}, {0.f, 0.f}};  // by OFFSET parity
+    const bool interior = ci >= 1 && ci + 1 < g.H && cj >= 1 && cj + 1 < g.W;
+#pragma unroll
+    for (int di = -1; di <= 1; ++di) {
+        const float dy = dy0 + (float)di;
+        const float a = iyy * dy * dy, b = 2.f * ixy * dy;
+#pragma unroll
+        for (int dj = -1; dj <= 1; ++dj) {
+            if (!interior && (cj + dj < 0 || cj + dj >= g.W || ci + di < 0 || ci + di >= g.H)) continue;
+            const float c = rawc[di * g.pitch + dj];
+            const float dx = dx0 + (float)dj;
+            float z = fmaf(fmaf(ixx, dx, b), dx, a);
+            z = fmaxf(z, 0.f);  // NaN -> 0 -> w = 1 (Python max(0, z), D10)
+            const float wr = __builtin_amdgcn_exp2f(z * kexp) * local_r;
+            sv[di & 1][dj & 1] = fmaf(wr, c, sv[di & 1][dj & 1]);
+            sa[di & 1][dj & 1] += wr;
+        }
+    }
+    // offset parity -> absolute raw-coordinate parity: swap columns / rows when the centre is odd
+    const bool oj = cj & 1, oi = ci & 1;
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+        const float v0 = oj ? sv[r][1] : sv[r][0], v1 = oj ? sv[r][0] : sv[r][1];
+        const float a0 = oj ? sa[r][1] : sa[r][0], a1 = oj ? sa[r][0] : sa[r][1];
+        sv[r][0] = v0; sv[r][1] = v1; sa[r][0] = a0; sa[r][1] = a1;
+    }
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+        n4[0][c] += oi ? sv[1][c] : sv[0][c];
+        n4[1][c] += oi ? sv[0][c] : sv[1][c];
+        d4[0][c] += oi ? sa[1][c] : sa[0][c];
+        d4[1][c] += oi ? sa[0][c] : sa[1][c];
+    }
+}
+
+// parity classes -> channels (wave-uniform CFA): val[cfa[i][j]] += n4[i][j] in fixed order
+__device__ __forceinline__ void classes_to_rgb(const Cfa4 cfa, const float n4[2][2], const float d4[2][2],
+                                               float val[3], float acc[3]) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int ch = cfa.c[i * 2 + j];
+#pragma unroll
+            for (int k = 0; k < 3; ++k)
+                if (ch == k) {
+                    val[k] += n4[i][j];
+                    acc[k] += d4[i][j];
+                }
+        }
+}
+
 // ---- the reference frame's contribution (merge.py:83-233) -------------------------------------------
 // Returns true when the accumulated-robustness rule says "overwrite" (merge.py:223-228).
 template <bool ISO>
@@ -164,13 +314,20 @@ __device__ __forceinline__ bool ref_contrib(const float* __restrict__ raw, const
 }
 
 // ---- per-frame kernels (operator API) ----------------------------------------------------------------
-template <typename WT, bool ISO>
+template <typename WT, int GEOM, bool ISO>
 __global__ void __launch_bounds__(256) k_accumulate(FramePtr f, Geo g, Cfa4 cfa, float* __restrict__ num,
                                                      float* __restrict__ den) {
     const int hj = blockIdx.x * 64 + (threadIdx.x & 63), hi = blockIdx.y * 4 + (threadIdx.x >> 6);
     if (hj >= g.sW || hi >= g.sH) return;
     float val[3] = {0.f, 0.f, 0.f}, acc[3] = {0.f, 0.f, 0.f};
-    comp_contrib<WT, ISO>(f, g, cfa, hi, hj, val, acc);
+    if (sizeof(WT) == 4) {
+        const Pix p = make_pix(g, hi, hj);
+        float n4[2][2] = {{0.f, 0.f}, {0.f, 0.f}}, d4[2][2] = {{0.f, 0.f}, {0.f, 0.f}};
+        comp_accum_fast<GEOM, ISO>(f, g, p, n4, d4);
+        classes_to_rgb(cfa, n4, d4, val, acc);
+    } else {
+        comp_contrib<WT, ISO>(f, g, cfa, hi, hj, val, acc);
+    }
     const size_t o = ((size_t)hi * g.sW + hj) * 3;
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
@@ -211,7 +368,7 @@ struct BurstArgs {
     int flags;
 };
 
-template <typename WT, bool ISO>
+template <typename WT, int GEOM, bool ISO>
 __global__ void __launch_bounds__(256) k_merge_burst(BurstArgs a, Geo g, Cfa4 cfa, float* __restrict__ num,
                                                       float* __restrict__ den) {
     const int hj = blockIdx.x * 64 + (threadIdx.x & 63), hi = blockIdx.y * 4 + (threadIdx.x >> 6);
@@ -225,13 +382,21 @@ __global__ void __launch_bounds__(256) k_merge_burst(BurstArgs a, Geo g, Cfa4 cf
             d3[k] = den[o + k];
         }
     }
-    for (int n = 0; n < a.n; ++n) {
-        float val[3] = {0.f, 0.f, 0.f}, acc[3] = {0.f, 0.f, 0.f};
-        comp_contrib<WT, ISO>(a.f[n], g, cfa, hi, hj, val, acc);
+    if (sizeof(WT) == 4) {
+        // fast path: parity-class sums over all frames, mapped to R/G/B once
+        const Pix p = make_pix(g, hi, hj);
+        float n4[2][2] = {{0.f, 0.f}, {0.f, 0.f}}, d4[2][2] = {{0.f, 0.f}, {0.f, 0.f}};
+        for (int n = 0; n < a.n; ++n) comp_accum_fast<GEOM, ISO>(a.f[n], g, p, n4, d4);
+        classes_to_rgb(cfa, n4, d4, n3, d3);
+    } else {
+        for (int n = 0; n < a.n; ++n) {
+            float val[3] = {0.f, 0.f, 0.f}, acc[3] = {0.f, 0.f, 0.f};
+            comp_contrib<WT, ISO>(a.f[n], g, cfa, hi, hj, val, acc);
 #pragma unroll
-        for (int k = 0; k < 3; ++k) {  // same float32 order as successive `num += val`
-            n3[k] += val[k];
-            d3[k] += acc[k];
+            for (int k = 0; k < 3; ++k) {  // same float32 order as successive `num += val`
+                n3[k] += val[k];
+                d3[k] += acc[k];
+            }
         }
     }
     if (a.flags & HHSR_MERGE_DO_REF) {
@@ -251,24 +416,21 @@ __global__ void __launch_bounds__(256) k_merge_burst(BurstArgs a, Geo g, Cfa4 cf
 }
 
 // ---- host entry points ----------------------------------------------------------------------------------
+static bool scale_is_pow2(double s) {  // 1, 2, 4, 8: (h + 0.5)/s is exact in float32
+    return s == 1.0 || s == 2.0 || s == 4.0 || s == 8.0;
+}
+
 static int fill_geo(Geo& g, int H, int W, int pitch, int ny, int nx, int ts, double scale, int sH, int sW) {
     g.H = H; g.W = W; g.pitch = pitch; g.gh = H / 2; g.gw = W / 2;
     g.ny = ny; g.nx = nx; g.ts = ts; g.sH = sH; g.sW = sW; g.scale = scale;
     return 0;
 }
 
-static inline bool weight_f32() {
-    // HHSR_WEIGHT_F32=1 selects the float32 weight chain (faster, ~1e-6 relative differences)
-    static const int v = [] {
-        const char* e = getenv("HHSR_WEIGHT_F32");
-        return (e && e[0] == '1') ? 1 : 0;
-    }();
-    return v != 0;
-}
 
 extern "C" int hhsr_accumulate(const float* raw, int H, int W, int pitch, const float* flow, int ny, int nx, int ts,
-                               const float* covs, const float* r, const uint8_t cfa[4], double scale, int iso,
+                               const float* covs, const float* r, const uint8_t cfa[4], double scale, int kflags,
                                float* num, float* den, int sH, int sW, void* stream) {
+    const int iso = kflags & HHSR_KERNEL_ISO, f64 = kflags & HHSR_WEIGHT_F64;
     HHSR_ARG(raw && flow && r && cfa && num && den && (iso || covs));
     HHSR_ARG(H >= 2 && W >= 2 && pitch >= W && ts > 0 && scale >= 1.0 && sH > 0 && sW > 0);
     HHSR_ARG((int64_t)ny * ts >= H && (int64_t)nx * ts >= W);  // every LR position has a flow tile
@@ -281,16 +443,20 @@ extern "C" int hhsr_accumulate(const float* raw, int H, int W, int pitch, const 
     FramePtr f{raw, reinterpret_cast<const float2*>(flow), reinterpret_cast<const float4*>(covs), r};
     const dim3 grid(hhsr_cdiv(sW, 64), hhsr_cdiv(sH, 4)), block(256);
     hipStream_t s = (hipStream_t)stream;
-    if (iso) hipLaunchKernelGGL((k_accumulate<double, true>), grid, block, 0, s, f, g, c, num, den);
-    else if (weight_f32()) hipLaunchKernelGGL((k_accumulate<float, false>), grid, block, 0, s, f, g, c, num, den);
-    else hipLaunchKernelGGL((k_accumulate<double, false>), grid, block, 0, s, f, g, c, num, den);
+    const bool p2 = scale_is_pow2(scale);
+#define HHSR_ACC(WT, GEOM, ISO) hipLaunchKernelGGL((k_accumulate<WT, GEOM, ISO>), grid, block, 0, s, f, g, c, num, den)
+    if (f64) { if (iso) HHSR_ACC(double, GEOM_F64, true); else HHSR_ACC(double, GEOM_F64, false); }
+    else if (p2) { if (iso) HHSR_ACC(float, GEOM_P2, true); else HHSR_ACC(float, GEOM_P2, false); }
+    else { if (iso) HHSR_ACC(float, GEOM_F64, true); else HHSR_ACC(float, GEOM_F64, false); }
+#undef HHSR_ACC
     HHSR_LAUNCHED();
 }
 
 extern "C" int hhsr_accumulate_ref(const float* raw, int H, int W, int pitch, const float* covs,
-                                   const uint8_t cfa[4], double scale, int iso, const float* acc_rob, int rad_max,
+                                   const uint8_t cfa[4], double scale, int kflags, const float* acc_rob, int rad_max,
                                    double max_multiplier, double max_frame_count, float* num, float* den, int sH,
                                    int sW, void* stream) {
+    const int iso = kflags & HHSR_KERNEL_ISO;
     HHSR_ARG(raw && cfa && num && den && (iso || covs));
     HHSR_ARG(H >= 2 && W >= 2 && pitch >= W && scale >= 1.0 && sH > 0 && sW > 0);
     HHSR_ARG(!acc_rob || (rad_max >= 0 && rad_max <= 8 && max_multiplier > 0.0));
@@ -314,8 +480,9 @@ extern "C" int hhsr_accumulate_ref(const float* raw, int H, int W, int pitch, co
 extern "C" int hhsr_merge_burst(const float* const* raws, const float* const* flows, const float* const* covs,
                                 const float* const* rs, int n_frames, int H, int W, int pitch, int ny, int nx,
                                 int ts, const float* ref_raw, const float* ref_covs, const uint8_t cfa[4],
-                                double scale, int iso, int flags, float* num, float* den, int sH, int sW,
+                                double scale, int kflags, int flags, float* num, float* den, int sH, int sW,
                                 void* stream) {
+    const int iso = kflags & HHSR_KERNEL_ISO, f64 = kflags & HHSR_WEIGHT_F64;
     HHSR_ARG(n_frames >= 0 && n_frames <= HHSR_MAX_FRAMES && cfa && num);
     HHSR_ARG(n_frames == 0 || (raws && flows && rs && (iso || covs)));
     HHSR_ARG(H >= 2 && W >= 2 && pitch >= W && ts > 0 && scale >= 1.0 && sH > 0 && sW > 0);
@@ -341,8 +508,11 @@ extern "C" int hhsr_merge_burst(const float* const* raws, const float* const* fl
     for (int k = 0; k < 4; ++k) c.c[k] = cfa[k];
     const dim3 grid(hhsr_cdiv(sW, 64), hhsr_cdiv(sH, 4)), block(256);
     hipStream_t s = (hipStream_t)stream;
-    if (iso) hipLaunchKernelGGL((k_merge_burst<double, true>), grid, block, 0, s, a, g, c, num, den);
-    else if (weight_f32()) hipLaunchKernelGGL((k_merge_burst<float, false>), grid, block, 0, s, a, g, c, num, den);
-    else hipLaunchKernelGGL((k_merge_burst<double, false>), grid, block, 0, s, a, g, c, num, den);
+    const bool p2 = scale_is_pow2(scale);
+#define HHSR_MB(WT, GEOM, ISO) hipLaunchKernelGGL((k_merge_burst<WT, GEOM, ISO>), grid, block, 0, s, a, g, c, num, den)
+    if (f64) { if (iso) HHSR_MB(double, GEOM_F64, true); else HHSR_MB(double, GEOM_F64, false); }
+    else if (p2) { if (iso) HHSR_MB(float, GEOM_P2, true); else HHSR_MB(float, GEOM_P2, false); }
+    else { if (iso) HHSR_MB(float, GEOM_F64, true); else HHSR_MB(float, GEOM_F64, false); }
+#undef HHSR_MB
     HHSR_LAUNCHED();
 }

@@ -5,27 +5,31 @@ from . import _lib
 
 
 def _common(config):
+    """(scale, kflags): bit 0 = iso kernel, bit 1 = float64 weight chain (config.hip.weight_fp64, the
+    reference's Numba typing; default float32 weights with float64 geometry)."""
     if config.mode != "bayer":
         raise NotImplementedError("grey mode is outside the MI355X hot path (bayer only)")
-    return float(config.scale), 1 if config.merging.kernel == "iso" else 0
+    hip = config.get("hip", None) if hasattr(config, "get") else None
+    f64 = bool(hip.get("weight_fp64", False)) if hip is not None else False
+    return float(config.scale), (1 if config.merging.kernel == "iso" else 0) | (2 if f64 else 0)
 
 
 def merge(comp_img, alignments, covs, r, num, den, cfa_pattern, config):
     """Accumulate one non-reference frame into num / den in place (merge.py:236-288)."""
-    scale, iso = _common(config)
+    scale, kflags = _common(config)
     ts = config.block_matching.tuning.tile_size
     H, W = comp_img.shape
     ny, nx, _ = alignments.shape
     sH, sW, _ = num.shape
     _lib.call("hhsr_accumulate", _lib.ptr(comp_img), H, W, W, _lib.ptr(alignments), ny, nx, int(ts),
-              _lib.ptr(covs), _lib.ptr(r), _lib.cfa_bytes(cfa_pattern), scale, iso, _lib.ptr(num), _lib.ptr(den),
+              _lib.ptr(covs), _lib.ptr(r), _lib.cfa_bytes(cfa_pattern), scale, kflags, _lib.ptr(num), _lib.ptr(den),
               sH, sW, _lib.stream())
 
 
 def merge_ref(ref_img, kernels, num, den, cfa_pattern, config, acc_rob=None):
     """Accumulate the reference frame (merge.py:22-80); with the accumulated-robustness denoiser enabled
     the window widens / the pixel is overwritten where few frames were merged."""
-    scale, iso = _common(config)
+    scale, kflags = _common(config)
     H, W = ref_img.shape
     sH, sW, _ = num.shape
     den_cfg = config.accumulated_robustness_denoiser
@@ -37,7 +41,7 @@ def merge_ref(ref_img, kernels, num, den, cfa_pattern, config, acc_rob=None):
     else:
         acc, rad_max, mult, mfc = None, 0, 0.0, 0.0
     _lib.call("hhsr_accumulate_ref", _lib.ptr(ref_img), H, W, W, _lib.ptr(kernels), _lib.cfa_bytes(cfa_pattern),
-              scale, iso, _lib.ptr(acc), rad_max, mult, mfc, _lib.ptr(num), _lib.ptr(den), sH, sW, _lib.stream())
+              scale, kflags, _lib.ptr(acc), rad_max, mult, mfc, _lib.ptr(num), _lib.ptr(den), sH, sW, _lib.stream())
 
 
 def merge_burst(frames, ref_img, ref_kernels, num, den, cfa_pattern, config, load_acc=False, do_ref=True,
@@ -47,7 +51,7 @@ def merge_burst(frames, ref_img, ref_kernels, num, den, cfa_pattern, config, loa
     order as successive merge() calls — then the reference frame is added and the result normalised,
     writing `num` once.  Not usable with the accumulated-robustness denoiser (its
     overwrite rule needs the sequential merge_ref)."""
-    scale, iso = _common(config)
+    scale, kflags = _common(config)
     if do_ref and config.accumulated_robustness_denoiser.enabled:
         raise ValueError("merge_burst cannot apply the accumulated robustness denoiser; use merge_ref")
     ts = config.block_matching.tuning.tile_size
@@ -71,5 +75,5 @@ def merge_burst(frames, ref_img, ref_kernels, num, den, cfa_pattern, config, loa
         _lib.call("hhsr_merge_burst", _lib.ptr_array([c[0] for c in chunk]), _lib.ptr_array([c[1] for c in chunk]),
                   _lib.ptr_array([c[2] for c in chunk]), _lib.ptr_array([c[3] for c in chunk]), len(chunk),
                   H, W, W, ny, nx, int(ts), _lib.ptr(ref_img if (f & 2) else None),
-                  _lib.ptr(ref_kernels if (f & 2) else None), cfa, scale, iso, f, _lib.ptr(num), _lib.ptr(den),
+                  _lib.ptr(ref_kernels if (f & 2) else None), cfa, scale, kflags, f, _lib.ptr(num), _lib.ptr(den),
                   sH, sW, _lib.stream())

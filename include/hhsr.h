@@ -117,15 +117,20 @@ int hhsr_rob_frame(const float* comp_means, int lh, int lw, const float* ref_mea
 /* 5x5 clamp-border minimum (robustness.py:670-686). */
 int hhsr_local_min5(const float* R, int H, int W, float* r, void* stream);
 
+/* kflags of the merge entry points */
+#define HHSR_KERNEL_ISO 1   /* merging.kernel == "iso": w = exp(-(dx^2+dy^2)) instead of the steerable kernel */
+#define HHSR_WEIGHT_F64 2   /* evaluate covariance interpolation / weights in float64 like the reference's
+                               Numba typing (validation mode; default = float32 weights, float64 geometry) */
+
 /* ---- merge, Alg. 4 / Alg. 11 (merge.py; utils.py:62-120) --------------------------------------
  * hhsr_accumulate: one comp frame, num/den += (merge.py:291-434).
  * hhsr_accumulate_ref: the reference frame (merge.py:83-233); acc_rob = NULL disables the
  * accumulated-robustness widening (rad_max / max_multiplier / max_frame_count ignored). */
 int hhsr_accumulate(const float* raw, int H, int W, int pitch, const float* flow, int ny, int nx, int ts,
-                    const float* covs, const float* r, const uint8_t cfa[4], double scale, int iso,
+                    const float* covs, const float* r, const uint8_t cfa[4], double scale, int kflags,
                     float* num, float* den, int sH, int sW, void* stream);
 int hhsr_accumulate_ref(const float* raw, int H, int W, int pitch, const float* covs,
-                        const uint8_t cfa[4], double scale, int iso,
+                        const uint8_t cfa[4], double scale, int kflags,
                         const float* acc_rob, int rad_max, double max_multiplier, double max_frame_count,
                         float* num, float* den, int sH, int sW, void* stream);
 int hhsr_divide(float* num, const float* den, int64_t n, void* stream);   /* num /= den */
@@ -142,7 +147,7 @@ int hhsr_add(float* A, const float* B, int64_t n, void* stream);          /* A +
 int hhsr_merge_burst(const float* const* raws, const float* const* flows, const float* const* covs,
                      const float* const* rs, int n_frames, int H, int W, int pitch,
                      int ny, int nx, int ts, const float* ref_raw, const float* ref_covs,
-                     const uint8_t cfa[4], double scale, int iso, int flags,
+                     const uint8_t cfa[4], double scale, int kflags, int flags,
                      float* num, float* den, int sH, int sW, void* stream);
 
 #ifdef __cplusplus
