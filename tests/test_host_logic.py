@@ -1,0 +1,95 @@
+"""Host-side logic (config shim, parameter derivation, level shapes, filter taps) — CPU only."""
+import numpy as np
+import pytest
+
+import oracle
+from helpers import base_config
+import handheld_super_resolution as hsr
+from handheld_super_resolution import params, utils_image
+from handheld_super_resolution.config import Config, OmegaConf, default_config
+
+
+def test_config_shim():
+    cfg = default_config()
+    assert cfg.block_matching.tuning.factors == [1, 2, 4, 4]
+    assert cfg.noise_model.get("alpha", None) is None
+    cfg.noise_model.update({"alpha": 1.0, "beta": 2.0})
+    assert cfg.noise_model.alpha == 1.0 and cfg["noise_model"]["beta"] == 2.0
+    cfg.exif = {"cfa_pattern": [[0, 1], [1, 2]]}
+    assert isinstance(cfg.exif, Config) and cfg.exif.cfa_pattern[1][1] == 2
+    with pytest.raises(AttributeError):
+        cfg.nope
+    merged = OmegaConf.merge(cfg, OmegaConf.from_dotlist(["scale=2", "robustness.tuning.t=0.2", "merging.kernel=iso"]))
+    assert merged.scale == 2 and merged.robustness.tuning.t == 0.2 and merged.merging.kernel == "iso"
+    assert merged.robustness.tuning.s1 == 2  # untouched siblings survive the merge
+    c2 = cfg.copy()
+    c2.scale = 3
+    assert cfg.scale == 1
+
+
+@pytest.mark.parametrize("snr", [3.0, 6.0, 10.0, 14.0, 14.5, 22.0, 22.5, 27.3, 30.0, 45.0])
+def test_params_match_oracle_and_reference(golden, snr):
+    a, b = default_config(), default_config()
+    params.update_snr_config(a, snr)
+    oracle.update_snr_config(b, snr)
+    assert OmegaConf.to_container(a) == OmegaConf.to_container(b)
+    row = [r for r in golden("params")["table"] if r[0] == snr][0]
+    t = a.merging.tuning
+    np.testing.assert_allclose([a.block_matching.tuning.tile_size, *a.block_matching.tuning.tile_sizes, t.k_detail,
+                                t.k_denoise, t.D_th, t.D_tr], row[1:], rtol=0, atol=1e-15)
+
+
+def test_level_shapes_table():
+    """SURVEY.md App. D."""
+    cases = {((3000, 4000), 16): ([(3008, 4000), (1500, 1996), (371, 495), (88, 119)],
+                                  [(3000, 4000), (1496, 1996), (370, 495), (88, 119)],
+                                  [(188, 250), (93, 124), (23, 30), (11, 14)]),
+             ((3000, 4000), 64): ([(3008, 4032), (1500, 2012), (371, 499), (88, 120)], None,
+                                  [(47, 63), (23, 31), (5, 7), (2, 3)]),
+             ((512, 512), 16): ([(512, 512), (252, 252), (59, 59), (10, 10)], None, [(32, 32), (15, 15), (3, 3), (1, 1)])}
+    for (shape, ts), (ref, mov, tiles) in cases.items():
+        cfg = base_config(ts=ts)
+        r, m, t = params.level_shapes(shape, cfg)
+        assert r == ref and t == tiles
+        if mov:
+            assert m == mov
+        assert (r, m, t) == oracle.level_shapes(shape, cfg)
+
+
+def test_sanitize():
+    cfg = base_config(ts=16)
+    params.sanitize_config(cfg, (512, 512))
+    with pytest.raises(ValueError):  # D8: 512x512 with Ts=32 has no tile at the coarsest level
+        params.sanitize_config(base_config(ts=32), (512, 512))
+    bad = base_config(ts=16)
+    bad.robustness.enabled = False
+    with pytest.raises(ValueError):
+        params.sanitize_config(bad, (512, 512))  # save_mask without robustness
+    bad = base_config(ts=16)
+    bad.block_matching.tuning.flow_upscale_mode = "cubic"
+    with pytest.raises(AssertionError):
+        params.sanitize_config(bad, (512, 512))
+
+
+def test_gaussian_taps_match_scipy():
+    from scipy.ndimage._filters import _gaussian_kernel1d
+
+    for f in (2, 4):
+        want = _gaussian_kernel1d(sigma=f * 0.5, order=0, radius=int(4 * f * 0.5 + 0.5))[::-1].astype(np.float32)
+        np.testing.assert_array_equal(utils_image.gaussian_taps(f), want)
+        np.testing.assert_array_equal(oracle.gaussian_taps(f)[0], want)
+
+
+def test_prepare_config_derives_like_process():
+    from handheld_super_resolution import synthetic as synth
+
+    ref, _, _ = synth.make_burst(160, 160, 1, seed=1)
+    cfg = default_config()
+    cfg.verbose = 0
+    cfg.block_matching.tuning.tile_size = 16
+    cfg.block_matching.tuning.factors = [1, 2, 2, 2]
+    hsr.prepare_config(cfg, ref, synth.ALPHA_ISO100, synth.BETA_ISO100, [[0, 1], [1, 2]], [2.0, 1.0, 1.5, 1.0])
+    assert cfg.block_matching.tuning.tile_sizes == [16, 16, 16, 8]
+    assert cfg.merging.tuning.k_detail == 0.25 and cfg.merging.tuning.D_tr == 1.0  # SNR clipped to 30
+    assert cfg.accumulated_robustness_denoiser.enabled is False
+    assert len(cfg.noise_model.std_curve) == 1001 and cfg.exif.white_balance[0] == 2.0
