@@ -134,51 +134,62 @@ __device__ __forceinline__ Pix make_pix(const Geo& g, int hi, int hj) {
     return p;
 }
 
-// Adds one comp frame's taps into the absolute-parity accumulators n4/d4[row parity][col parity].
+// Per-frame geometry of one output pixel: window centre, fractions, covariance cell.
+struct FrameGeo {
+    int ci, cj;      // centre raw pixel = int(lr + flow)
+    int x0, y0;      // top-left covariance cell
+    float frx, fry;  // lr + flow - centre, in [0, 1)
+    float fx, fy;    // signed fraction of the covariance position (D11)
+    bool valid;      // lr + flow inside the frame
+};
+
 template <int GEOM, bool ISO>
-__device__ __forceinline__ void comp_accum_fast(const FramePtr f, const Geo& g, const Pix& p, float n4[2][2],
-                                                float d4[2][2]) {
-    const float2 fl = f.flow[p.tile];
-    int ci, cj, x0 = 0, y0 = 0;
-    float frx, fry, fx = 0.f, fy = 0.f;
+__device__ __forceinline__ FrameGeo frame_geom(const float2 fl, const Geo& g, const Pix& p) {
+    FrameGeo q;
+    q.x0 = q.y0 = 0;
+    q.fx = q.fy = 0.f;
     if (GEOM == GEOM_P2) {
         const float fix = floorf(fl.x), fiy = floorf(fl.y);
         const int cx = fl.x >= fix + (1.f - p.lfx), cy = fl.y >= fiy + (1.f - p.lfy);  // exact
-        cj = p.lix + (int)fix + cx;
-        ci = p.liy + (int)fiy + cy;
-        if (cj < 0 || cj >= g.W || ci < 0 || ci >= g.H) return;
-        frx = (fl.x - fix) + (p.lfx - (float)cx);
-        fry = (fl.y - fiy) + (p.lfy - (float)cy);
+        q.cj = p.lix + (int)fix + cx;
+        q.ci = p.liy + (int)fiy + cy;
+        q.valid = q.cj >= 0 && q.cj < g.W && q.ci >= 0 && q.ci < g.H;
+        q.frx = (fl.x - fix) + (p.lfx - (float)cx);
+        q.fry = (fl.y - fiy) + (p.lfy - (float)cy);
         if (!ISO) {  // kmap = lr_mov/2 - 0.5, trunc toward zero + signed fraction (merge.py:349-361)
-            if (cj >= 1) { x0 = (cj - 1) >> 1; fx = 0.5f * ((float)((cj - 1) & 1) + frx); }
-            else         { x0 = 0;             fx = 0.5f * (frx - 1.f); }
-            if (ci >= 1) { y0 = (ci - 1) >> 1; fy = 0.5f * ((float)((ci - 1) & 1) + fry); }
-            else         { y0 = 0;             fy = 0.5f * (fry - 1.f); }
+            if (q.cj >= 1) { q.x0 = (q.cj - 1) >> 1; q.fx = 0.5f * ((float)((q.cj - 1) & 1) + q.frx); }
+            else           { q.x0 = 0;               q.fx = 0.5f * (q.frx - 1.f); }
+            if (q.ci >= 1) { q.y0 = (q.ci - 1) >> 1; q.fy = 0.5f * ((float)((q.ci - 1) & 1) + q.fry); }
+            else           { q.y0 = 0;               q.fy = 0.5f * (q.fry - 1.f); }
         }
     } else {
         const double mx = p.lr_x + (double)fl.x, my = p.lr_y + (double)fl.y;
-        if (!(mx >= 0.0 && mx < (double)g.W && my >= 0.0 && my < (double)g.H)) return;
-        cj = (int)mx;
-        ci = (int)my;
-        frx = (float)(mx - (double)cj);
-        fry = (float)(my - (double)ci);
+        q.valid = mx >= 0.0 && mx < (double)g.W && my >= 0.0 && my < (double)g.H;
+        q.cj = q.valid ? (int)mx : 0;
+        q.ci = q.valid ? (int)my : 0;
+        q.frx = (float)(mx - (double)q.cj);
+        q.fry = (float)(my - (double)q.ci);
         if (!ISO) {
             const double kj = mx / 2.0 - 0.5, ki = my / 2.0 - 0.5;
             const double tkj = trunc(kj), tki = trunc(ki);
-            fx = (float)(kj - tkj);
-            fy = (float)(ki - tki);
-            x0 = max((int)tkj, 0);
-            y0 = max((int)tki, 0);
+            q.fx = (float)(kj - tkj);
+            q.fy = (float)(ki - tki);
+            q.x0 = q.valid ? max((int)tkj, 0) : 0;
+            q.y0 = q.valid ? max((int)tki, 0) : 0;
         }
     }
-    const float local_r = f.r[p.ridx];
-    if (local_r == 0.f) return;
+    return q;
+}
+
+// The 9 taps of one frame -> absolute-parity accumulators n4/d4[row parity][col parity].
+// rawAt(di, dj): raw sample at (ci+di, cj+dj); covAt(k): covariance of cell k = (y0|y1, x0|x1).
+template <bool ISO, class RawAt, class CovAt>
+__device__ __forceinline__ void taps_accum(const FrameGeo& q, const Geo& g, const float local_r, RawAt rawAt,
+                                           CovAt covAt, float n4[2][2], float d4[2][2]) {
     float ixx = 2.f, ixy = 0.f, iyy = 2.f;  // iso kernel: z = 2 (dx^2 + dy^2)
     if (!ISO) {
-        const int x1 = min(x0 + 1, g.gw - 1), y1 = min(y0 + 1, g.gh - 1);
-        const float4* __restrict__ r0 = f.cov + (size_t)y0 * g.gw;
-        const float4* __restrict__ r1 = f.cov + (size_t)y1 * g.gw;
-        const float4 c00 = r0[x0], c01 = r0[x1], c10 = r1[x0], c11 = r1[x1];
+        const float4 c00 = covAt(0), c01 = covAt(1), c10 = covAt(2), c11 = covAt(3);
+        const float fx = q.fx, fy = q.fy;
         const float txx = c00.x + fx * (c01.x - c00.x), bxx = c10.x + fx * (c11.x - c10.x);
         const float txy = c00.y + fx * (c01.y - c00.y), bxy = c10.y + fx * (c11.y - c10.y);
         const float tyy = c00.w + fx * (c01.w - c00.w), byy = c10.w + fx * (c11.w - c10.w);
@@ -188,10 +199,10 @@ __device__ __forceinline__ void comp_accum_fast(const FramePtr f, const Geo& g, 
         ixy = -inv_det * cxy;
         iyy = inv_det * cxx;
     }
-    const float dx0 = 0.5f - frx, dy0 = 0.5f - fry;  // tap - (lr_mov - 0.5) for the centre tap
-    const float* __restrict__ rawc = f.raw + (size_t)ci * g.pitch + cj;
-    const float kexp = -0.72134752044448170368f;  // -0.5 * log2(e)
+    const float dx0 = 0.5f - q.frx, dy0 = 0.5f - q.fry;  // tap - (lr_mov - 0.5) for the centre tap
+    const float kexp = -0.72134752044448170368f;          // -0.5 * log2(e)
     float sv[2][2] = {{0.f, 0.f}, {0.f, 0.f}}, sa[2][2] = {{0.f, 0.f}, {0.f, 0.f}};  // by OFFSET parity
+    const int ci = q.ci, cj = q.cj;
     const bool interior = ci >= 1 && ci + 1 < g.H && cj >= 1 && cj + 1 < g.W;
 #pragma unroll
     for (int di = -1; di <= 1; ++di) {
@@ -200,7 +211,7 @@ __device__ __forceinline__ void comp_accum_fast(const FramePtr f, const Geo& g, 
 #pragma unroll
         for (int dj = -1; dj <= 1; ++dj) {
             if (!interior && (cj + dj < 0 || cj + dj >= g.W || ci + di < 0 || ci + di >= g.H)) continue;
-            const float c = rawc[di * g.pitch + dj];
+            const float c = rawAt(di, dj);
             const float dx = dx0 + (float)dj;
             float z = fmaf(fmaf(ixx, dx, b), dx, a);
             z = fmaxf(z, 0.f);  // NaN -> 0 -> w = 1 (Python max(0, z), D10)
@@ -224,6 +235,24 @@ __device__ __forceinline__ void comp_accum_fast(const FramePtr f, const Geo& g, 
         d4[0][c] += oi ? sa[1][c] : sa[0][c];
         d4[1][c] += oi ? sa[0][c] : sa[1][c];
     }
+}
+
+// One comp frame, operands straight from global memory (generic scales / per-frame operator API).
+template <int GEOM, bool ISO>
+__device__ __forceinline__ void comp_accum_fast(const FramePtr f, const Geo& g, const Pix& p, float n4[2][2],
+                                                float d4[2][2]) {
+    const FrameGeo q = frame_geom<GEOM, ISO>(f.flow[p.tile], g, p);
+    if (!q.valid) return;
+    const float local_r = f.r[p.ridx];
+    if (local_r == 0.f) return;
+    const float* __restrict__ rawc = f.raw + (size_t)q.ci * g.pitch + q.cj;
+    const int x1 = min(q.x0 + 1, g.gw - 1), y1 = min(q.y0 + 1, g.gh - 1);
+    const float4* __restrict__ r0 = ISO ? nullptr : f.cov + (size_t)q.y0 * g.gw;
+    const float4* __restrict__ r1 = ISO ? nullptr : f.cov + (size_t)y1 * g.gw;
+    const int x0 = q.x0, pitch = g.pitch;
+    taps_accum<ISO>(
+        q, g, local_r, [=](int di, int dj) { return rawc[di * pitch + dj]; },
+        [=](int k) { return (k & 2 ? r1 : r0)[k & 1 ? x1 : x0]; }, n4, d4);
 }
 
 // parity classes -> channels (wave-uniform CFA): val[cfa[i][j]] += n4[i][j] in fixed order
@@ -416,6 +445,132 @@ __global__ void __launch_bounds__(256) k_merge_burst(BurstArgs a, Geo g, Cfa4 cf
 }
 
 // ---- host entry points ----------------------------------------------------------------------------------
+// ---- fused burst kernel with LDS staging per flow tile ------------------------------------------------
+// For integer scales the HR tile of one flow vector is ts*scale pixels wide (a multiple of 16), so a 16x16
+// HR workgroup aligned to 16 sees ONE flow vector per frame.  Its raw footprint (<= 19x19 pixels) and
+// covariance footprint (<= 12x12 cells) are fetched once per frame with coalesced loads, staged in LDS
+// and read from there by the 9 taps / 4 covariance cells of every pixel: ~3 vector loads per
+// pixel-frame instead of 15 (the un-staged kernel is bound by the L1 request rate, profiles/r01_b).
+// Loads for frame n+1 are issued into registers before the taps of frame n are evaluated.
+constexpr int MT = 16;                  // HR workgroup edge
+constexpr int RWIN = 19, RPITCH = 21;   // raw window: (MT/s + 3) <= 19, odd-ish pitch against bank conflicts
+constexpr int CWIN = 12;                // covariance window edge (<= MT/2 + 3 cells)
+
+struct TileWin {
+    int rx0, ry0;  // raw window origin (may be negative: outside -> 0, never read by in-frame taps)
+    int cx0, cy0;  // covariance window origin
+};
+
+template <int GEOM, bool ISO>
+__global__ void __launch_bounds__(256) k_merge_burst_tile(BurstArgs a, Geo g, Cfa4 cfa, float* __restrict__ num,
+                                                           float* __restrict__ den) {
+    __shared__ float s_raw[RWIN * RPITCH];
+    __shared__ float4 s_cov[CWIN * CWIN];
+    const int tx = threadIdx.x & (MT - 1), ty = threadIdx.x >> 4;
+    const int hx0 = blockIdx.x * MT, hy0 = blockIdx.y * MT;
+    const int hj = hx0 + tx, hi = hy0 + ty;
+    const bool live = hj < g.sW && hi < g.sH;
+    // corner pixels of the workgroup (clamped into the image) bound every thread's window
+    const Pix p0 = make_pix(g, min(hy0, g.sH - 1), min(hx0, g.sW - 1));
+    const Pix p = make_pix(g, min(hi, g.sH - 1), min(hj, g.sW - 1));
+    const int tile = p0.tile;  // uniform: the workgroup lies inside one flow tile
+    float n4[2][2] = {{0.f, 0.f}, {0.f, 0.f}}, d4[2][2] = {{0.f, 0.f}, {0.f, 0.f}};
+
+    // staging slots of this thread: raw window elements tid and tid+256, covariance element tid
+    const int e0 = threadIdx.x, e1 = threadIdx.x + 256;
+    const int e0y = e0 / RWIN, e0x = e0 - e0y * RWIN, e1y = e1 / RWIN, e1x = e1 - e1y * RWIN;
+    const int cey = threadIdx.x / CWIN, cex = threadIdx.x - cey * CWIN;
+
+    // GEOM_F64 gives cj = 0 for invalid corners; recompute the corner centre without the validity clamp
+    auto corner_centre = [&](const float2 fl, const Pix& pc, int& cj, int& ci, int& x0, int& y0) {
+        if (GEOM == GEOM_P2) {
+            const FrameGeo q = frame_geom<GEOM, ISO>(fl, g, pc);
+            cj = q.cj; ci = q.ci;
+        } else {
+            cj = (int)floor(pc.lr_x + (double)fl.x);
+            ci = (int)floor(pc.lr_y + (double)fl.y);
+        }
+        x0 = cj >= 1 ? (cj - 1) >> 1 : 0;
+        y0 = ci >= 1 ? (ci - 1) >> 1 : 0;
+        if (GEOM != GEOM_P2 && !ISO) {  // the float64 path truncates kmap itself; same value for cj >= 1
+            x0 = max((int)trunc((pc.lr_x + (double)fl.x) / 2.0 - 0.5), 0);
+            y0 = max((int)trunc((pc.lr_y + (double)fl.y) / 2.0 - 0.5), 0);
+        }
+    };
+
+    float pr0 = 0.f, pr1 = 0.f, plr = 0.f;  // prefetched raw elements and robustness
+    float4 pc = make_float4(0.f, 0.f, 0.f, 0.f);
+    float2 pfl = make_float2(0.f, 0.f);
+    TileWin pw{0, 0, 0, 0};
+    auto prefetch = [&](int n) {
+        const FramePtr f = a.f[n];
+        pfl = f.flow[tile];
+        int cj, ci, x0, y0;
+        corner_centre(pfl, p0, cj, ci, x0, y0);
+        pw.rx0 = cj - 1; pw.ry0 = ci - 1; pw.cx0 = x0; pw.cy0 = y0;
+        {
+            const int y = pw.ry0 + e0y, x = pw.rx0 + e0x;
+            pr0 = (y >= 0 && y < g.H && x >= 0 && x < g.W) ? f.raw[(size_t)y * g.pitch + x] : 0.f;
+        }
+        if (e1 < RWIN * RWIN) {
+            const int y = pw.ry0 + e1y, x = pw.rx0 + e1x;
+            pr1 = (y >= 0 && y < g.H && x >= 0 && x < g.W) ? f.raw[(size_t)y * g.pitch + x] : 0.f;
+        }
+        if (!ISO && threadIdx.x < CWIN * CWIN) {
+            const int y = min(max(pw.cy0 + cey, 0), g.gh - 1), x = min(max(pw.cx0 + cex, 0), g.gw - 1);
+            pc = f.cov[(size_t)y * g.gw + x];
+        }
+        plr = f.r[p.ridx];
+    };
+
+    if (a.n > 0) prefetch(0);
+    for (int n = 0; n < a.n; ++n) {
+        __syncthreads();  // the previous frame's taps are done with the LDS windows
+        s_raw[e0y * RPITCH + e0x] = pr0;
+        if (e1 < RWIN * RWIN) s_raw[e1y * RPITCH + e1x] = pr1;
+        if (!ISO && threadIdx.x < CWIN * CWIN) s_cov[threadIdx.x] = pc;
+        const float2 fl = pfl;
+        const TileWin w = pw;
+        const float local_r = plr;
+        __syncthreads();
+        if (n + 1 < a.n) prefetch(n + 1);  // in flight while this frame's taps are evaluated
+        const FrameGeo q = frame_geom<GEOM, ISO>(fl, g, p);
+        if (live && q.valid && local_r != 0.f) {
+            const float* __restrict__ rc = s_raw + (q.ci - w.ry0) * RPITCH + (q.cj - w.rx0);
+            const int lx0 = q.x0 - w.cx0, ly0 = q.y0 - w.cy0;
+            const int lx1 = min(q.x0 + 1, g.gw - 1) - w.cx0, ly1 = min(q.y0 + 1, g.gh - 1) - w.cy0;
+            taps_accum<ISO>(
+                q, g, local_r, [=](int di, int dj) { return rc[di * RPITCH + dj]; },
+                [=](int k) { return s_cov[(k & 2 ? ly1 : ly0) * CWIN + (k & 1 ? lx1 : lx0)]; }, n4, d4);
+        }
+    }
+    if (!live) return;
+    const size_t o = ((size_t)hi * g.sW + hj) * 3;
+    float n3[3] = {0.f, 0.f, 0.f}, d3[3] = {0.f, 0.f, 0.f};
+    if (a.flags & HHSR_MERGE_LOAD_ACC) {
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            n3[k] = num[o + k];
+            d3[k] = den[o + k];
+        }
+    }
+    classes_to_rgb(cfa, n4, d4, n3, d3);
+    if (a.flags & HHSR_MERGE_DO_REF) {
+        float val[3] = {0.f, 0.f, 0.f}, acc[3] = {0.f, 0.f, 0.f};
+        ref_contrib<ISO>(a.ref_raw, a.ref_cov, g, cfa, hi, hj, nullptr, 0, 0.0, 0.0, val, acc);
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            n3[k] += val[k];
+            d3[k] += acc[k];
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        num[o + k] = (a.flags & HHSR_MERGE_DIVIDE) ? n3[k] / d3[k] : n3[k];
+        if (a.flags & HHSR_MERGE_STORE_DEN) den[o + k] = d3[k];
+    }
+}
+
 static bool scale_is_pow2(double s) {  // 1, 2, 4, 8: (h + 0.5)/s is exact in float32
     return s == 1.0 || s == 2.0 || s == 4.0 || s == 8.0;
 }
@@ -509,6 +664,18 @@ extern "C" int hhsr_merge_burst(const float* const* raws, const float* const* fl
     const dim3 grid(hhsr_cdiv(sW, 64), hhsr_cdiv(sH, 4)), block(256);
     hipStream_t s = (hipStream_t)stream;
     const bool p2 = scale_is_pow2(scale);
+    // LDS-staged kernel: integer scale, 16-px HR workgroups inside one flow tile, windows fit the LDS arrays
+    const int iscale = (int)scale;
+    const bool tiled = !f64 && (double)iscale == scale && iscale >= 1 && ((int64_t)ts * iscale) % MT == 0 &&
+                       n_frames > 0 && !getenv("HHSR_MERGE_NO_LDS");
+    if (tiled) {
+        const dim3 tgrid(hhsr_cdiv(sW, MT), hhsr_cdiv(sH, MT));
+#define HHSR_MT(GEOM, ISO) hipLaunchKernelGGL((k_merge_burst_tile<GEOM, ISO>), tgrid, block, 0, s, a, g, c, num, den)
+        if (p2) { if (iso) HHSR_MT(GEOM_P2, true); else HHSR_MT(GEOM_P2, false); }
+        else { if (iso) HHSR_MT(GEOM_F64, true); else HHSR_MT(GEOM_F64, false); }
+#undef HHSR_MT
+        HHSR_LAUNCHED();
+    }
 #define HHSR_MB(WT, GEOM, ISO) hipLaunchKernelGGL((k_merge_burst<WT, GEOM, ISO>), grid, block, 0, s, a, g, c, num, den)
     if (f64) { if (iso) HHSR_MB(double, GEOM_F64, true); else HHSR_MB(double, GEOM_F64, false); }
     else if (p2) { if (iso) HHSR_MB(float, GEOM_P2, true); else HHSR_MB(float, GEOM_P2, false); }
