@@ -22,6 +22,7 @@ SOURCES = {
     "hhsr_kernels.hip": ["-ffp-contract=off"],
     "hhsr_robustness.hip": ["-ffp-contract=off"],
     "hhsr_merge.hip": [],
+    "hhsr_grey.hip": ["-ffp-contract=off"],
 }
 
 
@@ -52,7 +53,8 @@ def build(force=False, verbose=True):
     with ThreadPoolExecutor(max_workers=max(1, min(len(jobs), os.cpu_count() or 1))) as ex:
         list(ex.map(run, jobs))
     if jobs or force or _stale(OUT, objs):
-        run([HIPCC, "--offload-arch=" + ARCH, "-shared", "-fPIC", "-o", OUT, *objs])
+        run([HIPCC, "--offload-arch=" + ARCH, "-shared", "-fPIC", "-o", OUT, *objs, "-L/opt/rocm/lib", "-lhipfft",
+             "-Wl,-rpath,/opt/rocm/lib"])
     return OUT
 
 

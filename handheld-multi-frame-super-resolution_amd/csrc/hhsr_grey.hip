@@ -1,0 +1,105 @@
+// Alg. 3 grey image as a planned real FFT round trip (reference utils_image.py:82-100).
+//
+// The reference does fft2 -> fftshift -> zero 4 bands -> ifftshift -> ifft2 -> .real on a complex64 image
+// (2 full complex transforms, 2 shift copies, 4 strided fills per frame).  Here: hipFFT (rocFFT) real-to-
+// complex 2-D plan -> one in-place mask kernel on the half spectrum (the Hermitian mask m' = (m(k)+m(-k))/2
+// with the 1/(H W) normalisation folded in) -> complex-to-real plan.  Half the transform work, no shift or
+// normalisation passes, no temporaries beyond the plan's own spectrum buffer.
+#include "hhsr_common.h"
+#include <hipfft/hipfft.h>
+#include <new>
+
+struct GreyPlan {
+    int H, W, Wh;
+    hipfftHandle r2c, c2r;
+    float2* spec;  // [H][W/2+1]
+};
+
+__device__ __forceinline__ bool lp_kept2(int u, int n) {
+    int i = u + n / 2;
+    if (i >= n) i -= n;
+    return i >= n / 4 && i < n - (n + 3) / 4;
+}
+
+__global__ void __launch_bounds__(256) k_lowpass_scale(float2* __restrict__ spec, int H, int W, int Wh, float norm) {
+    const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
+    if (x >= Wh) return;
+    const int ny = y == 0 ? 0 : H - y, nx = x == 0 ? 0 : W - x;
+    const int m = (int)(lp_kept2(y, H) && lp_kept2(x, W)) + (int)(lp_kept2(ny, H) && lp_kept2(nx, W));
+    const size_t o = (size_t)y * Wh + x;
+    if (m == 0) {
+        spec[o] = make_float2(0.f, 0.f);
+        return;
+    }
+    const float s = 0.5f * (float)m * norm;
+    float2 v = spec[o];
+    v.x *= s;
+    v.y *= s;
+    spec[o] = v;
+}
+
+extern "C" int hhsr_grey_plan_create(int H, int W, void** plan_out) {
+    HHSR_ARG(plan_out && H > 0 && W > 0);
+    *plan_out = nullptr;
+    GreyPlan* p = new (std::nothrow) GreyPlan();
+    if (!p) {
+        hhsr_set_error("hhsr_grey_plan_create: out of host memory");
+        return -2;
+    }
+    p->H = H;
+    p->W = W;
+    p->Wh = W / 2 + 1;
+    p->spec = nullptr;
+    p->r2c = p->c2r = 0;
+    hipError_t e = hipMalloc((void**)&p->spec, sizeof(float2) * (size_t)H * p->Wh);
+    if (e != hipSuccess) {
+        hhsr_set_error("hhsr_grey_plan_create: hipMalloc failed: %s", hipGetErrorString(e));
+        delete p;
+        return (int)e;
+    }
+    hipfftResult r1 = hipfftPlan2d(&p->r2c, H, W, HIPFFT_R2C);
+    hipfftResult r2 = r1 == HIPFFT_SUCCESS ? hipfftPlan2d(&p->c2r, H, W, HIPFFT_C2R) : r1;
+    if (r1 != HIPFFT_SUCCESS || r2 != HIPFFT_SUCCESS) {
+        hhsr_set_error("hhsr_grey_plan_create: hipfftPlan2d(%d, %d) failed (%d, %d)", H, W, (int)r1, (int)r2);
+        if (r1 == HIPFFT_SUCCESS) hipfftDestroy(p->r2c);
+        (void)hipFree(p->spec);
+        delete p;
+        return 1000 + (int)(r1 != HIPFFT_SUCCESS ? r1 : r2);
+    }
+    *plan_out = p;
+    return 0;
+}
+
+extern "C" int hhsr_grey_plan_destroy(void* plan) {
+    if (!plan) return 0;
+    GreyPlan* p = static_cast<GreyPlan*>(plan);
+    hipfftDestroy(p->r2c);
+    hipfftDestroy(p->c2r);
+    (void)hipFree(p->spec);
+    delete p;
+    return 0;
+}
+
+extern "C" int hhsr_grey_lowpass(void* plan, const float* src, float* dst, void* stream) {
+    HHSR_ARG(plan && src && dst);
+    GreyPlan* p = static_cast<GreyPlan*>(plan);
+    hipStream_t s = (hipStream_t)stream;
+    hipfftResult r = hipfftSetStream(p->r2c, s);
+    if (r == HIPFFT_SUCCESS) r = hipfftSetStream(p->c2r, s);
+    if (r == HIPFFT_SUCCESS)
+        r = hipfftExecR2C(p->r2c, const_cast<hipfftReal*>(src), reinterpret_cast<hipfftComplex*>(p->spec));
+    if (r != HIPFFT_SUCCESS) {
+        hhsr_set_error("hhsr_grey_lowpass: forward transform failed (%d)", (int)r);
+        return 1000 + (int)r;
+    }
+    hipLaunchKernelGGL(k_lowpass_scale, dim3(hhsr_cdiv(p->Wh, 256), p->H), dim3(256), 0, s, p->spec, p->H, p->W, p->Wh,
+                       1.0f / ((float)p->H * (float)p->W));
+    int rc = hhsr_launch_status("hhsr_grey_lowpass");
+    if (rc) return rc;
+    r = hipfftExecC2R(p->c2r, reinterpret_cast<hipfftComplex*>(p->spec), dst);
+    if (r != HIPFFT_SUCCESS) {
+        hhsr_set_error("hhsr_grey_lowpass: inverse transform failed (%d)", (int)r);
+        return 1000 + (int)r;
+    }
+    return 0;
+}

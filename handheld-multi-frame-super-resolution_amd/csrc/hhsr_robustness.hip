@@ -223,6 +223,93 @@ __global__ void __launch_bounds__(256) k_rob_frame(const float* __restrict__ cm,
     R[o] = (float)v;
 }
 
+// ---- the same, one 16x16 raw-pixel workgroup per flow-tile fragment, guide window in LDS -------------
+// A 16-aligned 16x16 block of raw pixels lies inside one flow tile (ts is a multiple of 16), so all its
+// pixels are displaced by the same flow vector and read the same <= 11x11 window of the frame's guide means.
+// The window (3 channels, clamp-to-edge coordinates as in robustness.py:403-409) is staged in LDS with
+// coalesced loads; the 27 taps of every pixel come from LDS: ~8 vector loads per pixel instead of 41.
+constexpr int RF_T = 16, RF_W = 12;
+
+__global__ void __launch_bounds__(256) k_rob_frame_tile(const float* __restrict__ cm, int lh, int lw,
+                                                         const float* __restrict__ rmean,
+                                                         const float* __restrict__ rvar,
+                                                         const float2* __restrict__ flow, int nx, int ts,
+                                                         const float* __restrict__ S, const double* __restrict__ stdc,
+                                                         const double* __restrict__ difc, int ncurve, double t,
+                                                         float* __restrict__ R, int H, int W) {
+    __shared__ float s_g[3][RF_W][RF_W + 1];
+    const int bx = blockIdx.x * RF_T, by = blockIdx.y * RF_T;
+    const int lx_ = threadIdx.x & (RF_T - 1), ly_ = threadIdx.x >> 4;
+    const int x = bx + lx_, y = by + ly_;
+    const int tix = bx / ts, tiy = by / ts;  // uniform
+    const float2 f = flow[(size_t)tiy * nx + tix];
+    const double fx = (double)f.x, fy = (double)f.y;
+    // window origin from the block's first pixel (LR position is monotone in the pixel coordinate)
+    const double ly0 = ((double)by + fy + 0.5) / 2.0 - 0.5, lx0 = ((double)bx + fx + 0.5) / 2.0 - 0.5;
+    const int wy0 = (int)rint(fmin(fmax(ly0, -4.0), (double)lh + 4.0)) - 1;
+    const int wx0 = (int)rint(fmin(fmax(lx0, -4.0), (double)lw + 4.0)) - 1;
+    const size_t gplane = (size_t)lh * lw;
+    for (int p = threadIdx.x; p < 3 * RF_W * RF_W; p += 256) {
+        const int c = p / (RF_W * RF_W), q = p - c * RF_W * RF_W;
+        const int i = q / RF_W, j = q - i * RF_W;
+        const int gy = clampi(wy0 + i, 0, lh - 1), gx = clampi(wx0 + j, 0, lw - 1);
+        s_g[c][i][j] = cm[c * gplane + (size_t)gy * lw + gx];
+    }
+    __syncthreads();
+    if (x >= W || y >= H) return;
+    const double ly = ((double)y + fy + 0.5) / 2.0 - 0.5;
+    const double lx = ((double)x + fx + 0.5) / 2.0 - 0.5;
+    float cmu[3] = {INFINITY, INFINITY, INFINITY};
+    if (ly >= 0.0 && ly < (double)lh && lx >= 0.0 && lx < (double)lw) {
+        const int cy = (int)rint(ly), cx = (int)rint(lx);  // round-half-even
+        float b0 = 0.f, b1 = 0.f, b2 = 0.f;
+        double wacc = 0.0;
+#pragma unroll
+        for (int i = -1; i <= 1; ++i) {
+            const int y_ = clampi(cy + i, 0, lh - 1);
+            const double wy = dodgson((double)y_ - ly);
+            const int wi = cy + i - wy0;
+#pragma unroll
+            for (int j = -1; j <= 1; ++j) {
+                const int x_ = clampi(cx + j, 0, lw - 1);
+                const double w = wy * dodgson((double)x_ - lx);
+                const int wj = cx + j - wx0;
+                b0 = (float)((double)b0 + (double)s_g[0][wi][wj] * w);
+                b1 = (float)((double)b1 + (double)s_g[1][wi][wj] * w);
+                b2 = (float)((double)b2 + (double)s_g[2][wi][wj] * w);
+                wacc += w;
+            }
+        }
+        cmu[0] = (float)((double)b0 / wacc);
+        cmu[1] = (float)((double)b1 / wacc);
+        cmu[2] = (float)((double)b2 / wacc);
+    }
+    const size_t plane = (size_t)H * W, o = (size_t)y * W + x;
+    double d_sq = 0.0, s_sq = 0.0;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        const float b = rmean[c * plane + o];
+        const float dp = fabsf(b - cmu[c]);
+        int id = 0;
+        const double bb = 1000.0 * (double)b;
+        if (isfinite(bb)) id = clampi((int)rint(bb), 0, ncurve - 1);
+        const double d_t = difc[id], s_t = stdc[id];
+        const double sp = (double)rvar[c * plane + o];
+        const double st2 = s_t * s_t;
+        s_sq += (st2 > sp) ? st2 : sp;
+        const float dp2f = dp * dp;
+        const double dp2 = (double)dp2f;
+        const double shrink = dp2 / (dp2 + d_t * d_t);
+        d_sq += dp2 * shrink * shrink;
+    }
+    const float dsf = (float)d_sq, ssf = (float)s_sq;
+    const float e = expf(-dsf / ssf);
+    double v = (double)(S[(size_t)tiy * nx + tix] * e) - t;
+    v = v > 0.0 ? v : 0.0;
+    v = v < 1.0 ? v : 1.0;
+    R[o] = (float)v;
+}
+
 extern "C" int hhsr_rob_frame(const float* comp_means, int lh, int lw, const float* ref_means,
                               const float* ref_vars, const float* flow, int ny, int nx, int ts, const float* S,
                               const double* std_curve, const double* diff_curve, int ncurve, double t, float* R,
@@ -231,9 +318,14 @@ extern "C" int hhsr_rob_frame(const float* comp_means, int lh, int lw, const flo
     HHSR_ARG(lh > 0 && lw > 0 && ts > 0 && ncurve > 0);
     const int H = 2 * lh, W = 2 * lw;
     HHSR_ARG(ny * ts >= H && nx * ts >= W);
-    hipLaunchKernelGGL(k_rob_frame, dim3(hhsr_cdiv(W, 64), hhsr_cdiv(H, 4)), dim3(256), 0, (hipStream_t)stream,
-                       comp_means, lh, lw, ref_means, ref_vars, reinterpret_cast<const float2*>(flow), nx, ts, S,
-                       std_curve, diff_curve, ncurve, t, R, H, W);
+    if (ts % RF_T == 0)
+        hipLaunchKernelGGL(k_rob_frame_tile, dim3(hhsr_cdiv(W, RF_T), hhsr_cdiv(H, RF_T)), dim3(256), 0,
+                           (hipStream_t)stream, comp_means, lh, lw, ref_means, ref_vars,
+                           reinterpret_cast<const float2*>(flow), nx, ts, S, std_curve, diff_curve, ncurve, t, R, H, W);
+    else
+        hipLaunchKernelGGL(k_rob_frame, dim3(hhsr_cdiv(W, 64), hhsr_cdiv(H, 4)), dim3(256), 0, (hipStream_t)stream,
+                           comp_means, lh, lw, ref_means, ref_vars, reinterpret_cast<const float2*>(flow), nx, ts, S,
+                           std_curve, diff_curve, ncurve, t, R, H, W);
     HHSR_LAUNCHED();
 }
 
@@ -241,7 +333,7 @@ extern "C" int hhsr_rob_frame(const float* comp_means, int lh, int lw, const flo
 constexpr int LM_TX = 64, LM_TY = 16;
 
 __global__ void __launch_bounds__(256) k_local_min5(const float* __restrict__ R, int H, int W,
-                                                     float* __restrict__ r) {
+                                                     float* __restrict__ r, float* __restrict__ acc) {
     __shared__ float s[LM_TY + 4][LM_TX + 4 + 1];
     __shared__ float s_row[LM_TY + 4][LM_TX + 1];
     const int x0 = blockIdx.x * LM_TX, y0 = blockIdx.y * LM_TY;
@@ -266,13 +358,14 @@ __global__ void __launch_bounds__(256) k_local_min5(const float* __restrict__ R,
 #pragma unroll
             for (int k = 1; k < 5; ++k) m = fminf(m, s_row[i + k][j]);
             r[(size_t)y * W + x] = m;
+            if (acc) acc[(size_t)y * W + x] += m;  // accumulated robustness (super_resolution.py:158-159)
         }
     }
 }
 
-extern "C" int hhsr_local_min5(const float* R, int H, int W, float* r, void* stream) {
+extern "C" int hhsr_local_min5(const float* R, int H, int W, float* r, float* acc_r, void* stream) {
     HHSR_ARG(R && r && H > 0 && W > 0 && R != r);
     hipLaunchKernelGGL(k_local_min5, dim3(hhsr_cdiv(W, LM_TX), hhsr_cdiv(H, LM_TY)), dim3(256), 0,
-                       (hipStream_t)stream, R, H, W, r);
+                       (hipStream_t)stream, R, H, W, r, acc_r);
     HHSR_LAUNCHED();
 }

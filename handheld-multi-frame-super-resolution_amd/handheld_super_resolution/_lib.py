@@ -23,6 +23,9 @@ PP = C.POINTER(C.c_void_p)
 _SIGS = {
     "hhsr_lowpass_mask_c2c": [P, I, I, L, L, P],
     "hhsr_lowpass_mask_r2c": [P, I, I, L, L, P],
+    "hhsr_grey_plan_create": [I, I, PP],
+    "hhsr_grey_lowpass": [P, P, P, P],
+    "hhsr_grey_plan_destroy": [P],
     "hhsr_pad_circular": [P, I, I, I, P, I, I, I, P],
     "hhsr_gauss_decimate": [P, I, I, I, P, I, I, FP, I, P],
     "hhsr_grad_hessian": [P, I, I, I, I, P, P, P, P],
@@ -35,7 +38,7 @@ _SIGS = {
     "hhsr_rob_upscale": [P, I, I, P, I, I, I, P, P],
     "hhsr_rob_s": [P, I, I, F, F, F, P, P],
     "hhsr_rob_frame": [P, I, I, P, P, P, I, I, I, P, P, P, I, D, P, P],
-    "hhsr_local_min5": [P, I, I, P, P],
+    "hhsr_local_min5": [P, I, I, P, P, P],
     "hhsr_accumulate": [P, I, I, I, P, I, I, I, P, P, U8P, D, I, P, P, I, I, P],
     "hhsr_accumulate_ref": [P, I, I, I, P, U8P, D, I, P, I, D, D, P, P, I, I, P],
     "hhsr_divide": [P, P, L, P],

@@ -38,7 +38,6 @@ class HipEngine:
     def partial(self, comp_imgs):
         """Packed accumulators [2, sH, sW, 3] of this rank's frames (+ accumulated robustness or None)."""
         from .merge import merge_burst
-        from .utils import add
 
         pipe = self.pipe
         sH, sW = pipe.output_size()
@@ -46,10 +45,7 @@ class HipEngine:
         acc_r = torch.zeros(tuple(pipe.ref.shape), dtype=torch.float32, device=pipe.device) if self.accumulate_r else None
         frames = []
         for img in comp_imgs:
-            f = pipe.process_frame(img)
-            frames.append(f)
-            if acc_r is not None:
-                add(acc_r, f[3])
+            frames.append(pipe.process_frame(img, acc_r))
         if frames:
             merge_burst(frames, None, None, acc[0], acc[1], pipe.cfa, self.config, do_ref=False, divide=False,
                         store_den=True)

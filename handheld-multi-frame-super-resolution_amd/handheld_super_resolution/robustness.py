@@ -61,10 +61,12 @@ def compute_s(flows, M_th, s1, s2):
     return S
 
 
-def local_min(R):
-    """Alg. 9: 5x5 clamp-border minimum (robustness.py:641-686)."""
+def local_min(R, accumulate_into=None):
+    """Alg. 9: 5x5 clamp-border minimum (robustness.py:641-686).  `accumulate_into` (float32 [H, W]) gets
+    += r in the same pass (the reference's separate add() of super_resolution.py:158-159)."""
     r = torch.empty_like(R)
-    _lib.call("hhsr_local_min5", _lib.ptr(R), R.shape[0], R.shape[1], _lib.ptr(r), _lib.stream())
+    _lib.call("hhsr_local_min5", _lib.ptr(R), R.shape[0], R.shape[1], _lib.ptr(r), _lib.ptr(accumulate_into),
+              _lib.stream())
     return r
 
 
@@ -76,12 +78,15 @@ def noise_curves_to_device(std_curve, diff_curve, device):
 
 
 def compute_robustness(comp_img, ref_local_means, ref_local_stds, flows, cfa_pattern, white_balance, noise_model,
-                       config, return_R=False):
+                       config, return_R=False, accumulate_into=None):
     """Alg. 6 (robustness.py:79-170): r float32 [H, W].  3 kernels instead of the reference's 8:
     guide + local stats; fused warp-upsample / colour distance / noise model / threshold; 5x5 min."""
     comp_img = _lib.f32c(comp_img)
     if not config.robustness.enabled:
-        return torch.ones_like(comp_img)
+        ones = torch.ones_like(comp_img)
+        if accumulate_into is not None:
+            accumulate_into += ones
+        return ones
     if config.mode != "bayer":
         raise NotImplementedError("grey mode is outside the MI355X hot path (bayer only)")
     ts = config.block_matching.tuning.tile_size
@@ -96,5 +101,5 @@ def compute_robustness(comp_img, ref_local_means, ref_local_stds, flows, cfa_pat
     _lib.call("hhsr_rob_frame", _lib.ptr(cm), H // 2, W // 2, _lib.ptr(ref_local_means), _lib.ptr(ref_local_stds),
               _lib.ptr(flows), ny, nx, int(ts), _lib.ptr(S), _lib.ptr(std_curve), _lib.ptr(diff_curve),
               int(std_curve.numel()), float(t.t), _lib.ptr(R), _lib.stream())
-    r = local_min(R)
+    r = local_min(R, accumulate_into)
     return (r, R) if return_R else r

@@ -66,13 +66,15 @@ class BurstPipeline:
         self.grey_ref = grey
         return self
 
-    def process_frame(self, img):
-        """grey -> align -> robustness -> kernels for one comp frame; returns (raw, flow, covs, r)."""
+    def process_frame(self, img, accumulate_r=None):
+        """grey -> align -> robustness -> kernels for one comp frame; returns (raw, flow, covs, r).
+        `accumulate_r`: optional float32 [H, W] that receives += r (fused into the local-min pass)."""
         cfg = self.config
         raw = _lib.f32c(img, self.device)
         grey = compute_grey_images(raw, self.grey_method)
         flow = align(*self.align_state, grey, cfg)
-        r = compute_robustness(raw, self.ref_means, self.ref_vars, flow, self.cfa, self.wb, self.curves, cfg)
+        r = compute_robustness(raw, self.ref_means, self.ref_vars, flow, self.cfa, self.wb, self.curves, cfg,
+                               accumulate_into=accumulate_r)
         covs = estimate_kernels(raw, cfg)
         return raw, flow, covs, r
 
@@ -123,9 +125,7 @@ def main(ref_img, comp_imgs, config):
             torch.cuda.synchronize()
             print("\nProcessing image {} ---------\n".format(im_id + 1))
             im_time = time.perf_counter()
-        raw, flow, covs, r = pipe.process_frame(comp_imgs[im_id])
-        if accumulate_r:
-            add(accumulated_r, r)
+        raw, flow, covs, r = pipe.process_frame(comp_imgs[im_id], accumulated_r)
         if fused:
             frames.append((raw, flow, covs, r))
         else:

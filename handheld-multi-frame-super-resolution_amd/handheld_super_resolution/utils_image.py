@@ -5,6 +5,38 @@ import torch
 from . import _lib
 
 
+class _GreyPlan:
+    """Owner of one C-side hipFFT plan (H, W, device); destroyed with the object."""
+
+    def __init__(self, H, W):
+        import ctypes
+
+        h = ctypes.c_void_p()
+        _lib.call("hhsr_grey_plan_create", H, W, ctypes.byref(h))
+        self.handle = h
+
+    def __del__(self):
+        try:
+            if self.handle:
+                _lib.load().hhsr_grey_plan_destroy(self.handle)
+        except Exception:
+            pass
+
+
+_grey_plans = {}
+
+
+def _grey_plan(H, W, device):
+    key = (H, W, device.index, torch.cuda.current_stream(device).cuda_stream)
+    p = _grey_plans.get(key)
+    if p is None:
+        if len(_grey_plans) >= 8:
+            _grey_plans.clear()
+        with torch.cuda.device(device):
+            p = _grey_plans[key] = _GreyPlan(H, W)
+    return p
+
+
 def compute_grey_images(img, method):
     """raw -> grey.  "FFT": ideal half-band low-pass (utils_image.py:82-100).  The reference runs a full
     complex FFT, zeroes the outer quarter bands of the shifted spectrum and keeps the real part; here the
@@ -14,6 +46,11 @@ def compute_grey_images(img, method):
     img = _lib.f32c(img)
     H, W = img.shape
     if method == "FFT":
+        # planned rocFFT round trip inside libhhsr_hip.so: r2c -> Hermitian mask (+ normalisation) -> c2r
+        out = torch.empty_like(img)
+        _lib.call("hhsr_grey_lowpass", _grey_plan(H, W, img.device).handle, _lib.ptr(img), _lib.ptr(out), _lib.stream())
+        return out
+    if method == "FFT_torch":  # same maths through torch.fft (rocFFT behind torch), kept for cross-checking
         spec = torch.fft.rfft2(img)
         _lib.call("hhsr_lowpass_mask_r2c", _lib.ptr(spec), H, W, spec.stride(0), spec.stride(1), _lib.stream())
         return torch.fft.irfft2(spec, s=(H, W))

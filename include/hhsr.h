@@ -10,15 +10,16 @@
  *
  * Conventions
  *  - every pointer is a DEVICE pointer owned by the caller unless the parameter is documented as
- *    "host"; functions never allocate, free or synchronise: they only enqueue work on `stream`
- *    (a hipStream_t passed as void*; NULL = the null stream);
+ *    "host"; functions never allocate, free or synchronise (the hhsr_grey_plan_create/destroy pair
+ *    excepted): they only enqueue work on `stream` (a hipStream_t passed as void*; NULL = null stream);
  *  - images are row-major float32; `pitch` arguments are in ELEMENTS;
  *  - flow fields are float32 [ny][nx][2] = (dx, dy) per tile, moving(p + flow) ~ ref(p);
  *  - covariances are float32 [H/2][W/2][2][2]; accumulators float32 [sH][sW][3];
  *  - the CFA is 4 bytes {c00, c01, c10, c11} with 0=R, 1=G, 2=B;
  *  - return value: 0 = OK, >0 = hipError_t of the launch, <0 = invalid argument; the message is
  *    available from hhsr_last_error() (thread local).  No C++ exception crosses the boundary.
- *  - no global mutable state: re-entrant across host threads and streams.
+ *  - no global mutable state: re-entrant across host threads and streams (a grey plan is caller-owned
+ *    state).
  */
 #ifndef HHSR_H
 #define HHSR_H
@@ -48,6 +49,15 @@ const char* hhsr_last_error(void);
  * transposed half spectrum, which is masked in place as it lies. */
 int hhsr_lowpass_mask_c2c(float* spec, int H, int W, int64_t stride_y, int64_t stride_x, void* stream);
 int hhsr_lowpass_mask_r2c(float* spec, int H, int W, int64_t stride_y, int64_t stride_x, void* stream);
+
+/* Planned grey transform: real-to-complex rocFFT plan -> Hermitian low-pass mask (normalisation folded
+ * in) -> complex-to-real plan; dst = Re(ifft2(mask * fft2(src))), src/dst contiguous [H][W], src intact.
+ * hhsr_grey_plan_create is the ONE place the library allocates (the plan and its [H][W/2+1] spectrum
+ * buffer, owned by the plan); a plan is mutable state: use it from one stream at a time.
+ * Returns 1000 + hipfftResult on a hipFFT error. */
+int hhsr_grey_plan_create(int H, int W, void** plan_out);
+int hhsr_grey_lowpass(void* plan, const float* src, float* dst, void* stream);
+int hhsr_grey_plan_destroy(void* plan);
 
 /* ---- pyramid (alignment.py:27-37, 74-82; utils_image.py:360-391) ------------------------------ */
 /* dst[y][x] = src[y mod H][x mod W], dst is Hp x Wp (F.pad 'circular', bottom/right). */
@@ -114,8 +124,9 @@ int hhsr_rob_frame(const float* comp_means, int lh, int lw, const float* ref_mea
                    const float* flow, int ny, int nx, int ts, const float* S,
                    const double* std_curve, const double* diff_curve, int ncurve,
                    double t, float* R, void* stream);
-/* 5x5 clamp-border minimum (robustness.py:670-686). */
-int hhsr_local_min5(const float* R, int H, int W, float* r, void* stream);
+/* 5x5 clamp-border minimum (robustness.py:670-686).  acc_r != NULL additionally does acc_r += r
+ * (the accumulated robustness of super_resolution.py:158-159, fused to save a pass). */
+int hhsr_local_min5(const float* R, int H, int W, float* r, float* acc_r, void* stream);
 
 /* kflags of the merge entry points */
 #define HHSR_KERNEL_ISO 1   /* merging.kernel == "iso": w = exp(-(dx^2+dy^2)) instead of the steerable kernel */

@@ -40,7 +40,8 @@ def smooth(rng, h, w, sigma=2.0):
 def test_grey_fft(shape):
     img = np.random.default_rng(1).random(shape, dtype=np.float32)
     want = oracle.grey_fft(img)
-    assert_close(N(utils_image.compute_grey_images(T(img), "FFT")), want, 0, 3e-6, "r2c")
+    assert_close(N(utils_image.compute_grey_images(T(img), "FFT")), want, 0, 3e-6, "planned r2c")
+    assert_close(N(utils_image.compute_grey_images(T(img), "FFT_torch")), want, 0, 3e-6, "torch r2c")
     assert_close(N(utils_image.compute_grey_images(T(img), "FFT_c2c")), want, 0, 3e-6, "c2c")
 
 
