@@ -183,16 +183,19 @@ __device__ __forceinline__ CostIdx wave_argmin(CostIdx v) {
     return v;
 }
 
-template <bool L1>
+template <int TS, bool L1>
 __global__ void __launch_bounds__(256) k_bm_wave(const float* __restrict__ ref, int ref_pitch,
                                                   const float* __restrict__ mov, int mh, int mw, int mov_pitch,
-                                                  float* __restrict__ flow, int nx, int ntiles, int ts, int r,
-                                                  int mode) {
-    extern __shared__ float lds[];
+                                                  float* __restrict__ flow, int nx, int ntiles, int r, int mode) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    constexpr int ts = TS;
     const int wave = threadIdx.x / HHSR_WAVE, lane = threadIdx.x & (HHSR_WAVE - 1);
     const int P = ts + 2 * r, Pp = P | 1, n1 = 2 * r + 1, n = n1 * n1;
-    float* s_ref = lds + (size_t)wave * (ts * ts + P * Pp);
+    const int nparts = 4 * n;                       // (candidate, row quarter) work items, n > 16 path
+    const int slice = (ts * ts + P * Pp + nparts + 3) & ~3;
+    float* s_ref = lds + (size_t)wave * slice;
     float* s_win = s_ref + ts * ts;
+    float* s_part = s_win + P * Pp;
     const int tile = blockIdx.x * 4 + wave;
     bool active = tile < ntiles;
     const int tsafe = active ? tile : 0;
@@ -210,11 +213,12 @@ __global__ void __launch_bounds__(256) k_bm_wave(const float* __restrict__ ref, 
     if (active) {
         const int y0 = ty * ts + (int)r1 - r, x0 = tx * ts + (int)r0 - r;
         for (int p = lane; p < ts * ts; p += HHSR_WAVE) {
-            const int i = p / ts, j = p - i * ts;
+            const int i = p / ts, j = p % ts;
             s_ref[p] = ref[(size_t)(ty * ts + i) * ref_pitch + tx * ts + j];
         }
+        const float rcpP = 1.0f / (float)P;
         for (int p = lane; p < P * P; p += HHSR_WAVE) {
-            const int i = p / P, j = p - i * P;
+            const int i = (int)(((float)p + 0.5f) * rcpP), j = p - i * P;  // exact floor(p / P) for p < 2^16
             const int y = y0 + i, x = x0 + j;
             float v;
             if (L1) {  // zero outside the moving level (block_matching.py:131-139)
@@ -226,15 +230,20 @@ __global__ void __launch_bounds__(256) k_bm_wave(const float* __restrict__ ref, 
         }
     }
     __syncthreads();
-    if (!active) return;
     CostIdx best{INFINITY, 0};
     if (n <= 16) {
+        if (!active) return;
+        float rv[TS * TS / HHSR_WAVE > 0 ? TS * TS / HHSR_WAVE : 1];
+        constexpr int PPT = TS * TS / HHSR_WAVE;
+#pragma unroll
+        for (int k = 0; k < PPT; ++k) rv[k] = s_ref[lane + k * HHSR_WAVE];
         for (int c = 0; c < n; ++c) {
             const int dy = c / n1, dx = c - dy * n1;
             float acc = 0.f;
-            for (int p = lane; p < ts * ts; p += HHSR_WAVE) {
-                const int i = p / ts, j = p - i * ts;
-                const float d = s_ref[p] - s_win[(i + dy) * Pp + j + dx];
+#pragma unroll
+            for (int k = 0; k < PPT; ++k) {
+                const int p = lane + k * HHSR_WAVE;
+                const float d = rv[k] - s_win[(p / ts + dy) * Pp + p % ts + dx];
                 acc += L1 ? fabsf(d) : d * d;
             }
 #pragma unroll
@@ -245,19 +254,34 @@ __global__ void __launch_bounds__(256) k_bm_wave(const float* __restrict__ ref, 
             }
         }
     } else {
-        for (int c = lane; c < n; c += HHSR_WAVE) {
-            const int dy = c / n1, dx = c - dy * n1;
-            float acc = 0.f;
-            for (int i = 0; i < ts; ++i) {
-                const float* wrow = s_win + (i + dy) * Pp + dx;
-                const float* rrow = s_ref + i * ts;
-                for (int j = 0; j < ts; ++j) {
-                    const float d = rrow[j] - wrow[j];
-                    acc += L1 ? fabsf(d) : d * d;
+        // work item = (candidate, quarter of the tile rows); 4n items over 64 lanes
+        if (active) {
+            constexpr int QR = TS / 4;  // rows per quarter
+            for (int it = lane; it < nparts; it += HHSR_WAVE) {
+                const int c = it >> 2, q = it & 3;
+                const int dy = c / n1, dx = c - dy * n1;
+                float acc = 0.f;
+                for (int i = q * QR; i < (q + 1) * QR; ++i) {
+                    const float* wrow = s_win + (i + dy) * Pp + dx;
+                    const float4* rrow = reinterpret_cast<const float4*>(s_ref + i * ts);
+#pragma unroll
+                    for (int j4 = 0; j4 < TS / 4; ++j4) {
+                        const float4 rr = rrow[j4];  // one broadcast 16-byte LDS read
+                        const float d0 = rr.x - wrow[4 * j4], d1 = rr.y - wrow[4 * j4 + 1];
+                        const float d2 = rr.z - wrow[4 * j4 + 2], d3 = rr.w - wrow[4 * j4 + 3];
+                        if (L1) acc += fabsf(d0) + fabsf(d1) + fabsf(d2) + fabsf(d3);
+                        else acc += d0 * d0 + d1 * d1 + d2 * d2 + d3 * d3;
+                    }
                 }
+                s_part[it] = acc;
             }
-            if (acc < best.c) {
-                best.c = acc;
+        }
+        __syncthreads();
+        if (!active) return;
+        for (int c = lane; c < n; c += HHSR_WAVE) {
+            const float tot = (s_part[4 * c] + s_part[4 * c + 1]) + (s_part[4 * c + 2] + s_part[4 * c + 3]);
+            if (tot < best.c) {
+                best.c = tot;
                 best.i = c;
             }
         }
@@ -281,17 +305,23 @@ static size_t bm_lds(int ts, int r) {
 }
 
 static size_t bm_wave_lds(int ts, int r) {
-    const int P = ts + 2 * r, Pp = P | 1;
-    return (size_t)4 * (ts * ts + P * Pp) * sizeof(float);
+    const int P = ts + 2 * r, Pp = P | 1, n = (2 * r + 1) * (2 * r + 1);
+    return (size_t)4 * ((ts * ts + P * Pp + 4 * n + 3) & ~3) * sizeof(float);
 }
 
 template <bool L1>
 static void bm_launch(const float* ref, int ref_pitch, const float* mov, int mh, int mw, int mov_pitch, float* flow,
                       int ny, int nx, int ts, int r, int mode, hipStream_t s) {
-    if (bm_wave_lds(ts, r) <= 48 * 1024) {
+    if (ts <= 32 && bm_wave_lds(ts, r) <= 56 * 1024) {
         const int ntiles = nx * ny;
-        hipLaunchKernelGGL(k_bm_wave<L1>, dim3(hhsr_cdiv(ntiles, 4)), dim3(256), bm_wave_lds(ts, r), s, ref, ref_pitch,
-                           mov, mh, mw, mov_pitch, flow, nx, ntiles, ts, r, mode);
+        const dim3 g(hhsr_cdiv(ntiles, 4)), b(256);
+        const size_t l = bm_wave_lds(ts, r);
+#define BMW(TS) hipLaunchKernelGGL((k_bm_wave<TS, L1>), g, b, l, s, ref, ref_pitch, mov, mh, mw, mov_pitch, flow, nx, \
+                                   ntiles, r, mode)
+        if (ts == 8) BMW(8);
+        else if (ts == 16) BMW(16);
+        else BMW(32);
+#undef BMW
     } else {  // large tiles (ts = 64): one workgroup per tile
         hipLaunchKernelGGL(k_block_match<L1>, dim3(nx, ny), dim3(256), bm_lds(ts, r), s, ref, ref_pitch, mov, mh, mw,
                            mov_pitch, flow, nx, ts, r, mode);
