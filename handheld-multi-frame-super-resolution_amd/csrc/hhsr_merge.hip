@@ -183,7 +183,9 @@ __device__ __forceinline__ FrameGeo frame_geom(const float2 fl, const Geo& g, co
 
 // The 9 taps of one frame -> absolute-parity accumulators n4/d4[row parity][col parity].
 // rawAt(di, dj): raw sample at (ci+di, cj+dj); covAt(k): covariance of cell k = (y0|y1, x0|x1).
-template <bool ISO, class RawAt, class CovAt>
+// REF = the reference frame's variant (merge.py:83-233): the inverse falls back to the identity when
+// |det| <= 1e-10 or NaN (linalg.py:53-64) instead of propagating NaN.
+template <bool ISO, bool REF, class RawAt, class CovAt>
 __device__ __forceinline__ void taps_accum(const FrameGeo& q, const Geo& g, const float local_r, RawAt rawAt,
                                            CovAt covAt, float n4[2][2], float d4[2][2]) {
     float ixx = 2.f, ixy = 0.f, iyy = 2.f;  // iso kernel: z = 2 (dx^2 + dy^2)
@@ -194,30 +196,42 @@ __device__ __forceinline__ void taps_accum(const FrameGeo& q, const Geo& g, cons
         const float txy = c00.y + fx * (c01.y - c00.y), bxy = c10.y + fx * (c11.y - c10.y);
         const float tyy = c00.w + fx * (c01.w - c00.w), byy = c10.w + fx * (c11.w - c10.w);
         const float cxx = txx + fy * (bxx - txx), cxy = txy + fy * (bxy - txy), cyy = tyy + fy * (byy - tyy);
-        const float inv_det = __builtin_amdgcn_rcpf(cxx * cyy - cxy * cxy);
+        const float det = cxx * cyy - cxy * cxy;
+        const float inv_det = __builtin_amdgcn_rcpf(det);
         ixx = inv_det * cyy;
         ixy = -inv_det * cxy;
         iyy = inv_det * cxx;
+        if (REF && !(fabsf(det) > 1e-10f)) {
+            ixx = 1.f;
+            ixy = 0.f;
+            iyy = 1.f;
+        }
     }
     const float dx0 = 0.5f - q.frx, dy0 = 0.5f - q.fry;  // tap - (lr_mov - 0.5) for the centre tap
-    const float kexp = -0.72134752044448170368f;          // -0.5 * log2(e)
+    // w = exp(-z/2) = exp2(z * kexp), kexp = -0.5*log2(e) folded into the quadratic form; since kexp < 0
+    // the clamp max(0, z) becomes min(0, kexp*z), which also maps NaN -> 0 -> w = 1 (D10).  The robustness
+    // factor is applied once to the four class sums instead of to every tap weight.
+    const float kexp = -0.72134752044448170368f;
+    ixx *= kexp;
+    ixy *= 2.f * kexp;
+    iyy *= kexp;
     float sv[2][2] = {{0.f, 0.f}, {0.f, 0.f}}, sa[2][2] = {{0.f, 0.f}, {0.f, 0.f}};  // by OFFSET parity
     const int ci = q.ci, cj = q.cj;
     const bool interior = ci >= 1 && ci + 1 < g.H && cj >= 1 && cj + 1 < g.W;
+    const float dxm = dx0 - 1.f, dxp = dx0 + 1.f;
 #pragma unroll
     for (int di = -1; di <= 1; ++di) {
         const float dy = dy0 + (float)di;
-        const float a = iyy * dy * dy, b = 2.f * ixy * dy;
+        const float a = iyy * dy * dy, b = ixy * dy;
 #pragma unroll
         for (int dj = -1; dj <= 1; ++dj) {
             if (!interior && (cj + dj < 0 || cj + dj >= g.W || ci + di < 0 || ci + di >= g.H)) continue;
             const float c = rawAt(di, dj);
-            const float dx = dx0 + (float)dj;
-            float z = fmaf(fmaf(ixx, dx, b), dx, a);
-            z = fmaxf(z, 0.f);  // NaN -> 0 -> w = 1 (Python max(0, z), D10)
-            const float wr = __builtin_amdgcn_exp2f(z * kexp) * local_r;
-            sv[di & 1][dj & 1] = fmaf(wr, c, sv[di & 1][dj & 1]);
-            sa[di & 1][dj & 1] += wr;
+            const float dx = dj < 0 ? dxm : (dj > 0 ? dxp : dx0);
+            const float z = fminf(fmaf(fmaf(ixx, dx, b), dx, a), 0.f);
+            const float w = __builtin_amdgcn_exp2f(z);
+            sv[di & 1][dj & 1] = fmaf(w, c, sv[di & 1][dj & 1]);
+            sa[di & 1][dj & 1] += w;
         }
     }
     // offset parity -> absolute raw-coordinate parity: swap columns / rows when the centre is odd
@@ -230,10 +244,10 @@ __device__ __forceinline__ void taps_accum(const FrameGeo& q, const Geo& g, cons
     }
 #pragma unroll
     for (int c = 0; c < 2; ++c) {
-        n4[0][c] += oi ? sv[1][c] : sv[0][c];
-        n4[1][c] += oi ? sv[0][c] : sv[1][c];
-        d4[0][c] += oi ? sa[1][c] : sa[0][c];
-        d4[1][c] += oi ? sa[0][c] : sa[1][c];
+        n4[0][c] = fmaf(local_r, oi ? sv[1][c] : sv[0][c], n4[0][c]);
+        n4[1][c] = fmaf(local_r, oi ? sv[0][c] : sv[1][c], n4[1][c]);
+        d4[0][c] = fmaf(local_r, oi ? sa[1][c] : sa[0][c], d4[0][c]);
+        d4[1][c] = fmaf(local_r, oi ? sa[0][c] : sa[1][c], d4[1][c]);
     }
 }
 
@@ -250,8 +264,42 @@ __device__ __forceinline__ void comp_accum_fast(const FramePtr f, const Geo& g, 
     const float4* __restrict__ r0 = ISO ? nullptr : f.cov + (size_t)q.y0 * g.gw;
     const float4* __restrict__ r1 = ISO ? nullptr : f.cov + (size_t)y1 * g.gw;
     const int x0 = q.x0, pitch = g.pitch;
-    taps_accum<ISO>(
+    taps_accum<ISO, false>(
         q, g, local_r, [=](int di, int dj) { return rawc[di * pitch + dj]; },
+        [=](int k) { return (k & 2 ? r1 : r0)[k & 1 ? x1 : x0]; }, n4, d4);
+}
+
+// Reference frame, float32 weights, no accumulated-robustness denoiser (merge.py:83-233 with rad = 1).
+// Position = idx/scale stored in float32 like the reference's local array; centre = round-half-even;
+// covariance cell from floor((pos - 0.5)/2) with the signed modf fraction (linalg.py:190-200).
+template <bool ISO>
+__device__ __forceinline__ void ref_accum_fast(const float* __restrict__ raw, const float4* __restrict__ cov,
+                                               const Geo& g, int oi, int oj, float n4[2][2], float d4[2][2]) {
+    const float pyf = (float)((double)oi / g.scale), pxf = (float)((double)oj / g.scale);
+    FrameGeo q;
+    q.cj = (int)rintf(pxf);
+    q.ci = (int)rintf(pyf);
+    q.frx = 0.5f - ((float)q.cj - pxf);  // so that dx0 = centre - pos (no half-pixel offset here, D7)
+    q.fry = 0.5f - ((float)q.ci - pyf);
+    q.valid = true;
+    q.x0 = q.y0 = 0;
+    q.fx = q.fy = 0.f;
+    int x1 = 0, y1 = 0;
+    if (!ISO) {
+        const float gy = (pyf - 0.5f) * 0.5f, gx = (pxf - 0.5f) * 0.5f;  // == float32((pos - 0.5)/2)
+        q.x0 = (int)fmaxf(floorf(gx), 0.f);
+        q.y0 = (int)fmaxf(floorf(gy), 0.f);
+        q.fx = gx - truncf(gx);
+        q.fy = gy - truncf(gy);
+        x1 = min(q.x0 + 1, g.gw - 1);
+        y1 = min(q.y0 + 1, g.gh - 1);
+    }
+    const float* __restrict__ rawc = raw + (size_t)q.ci * g.pitch + q.cj;
+    const float4* __restrict__ r0 = ISO ? nullptr : cov + (size_t)q.y0 * g.gw;
+    const float4* __restrict__ r1 = ISO ? nullptr : cov + (size_t)y1 * g.gw;
+    const int x0 = q.x0, pitch = g.pitch;
+    taps_accum<ISO, true>(
+        q, g, 1.0f, [=](int di, int dj) { return rawc[di * pitch + dj]; },
         [=](int k) { return (k & 2 ? r1 : r0)[k & 1 ? x1 : x0]; }, n4, d4);
 }
 
@@ -539,7 +587,7 @@ __global__ void __launch_bounds__(256) k_merge_burst_tile(BurstArgs a, Geo g, Cf
             const float* __restrict__ rc = s_raw + (q.ci - w.ry0) * RPITCH + (q.cj - w.rx0);
             const int lx0 = q.x0 - w.cx0, ly0 = q.y0 - w.cy0;
             const int lx1 = min(q.x0 + 1, g.gw - 1) - w.cx0, ly1 = min(q.y0 + 1, g.gh - 1) - w.cy0;
-            taps_accum<ISO>(
+            taps_accum<ISO, false>(
                 q, g, local_r, [=](int di, int dj) { return rc[di * RPITCH + dj]; },
                 [=](int k) { return s_cov[(k & 2 ? ly1 : ly0) * CWIN + (k & 1 ? lx1 : lx0)]; }, n4, d4);
         }
@@ -554,16 +602,8 @@ __global__ void __launch_bounds__(256) k_merge_burst_tile(BurstArgs a, Geo g, Cf
             d3[k] = den[o + k];
         }
     }
+    if (a.flags & HHSR_MERGE_DO_REF) ref_accum_fast<ISO>(a.ref_raw, a.ref_cov, g, hi, hj, n4, d4);
     classes_to_rgb(cfa, n4, d4, n3, d3);
-    if (a.flags & HHSR_MERGE_DO_REF) {
-        float val[3] = {0.f, 0.f, 0.f}, acc[3] = {0.f, 0.f, 0.f};
-        ref_contrib<ISO>(a.ref_raw, a.ref_cov, g, cfa, hi, hj, nullptr, 0, 0.0, 0.0, val, acc);
-#pragma unroll
-        for (int k = 0; k < 3; ++k) {
-            n3[k] += val[k];
-            d3[k] += acc[k];
-        }
-    }
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
         num[o + k] = (a.flags & HHSR_MERGE_DIVIDE) ? n3[k] / d3[k] : n3[k];

@@ -337,9 +337,9 @@ def test_merge_burst_equals_sequential(scale):
     utils.divide(num, den)
     out = torch.empty_like(num)
     merge.merge_burst(tf, T(ref), rc, out, None, cfa, cfg)
-    # same taps and weights; only the float32 association differs (parity-class sums over all frames vs
-    # per-frame R/G/B sums)
-    assert_close(N(out), N(num), 2e-6, 1e-7, "fused == sequential")
+    # same taps; the fused kernel sums parity classes over all frames and evaluates the reference frame's
+    # weights in float32 (merge_ref keeps the reference's float64 typing)
+    assert_close(N(out), N(num), 2e-5, 1e-6, "fused == sequential")
     # partial sums (the multi-GPU shape): shard A + shard B == all
     nA, dA = torch.empty_like(num), torch.empty_like(num)
     nB, dB = torch.empty_like(num), torch.empty_like(num)
@@ -356,6 +356,8 @@ def test_merge_burst_equals_sequential(scale):
     oracle.merge_ref(ref, oracle.estimate_kernels(ref, cfg), onum, oden, cfa, cfg)
     assert_close(N(num_seq), onum, 2e-5, 1e-6, "num vs oracle")
     assert_close(N(den_seq), oden, 2e-5, 1e-6, "den vs oracle")
+    with np.errstate(all="ignore"):
+        assert_close(N(out), onum / oden, 2e-5, 1e-6, "fused output vs oracle")
 
 
 def test_divide_add():
@@ -400,7 +402,7 @@ def test_e2e_golden_128(golden):
     cfg2.block_matching.tuning.factors = [1, 2, 2, 2]
     cfg2.hip = {"fused_merge": False}
     out2, _ = hsr.main(ref, comp, cfg2)
-    assert_close(N(out2), o, 2e-6, 1e-7, "sequential == fused")
+    assert_close(N(out2), o, 2e-5, 1e-6, "sequential == fused")
 
 
 @pytest.mark.parametrize("metric0", ["L1", "L2", "L1_ref_effective"])
@@ -487,7 +489,7 @@ def test_full_size_properties():
     cfg2.hip = {"fused_merge": False}
     out2, _ = hsr.main(ref, comp, cfg2)
     assert out.shape == (6000, 8000, 3)
-    assert bool((((out - out2).abs() <= 2e-6 * out2.abs() + 1e-7) | (out.isnan() & out2.isnan())).all())
+    assert bool((((out - out2).abs() <= 2e-5 * out2.abs() + 1e-6) | (out.isnan() & out2.isnan())).all())
     # (4) constant-colour scene (no noise) reproduces the colour: kernel regression is a partition of unity
     const = torch.full((H, W), 0.4, device=DEV)
     cfg3 = base_config(ts=16, scale=2, metrics=("L2", "L2", "L2", "L2"))
