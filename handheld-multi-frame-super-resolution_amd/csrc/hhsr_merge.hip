@@ -211,7 +211,11 @@ __device__ __forceinline__ void taps_accum(const FrameGeo& q, const Geo& g, cons
     // w = exp(-z/2) = exp2(z * kexp), kexp = -0.5*log2(e) folded into the quadratic form; since kexp < 0
     // the clamp max(0, z) becomes min(0, kexp*z), which also maps NaN -> 0 -> w = 1 (D10).  The robustness
     // factor is applied once to the four class sums instead of to every tap weight.
-    const float kexp = -0.72134752044448170368f;
+    // v_exp_f32 flushes results below 2^-126 to zero, but the reference keeps weights down to the float32
+    // denormal limit in its float32 accumulators (a far-off sample can be the ONLY sample of a colour in a
+    // border pixel's window: 1e-40/1e-40 is a colour, 0/0 is NaN).  So e = exp2(z/2) is evaluated with the
+    // hardware instruction (normal down to z = -252) and w = e*e underflows gradually (f32 denormals are on).
+    const float kexp = -0.36067376022224085184f;  // -0.25 * log2(e): exp(-q/2) = (exp2(q * kexp))^2
     ixx *= kexp;
     ixy *= 2.f * kexp;
     iyy *= kexp;
@@ -229,7 +233,8 @@ __device__ __forceinline__ void taps_accum(const FrameGeo& q, const Geo& g, cons
             const float c = rawAt(di, dj);
             const float dx = dj < 0 ? dxm : (dj > 0 ? dxp : dx0);
             const float z = fminf(fmaf(fmaf(ixx, dx, b), dx, a), 0.f);
-            const float w = __builtin_amdgcn_exp2f(z);
+            const float e = __builtin_amdgcn_exp2f(z);
+            const float w = e * e;
             sv[di & 1][dj & 1] = fmaf(w, c, sv[di & 1][dj & 1]);
             sa[di & 1][dj & 1] += w;
         }

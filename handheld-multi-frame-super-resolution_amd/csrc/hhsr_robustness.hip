@@ -90,6 +90,13 @@ __device__ __forceinline__ double dodgson(double x) {  // utils_image.py:399-406
     return 0.0;
 }
 
+__device__ __forceinline__ float dodgsonf(float x) {
+    const float a = fabsf(x);
+    if (a <= 0.5f) return fmaf(-2.0f * a, a, 1.0f);
+    if (a <= 1.5f) return fmaf(a, a, fmaf(-2.5f, a, 1.5f));
+    return 0.0f;
+}
+
 // Interpolates the three channels of a [3][lh][lw] map at raw pixel (y, x) displaced by (fx, fy).
 // Returns false (outside the guide image -> +inf, robustness.py:386-391) or true with out[3].
 __device__ __forceinline__ bool dodgson_sample(const float* __restrict__ LR, int lh, int lw, int y, int x, double fx,
@@ -231,11 +238,12 @@ __global__ void __launch_bounds__(256) k_rob_frame(const float* __restrict__ cm,
 constexpr int RF_T = 16, RF_W = 12;
 
 // Arithmetic of this fused kernel (vs the reference's Numba typing):
-//   * Dodgson weights and tap positions: float64, identical to the reference;
-//   * the warped mean is accumulated in float64 WITHOUT the reference's rounding of the float32 buffer
-//     after every tap (robustness.py:414-415) — the two differ by the reference's own rounding noise
-//     (<= 1e-7 relative on the means); this removes 54 float<->double conversions per pixel, which
-//     dominated the kernel (fp64 conversion rate), and the result is rounded to float32 once;
+//   * guide positions, the in/out-of-image test, the window centre (round-half-even) and the clamped tap
+//     coordinates: float64, identical decisions to the reference;
+//   * Dodgson weights and the weighted mean: float32 FMAs.  The reference evaluates the weights in
+//     float64 but rounds its float32 buffer after every tap (robustness.py:414-415), so its means already
+//     carry ~1e-7 relative rounding noise; float32 weights stay within that (this replaces ~150 fp64
+//     operations and 54 float<->double conversions per pixel, which bounded the kernel);
 //   * the noise-curve index is taken in float64 (exact same index as the reference); the shrink
 //     d^2/(d^2 + d_t^2) and sigma^2 sums are float32 (relative error 1e-7 on values that feed
 //     exp(-d^2/sigma^2));
@@ -247,7 +255,7 @@ __global__ void __launch_bounds__(256) k_rob_frame_tile(const float* __restrict_
                                                          const float* __restrict__ S, const double* __restrict__ stdc,
                                                          const double* __restrict__ difc, int ncurve, double t,
                                                          float* __restrict__ R, int H, int W) {
-    __shared__ double s_g[3][RF_W][RF_W + 1];
+    __shared__ float s_g[3][RF_W][RF_W + 1];
     const int bx = blockIdx.x * RF_T, by = blockIdx.y * RF_T;
     const int lx_ = threadIdx.x & (RF_T - 1), ly_ = threadIdx.x >> 4;
     const int x = bx + lx_, y = by + ly_;
@@ -263,7 +271,7 @@ __global__ void __launch_bounds__(256) k_rob_frame_tile(const float* __restrict_
         const int c = p / (RF_W * RF_W), q = p - c * RF_W * RF_W;
         const int i = q / RF_W, j = q - i * RF_W;
         const int gy = clampi(wy0 + i, 0, lh - 1), gx = clampi(wx0 + j, 0, lw - 1);
-        s_g[c][i][j] = (double)cm[c * gplane + (size_t)gy * lw + gx];
+        s_g[c][i][j] = cm[c * gplane + (size_t)gy * lw + gx];
     }
     // the reference-frame operands do not depend on the LDS window: issue their loads before the barrier
     const bool live = x < W && y < H;
@@ -282,27 +290,29 @@ __global__ void __launch_bounds__(256) k_rob_frame_tile(const float* __restrict_
     float cmu[3] = {INFINITY, INFINITY, INFINITY};
     if (ly >= 0.0 && ly < (double)lh && lx >= 0.0 && lx < (double)lw) {
         const int cy = (int)rint(ly), cx = (int)rint(lx);  // round-half-even
-        double wxv[3], b0 = 0.0, b1 = 0.0, b2 = 0.0, wacc = 0.0;
+        const float ry = (float)((double)cy - ly), rx = (float)((double)cx - lx);  // in [-0.5, 0.5]
+        float wxv[3], b0 = 0.f, b1 = 0.f, b2 = 0.f, wacc = 0.f;
 #pragma unroll
-        for (int j = -1; j <= 1; ++j) wxv[j + 1] = dodgson((double)clampi(cx + j, 0, lw - 1) - lx);
+        for (int j = -1; j <= 1; ++j)  // tap coordinate clamped to the guide image (robustness.py:407)
+            wxv[j + 1] = dodgsonf(rx + (float)(clampi(cx + j, 0, lw - 1) - cx));
 #pragma unroll
         for (int i = -1; i <= 1; ++i) {
-            const double wy = dodgson((double)clampi(cy + i, 0, lh - 1) - ly);
+            const float wy = dodgsonf(ry + (float)(clampi(cy + i, 0, lh - 1) - cy));
             const int wi = cy + i - wy0;
 #pragma unroll
             for (int j = -1; j <= 1; ++j) {
-                const double w = wy * wxv[j + 1];
+                const float w = wy * wxv[j + 1];
                 const int wj = cx + j - wx0;
-                b0 += s_g[0][wi][wj] * w;
-                b1 += s_g[1][wi][wj] * w;
-                b2 += s_g[2][wi][wj] * w;
+                b0 = fmaf(s_g[0][wi][wj], w, b0);
+                b1 = fmaf(s_g[1][wi][wj], w, b1);
+                b2 = fmaf(s_g[2][wi][wj], w, b2);
                 wacc += w;
             }
         }
-        const double iw = 1.0 / wacc;
-        cmu[0] = (float)(b0 * iw);
-        cmu[1] = (float)(b1 * iw);
-        cmu[2] = (float)(b2 * iw);
+        const float iw = 1.0f / wacc;
+        cmu[0] = b0 * iw;
+        cmu[1] = b1 * iw;
+        cmu[2] = b2 * iw;
     }
     float d_sq = 0.f, s_sq = 0.f;
 #pragma unroll
