@@ -70,6 +70,18 @@ class HipEngine:
         return acc[0]
 
 
+def _reduce_sum(t, dst, group):
+    """Sum-reduce to `dst`.  RCCL ("nccl") reduces device tensors in place over xGMI; a host-only backend
+    (gloo, used by the CPU tests) gets a staged copy."""
+    if t.is_cuda and dist.get_backend(group) != "nccl":
+        h = t.cpu()
+        dist.reduce(h, dst=dst, op=dist.ReduceOp.SUM, group=group)
+        t.copy_(h)
+        return t
+    dist.reduce(t, dst=dst, op=dist.ReduceOp.SUM, group=group)
+    return t
+
+
 def main_sharded(ref_img, comp_imgs, config, group=None, engine=None):
     """Frame-sharded equivalent of main().  Returns (output, debug_dict) on rank 0 and (None, {}) on
     the other ranks.  Works un-initialised / with world_size 1 (then it is main() without collectives)."""
@@ -80,10 +92,10 @@ def main_sharded(ref_img, comp_imgs, config, group=None, engine=None):
     mine = [comp_imgs[i] for i in shard_indices(len(comp_imgs), rank, world)]
     acc, acc_r = eng.partial(mine)
     if world > 1:
-        dist.reduce(acc, dst=dist.get_global_rank(group, 0) if group is not None else 0, op=dist.ReduceOp.SUM, group=group)
+        dst = dist.get_global_rank(group, 0) if group is not None else 0
+        acc = _reduce_sum(acc, dst, group)
         if acc_r is not None:
-            dist.reduce(acc_r, dst=dist.get_global_rank(group, 0) if group is not None else 0, op=dist.ReduceOp.SUM,
-                        group=group)
+            acc_r = _reduce_sum(acc_r, dst, group)
     if rank != 0:
         return None, {}
     out = eng.finish(acc, acc_r)
