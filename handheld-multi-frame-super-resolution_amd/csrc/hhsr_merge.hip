@@ -448,7 +448,16 @@ struct BurstArgs {
     const float* ref_raw;
     const float4* ref_cov;
     int flags;
+    float* acc_r;  // optional [H][W]: sum of the frames' robustness (integer scales only)
+    int iscale;    // (int)scale when acc_r is used
 };
+
+// The HR pixels with hi % s == 0 and hj % s == 0 map one-to-one onto the LR pixels (integer scale s): they
+// carry the accumulated robustness sum_n r_n of "their" LR pixel (super_resolution.py:158-159), which costs
+// no extra HBM traffic here because r is read for the merge anyway.
+__device__ __forceinline__ bool owns_lr_pixel(const BurstArgs& a, int hi, int hj) {
+    return a.acc_r != nullptr && (hi % a.iscale) == 0 && (hj % a.iscale) == 0;
+}
 
 template <typename WT, int GEOM, bool ISO>
 __global__ void __launch_bounds__(256) k_merge_burst(BurstArgs a, Geo g, Cfa4 cfa, float* __restrict__ num,
@@ -463,6 +472,12 @@ __global__ void __launch_bounds__(256) k_merge_burst(BurstArgs a, Geo g, Cfa4 cf
             n3[k] = num[o + k];
             d3[k] = den[o + k];
         }
+    }
+    if (owns_lr_pixel(a, hi, hj)) {
+        const Pix p = make_pix(g, hi, hj);
+        float racc = (a.flags & HHSR_MERGE_LOAD_ACC) ? a.acc_r[p.ridx] : 0.f;
+        for (int n = 0; n < a.n; ++n) racc += a.f[n].r[p.ridx];
+        a.acc_r[p.ridx] = racc;
     }
     if (sizeof(WT) == 4) {
         // fast path: parity-class sums over all frames, mapped to R/G/B once
@@ -528,6 +543,7 @@ __global__ void __launch_bounds__(256) k_merge_burst_tile(BurstArgs a, Geo g, Cf
     const Pix p = make_pix(g, min(hi, g.sH - 1), min(hj, g.sW - 1));
     const int tile = p0.tile;  // uniform: the workgroup lies inside one flow tile
     float n4[2][2] = {{0.f, 0.f}, {0.f, 0.f}}, d4[2][2] = {{0.f, 0.f}, {0.f, 0.f}};
+    float racc = 0.f;  // sum of this pixel's robustness over the frames
 
     // staging slots of this thread: raw window elements tid and tid+256, covariance element tid
     const int e0 = threadIdx.x, e1 = threadIdx.x + 256;
@@ -587,6 +603,7 @@ __global__ void __launch_bounds__(256) k_merge_burst_tile(BurstArgs a, Geo g, Cf
         const float local_r = plr;
         __syncthreads();
         if (n + 1 < a.n) prefetch(n + 1);  // in flight while this frame's taps are evaluated
+        racc += local_r;
         const FrameGeo q = frame_geom<GEOM, ISO>(fl, g, p);
         if (live && q.valid && local_r != 0.f) {
             const float* __restrict__ rc = s_raw + (q.ci - w.ry0) * RPITCH + (q.cj - w.rx0);
@@ -598,6 +615,8 @@ __global__ void __launch_bounds__(256) k_merge_burst_tile(BurstArgs a, Geo g, Cf
         }
     }
     if (!live) return;
+    if (owns_lr_pixel(a, hi, hj))
+        a.acc_r[p.ridx] = ((a.flags & HHSR_MERGE_LOAD_ACC) ? a.acc_r[p.ridx] : 0.f) + racc;
     const size_t o = ((size_t)hi * g.sW + hj) * 3;
     float n3[3] = {0.f, 0.f, 0.f}, d3[3] = {0.f, 0.f, 0.f};
     if (a.flags & HHSR_MERGE_LOAD_ACC) {
@@ -680,8 +699,8 @@ extern "C" int hhsr_accumulate_ref(const float* raw, int H, int W, int pitch, co
 extern "C" int hhsr_merge_burst(const float* const* raws, const float* const* flows, const float* const* covs,
                                 const float* const* rs, int n_frames, int H, int W, int pitch, int ny, int nx,
                                 int ts, const float* ref_raw, const float* ref_covs, const uint8_t cfa[4],
-                                double scale, int kflags, int flags, float* num, float* den, int sH, int sW,
-                                void* stream) {
+                                double scale, int kflags, int flags, float* num, float* den, float* acc_r, int sH,
+                                int sW, void* stream) {
     const int iso = kflags & HHSR_KERNEL_ISO, f64 = kflags & HHSR_WEIGHT_F64;
     HHSR_ARG(n_frames >= 0 && n_frames <= HHSR_MAX_FRAMES && cfa && num);
     HHSR_ARG(n_frames == 0 || (raws && flows && rs && (iso || covs)));
@@ -698,6 +717,9 @@ extern "C" int hhsr_merge_burst(const float* const* raws, const float* const* fl
                           iso ? nullptr : reinterpret_cast<const float4*>(covs[n]), rs[n]};
     }
     for (int n = n_frames; n < HHSR_MAX_FRAMES; ++n) a.f[n] = FramePtr{nullptr, nullptr, nullptr, nullptr};
+    HHSR_ARG(!acc_r || ((double)(int)scale == scale && n_frames > 0));  // LR <-> HR pixel ownership needs an integer scale
+    a.acc_r = acc_r;
+    a.iscale = (int)scale;
     a.n = n_frames;
     a.ref_raw = ref_raw;
     a.ref_cov = reinterpret_cast<const float4*>(ref_covs);

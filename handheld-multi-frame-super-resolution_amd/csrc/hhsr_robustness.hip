@@ -186,13 +186,45 @@ extern "C" int hhsr_rob_s(const float* flow, int ny, int nx, float Mt, float s1,
     HHSR_LAUNCHED();
 }
 
-// ---- fused per-frame robustness -> R ----------------------------------------------------------------
+// ---- frame-independent part of the noise model (robustness.py:505-528) ------------------------------
+// sigma^2(p) = sum_c max(var_c(p), sigma_t(b_c(p))^2) depends only on the reference frame: computed once per
+// burst (float64 sum like the reference, stored float32) instead of once per frame — the per-frame kernel
+// then reads 4 raw-resolution planes (3 means + sigma^2) instead of 6.
+__global__ void __launch_bounds__(256) k_rob_sigma(const float* __restrict__ rmean, const float* __restrict__ rvar,
+                                                    const double* __restrict__ stdc, int ncurve,
+                                                    float* __restrict__ ssq, size_t n) {
+    const size_t o = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (o >= n) return;
+    double s_sq = 0.0;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        const float b = rmean[c * n + o];
+        int id = 0;
+        const double bb = 1000.0 * (double)b;
+        if (isfinite(bb)) id = clampi((int)rint(bb), 0, ncurve - 1);  // non-finite (D6 border): see k_rob_frame
+        const double s_t = stdc[id];
+        const double sp = (double)rvar[c * n + o];
+        const double st2 = s_t * s_t;
+        s_sq += (st2 > sp) ? st2 : sp;  // Python max(sigma_p_sq, sigma_t^2)
+    }
+    ssq[o] = (float)s_sq;
+}
+
+extern "C" int hhsr_rob_sigma(const float* ref_means, const float* ref_vars, int H, int W, const double* std_curve,
+                              int ncurve, float* sigma_sq, void* stream) {
+    HHSR_ARG(ref_means && ref_vars && std_curve && sigma_sq && H > 0 && W > 0 && ncurve > 0);
+    const size_t n = (size_t)H * W;
+    hipLaunchKernelGGL(k_rob_sigma, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, ref_means,
+                       ref_vars, std_curve, ncurve, sigma_sq, n);
+    HHSR_LAUNCHED();
+}
+
+// ---- fused per-frame robustness -> R (generic tile sizes) ---------------------------------------------
 __global__ void __launch_bounds__(256) k_rob_frame(const float* __restrict__ cm, int lh, int lw,
-                                                    const float* __restrict__ rmean, const float* __restrict__ rvar,
+                                                    const float* __restrict__ rmean, const float* __restrict__ ssq,
                                                     const float2* __restrict__ flow, int nx, int ts,
-                                                    const float* __restrict__ S, const double* __restrict__ stdc,
-                                                    const double* __restrict__ difc, int ncurve, double t,
-                                                    float* __restrict__ R, int H, int W) {
+                                                    const float* __restrict__ S, const double* __restrict__ difc,
+                                                    int ncurve, double t, float* __restrict__ R, int H, int W) {
     const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
     if (x >= W || y >= H) return;
     const int tix = x / ts, tiy = y / ts;
@@ -201,7 +233,7 @@ __global__ void __launch_bounds__(256) k_rob_frame(const float* __restrict__ cm,
     const bool inb = dodgson_sample(cm, lh, lw, y, x, (double)f.x, (double)f.y, cmu);
     if (!inb) cmu[0] = cmu[1] = cmu[2] = INFINITY;
     const size_t plane = (size_t)H * W, o = (size_t)y * W + x;
-    double d_sq = 0.0, s_sq = 0.0;
+    double d_sq = 0.0;
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
         const float b = rmean[c * plane + o];
@@ -212,16 +244,13 @@ __global__ void __launch_bounds__(256) k_rob_frame(const float* __restrict__ cm,
         int id = 0;
         const double bb = 1000.0 * (double)b;
         if (isfinite(bb)) id = clampi((int)rint(bb), 0, ncurve - 1);
-        const double d_t = difc[id], s_t = stdc[id];
-        const double sp = (double)rvar[c * plane + o];
-        const double st2 = s_t * s_t;
-        s_sq += (st2 > sp) ? st2 : sp;  // Python max(sigma_p_sq, sigma_t^2)
+        const double d_t = difc[id];
         const float dp2f = dp * dp;
         const double dp2 = (double)dp2f;
         const double shrink = dp2 / (dp2 + d_t * d_t);
         d_sq += dp2 * shrink * shrink;
     }
-    const float dsf = (float)d_sq, ssf = (float)s_sq;
+    const float dsf = (float)d_sq, ssf = ssq[o];
     // R = clamp(S * exp(-d^2/sigma^2) - t, 0, 1), float32 up to the subtraction (robustness.py:636-639)
     const float e = expf(-dsf / ssf);
     double v = (double)(S[(size_t)tiy * nx + tix] * e) - t;
@@ -250,9 +279,9 @@ constexpr int RF_T = 16, RF_W = 12;
 // Net effect on R: <= 1e-4 absolute on the few pixels in the transition band 0 < R < 1 (tests: 1e-4).
 __global__ void __launch_bounds__(256) k_rob_frame_tile(const float* __restrict__ cm, int lh, int lw,
                                                          const float* __restrict__ rmean,
-                                                         const float* __restrict__ rvar,
+                                                         const float* __restrict__ ssq,
                                                          const float2* __restrict__ flow, int nx, int ts,
-                                                         const float* __restrict__ S, const double* __restrict__ stdc,
+                                                         const float* __restrict__ S,
                                                          const double* __restrict__ difc, int ncurve, double t,
                                                          float* __restrict__ R, int H, int W) {
     __shared__ float s_g[3][RF_W][RF_W + 1];
@@ -276,12 +305,10 @@ __global__ void __launch_bounds__(256) k_rob_frame_tile(const float* __restrict_
     // the reference-frame operands do not depend on the LDS window: issue their loads before the barrier
     const bool live = x < W && y < H;
     const size_t plane = (size_t)H * W, o = live ? (size_t)y * W + x : 0;
-    float rb[3], rv[3];
+    float rb[3];
 #pragma unroll
-    for (int c = 0; c < 3; ++c) {
-        rb[c] = rmean[c * plane + o];
-        rv[c] = rvar[c * plane + o];
-    }
+    for (int c = 0; c < 3; ++c) rb[c] = rmean[c * plane + o];
+    const float s_sq = ssq[o];
     const float Sv = S[(size_t)tiy * nx + tix];
     __syncthreads();
     if (!live) return;
@@ -314,7 +341,7 @@ __global__ void __launch_bounds__(256) k_rob_frame_tile(const float* __restrict_
         cmu[1] = b1 * iw;
         cmu[2] = b2 * iw;
     }
-    float d_sq = 0.f, s_sq = 0.f;
+    float d_sq = 0.f;
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
         const float b = rb[c];
@@ -322,9 +349,7 @@ __global__ void __launch_bounds__(256) k_rob_frame_tile(const float* __restrict_
         int id = 0;
         const double bb = 1000.0 * (double)b;  // index decided in float64 like the reference
         if (isfinite(bb)) id = clampi((int)rint(bb), 0, ncurve - 1);
-        const float d_t = (float)difc[id], s_t = (float)stdc[id];
-        const float st2 = s_t * s_t;
-        s_sq += (st2 > rv[c]) ? st2 : rv[c];
+        const float d_t = (float)difc[id];
         const float dp2 = dp * dp;
         const float shrink = dp2 / (dp2 + d_t * d_t);
         d_sq += dp2 * shrink * shrink;
@@ -337,21 +362,20 @@ __global__ void __launch_bounds__(256) k_rob_frame_tile(const float* __restrict_
 }
 
 extern "C" int hhsr_rob_frame(const float* comp_means, int lh, int lw, const float* ref_means,
-                              const float* ref_vars, const float* flow, int ny, int nx, int ts, const float* S,
-                              const double* std_curve, const double* diff_curve, int ncurve, double t, float* R,
-                              void* stream) {
-    HHSR_ARG(comp_means && ref_means && ref_vars && flow && S && std_curve && diff_curve && R);
+                              const float* ref_sigma_sq, const float* flow, int ny, int nx, int ts, const float* S,
+                              const double* diff_curve, int ncurve, double t, float* R, void* stream) {
+    HHSR_ARG(comp_means && ref_means && ref_sigma_sq && flow && S && diff_curve && R);
     HHSR_ARG(lh > 0 && lw > 0 && ts > 0 && ncurve > 0);
     const int H = 2 * lh, W = 2 * lw;
     HHSR_ARG(ny * ts >= H && nx * ts >= W);
     if (ts % RF_T == 0)
         hipLaunchKernelGGL(k_rob_frame_tile, dim3(hhsr_cdiv(W, RF_T), hhsr_cdiv(H, RF_T)), dim3(256), 0,
-                           (hipStream_t)stream, comp_means, lh, lw, ref_means, ref_vars,
-                           reinterpret_cast<const float2*>(flow), nx, ts, S, std_curve, diff_curve, ncurve, t, R, H, W);
+                           (hipStream_t)stream, comp_means, lh, lw, ref_means, ref_sigma_sq,
+                           reinterpret_cast<const float2*>(flow), nx, ts, S, diff_curve, ncurve, t, R, H, W);
     else
         hipLaunchKernelGGL(k_rob_frame, dim3(hhsr_cdiv(W, 64), hhsr_cdiv(H, 4)), dim3(256), 0, (hipStream_t)stream,
-                           comp_means, lh, lw, ref_means, ref_vars, reinterpret_cast<const float2*>(flow), nx, ts, S,
-                           std_curve, diff_curve, ncurve, t, R, H, W);
+                           comp_means, lh, lw, ref_means, ref_sigma_sq, reinterpret_cast<const float2*>(flow), nx, ts,
+                           S, diff_curve, ncurve, t, R, H, W);
     HHSR_LAUNCHED();
 }
 

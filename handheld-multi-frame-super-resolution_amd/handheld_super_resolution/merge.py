@@ -44,13 +44,19 @@ def merge_ref(ref_img, kernels, num, den, cfa_pattern, config, acc_rob=None):
               scale, kflags, _lib.ptr(acc), rad_max, mult, mfc, _lib.ptr(num), _lib.ptr(den), sH, sW, _lib.stream())
 
 
+def can_fuse_acc_r(config):
+    """merge_burst can also produce the accumulated robustness (integer scales)."""
+    return float(config.scale).is_integer()
+
+
 def merge_burst(frames, ref_img, ref_kernels, num, den, cfa_pattern, config, load_acc=False, do_ref=True,
-                divide=True, store_den=False):
+                divide=True, store_den=False, acc_r=None):
     """Fused merge of a whole (shard of a) burst: `frames` is a list of (raw, flow, covs, r).  Per output
     pixel the frames are summed in list order with the accumulators in registers — the same float32
     order as successive merge() calls — then the reference frame is added and the result normalised,
     writing `num` once.  Not usable with the accumulated-robustness denoiser (its
-    overwrite rule needs the sequential merge_ref)."""
+    overwrite rule needs the sequential merge_ref).  `acc_r` (float32 [H, W], integer scales) receives the sum
+    of the frames' robustness maps in the same pass."""
     scale, kflags = _common(config)
     if do_ref and config.accumulated_robustness_denoiser.enabled:
         raise ValueError("merge_burst cannot apply the accumulated robustness denoiser; use merge_ref")
@@ -76,4 +82,4 @@ def merge_burst(frames, ref_img, ref_kernels, num, den, cfa_pattern, config, loa
                   _lib.ptr_array([c[2] for c in chunk]), _lib.ptr_array([c[3] for c in chunk]), len(chunk),
                   H, W, W, ny, nx, int(ts), _lib.ptr(ref_img if (f & 2) else None),
                   _lib.ptr(ref_kernels if (f & 2) else None), cfa, scale, kflags, f, _lib.ptr(num), _lib.ptr(den),
-                  sH, sW, _lib.stream())
+                  _lib.ptr(acc_r if chunk else None), sH, sW, _lib.stream())

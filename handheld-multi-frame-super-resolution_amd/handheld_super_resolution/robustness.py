@@ -77,8 +77,18 @@ def noise_curves_to_device(std_curve, diff_curve, device):
     return s.contiguous(), d.contiguous()
 
 
+def noise_sigma_sq(ref_local_means, ref_local_stds, std_curve):
+    """sigma^2 = sum_c max(var_c, sigma_t(mu_c)^2) of the reference frame (robustness.py:505-528): it does
+    not depend on the compared frame, so a burst computes it once."""
+    _, H, W = ref_local_means.shape
+    out = torch.empty((H, W), dtype=torch.float32, device=ref_local_means.device)
+    _lib.call("hhsr_rob_sigma", _lib.ptr(ref_local_means), _lib.ptr(ref_local_stds), H, W, _lib.ptr(std_curve),
+              int(std_curve.numel()), _lib.ptr(out), _lib.stream())
+    return out
+
+
 def compute_robustness(comp_img, ref_local_means, ref_local_stds, flows, cfa_pattern, white_balance, noise_model,
-                       config, return_R=False, accumulate_into=None):
+                       config, return_R=False, accumulate_into=None, ref_sigma_sq=None):
     """Alg. 6 (robustness.py:79-170): r float32 [H, W].  3 kernels instead of the reference's 8:
     guide + local stats; fused warp-upsample / colour distance / noise model / threshold; 5x5 min."""
     comp_img = _lib.f32c(comp_img)
@@ -95,11 +105,13 @@ def compute_robustness(comp_img, ref_local_means, ref_local_stds, flows, cfa_pat
     assert std_curve.dtype == torch.float64 and diff_curve.dtype == torch.float64 and std_curve.is_cuda
     H, W = comp_img.shape
     ny, nx, _ = flows.shape
+    if ref_sigma_sq is None:  # a BurstPipeline passes the per-burst map; stand-alone callers get it here
+        ref_sigma_sq = noise_sigma_sq(ref_local_means, ref_local_stds, std_curve)
     cm, _ = compute_local_stats_from_raw(comp_img, cfa_pattern, white_balance)
     S = compute_s(flows, t.Mt, t.s1, t.s2)
     R = torch.empty((H, W), dtype=torch.float32, device=comp_img.device)
-    _lib.call("hhsr_rob_frame", _lib.ptr(cm), H // 2, W // 2, _lib.ptr(ref_local_means), _lib.ptr(ref_local_stds),
-              _lib.ptr(flows), ny, nx, int(ts), _lib.ptr(S), _lib.ptr(std_curve), _lib.ptr(diff_curve),
-              int(std_curve.numel()), float(t.t), _lib.ptr(R), _lib.stream())
+    _lib.call("hhsr_rob_frame", _lib.ptr(cm), H // 2, W // 2, _lib.ptr(ref_local_means), _lib.ptr(ref_sigma_sq),
+              _lib.ptr(flows), ny, nx, int(ts), _lib.ptr(S), _lib.ptr(diff_curve), int(diff_curve.numel()),
+              float(t.t), _lib.ptr(R), _lib.stream())
     r = local_min(R, accumulate_into)
     return (r, R) if return_R else r

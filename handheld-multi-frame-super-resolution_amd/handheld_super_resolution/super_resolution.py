@@ -20,9 +20,9 @@ from .utils_image import compute_grey_images
 from .utils import divide, add, getTime
 from .alignment import align, init_alignment
 from .params import sanitize_config, update_snr_config
-from .robustness import init_robustness, compute_robustness, noise_curves_to_device
+from .robustness import init_robustness, compute_robustness, noise_curves_to_device, noise_sigma_sq
 from .kernels import estimate_kernels
-from .merge import merge, merge_ref, merge_burst
+from .merge import merge, merge_ref, merge_burst, can_fuse_acc_r
 
 
 def denoiser_enabled(config):
@@ -33,6 +33,10 @@ def denoiser_enabled(config):
         return bool(den.enabled)
     den.enabled = bool(den.median.enabled or den.gauss.enabled or den.merge.enabled)
     return den.enabled
+
+
+def n_images_of(comp_imgs):
+    return len(comp_imgs)
 
 
 def _device():
@@ -63,6 +67,8 @@ class BurstPipeline:
         grey = compute_grey_images(self.ref, self.grey_method)
         self.align_state = init_alignment(grey, cfg)
         self.ref_means, self.ref_vars = init_robustness(self.ref, self.cfa, self.wb, cfg)
+        self.ref_sigma_sq = (noise_sigma_sq(self.ref_means, self.ref_vars, self.curves[0])
+                             if cfg.robustness.enabled else None)
         self.grey_ref = grey
         return self
 
@@ -74,7 +80,7 @@ class BurstPipeline:
         grey = compute_grey_images(raw, self.grey_method)
         flow = align(*self.align_state, grey, cfg)
         r = compute_robustness(raw, self.ref_means, self.ref_vars, flow, self.cfa, self.wb, self.curves, cfg,
-                               accumulate_into=accumulate_r)
+                               accumulate_into=accumulate_r, ref_sigma_sq=self.ref_sigma_sq)
         covs = estimate_kernels(raw, cfg)
         return raw, flow, covs, r
 
@@ -109,6 +115,7 @@ def main(ref_img, comp_imgs, config):
     H, W = pipe.ref.shape
     sH, sW = pipe.output_size()
     accumulated_r = torch.zeros((H, W), dtype=torch.float32, device=dev) if accumulate_r else None
+    fuse_acc = accumulate_r and fused and can_fuse_acc_r(config) and n_images_of(comp_imgs) > 0
     num = torch.empty((sH, sW, 3), dtype=torch.float32, device=dev)
     den = None
     if not fused:
@@ -125,7 +132,7 @@ def main(ref_img, comp_imgs, config):
             torch.cuda.synchronize()
             print("\nProcessing image {} ---------\n".format(im_id + 1))
             im_time = time.perf_counter()
-        raw, flow, covs, r = pipe.process_frame(comp_imgs[im_id], accumulated_r)
+        raw, flow, covs, r = pipe.process_frame(comp_imgs[im_id], None if fuse_acc else accumulated_r)
         if fused:
             frames.append((raw, flow, covs, r))
         else:
@@ -139,7 +146,8 @@ def main(ref_img, comp_imgs, config):
 
     ref_covs = estimate_kernels(pipe.ref, config)
     if fused:
-        merge_burst(frames, pipe.ref, ref_covs, num, None, pipe.cfa, config, do_ref=True, divide=True)
+        merge_burst(frames, pipe.ref, ref_covs, num, None, pipe.cfa, config, do_ref=True, divide=True,
+                    acc_r=accumulated_r if fuse_acc else None)
     else:
         merge_ref(pipe.ref, ref_covs, num, den, pipe.cfa, config, accumulated_r if denoiser_on else None)
         divide(num, den)

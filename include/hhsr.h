@@ -117,13 +117,16 @@ int hhsr_rob_upscale(const float* stats, int lh, int lw, const float* flow, int 
                      float* out, void* stream);
 /* Per-tile flow-irregularity map S (robustness.py:570-612). */
 int hhsr_rob_s(const float* flow, int ny, int nx, float Mt, float s1, float s2, float* S, void* stream);
-/* Fused warp-upsample of the frame's guide means + colour distance + noise model + threshold
+/* Frame-independent noise-model term (robustness.py:505-528, once per burst):
+ * sigma_sq[p] = sum_c max(ref_vars[c][p], std_curve[round(1000 ref_means[c][p])]^2), float32 [H][W]. */
+int hhsr_rob_sigma(const float* ref_means, const float* ref_vars, int H, int W,
+                   const double* std_curve, int ncurve, float* sigma_sq, void* stream);
+/* Fused warp-upsample of the frame's guide means + colour distance + noise-model shrink + threshold
  * (robustness.py:359-421, 453-461, 505-528, 627-639) -> R float32 [2lh][2lw].
- * std_curve / diff_curve: device double[ncurve]. */
-int hhsr_rob_frame(const float* comp_means, int lh, int lw, const float* ref_means, const float* ref_vars,
+ * ref_sigma_sq from hhsr_rob_sigma; diff_curve: device double[ncurve]. */
+int hhsr_rob_frame(const float* comp_means, int lh, int lw, const float* ref_means, const float* ref_sigma_sq,
                    const float* flow, int ny, int nx, int ts, const float* S,
-                   const double* std_curve, const double* diff_curve, int ncurve,
-                   double t, float* R, void* stream);
+                   const double* diff_curve, int ncurve, double t, float* R, void* stream);
 /* 5x5 clamp-border minimum (robustness.py:670-686).  acc_r != NULL additionally does acc_r += r
  * (the accumulated robustness of super_resolution.py:158-159, fused to save a pass). */
 int hhsr_local_min5(const float* R, int H, int W, float* r, float* acc_r, void* stream);
@@ -150,6 +153,8 @@ int hhsr_add(float* A, const float* B, int64_t n, void* stream);          /* A +
 /* Fused burst merge: for every HR pixel, sum the contributions of `n_frames` comp frames with the
  * accumulators held in registers (same left-to-right float32 order as n calls of hhsr_accumulate),
  * then optionally add the reference frame and normalise.  HOST arrays of device pointers.
+ * acc_r (optional, float32 [H][W], integer scales only) receives sum_n r_n — the accumulated robustness of
+ * super_resolution.py:158-159 — at no extra HBM traffic (+= with HHSR_MERGE_LOAD_ACC).
  * flags: */
 #define HHSR_MERGE_LOAD_ACC 1   /* start from the existing num/den instead of zero          */
 #define HHSR_MERGE_DO_REF 2     /* add the reference frame (ref_raw/ref_covs) after the comps */
@@ -159,7 +164,7 @@ int hhsr_merge_burst(const float* const* raws, const float* const* flows, const 
                      const float* const* rs, int n_frames, int H, int W, int pitch,
                      int ny, int nx, int ts, const float* ref_raw, const float* ref_covs,
                      const uint8_t cfa[4], double scale, int kflags, int flags,
-                     float* num, float* den, int sH, int sW, void* stream);
+                     float* num, float* den, float* acc_r, int sH, int sW, void* stream);
 
 #ifdef __cplusplus
 }
