@@ -43,10 +43,8 @@ class HipEngine:
         sH, sW = pipe.output_size()
         acc = torch.empty((2, sH, sW, 3), dtype=torch.float32, device=pipe.device)
         acc_r = torch.zeros(tuple(pipe.ref.shape), dtype=torch.float32, device=pipe.device) if self.accumulate_r else None
-        frames = []
         fuse_acc = acc_r is not None and can_fuse_acc_r(self.config) and len(comp_imgs) > 0
-        for img in comp_imgs:
-            frames.append(pipe.process_frame(img, None if fuse_acc else acc_r))
+        frames = pipe.process_frames(list(comp_imgs), None if fuse_acc else acc_r)
         if frames:
             merge_burst(frames, None, None, acc[0], acc[1], pipe.cfa, self.config, do_ref=False, divide=False,
                         store_den=True, acc_r=acc_r if fuse_acc else None)

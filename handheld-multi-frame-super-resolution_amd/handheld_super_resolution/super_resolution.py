@@ -46,6 +46,9 @@ def _device():
     return torch.device("cuda", torch.cuda.current_device())
 
 
+_stream_pool = {}  # device index -> side streams, shared by all pipelines of the process
+
+
 class BurstPipeline:
     """Device-resident state of one burst: reference-frame precompute + per-frame stage chain."""
 
@@ -59,6 +62,7 @@ class BurstPipeline:
         self.curves = noise_curves_to_device(config.noise_model.std_curve, config.noise_model.diff_curve, self.device)
         self.grey_method = config.grey_method
         self.ref = None
+        self._streams = _stream_pool.setdefault(self.device.index, [])
 
     def init_ref(self, ref_img):
         cfg = self.config
@@ -83,6 +87,38 @@ class BurstPipeline:
                                accumulate_into=accumulate_r, ref_sigma_sq=self.ref_sigma_sq)
         covs = estimate_kernels(raw, cfg)
         return raw, flow, covs, r
+
+    def process_frames(self, comp_imgs, accumulate_r=None, n_streams=None):
+        """process_frame() over a list of frames.  Frames are independent until the merge, so they are
+        issued round-robin on `n_streams` HIP streams (config.hip.streams, default 2): the launch-latency-
+        bound coarse pyramid levels of one frame overlap the bandwidth-bound kernels of another.  The caller's
+        stream waits for all of them before returning.  A per-frame `accumulate_r` (read-modify-write of one
+        map) forces a single stream."""
+        n = len(comp_imgs)
+        if n_streams is None:
+            hip = self.config.get("hip", None) if hasattr(self.config, "get") else None
+            n_streams = int(hip.get("streams", 2)) if hip is not None else 2
+        if n_streams <= 1 or accumulate_r is not None or n < 2:
+            return [self.process_frame(img, accumulate_r) for img in comp_imgs]
+        main = torch.cuda.current_stream(self.device)
+        if len(self._streams) < n_streams:
+            self._streams += [torch.cuda.Stream(self.device) for _ in range(n_streams - len(self._streams))]
+        pool = self._streams[:n_streams]
+        ready = torch.cuda.Event()
+        ready.record(main)
+        frames = []
+        for i in range(n):
+            s = pool[i % n_streams]
+            if i < n_streams:
+                s.wait_event(ready)  # reference-frame state was produced on the caller's stream
+            with torch.cuda.stream(s):
+                f = self.process_frame(comp_imgs[i])
+            for t in f[1:]:
+                t.record_stream(main)  # consumed by the merge on the caller's stream
+            frames.append(f)
+        for s in pool:
+            main.wait_stream(s)
+        return frames
 
     def output_size(self):
         s = self.config.scale
@@ -127,6 +163,9 @@ def main(ref_img, comp_imgs, config):
 
     frames = []
     n_images = len(comp_imgs)
+    if fused and not verbose and not debug_mode:
+        frames = pipe.process_frames([comp_imgs[i] for i in range(n_images)], None if fuse_acc else accumulated_r)
+        n_images = 0  # the per-frame loop below is the verbose / debug / sequential-merge path
     for im_id in range(n_images):
         if verbose:
             torch.cuda.synchronize()
