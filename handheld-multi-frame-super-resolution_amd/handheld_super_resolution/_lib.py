@@ -23,7 +23,7 @@ PP = C.POINTER(C.c_void_p)
 _SIGS = {
     "hhsr_lowpass_mask_c2c": [P, I, I, L, L, P],
     "hhsr_lowpass_mask_r2c": [P, I, I, L, L, P],
-    "hhsr_grey_plan_create": [I, I, PP],
+    "hhsr_grey_plan_create": [I, I, I, PP],
     "hhsr_grey_lowpass": [P, P, P, P],
     "hhsr_grey_plan_destroy": [P],
     "hhsr_pad_circular": [P, I, I, I, P, I, I, I, P],

@@ -10,9 +10,10 @@ class _GreyPlan:
 
     def __init__(self, H, W):
         import ctypes
+        import os
 
         h = ctypes.c_void_p()
-        _lib.call("hhsr_grey_plan_create", H, W, ctypes.byref(h))
+        _lib.call("hhsr_grey_plan_create", H, W, int(os.environ.get("HHSR_GREY_PLAN", "0")), ctypes.byref(h))
         self.handle = h
 
     def __del__(self):

@@ -55,7 +55,9 @@ int hhsr_lowpass_mask_r2c(float* spec, int H, int W, int64_t stride_y, int64_t s
  * hhsr_grey_plan_create is the ONE place the library allocates (the plan and its [H][W/2+1] spectrum
  * buffer, owned by the plan); a plan is mutable state: use it from one stream at a time.
  * Returns 1000 + hipfftResult on a hipFFT error. */
-int hhsr_grey_plan_create(int H, int W, void** plan_out);
+#define HHSR_GREY_PRUNED 1   /* batched row plans + strided column plans on the kept x-bins only (experiment) */
+#define HHSR_GREY_TPRUNED 2  /* row plans with a transposed spectrum + contiguous column plans on the kept bins */
+int hhsr_grey_plan_create(int H, int W, int flags, void** plan_out);
 int hhsr_grey_lowpass(void* plan, const float* src, float* dst, void* stream);
 int hhsr_grey_plan_destroy(void* plan);
 
