@@ -558,6 +558,235 @@ extern "C" int hhsr_ica(const float* ref, const float* gx, const float* gy, int 
     HHSR_LAUNCHED();
 }
 
+// ---- fused level kernel: block matching + ICA, one wave64 per tile ----------------------------------------
+// One launch per pyramid level instead of two (reference alignment.py:125-147).  Each wave stages
+//   * its reference tile with a 1-pixel halo (the [-1,0,1] gradients of ICA.py:20-21 are taken from it:
+//     zero outside the LEVEL, exactly the values hhsr_grad_hessian writes), and
+//   * ONE moving window of (TS + 2r + 2M + 1)^2 pixels around round(flow_in) that serves both the
+//     (2r+1)^2 block-matching candidates and the bilinear taps of the ICA iterations,
+// i.e. ~3.3 vector loads per pixel for the whole level step (separate kernels: ~7).  The window is staged
+// with the block-matching border rule (L2: clamp-to-edge, L1: zero-fill); ICA's own rule (zero outside /
+// clamped coordinates for TS = 8) differs only where the window leaves the moving level, and there
+// (wave-uniform test) the ICA taps are read from global memory with the exact rule.
+template <int TS, bool L1>
+__global__ void __launch_bounds__(256) k_align_wave(const float* __restrict__ ref, int rh, int rw, int ref_pitch,
+                                                     const float* __restrict__ hess, const float* __restrict__ mov,
+                                                     int mh, int mw, int mov_pitch, float* __restrict__ flow, int nx,
+                                                     int ntiles, int r, int mode, int n_iter) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    constexpr int M = ICA_M;
+    constexpr int RS = TS + 2, RP = RS | 1;            // reference tile + halo
+    constexpr int PPT = TS * TS / HHSR_WAVE > 0 ? TS * TS / HHSR_WAVE : 1;
+    const int wave = threadIdx.x / HHSR_WAVE, lane = threadIdx.x & (HHSR_WAVE - 1);
+    const int n1 = 2 * r + 1, n = n1 * n1, nparts = 4 * n;
+    const int WS = TS + 2 * r + 2 * M + 1, WP = WS | 1;  // moving window
+    const int slice = (RS * RP + WS * WP + nparts + 3) & ~3;
+    float* s_ref = lds + (size_t)wave * slice;
+    float* s_win = s_ref + RS * RP;
+    float* s_part = s_win + WS * WP;
+    const int tile = blockIdx.x * 4 + wave;
+    bool active = tile < ntiles;
+    const int tsafe = active ? tile : 0;
+    const int ty = tsafe / nx, tx = tsafe - ty * nx;
+    float* fl = flow + (size_t)tsafe * 2;
+    const float f0 = fl[0], f1 = fl[1];
+    const float r0 = rintf(f0), r1 = rintf(f1);  // round-half-even
+    const int ox = tx * TS + (int)r0 - r - M, oy = ty * TS + (int)r1 - r - M;  // window origin in the moving level
+    if (active) {
+        for (int p = lane; p < RS * RS; p += HHSR_WAVE) {
+            const int i = p / RS, j = p - i * RS;
+            const int y = ty * TS + i - 1, x = tx * TS + j - 1;
+            s_ref[i * RP + j] = (y >= 0 && y < rh && x >= 0 && x < rw) ? ref[(size_t)y * ref_pitch + x] : 0.f;
+        }
+        const float rcpW = 1.0f / (float)WS;
+        for (int p = lane; p < WS * WS; p += HHSR_WAVE) {
+            const int i = (int)(((float)p + 0.5f) * rcpW), j = p - i * WS;  // exact floor(p / WS)
+            const int y = oy + i, x = ox + j;
+            float v;
+            if (L1) v = (y >= 0 && y < mh && x >= 0 && x < mw) ? mov[(size_t)y * mov_pitch + x] : 0.f;
+            else v = mov[(size_t)clampi(y, 0, mh - 1) * mov_pitch + clampi(x, 0, mw - 1)];
+            s_win[i * WP + j] = v;
+        }
+    }
+    __syncthreads();
+    // ---------------- block matching ----------------
+    float nfx = f0, nfy = f1;  // flow after block matching
+    if (L1 && mode == 1) {     // "L1_ref_effective": flow <- round(flow)
+        nfx = r0;
+        nfy = r1;
+    } else {
+        CostIdx best{INFINITY, 0};
+        if (n <= 16) {
+            if (active) {
+                float rv[PPT];
+#pragma unroll
+                for (int k = 0; k < PPT; ++k) {
+                    const int p = lane + k * HHSR_WAVE;
+                    rv[k] = s_ref[(p / TS + 1) * RP + p % TS + 1];
+                }
+                for (int c = 0; c < n; ++c) {
+                    const int dy = c / n1, dx = c - dy * n1;
+                    float acc = 0.f;
+#pragma unroll
+                    for (int k = 0; k < PPT; ++k) {
+                        const int p = lane + k * HHSR_WAVE;
+                        const float d = rv[k] - s_win[(p / TS + dy + M) * WP + p % TS + dx + M];
+                        acc += L1 ? fabsf(d) : d * d;
+                    }
+#pragma unroll
+                    for (int o = 1; o < HHSR_WAVE; o <<= 1) acc += __shfl_xor(acc, o, HHSR_WAVE);
+                    if (acc < best.c) {
+                        best.c = acc;
+                        best.i = c;
+                    }
+                }
+            }
+        } else {
+            if (active) {
+                constexpr int QR = TS / 4;
+                for (int it = lane; it < nparts; it += HHSR_WAVE) {
+                    const int c = it >> 2, q = it & 3;
+                    const int dy = c / n1, dx = c - dy * n1;
+                    float acc = 0.f;
+                    for (int i = q * QR; i < (q + 1) * QR; ++i) {
+                        const float* wrow = s_win + (i + dy + M) * WP + dx + M;
+                        const float* rrow = s_ref + (i + 1) * RP + 1;
+#pragma unroll
+                        for (int j = 0; j < TS; ++j) {
+                            const float d = rrow[j] - wrow[j];
+                            acc += L1 ? fabsf(d) : d * d;
+                        }
+                    }
+                    s_part[it] = acc;
+                }
+            }
+            __syncthreads();
+            if (active) {
+                for (int c = lane; c < n; c += HHSR_WAVE) {
+                    const float tot = (s_part[4 * c] + s_part[4 * c + 1]) + (s_part[4 * c + 2] + s_part[4 * c + 3]);
+                    if (tot < best.c) {
+                        best.c = tot;
+                        best.i = c;
+                    }
+                }
+                best = wave_argmin(best);
+            }
+        }
+        const int dy = best.i / n1 - r, dx = best.i % n1 - r;
+        if (L1) {  // flow <- round(flow) + shift
+            nfx = r0 + (float)dx;
+            nfy = r1 + (float)dy;
+        } else {   // shift added to the UN-rounded flow
+            nfx = f0 + (float)dx;
+            nfy = f1 + (float)dy;
+        }
+    }
+    if (!active) return;
+    // ---------------- ICA ----------------
+    const float* h = hess + (size_t)tile * 4;
+    const float A00 = h[0], A01 = h[1], A10 = h[2], A11 = h[3];
+    const float det = A00 * A11 - A01 * A10;
+    float fxv = nfx, fyv = nfy;
+    if (!(fabsf(det) < 1e-10f)) {  // else: not solvable, the block-matching result stands (ICA.py:124-125)
+        const float det_inv = 1.0f / det;
+        float rc[PPT], lgx[PPT], lgy[PPT];
+#pragma unroll
+        for (int k = 0; k < PPT; ++k) {
+            const int p = lane + k * HHSR_WAVE;
+            const float* c = s_ref + (p / TS + 1) * RP + p % TS + 1;
+            rc[k] = c[0];
+            lgx[k] = c[1] - c[-1];
+            lgy[k] = c[RP] - c[-RP];
+        }
+        for (int it = 0; it < n_iter; ++it) {
+            const float tx_ = truncf(fxv), ty_ = truncf(fyv);
+            const float frx = fxv - tx_, fry = fyv - ty_;  // signed fraction of modf (D11)
+            const int ix = (int)tx_, iy = (int)ty_;
+            // LDS coordinates of the tile's first tap; usable when all taps are inside the staged window AND
+            // the tapped region lies inside the moving level (where every border rule agrees)
+            const int sx = tx * TS + ix - ox, sy = ty * TS + iy - oy;
+            const bool in_lds = sx >= 0 && sy >= 0 && sx + TS + 1 <= WS && sy + TS + 1 <= WS &&
+                                tx * TS + ix >= 0 && ty * TS + iy >= 0 && tx * TS + ix + TS < mw &&
+                                ty * TS + iy + TS < mh;
+            float B0 = 0.f, B1 = 0.f;
+#pragma unroll
+            for (int k = 0; k < PPT; ++k) {
+                const int p = lane + k * HHSR_WAVE;
+                const int i = p / TS, j = p % TS;
+                float m00, m01, m10, m11;
+                if (in_lds) {
+                    const float* w = s_win + (i + sy) * WP + (j + sx);
+                    m00 = w[0];
+                    m01 = w[1];
+                    m10 = w[WP];
+                    m11 = w[WP + 1];
+                } else if (TS == 8) {  // clamped coordinates (ICA.py:152-156)
+                    const int x0 = clampi(tx * TS + j + ix, 0, mw - 1), y0 = clampi(ty * TS + i + iy, 0, mh - 1);
+                    const int x1 = clampi(x0 + 1, 0, mw - 1), y1 = clampi(y0 + 1, 0, mh - 1);
+                    m00 = mov[(size_t)y0 * mov_pitch + x0];
+                    m01 = mov[(size_t)y0 * mov_pitch + x1];
+                    m10 = mov[(size_t)y1 * mov_pitch + x0];
+                    m11 = mov[(size_t)y1 * mov_pitch + x1];
+                } else {  // zero outside (ICA.py:240-243)
+                    const int x0 = tx * TS + j + ix, y0 = ty * TS + i + iy;
+                    const bool xa = x0 >= 0 && x0 < mw, xb = x0 + 1 >= 0 && x0 + 1 < mw;
+                    const bool ya = y0 >= 0 && y0 < mh, yb = y0 + 1 >= 0 && y0 + 1 < mh;
+                    m00 = (ya && xa) ? mov[(size_t)y0 * mov_pitch + x0] : 0.f;
+                    m01 = (ya && xb) ? mov[(size_t)y0 * mov_pitch + x0 + 1] : 0.f;
+                    m10 = (yb && xa) ? mov[(size_t)(y0 + 1) * mov_pitch + x0] : 0.f;
+                    m11 = (yb && xb) ? mov[(size_t)(y0 + 1) * mov_pitch + x0 + 1] : 0.f;
+                }
+                const float top = m00 + (m01 - m00) * frx;
+                const float bot = m10 + (m11 - m10) * frx;
+                const float gradt = (top + (bot - top) * fry) - rc[k];
+                B0 += -lgx[k] * gradt;
+                B1 += -lgy[k] * gradt;
+            }
+            B0 = wave_allsum(B0);
+            B1 = wave_allsum(B1);
+            fxv = fxv + det_inv * (A11 * B0 - A01 * B1);
+            fyv = fyv + det_inv * (-A10 * B0 + A00 * B1);
+        }
+    }
+    if (lane == 0) {
+        fl[0] = fxv;
+        fl[1] = fyv;
+    }
+}
+
+static size_t align_wave_lds(int ts, int r) {
+    const int RS = ts + 2, RP = RS | 1, WS = ts + 2 * r + 2 * ICA_M + 1, WP = WS | 1, n = (2 * r + 1) * (2 * r + 1);
+    return (size_t)4 * ((RS * RP + WS * WP + 4 * n + 3) & ~3) * sizeof(float);
+}
+
+extern "C" int hhsr_align_level(const float* ref, int rh, int rw, int ref_pitch, const float* hess, const float* mov,
+                                int mh, int mw, int mov_pitch, float* flow, int ny, int nx, int ts, int r, int metric,
+                                int n_iter, void* stream) {
+    HHSR_ARG(ref && hess && mov && flow && rh > 0 && rw > 0 && mh > 0 && mw > 0 && ny > 0 && nx > 0);
+    HHSR_ARG(r >= 0 && n_iter > 0 && metric >= 0 && metric <= 2);  // 0 = L2, 1 = L1 (intended), 2 = L1_ref_effective
+    HHSR_ARG(ts == 8 || ts == 16 || ts == 32);
+    HHSR_ARG(metric == 0 || ts >= 16);  // block_matching.py:87: no L1 search for 8-pixel tiles
+    HHSR_ARG(ny * ts <= rh && nx * ts <= rw);
+    const size_t l = align_wave_lds(ts, r);
+    HHSR_ARG(l <= 64 * 1024);
+    const int ntiles = nx * ny;
+    const dim3 g(hhsr_cdiv(ntiles, 4)), b(256);
+    hipStream_t s = (hipStream_t)stream;
+    const int mode = metric == 2 ? 1 : 0;
+#define ALW(TS, L1) hipLaunchKernelGGL((k_align_wave<TS, L1>), g, b, l, s, ref, rh, rw, ref_pitch, hess, mov, mh, mw, \
+                                       mov_pitch, flow, nx, ntiles, r, mode, n_iter)
+    if (metric == 0) {
+        if (ts == 8) ALW(8, false);
+        else if (ts == 16) ALW(16, false);
+        else ALW(32, false);
+    } else {
+        if (ts == 16) ALW(16, true);
+        else ALW(32, true);
+    }
+#undef ALW
+    HHSR_LAUNCHED();
+}
+
 // ---- flow upscaling (nearest) ---------------------------------------------------------------------
 __global__ void __launch_bounds__(256) k_flow_upscale(const float2* __restrict__ src, int sny, int snx,
                                                        float2* __restrict__ dst, int dny, int dnx, int rep,

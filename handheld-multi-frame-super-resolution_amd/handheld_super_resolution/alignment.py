@@ -77,8 +77,23 @@ def upscale_lvl(alignments, npatchs, l, config):
 
 def align_lvl(ref_lvl, tyled_pyr_lvl, ref_fft_lvl, ref_gradx_lvl, ref_grady_lvl, ref_hessian_lvl, moving_lvl,
               alignments, l, config):
-    """Block matching then ICA on one level (alignment.py:125-147)."""
+    """Block matching then ICA on one level (alignment.py:125-147).  For tiles up to 32 pixels both steps
+    run in ONE fused kernel (hhsr_align_level; config.hip.fused_align: false selects the two-kernel path,
+    which is also what 64-pixel tiles use)."""
     metric = config.block_matching.tuning.metrics[l]
+    bm = config.block_matching.tuning
+    ts, r = bm.tile_sizes[l], bm.search_radii[l]
+    hip = config.get("hip", None) if hasattr(config, "get") else None
+    fused = True if hip is None else bool(hip.get("fused_align", True))
+    code = {"L2": 0, "L1": 1, "L1_ref_effective": 2}.get(metric)
+    if fused and code is not None and ts in (8, 16, 32) and not (code != 0 and ts == 8):
+        ny, nx, _ = alignments.shape
+        mh, mw = moving_lvl.shape
+        rh, rw = ref_lvl.shape
+        assert ref_lvl.is_contiguous() and moving_lvl.is_contiguous() and alignments.is_contiguous()
+        _lib.call("hhsr_align_level", _lib.ptr(ref_lvl), rh, rw, rw, _lib.ptr(ref_hessian_lvl), _lib.ptr(moving_lvl),
+                  mh, mw, mw, _lib.ptr(alignments), ny, nx, ts, r, code, int(config.ica.tuning.n_iter), _lib.stream())
+        return
     if metric == "L2":
         align_lvl_block_matching_L2(ref_lvl, ref_fft_lvl, moving_lvl, alignments, l, config)
     elif metric == "L1":

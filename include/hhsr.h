@@ -95,6 +95,14 @@ int hhsr_ica(const float* ref, const float* gx, const float* gy, int ref_pitch, 
              const float* mov, int mh, int mw, int mov_pitch,
              float* flow, int ny, int nx, int ts, int n_iter, int flags, void* stream);
 
+/* ---- one pyramid level in one launch: block matching then ICA (alignment.py:125-147), ts in {8, 16, 32}.
+ * metric: 0 = L2, 1 = L1 (intended semantics), 2 = L1_ref_effective.  Gradients are taken from the
+ * reference level itself (rh x rw) — bit-identical to hhsr_grad_hessian's — `hess` from hhsr_grad_hessian.
+ * Same results as hhsr_bm_* followed by hhsr_ica (flags bit 0 is irrelevant below ts = 64). */
+int hhsr_align_level(const float* ref, int rh, int rw, int ref_pitch, const float* hess,
+                     const float* mov, int mh, int mw, int mov_pitch,
+                     float* flow, int ny, int nx, int ts, int r, int metric, int n_iter, void* stream);
+
 /* ---- flow upscaling, nearest mode (alignment.py:150-172): dst[y][x] = mult*src[y/rep][x/rep],
  * zero where y/rep >= sny or x/rep >= snx. */
 int hhsr_flow_upscale_nearest(const float* src, int sny, int snx, float* dst, int dny, int dnx,

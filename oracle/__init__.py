@@ -25,7 +25,7 @@ oracle defines its intended semantics.
 from .params import update_snr_config, sanitize_config, lerp  # noqa: F401
 from .grey import compute_grey_images, grey_fft, decimate_to_grey  # noqa: F401
 from .pyramid import gaussian_taps, downsample, build_gaussian_pyramid  # noqa: F401
-from .align import (init_alignment, align, init_ica, bm_l2, bm_l1, ica, upscale_lvl,  # noqa: F401
+from .align import (init_alignment, align, align_lvl, init_ica, bm_l2, bm_l1, ica, upscale_lvl,  # noqa: F401
                     level_shapes)
 from .kernels import estimate_kernels, gat  # noqa: F401
 from .robustness import (init_robustness, compute_robustness, guide_image, local_stats,  # noqa: F401

@@ -186,6 +186,28 @@ def test_ica_singular_tile_untouched():
     assert_close(N(f), f0, 0, 0, "singular")
 
 
+@pytest.mark.parametrize("ts,r,metric", [(8, 4, "L2"), (16, 4, "L2"), (16, 1, "L1"), (32, 4, "L2"), (32, 2, "L1"),
+                                         (16, 1, "L1_ref_effective")])
+def test_fused_align_level(ts, r, metric):
+    """hhsr_align_level == hhsr_bm_* followed by hhsr_ica (and == the oracle), incl. border tiles."""
+    rng = np.random.default_rng(100 + ts + r)
+    ny, nx = 5, 6
+    ref, mov, flow = _bm_inputs(rng, ts, r, ny, nx, (1, -2))
+    cfg = base_config(ts=16, metrics=(metric,) * 4)
+    cfg.block_matching.tuning.tile_sizes = [ts] * 4
+    cfg.block_matching.tuning.search_radii = [r] * 4
+    gx, gy, H = ICA.init_ica(T(ref), ts)
+    f_fused = T(flow)
+    alignment.align_lvl(T(ref), None, None, gx, gy, H, T(mov), f_fused, 0, cfg)
+    cfg.hip = {"fused_align": False}
+    f_sep = T(flow)
+    alignment.align_lvl(T(ref), None, None, gx, gy, H, T(mov), f_sep, 0, cfg)
+    assert_close(N(f_fused), N(f_sep), 0, 2e-5, f"fused vs separate ts={ts} {metric}")
+    ogx, ogy, oH = oracle.init_ica(ref, ts)
+    want = oracle.align_lvl(ref, ogx, ogy, oH, mov, flow, 0, cfg)
+    assert_close(N(f_fused), want, 0, 2e-4, f"fused vs oracle ts={ts} {metric}", max_bad_frac=0.07)
+
+
 @pytest.mark.parametrize("mode", ["nearest", "bilinear", "bicubic"])
 def test_upscale(golden, mode):
     g = golden("upscale")
