@@ -63,6 +63,7 @@ def main():
     ap.add_argument("--scale", type=float, default=2)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-crop", type=int, default=512)
+    ap.add_argument("--streams", type=int, default=None, help="HIP streams for the frame pipeline (default: config, 2)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -87,6 +88,8 @@ def main():
     cfg = hsr.default_config()
     cfg.verbose = 0
     cfg.scale = scale
+    if args.streams is not None:
+        cfg.hip = {"streams": args.streams}
     ref_host_mean = float(ref.mean())
     hsr.prepare_config(cfg, np.full((H, W), ref_host_mean, np.float32), synth.ALPHA_ISO100, synth.BETA_ISO100,
                        [[0, 1], [1, 2]], [1.0, 1.0, 1.0])

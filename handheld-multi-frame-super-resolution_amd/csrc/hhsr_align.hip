@@ -171,16 +171,9 @@ struct CostIdx {
 };
 
 __device__ __forceinline__ CostIdx wave_argmin(CostIdx v) {
-#pragma unroll
-    for (int o = 1; o < HHSR_WAVE; o <<= 1) {
-        const float oc = __shfl_xor(v.c, o, HHSR_WAVE);
-        const int oi = __shfl_xor(v.i, o, HHSR_WAVE);
-        if (oc < v.c || (oc == v.c && oi < v.i)) {
-            v.c = oc;
-            v.i = oi;
-        }
-    }
-    return v;
+    CostIdx o;
+    o.i = wave_argmin_first(v.c, v.i, &o.c);
+    return o;
 }
 
 template <int TS, bool L1>
@@ -246,8 +239,7 @@ __global__ void __launch_bounds__(256) k_bm_wave(const float* __restrict__ ref, 
                 const float d = rv[k] - s_win[(p / ts + dy) * Pp + p % ts + dx];
                 acc += L1 ? fabsf(d) : d * d;
             }
-#pragma unroll
-            for (int o = 1; o < HHSR_WAVE; o <<= 1) acc += __shfl_xor(acc, o, HHSR_WAVE);
+            acc = wave_sum_uniform(acc);
             if (acc < best.c) {  // strict: the first minimum wins
                 best.c = acc;
                 best.i = c;
@@ -443,11 +435,7 @@ __global__ void __launch_bounds__(NT) k_ica(const float* __restrict__ ref, const
 // iteration samples global memory instead.  ~4.7 vector loads per pixel instead of 15.
 constexpr int ICA_M = 2;
 
-__device__ __forceinline__ float wave_allsum(float v) {
-#pragma unroll
-    for (int o = 1; o < HHSR_WAVE; o <<= 1) v += __shfl_xor(v, o, HHSR_WAVE);
-    return v;
-}
+__device__ __forceinline__ float wave_allsum(float v) { return wave_sum_uniform(v); }
 
 template <int TS>
 __global__ void __launch_bounds__(256) k_ica_wave(const float* __restrict__ ref, const float* __restrict__ gx,
@@ -633,8 +621,7 @@ __global__ void __launch_bounds__(256) k_align_wave(const float* __restrict__ re
                         const float d = rv[k] - s_win[(p / TS + dy + M) * WP + p % TS + dx + M];
                         acc += L1 ? fabsf(d) : d * d;
                     }
-#pragma unroll
-                    for (int o = 1; o < HHSR_WAVE; o <<= 1) acc += __shfl_xor(acc, o, HHSR_WAVE);
+                    acc = wave_sum_uniform(acc);
                     if (acc < best.c) {
                         best.c = acc;
                         best.i = c;

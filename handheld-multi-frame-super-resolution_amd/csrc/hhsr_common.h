@@ -61,6 +61,47 @@ __device__ __forceinline__ void block_sum2(float& a, float& b, float* sm) {
     b = rb;
 }
 
+// ---- wave64 reductions on the DPP path (no LDS crossbar, 6 VALU instructions) -----------------------------
+// quad_perm xor-1 / xor-2, row_half_mirror, row_mirror leave every lane of a 16-lane row with the row total;
+// row_bcast:15 / row_bcast:31 carry the totals across the four rows into lane 63, which is read back as a
+// wave-uniform scalar.  Fixed association -> deterministic.
+#define HHSR_DPP(v, ctrl, rmask) \
+    __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, (v)), (ctrl), (rmask), 0xf, false))
+
+__device__ __forceinline__ float wave_sum_uniform(float v) {
+    v += HHSR_DPP(v, 0xB1, 0xf);   // quad_perm [1,0,3,2]
+    v += HHSR_DPP(v, 0x4E, 0xf);   // quad_perm [2,3,0,1]
+    v += HHSR_DPP(v, 0x141, 0xf);  // row_half_mirror
+    v += HHSR_DPP(v, 0x140, 0xf);  // row_mirror
+    v += HHSR_DPP(v, 0x142, 0xa);  // row_bcast:15 into rows 1 and 3
+    v += HHSR_DPP(v, 0x143, 0xc);  // row_bcast:31 into rows 2 and 3
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
+}
+
+__device__ __forceinline__ float wave_min_uniform(float v) {
+    // masked-out rows of the broadcast steps must see +inf, not 0: keep the old value with bound_ctrl = 0
+#define HHSR_DPPM(v, ctrl, rmask) \
+    __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, (v)), __builtin_bit_cast(int, (v)), (ctrl), (rmask), 0xf, false))
+    v = fminf(v, HHSR_DPPM(v, 0xB1, 0xf));
+    v = fminf(v, HHSR_DPPM(v, 0x4E, 0xf));
+    v = fminf(v, HHSR_DPPM(v, 0x141, 0xf));
+    v = fminf(v, HHSR_DPPM(v, 0x140, 0xf));
+    v = fminf(v, HHSR_DPPM(v, 0x142, 0xa));
+    v = fminf(v, HHSR_DPPM(v, 0x143, 0xc));
+#undef HHSR_DPPM
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
+}
+
+// First minimum: smallest index among the lanes holding the minimal cost (wave-uniform result).
+__device__ __forceinline__ int wave_argmin_first(float cost, int idx, float* min_cost = nullptr) {
+    const float mn = wave_min_uniform(cost);
+    // indices are < 2^24: carry them through the float min network exactly
+    const float cand = (cost == mn) ? (float)idx : 3.0e38f;
+    const int best = (int)wave_min_uniform(cand);
+    if (min_cost) *min_cost = mn;
+    return best;
+}
+
 __device__ __forceinline__ int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
 
 // Python/Numba `max(0, z)`: returns z only when z > 0, so NaN -> 0 (reference quirk D10).
