@@ -556,19 +556,20 @@ extern "C" int hhsr_ica(const float* ref, const float* gx, const float* gy, int 
 // with the block-matching border rule (L2: clamp-to-edge, L1: zero-fill); ICA's own rule (zero outside /
 // clamped coordinates for TS = 8) differs only where the window leaves the moving level, and there
 // (wave-uniform test) the ICA taps are read from global memory with the exact rule.
-template <int TS, bool L1>
+template <int TS, int R, bool L1>
 __global__ void __launch_bounds__(256) k_align_wave(const float* __restrict__ ref, int rh, int rw, int ref_pitch,
                                                      const float* __restrict__ hess, const float* __restrict__ mov,
                                                      int mh, int mw, int mov_pitch, float* __restrict__ flow, int nx,
-                                                     int ntiles, int r, int mode, int n_iter) {
+                                                     int ntiles, int mode, int n_iter) {
+    constexpr int r = R;
     extern __shared__ __attribute__((aligned(16))) float lds[];
     constexpr int M = ICA_M;
     constexpr int RS = TS + 2, RP = RS | 1;            // reference tile + halo
     constexpr int PPT = TS * TS / HHSR_WAVE > 0 ? TS * TS / HHSR_WAVE : 1;
     const int wave = threadIdx.x / HHSR_WAVE, lane = threadIdx.x & (HHSR_WAVE - 1);
-    const int n1 = 2 * r + 1, n = n1 * n1, nparts = 4 * n;
-    const int WS = TS + 2 * r + 2 * M + 1, WP = WS | 1;  // moving window
-    const int slice = (RS * RP + WS * WP + nparts + 3) & ~3;
+    constexpr int n1 = 2 * r + 1, n = n1 * n1, nparts = 4 * n;
+    constexpr int WS = TS + 2 * r + 2 * M + 1, WP = WS | 1;  // moving window
+    constexpr int slice = (RS * RP + WS * WP + nparts + 3) & ~3;
     float* s_ref = lds + (size_t)wave * slice;
     float* s_win = s_ref + RS * RP;
     float* s_part = s_win + WS * WP;
@@ -581,19 +582,34 @@ __global__ void __launch_bounds__(256) k_align_wave(const float* __restrict__ re
     const float r0 = rintf(f0), r1 = rintf(f1);  // round-half-even
     const int ox = tx * TS + (int)r0 - r - M, oy = ty * TS + (int)r1 - r - M;  // window origin in the moving level
     if (active) {
-        for (int p = lane; p < RS * RS; p += HHSR_WAVE) {
+        // all global loads of the two windows are issued back to back into registers, then stored to LDS
+        // (a load -> store loop serialises on memory latency: 14-40 round trips per tile)
+        constexpr int NR = (RS * RS + HHSR_WAVE - 1) / HHSR_WAVE, NW = (WS * WS + HHSR_WAVE - 1) / HHSR_WAVE;
+        float vr[NR], vw[NW];
+#pragma unroll
+        for (int k = 0; k < NR; ++k) {
+            const int p = lane + k * HHSR_WAVE;
             const int i = p / RS, j = p - i * RS;
             const int y = ty * TS + i - 1, x = tx * TS + j - 1;
-            s_ref[i * RP + j] = (y >= 0 && y < rh && x >= 0 && x < rw) ? ref[(size_t)y * ref_pitch + x] : 0.f;
+            vr[k] = (p < RS * RS && y >= 0 && y < rh && x >= 0 && x < rw) ? ref[(size_t)y * ref_pitch + x] : 0.f;
         }
-        const float rcpW = 1.0f / (float)WS;
-        for (int p = lane; p < WS * WS; p += HHSR_WAVE) {
-            const int i = (int)(((float)p + 0.5f) * rcpW), j = p - i * WS;  // exact floor(p / WS)
+#pragma unroll
+        for (int k = 0; k < NW; ++k) {
+            const int p = lane + k * HHSR_WAVE;
+            const int i = p / WS, j = p - i * WS;
             const int y = oy + i, x = ox + j;
-            float v;
-            if (L1) v = (y >= 0 && y < mh && x >= 0 && x < mw) ? mov[(size_t)y * mov_pitch + x] : 0.f;
-            else v = mov[(size_t)clampi(y, 0, mh - 1) * mov_pitch + clampi(x, 0, mw - 1)];
-            s_win[i * WP + j] = v;
+            if (L1) vw[k] = (p < WS * WS && y >= 0 && y < mh && x >= 0 && x < mw) ? mov[(size_t)y * mov_pitch + x] : 0.f;
+            else vw[k] = p < WS * WS ? mov[(size_t)clampi(y, 0, mh - 1) * mov_pitch + clampi(x, 0, mw - 1)] : 0.f;
+        }
+#pragma unroll
+        for (int k = 0; k < NR; ++k) {
+            const int p = lane + k * HHSR_WAVE;
+            if (p < RS * RS) s_ref[(p / RS) * RP + p % RS] = vr[k];
+        }
+#pragma unroll
+        for (int k = 0; k < NW; ++k) {
+            const int p = lane + k * HHSR_WAVE;
+            if (p < WS * WS) s_win[(p / WS) * WP + p % WS] = vw[k];
         }
     }
     __syncthreads();
@@ -754,22 +770,25 @@ extern "C" int hhsr_align_level(const float* ref, int rh, int rw, int ref_pitch,
     HHSR_ARG(ts == 8 || ts == 16 || ts == 32);
     HHSR_ARG(metric == 0 || ts >= 16);  // block_matching.py:87: no L1 search for 8-pixel tiles
     HHSR_ARG(ny * ts <= rh && nx * ts <= rw);
+    HHSR_ARG(r == 1 || r == 2 || r == 4);  // compiled search radii (other radii: hhsr_bm_* + hhsr_ica)
     const size_t l = align_wave_lds(ts, r);
     HHSR_ARG(l <= 64 * 1024);
     const int ntiles = nx * ny;
     const dim3 g(hhsr_cdiv(ntiles, 4)), b(256);
     hipStream_t s = (hipStream_t)stream;
     const int mode = metric == 2 ? 1 : 0;
-#define ALW(TS, L1) hipLaunchKernelGGL((k_align_wave<TS, L1>), g, b, l, s, ref, rh, rw, ref_pitch, hess, mov, mh, mw, \
-                                       mov_pitch, flow, nx, ntiles, r, mode, n_iter)
+#define ALW(TS, R, L1) hipLaunchKernelGGL((k_align_wave<TS, R, L1>), g, b, l, s, ref, rh, rw, ref_pitch, hess, mov, mh, \
+                                          mw, mov_pitch, flow, nx, ntiles, mode, n_iter)
+#define ALW_R(TS, L1) do { if (r == 1) ALW(TS, 1, L1); else if (r == 2) ALW(TS, 2, L1); else ALW(TS, 4, L1); } while (0)
     if (metric == 0) {
-        if (ts == 8) ALW(8, false);
-        else if (ts == 16) ALW(16, false);
-        else ALW(32, false);
+        if (ts == 8) ALW_R(8, false);
+        else if (ts == 16) ALW_R(16, false);
+        else ALW_R(32, false);
     } else {
-        if (ts == 16) ALW(16, true);
-        else ALW(32, true);
+        if (ts == 16) ALW_R(16, true);
+        else ALW_R(32, true);
     }
+#undef ALW_R
 #undef ALW
     HHSR_LAUNCHED();
 }

@@ -81,27 +81,43 @@ struct Taps {
 constexpr int GD_TX = 32, GD_TY = 16;  // output tile per 256-thread workgroup
 
 // out[y][x] = sum_j g[j] * (sum_i g[i] * src[f*y+i][f*x+j]): rows first, then columns, both in float32 in
-// tap order — the association of the reference's two chained valid conv2d calls.
+// tap order — the association of the reference's two chained valid conv2d calls.  F and the tap count
+// NT = 4F+1 are compile-time so that the tile loads are issued back to back (a runtime-bound load->LDS
+// loop serialises on memory latency) and the tap loops unroll.
+template <int F>
 __global__ void __launch_bounds__(256) k_gauss_decimate(const float* __restrict__ src, int H, int W, int sp,
-                                                         float* __restrict__ dst, int h2, int w2, int dp, int f,
-                                                         int nt, Taps taps) {
+                                                         float* __restrict__ dst, int h2, int w2, int dp, Taps taps) {
     extern __shared__ float lds[];
-    const int IH = (GD_TY - 1) * f + nt, IW = (GD_TX - 1) * f + nt;
-    const int IWp = IW | 1;  // odd pitch: the strided column reads below stay <= 2-way conflicted
+    constexpr int f = F, nt = 4 * F + 1;
+    constexpr int IH = (GD_TY - 1) * f + nt, IW = (GD_TX - 1) * f + nt;
+    constexpr int IWp = IW | 1;  // odd pitch: the strided column reads below stay <= 2-way conflicted
     float* s_in = lds;                  // [IH][IWp]
     float* s_tmp = lds + IH * IWp;      // [GD_TY][IWp]
     const int ox0 = blockIdx.x * GD_TX, oy0 = blockIdx.y * GD_TY;
     const int ix0 = ox0 * f, iy0 = oy0 * f;
     const int tid = threadIdx.x;
-    for (int p = tid; p < IH * IW; p += 256) {
-        const int r = p / IW, c = p - r * IW;
-        const int y = min(iy0 + r, H - 1), x = min(ix0 + c, W - 1);
-        s_in[r * IWp + c] = src[(size_t)y * sp + x];
+    constexpr int NL = (IH * IW + 255) / 256;
+    constexpr int CH = 8;  // loads in flight per thread
+    for (int k0 = 0; k0 < NL; k0 += CH) {
+        float v[CH];
+#pragma unroll
+        for (int k = 0; k < CH; ++k) {
+            const int p = tid + (k0 + k) * 256;
+            const int r = p / IW, c = p - r * IW;
+            const int y = min(iy0 + r, H - 1), x = min(ix0 + c, W - 1);
+            v[k] = (k0 + k < NL && p < IH * IW) ? src[(size_t)y * sp + x] : 0.f;
+        }
+#pragma unroll
+        for (int k = 0; k < CH; ++k) {
+            const int p = tid + (k0 + k) * 256;
+            if (k0 + k < NL && p < IH * IW) s_in[(p / IW) * IWp + p % IW] = v[k];
+        }
     }
     __syncthreads();
     for (int p = tid; p < GD_TY * IW; p += 256) {
         const int r = p / IW, c = p - r * IW;
         float acc = 0.f;
+#pragma unroll
         for (int i = 0; i < nt; ++i) acc += taps.g[i] * s_in[(r * f + i) * IWp + c];
         s_tmp[r * IWp + c] = acc;
     }
@@ -111,6 +127,7 @@ __global__ void __launch_bounds__(256) k_gauss_decimate(const float* __restrict_
         const int oy = oy0 + r, ox = ox0 + c;
         if (oy < h2 && ox < w2) {
             float acc = 0.f;
+#pragma unroll
             for (int j = 0; j < nt; ++j) acc += taps.g[j] * s_tmp[r * IWp + c * f + j];
             dst[(size_t)oy * dp + ox] = acc;
         }
@@ -120,7 +137,7 @@ __global__ void __launch_bounds__(256) k_gauss_decimate(const float* __restrict_
 extern "C" int hhsr_gauss_decimate(const float* src, int H, int W, int src_pitch, float* dst, int dst_pitch,
                                    int factor, const float* taps, int ntaps, void* stream) {
     HHSR_ARG(src && dst && taps && H > 0 && W > 0 && src_pitch >= W);
-    HHSR_ARG(factor >= 2 && factor <= 4 && ntaps >= 1 && ntaps <= HHSR_MAX_TAPS && (ntaps & 1));
+    HHSR_ARG((factor == 2 || factor == 4) && ntaps == 4 * factor + 1);  // the reference's kernels: radius int(2f + 0.5)
     const int r = (ntaps - 1) / 2;
     const int h2 = (H - 2 * r) / factor, w2 = (W - 2 * r) / factor;
     HHSR_ARG(h2 > 0 && w2 > 0 && dst_pitch >= w2);
@@ -128,7 +145,12 @@ extern "C" int hhsr_gauss_decimate(const float* src, int H, int W, int src_pitch
     for (int i = 0; i < HHSR_MAX_TAPS; ++i) t.g[i] = i < ntaps ? taps[i] : 0.f;
     const int IH = (GD_TY - 1) * factor + ntaps, IWp = ((GD_TX - 1) * factor + ntaps) | 1;
     const size_t lds = (size_t)(IH + GD_TY) * IWp * sizeof(float);
-    hipLaunchKernelGGL(k_gauss_decimate, dim3(hhsr_cdiv(w2, GD_TX), hhsr_cdiv(h2, GD_TY)), dim3(256), lds,
-                       (hipStream_t)stream, src, H, W, src_pitch, dst, h2, w2, dst_pitch, factor, ntaps, t);
+    const dim3 g(hhsr_cdiv(w2, GD_TX), hhsr_cdiv(h2, GD_TY));
+    if (factor == 2)
+        hipLaunchKernelGGL(k_gauss_decimate<2>, g, dim3(256), lds, (hipStream_t)stream, src, H, W, src_pitch, dst, h2, w2,
+                           dst_pitch, t);
+    else
+        hipLaunchKernelGGL(k_gauss_decimate<4>, g, dim3(256), lds, (hipStream_t)stream, src, H, W, src_pitch, dst, h2, w2,
+                           dst_pitch, t);
     HHSR_LAUNCHED();
 }

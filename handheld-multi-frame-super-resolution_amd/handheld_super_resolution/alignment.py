@@ -86,7 +86,7 @@ def align_lvl(ref_lvl, tyled_pyr_lvl, ref_fft_lvl, ref_gradx_lvl, ref_grady_lvl,
     hip = config.get("hip", None) if hasattr(config, "get") else None
     fused = True if hip is None else bool(hip.get("fused_align", True))
     code = {"L2": 0, "L1": 1, "L1_ref_effective": 2}.get(metric)
-    if fused and code is not None and ts in (8, 16, 32) and not (code != 0 and ts == 8):
+    if fused and code is not None and ts in (8, 16, 32) and r in (1, 2, 4) and not (code != 0 and ts == 8):
         ny, nx, _ = alignments.shape
         mh, mw = moving_lvl.shape
         rh, rw = ref_lvl.shape

@@ -66,7 +66,7 @@ int hhsr_grey_plan_destroy(void* plan);
 int hhsr_pad_circular(const float* src, int H, int W, int src_pitch,
                       float* dst, int Hp, int Wp, int dst_pitch, void* stream);
 /* Valid separable Gaussian (rows then columns) + decimation by `factor`:
- * dst is floor((H-2r)/f) x floor((W-2r)/f), r = (ntaps-1)/2, 2 <= factor <= 4.  `taps` is a HOST array. */
+ * dst is floor((H-2r)/f) x floor((W-2r)/f), r = (ntaps-1)/2; factor 2 or 4 with ntaps = 4*factor+1 (the reference's kernels).  `taps` is a HOST array. */
 int hhsr_gauss_decimate(const float* src, int H, int W, int src_pitch,
                         float* dst, int dst_pitch, int factor,
                         const float* taps, int ntaps, void* stream);
