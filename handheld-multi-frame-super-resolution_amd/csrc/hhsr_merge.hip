@@ -449,7 +449,7 @@ struct BurstArgs {
     const float4* ref_cov;
     int flags;
     float* acc_r;  // optional [H][W]: sum of the frames' robustness (integer scales only)
-    int iscale;    // (int)scale when acc_r is used
+    int iscale;    // (int)scale (integer scales: accumulated robustness ownership, tile window sizes)
 };
 
 // The HR pixels with hi % s == 0 and hj % s == 0 map one-to-one onto the LR pixels (integer scale s): they
@@ -535,7 +535,16 @@ __global__ void __launch_bounds__(256) k_merge_burst_tile(BurstArgs a, Geo g, Cf
     __shared__ float s_raw[RWIN * RPITCH];
     __shared__ float4 s_cov[CWIN * CWIN];
     const int tx = threadIdx.x & (MT - 1), ty = threadIdx.x >> 4;
-    const int hx0 = blockIdx.x * MT, hy0 = blockIdx.y * MT;
+    // XCD-aware workgroup -> tile mapping: the dispatcher places workgroup b on XCD b % 8 (observed, used for
+    // L2 locality only).  Give every XCD one contiguous band of tile rows so that the heavily overlapping
+    // windows of neighbouring tiles hit the same 4 MB L2 instead of being fetched once per XCD.
+    const int nbx = gridDim.x, nblk = gridDim.x * gridDim.y;
+    int bid = blockIdx.y * nbx + blockIdx.x;
+    {   // bijection: XCD x owns ids {b : b % 8 == x} -> contiguous tiles [start_x, start_x + count_x)
+        const int xcd = bid & 7, loc = bid >> 3, q = nblk >> 3, rem = nblk & 7;
+        bid = xcd * q + min(xcd, rem) + loc;
+    }
+    const int hx0 = (bid % nbx) * MT, hy0 = (bid / nbx) * MT;
     const int hj = hx0 + tx, hi = hy0 + ty;
     const bool live = hj < g.sW && hi < g.sH;
     // corner pixels of the workgroup (clamped into the image) bound every thread's window
@@ -545,10 +554,14 @@ __global__ void __launch_bounds__(256) k_merge_burst_tile(BurstArgs a, Geo g, Cf
     float n4[2][2] = {{0.f, 0.f}, {0.f, 0.f}}, d4[2][2] = {{0.f, 0.f}, {0.f, 0.f}};
     float racc = 0.f;  // sum of this pixel's robustness over the frames
 
-    // staging slots of this thread: raw window elements tid and tid+256, covariance element tid
+    // staging slots of this thread: raw window elements tid and tid+256, covariance element tid.  Only the
+    // (MT/s + 3)^2 raw pixels and (MT/(2s) + 3)^2 covariance cells the taps can reach are fetched.
+    const int rwin = min(RWIN, (MT + a.iscale - 1) / a.iscale + 3);
+    const int cwin = min(CWIN, (MT + 2 * a.iscale - 1) / (2 * a.iscale) + 3);
     const int e0 = threadIdx.x, e1 = threadIdx.x + 256;
-    const int e0y = e0 / RWIN, e0x = e0 - e0y * RWIN, e1y = e1 / RWIN, e1x = e1 - e1y * RWIN;
-    const int cey = threadIdx.x / CWIN, cex = threadIdx.x - cey * CWIN;
+    const int e0y = e0 / rwin, e0x = e0 - e0y * rwin, e1y = e1 / rwin, e1x = e1 - e1y * rwin;
+    const int cey = threadIdx.x / cwin, cex = threadIdx.x - cey * cwin;
+    const bool has0 = e0 < rwin * rwin, has1 = e1 < rwin * rwin, hasc = threadIdx.x < cwin * cwin;
 
     // GEOM_F64 gives cj = 0 for invalid corners; recompute the corner centre without the validity clamp
     auto corner_centre = [&](const float2 fl, const Pix& pc, int& cj, int& ci, int& x0, int& y0) {
@@ -577,15 +590,15 @@ __global__ void __launch_bounds__(256) k_merge_burst_tile(BurstArgs a, Geo g, Cf
         int cj, ci, x0, y0;
         corner_centre(pfl, p0, cj, ci, x0, y0);
         pw.rx0 = cj - 1; pw.ry0 = ci - 1; pw.cx0 = x0; pw.cy0 = y0;
-        {
+        if (has0) {
             const int y = pw.ry0 + e0y, x = pw.rx0 + e0x;
             pr0 = (y >= 0 && y < g.H && x >= 0 && x < g.W) ? f.raw[(size_t)y * g.pitch + x] : 0.f;
         }
-        if (e1 < RWIN * RWIN) {
+        if (has1) {
             const int y = pw.ry0 + e1y, x = pw.rx0 + e1x;
             pr1 = (y >= 0 && y < g.H && x >= 0 && x < g.W) ? f.raw[(size_t)y * g.pitch + x] : 0.f;
         }
-        if (!ISO && threadIdx.x < CWIN * CWIN) {
+        if (!ISO && hasc) {
             const int y = min(max(pw.cy0 + cey, 0), g.gh - 1), x = min(max(pw.cx0 + cex, 0), g.gw - 1);
             pc = f.cov[(size_t)y * g.gw + x];
         }
@@ -595,9 +608,9 @@ __global__ void __launch_bounds__(256) k_merge_burst_tile(BurstArgs a, Geo g, Cf
     if (a.n > 0) prefetch(0);
     for (int n = 0; n < a.n; ++n) {
         __syncthreads();  // the previous frame's taps are done with the LDS windows
-        s_raw[e0y * RPITCH + e0x] = pr0;
-        if (e1 < RWIN * RWIN) s_raw[e1y * RPITCH + e1x] = pr1;
-        if (!ISO && threadIdx.x < CWIN * CWIN) s_cov[threadIdx.x] = pc;
+        if (has0) s_raw[e0y * RPITCH + e0x] = pr0;
+        if (has1) s_raw[e1y * RPITCH + e1x] = pr1;
+        if (!ISO && hasc) s_cov[cey * CWIN + cex] = pc;
         const float2 fl = pfl;
         const TileWin w = pw;
         const float local_r = plr;
