@@ -23,6 +23,7 @@ SOURCES = {
     "hhsr_robustness.hip": ["-ffp-contract=off"],
     "hhsr_merge.hip": [],
     "hhsr_grey.hip": ["-ffp-contract=off"],
+    "hhsr_fft.hip": [],
 }
 
 
@@ -35,7 +36,7 @@ def _stale(target, deps):
 
 def build(force=False, verbose=True):
     os.makedirs(OBJ, exist_ok=True)
-    headers = [os.path.join(CSRC, "hhsr_common.h"), os.path.join(HERE, "..", "include", "hhsr.h"), __file__]
+    headers = [os.path.join(CSRC, "hhsr_common.h"), os.path.join(CSRC, "hhsr_fft.h"), os.path.join(HERE, "..", "include", "hhsr.h"), __file__]
     jobs = []
     objs = []
     for src, extra in SOURCES.items():

@@ -1,0 +1,26 @@
+// Internal interface of the fused in-LDS FFT low-pass (hhsr_fft.hip), used by the grey plan (hhsr_grey.hip).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stddef.h>
+
+#define HHSR_MAX_RADICES 16
+
+struct HhsrRadices {
+    int n;
+    int r[HHSR_MAX_RADICES];
+};
+
+struct HhsrFft {
+    bool ok = false;
+    int H = 0, W = 0, Wk = 0;       // Wk: number of kept x-bins (kx = 0 .. Wk-1)
+    HhsrRadices radM{}, radH{};     // radix schedules of the W/2-point and H-point transforms
+    float2 *twM = nullptr, *twH = nullptr, *twW = nullptr;  // exp(-2 pi i k / {W/2, H, W})
+    float2* T = nullptr;            // transposed kept half spectrum [Wk][H]
+    size_t lds_rows = 0, lds_cols = 0;
+    int twlenM = 0, twlenH = 0;     // lengths of the per-pass twiddle tables
+    int rb = 0;                     // rows per workgroup of the row kernels (4, 2 or 1 by LDS budget)
+};
+
+bool hhsr_fft_create(HhsrFft& f, int H, int W);   // false: sizes unsupported (caller uses the library plans)
+void hhsr_fft_destroy(HhsrFft& f);
+int hhsr_fft_lowpass(const HhsrFft& f, const float* src, float* dst, hipStream_t s);

@@ -6,6 +6,7 @@
 // with the 1/(H W) normalisation folded in) -> complex-to-real plan.  Half the transform work, no shift or
 // normalisation passes, no temporaries beyond the plan's own spectrum buffer.
 #include "hhsr_common.h"
+#include "hhsr_fft.h"
 #include <hipfft/hipfft.h>
 #include <new>
 
@@ -15,6 +16,7 @@ struct GreyPlan {
     hipfftHandle r2c, c2r;       // 2-D plans (plain) or batched row plans (pruned)
     hipfftHandle col;            // pruned: batched strided column C2C plan
     float2* spec;                // [H][W/2+1]
+    HhsrFft fft;                 // fused in-LDS transforms (HHSR_GREY_FUSED), when the sizes allow
 };
 
 __device__ __forceinline__ bool lp_kept2(int u, int n) {
@@ -108,6 +110,10 @@ extern "C" int hhsr_grey_plan_create(int H, int W, int flags, void** plan_out) {
     p->Wk = 0;
     for (int x = 0; x < p->Wh; ++x)
         if (host_kept(x, W) || host_kept(x == 0 ? 0 : W - x, W)) p->Wk = x + 1;
+    if ((flags & 4) && hhsr_fft_create(p->fft, H, W)) {  // fused kernels: no library plans needed
+        *plan_out = p;
+        return 0;
+    }
     hipError_t e = hipMalloc((void**)&p->spec, sizeof(float2) * (size_t)H * p->Wh);
     if (e != hipSuccess) {
         hhsr_set_error("hhsr_grey_plan_create: hipMalloc failed: %s", hipGetErrorString(e));
@@ -149,6 +155,11 @@ extern "C" int hhsr_grey_plan_create(int H, int W, int flags, void** plan_out) {
 extern "C" int hhsr_grey_plan_destroy(void* plan) {
     if (!plan) return 0;
     GreyPlan* p = static_cast<GreyPlan*>(plan);
+    if (p->fft.ok) {
+        hhsr_fft_destroy(p->fft);
+        delete p;
+        return 0;
+    }
     hipfftDestroy(p->r2c);
     hipfftDestroy(p->c2r);
     if (p->col) hipfftDestroy(p->col);
@@ -161,6 +172,7 @@ extern "C" int hhsr_grey_lowpass(void* plan, const float* src, float* dst, void*
     HHSR_ARG(plan && src && dst);
     GreyPlan* p = static_cast<GreyPlan*>(plan);
     hipStream_t s = (hipStream_t)stream;
+    if (p->fft.ok) return hhsr_fft_lowpass(p->fft, src, dst, s);
     hipfftComplex* sp = reinterpret_cast<hipfftComplex*>(p->spec);
     hipfftResult r = hipfftSetStream(p->r2c, s);
     if (r == HIPFFT_SUCCESS) r = hipfftSetStream(p->c2r, s);

@@ -13,7 +13,7 @@ class _GreyPlan:
         import os
 
         h = ctypes.c_void_p()
-        _lib.call("hhsr_grey_plan_create", H, W, int(os.environ.get("HHSR_GREY_PLAN", "0")), ctypes.byref(h))
+        _lib.call("hhsr_grey_plan_create", H, W, int(os.environ.get("HHSR_GREY_PLAN", "4")), ctypes.byref(h))
         self.handle = h
 
     def __del__(self):

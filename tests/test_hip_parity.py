@@ -45,6 +45,21 @@ def test_grey_fft(shape):
     assert_close(N(utils_image.compute_grey_images(T(img), "FFT_c2c")), want, 0, 3e-6, "c2c")
 
 
+def test_grey_fused_vs_library_plans(monkeypatch):
+    """The fused in-LDS FFT kernels (default where the sizes factor into 2/3/5) and the rocFFT plans
+    (fallback) implement the same low-pass."""
+    img = np.random.default_rng(3).random((240, 400), dtype=np.float32)  # 200 = 5*5*4*2, 240 = 5*4*4*3
+    want = oracle.grey_fft(img)
+    outs = {}
+    for mode in ("4", "0"):
+        monkeypatch.setenv("HHSR_GREY_PLAN", mode)
+        utils_image._grey_plans.clear()
+        outs[mode] = N(utils_image.compute_grey_images(T(img), "FFT"))
+        assert_close(outs[mode], want, 0, 3e-6, "plan " + mode)
+    utils_image._grey_plans.clear()
+    assert np.abs(outs["4"] - outs["0"]).max() < 2e-6
+
+
 def test_grey_golden(golden):
     g = golden("grey")
     for tag in "abc":
