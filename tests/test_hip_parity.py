@@ -480,6 +480,27 @@ def test_e2e_large_tiles(ts, snr):
     assert_close(o, want, 0, 1e-3, "output", max_bad_frac=0.01)
 
 
+@pytest.mark.parametrize("shape,scale", [((502, 618), 2), ((486, 520), 1.5), ((512, 640), 3)])
+def test_e2e_ragged_sizes_and_scales(shape, scale):
+    """Frame sizes that are not multiples of the tile size (circular padding of the reference frame only,
+    D16; partial tiles at the right / bottom) and non-power-of-two scales (float64 geometry path)."""
+    H, W = shape
+    ref, comp, _ = synth.make_burst(H, W, 3, seed=23, max_shift=3.0, occluder=True)
+    cfg = base_config(ts=16, scale=scale, metrics=("L1", "L2", "L2", "L2"))
+    cap = {}
+    want, wdbg = oracle.main(ref, comp, cfg, capture=cap)
+    cfg.debug = True
+    out, dbg = hsr.main(ref, comp, cfg)
+    assert_close(np.stack(dbg["flow"]), np.stack(cap["flow"]), 0, 3e-3, "flow", max_bad_frac=0.03)
+    assert_close(np.stack(dbg["robustness"]), np.stack(cap["r"]), 0, 2e-3, "r", max_bad_frac=0.02)
+    o = N(out)
+    assert o.shape == want.shape
+    assert_close(o, want, 0, 1e-3, "output", max_bad_frac=0.01)
+    with np.errstate(all="ignore"):
+        assert np.nanpercentile(np.abs(o - want), 99) < 2e-4
+    assert_close(N(dbg["accumulated robustness"]), wdbg["accumulated robustness"], 0, 4e-3, "acc r", max_bad_frac=0.02)
+
+
 def test_process_facade():
     ref, comp, _ = synth.make_burst(512, 512, 3, seed=3)
     cfg = hsr.default_config()
