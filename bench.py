@@ -151,9 +151,18 @@ def main():
     if k_ms:
         avg_ms = float(np.mean(k_ms))
         achieved = float(np.mean(k_bytes)) / (avg_ms * 1e-3) / 1e9
-        roof = {"kernel": "k_merge_burst", "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
-                "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
-                "avg_launch_ms": round(avg_ms, 4), "bytes_per_launch": float(np.mean(k_bytes))}
+        traffic = None
+        try:  # HBM bytes per launch from the committed rocprofv3 --pmc passes of this exact workload
+            with open(os.path.join(ROOT, "profiles", "r01_pmc_merge.json")) as f:
+                pm = json.load(f)
+            if pm.get("workload") == f"{H}x{W}x{NF} x{scale}" and world == 1:
+                traffic = pm["traffic_bytes_per_launch"]
+        except Exception:
+            pass
+        roof = {"kernel": "k_merge_burst_tile (hhsr_merge_burst)", "bound": "hbm", "achieved": round(achieved, 1),
+                "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+                "avg_launch_ms": round(avg_ms, 4), "bytes_per_launch": float(np.mean(k_bytes)),
+                "note": "fused burst merge keeps the accumulators in registers: VALU-issue bound, not HBM bound"}
 
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
