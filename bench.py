@@ -139,18 +139,16 @@ def main():
     out_pix = round(scale * H) * round(scale * W)
     value = out_pix / (ms_per_step * 1e-3) / 1e6
 
-    # dominant-kernel roofline (rank 0's launches with >= 1 comp frame; with N ranks each launch covers its shard)
+    # dominant-kernel roofline: all hhsr_merge_burst launches of one step (one launch on one GPU; one per
+    # output slab on the ranks of a multi-GPU run) against the algorithmic bytes they cover
     P, S = H * W, float(scale) ** 2
-    k_ms, k_bytes = [], []
-    for e0, e1, nfr in ev:
-        if world > 1 and nfr == 0:
-            continue  # rank 0's ref + divide pass
-        k_ms.append(e0.elapsed_time(e1))
-        k_bytes.append(merge_burst_bytes(nfr, P, S, with_ref=(world == 1), partial=(world > 1)))
     roof = None
-    if k_ms:
-        avg_ms = float(np.mean(k_ms))
-        achieved = float(np.mean(k_bytes)) / (avg_ms * 1e-3) / 1e9
+    step_ms = [e0.elapsed_time(e1) for e0, e1, nfr in ev if nfr > 0]
+    if step_ms:
+        avg_ms = float(np.sum(step_ms)) / args.steps
+        n_local = len(hdist.shard_indices(NF - 1, rank, world))
+        nbytes = merge_burst_bytes(n_local, P, S, with_ref=(world == 1), partial=(world > 1))
+        achieved = nbytes / (avg_ms * 1e-3) / 1e9
         traffic = None
         try:  # HBM bytes per launch from the committed rocprofv3 --pmc passes of this exact workload
             with open(os.path.join(ROOT, "profiles", "r01_pmc_merge.json")) as f:
@@ -161,7 +159,7 @@ def main():
             pass
         roof = {"kernel": "k_merge_burst_tile (hhsr_merge_burst)", "bound": "hbm", "achieved": round(achieved, 1),
                 "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
-                "avg_launch_ms": round(avg_ms, 4), "bytes_per_launch": float(np.mean(k_bytes)),
+                "avg_launch_ms": round(avg_ms, 4), "bytes_per_launch": nbytes,
                 "note": "fused burst merge keeps the accumulators in registers: VALU-issue bound, not HBM bound"}
 
     cpu = None

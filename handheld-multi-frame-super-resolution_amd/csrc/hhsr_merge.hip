@@ -23,6 +23,7 @@ struct Geo {
     int gh, gw;         // covariance grid (H/2, W/2)
     int ny, nx, ts;     // flow tile grid
     int sH, sW;         // output
+    int row0, row1;     // output rows [row0, row1) handled by this launch (merge_burst slabs); num/den point at row0
     double scale;
 };
 
@@ -462,9 +463,9 @@ __device__ __forceinline__ bool owns_lr_pixel(const BurstArgs& a, int hi, int hj
 template <typename WT, int GEOM, bool ISO>
 __global__ void __launch_bounds__(256) k_merge_burst(BurstArgs a, Geo g, Cfa4 cfa, float* __restrict__ num,
                                                       float* __restrict__ den) {
-    const int hj = blockIdx.x * 64 + (threadIdx.x & 63), hi = blockIdx.y * 4 + (threadIdx.x >> 6);
-    if (hj >= g.sW || hi >= g.sH) return;
-    const size_t o = ((size_t)hi * g.sW + hj) * 3;
+    const int hj = blockIdx.x * 64 + (threadIdx.x & 63), hi = g.row0 + blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (hj >= g.sW || hi >= g.row1) return;
+    const size_t o = ((size_t)(hi - g.row0) * g.sW + hj) * 3;
     float n3[3] = {0.f, 0.f, 0.f}, d3[3] = {0.f, 0.f, 0.f};
     if (a.flags & HHSR_MERGE_LOAD_ACC) {
 #pragma unroll
@@ -544,12 +545,12 @@ __global__ void __launch_bounds__(256) k_merge_burst_tile(BurstArgs a, Geo g, Cf
         const int xcd = bid & 7, loc = bid >> 3, q = nblk >> 3, rem = nblk & 7;
         bid = xcd * q + min(xcd, rem) + loc;
     }
-    const int hx0 = (bid % nbx) * MT, hy0 = (bid / nbx) * MT;
+    const int hx0 = (bid % nbx) * MT, hy0 = g.row0 + (bid / nbx) * MT;
     const int hj = hx0 + tx, hi = hy0 + ty;
-    const bool live = hj < g.sW && hi < g.sH;
+    const bool live = hj < g.sW && hi < g.row1;
     // corner pixels of the workgroup (clamped into the image) bound every thread's window
-    const Pix p0 = make_pix(g, min(hy0, g.sH - 1), min(hx0, g.sW - 1));
-    const Pix p = make_pix(g, min(hi, g.sH - 1), min(hj, g.sW - 1));
+    const Pix p0 = make_pix(g, min(hy0, g.row1 - 1), min(hx0, g.sW - 1));
+    const Pix p = make_pix(g, min(hi, g.row1 - 1), min(hj, g.sW - 1));
     const int tile = p0.tile;  // uniform: the workgroup lies inside one flow tile
     float n4[2][2] = {{0.f, 0.f}, {0.f, 0.f}}, d4[2][2] = {{0.f, 0.f}, {0.f, 0.f}};
     float racc = 0.f;  // sum of this pixel's robustness over the frames
@@ -630,7 +631,7 @@ __global__ void __launch_bounds__(256) k_merge_burst_tile(BurstArgs a, Geo g, Cf
     if (!live) return;
     if (owns_lr_pixel(a, hi, hj))
         a.acc_r[p.ridx] = ((a.flags & HHSR_MERGE_LOAD_ACC) ? a.acc_r[p.ridx] : 0.f) + racc;
-    const size_t o = ((size_t)hi * g.sW + hj) * 3;
+    const size_t o = ((size_t)(hi - g.row0) * g.sW + hj) * 3;
     float n3[3] = {0.f, 0.f, 0.f}, d3[3] = {0.f, 0.f, 0.f};
     if (a.flags & HHSR_MERGE_LOAD_ACC) {
 #pragma unroll
@@ -655,6 +656,7 @@ static bool scale_is_pow2(double s) {  // 1, 2, 4, 8: (h + 0.5)/s is exact in fl
 static int fill_geo(Geo& g, int H, int W, int pitch, int ny, int nx, int ts, double scale, int sH, int sW) {
     g.H = H; g.W = W; g.pitch = pitch; g.gh = H / 2; g.gw = W / 2;
     g.ny = ny; g.nx = nx; g.ts = ts; g.sH = sH; g.sW = sW; g.scale = scale;
+    g.row0 = 0; g.row1 = sH;
     return 0;
 }
 
@@ -713,7 +715,7 @@ extern "C" int hhsr_merge_burst(const float* const* raws, const float* const* fl
                                 const float* const* rs, int n_frames, int H, int W, int pitch, int ny, int nx,
                                 int ts, const float* ref_raw, const float* ref_covs, const uint8_t cfa[4],
                                 double scale, int kflags, int flags, float* num, float* den, float* acc_r, int sH,
-                                int sW, void* stream) {
+                                int sW, int row0, int nrows, void* stream) {
     const int iso = kflags & HHSR_KERNEL_ISO, f64 = kflags & HHSR_WEIGHT_F64;
     HHSR_ARG(n_frames >= 0 && n_frames <= HHSR_MAX_FRAMES && cfa && num);
     HHSR_ARG(n_frames == 0 || (raws && flows && rs && (iso || covs)));
@@ -739,17 +741,20 @@ extern "C" int hhsr_merge_burst(const float* const* raws, const float* const* fl
     a.flags = flags;
     Geo g;
     fill_geo(g, H, W, pitch, ny, nx, ts, scale, sH, sW);
+    HHSR_ARG(row0 >= 0 && nrows > 0 && row0 + nrows <= sH);
+    g.row0 = row0;
+    g.row1 = row0 + nrows;
     Cfa4 c;
     for (int k = 0; k < 4; ++k) c.c[k] = cfa[k];
-    const dim3 grid(hhsr_cdiv(sW, 64), hhsr_cdiv(sH, 4)), block(256);
+    const dim3 grid(hhsr_cdiv(sW, 64), hhsr_cdiv(nrows, 4)), block(256);
     hipStream_t s = (hipStream_t)stream;
     const bool p2 = scale_is_pow2(scale);
     // LDS-staged kernel: integer scale, 16-px HR workgroups inside one flow tile, windows fit the LDS arrays
     const int iscale = (int)scale;
     const bool tiled = !f64 && (double)iscale == scale && iscale >= 1 && ((int64_t)ts * iscale) % MT == 0 &&
-                       n_frames > 0 && !getenv("HHSR_MERGE_NO_LDS");
+                       n_frames > 0 && row0 % MT == 0 && !getenv("HHSR_MERGE_NO_LDS");
     if (tiled) {
-        const dim3 tgrid(hhsr_cdiv(sW, MT), hhsr_cdiv(sH, MT));
+        const dim3 tgrid(hhsr_cdiv(sW, MT), hhsr_cdiv(nrows, MT));
 #define HHSR_MT(GEOM, ISO) hipLaunchKernelGGL((k_merge_burst_tile<GEOM, ISO>), tgrid, block, 0, s, a, g, c, num, den)
         if (p2) { if (iso) HHSR_MT(GEOM_P2, true); else HHSR_MT(GEOM_P2, false); }
         else { if (iso) HHSR_MT(GEOM_F64, true); else HHSR_MT(GEOM_F64, false); }

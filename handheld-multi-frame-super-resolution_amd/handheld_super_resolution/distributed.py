@@ -5,19 +5,34 @@ Every comp frame's contribution to num/den depends only on the reference-frame s
 (reference super_resolution.py:133-173) and contributions are summed (merge.py:432-434), so:
   * one process per GPU, rank k takes comp frames k, k+G, k+2G, ... (no data-path collective);
   * every rank replicates the cheap reference-frame precompute;
-  * ONE sum-reduce to rank 0 of the packed float32 buffer [2, sH, sW, 3] (num | den) — RCCL over xGMI
-    with backend "nccl" (+ the [H, W] accumulated robustness when the mask is requested);
-  * rank 0 adds the reference frame (Alg. 11, which may overwrite rather than add) and normalises.
-The engine that does the per-rank compute is injected so that the sharding / reduction logic can be
-exercised without a GPU (tests run it with world_size 2 on gloo).
+  * ONE exchange of the float32 accumulators: the output is cut into G row slabs; every rank merges its
+    frames slab by slab into a slab-major buffer [G][2][rows][sW][3] (num | den per slab) and a single
+    all-to-all (= a reduce-scatter on the fully connected xGMI fabric: 7 concurrent point-to-point
+    transfers per GPU, 1/8 of the buffer each — RCCL's ring reduce would cross 7 links in sequence) hands
+    slab j of every rank to rank j, which sums the G partials;
+  * each rank adds the reference frame (Alg. 11) and normalises ITS slab — so the finish is parallel too — and
+    sends the finished [rows][sW][3] slab to rank 0 (half the volume of the accumulators);
+  * the [H][W] accumulated robustness, when requested, is a plain sum-reduce to rank 0.
+The accumulated-robustness *denoiser* (merge.py:223-228 overwrite rule) needs the full accumulators on one
+rank and falls back to one reduce + rank-0 finish.  The engine that does the per-rank compute is injected
+so that the sharding / exchange logic can be exercised without a GPU (tests run it on gloo, world_size 2).
 """
 import torch
 import torch.distributed as dist
+
+SLAB_ALIGN = 16  # slabs start on the 16-pixel tile grid of the fused merge kernel
 
 
 def shard_indices(n_frames, rank, world):
     """Indices of the comp frames rank `rank` of `world` processes (round-robin: balanced to +-1)."""
     return list(range(rank, n_frames, world))
+
+
+def slab_bounds(sH, world):
+    """Row slabs [b[j], b[j+1]) of the output, one per rank, starts aligned to SLAB_ALIGN."""
+    rows = -(-sH // world)
+    rows = -(-rows // SLAB_ALIGN) * SLAB_ALIGN
+    return [min(j * rows, sH) for j in range(world + 1)]
 
 
 class HipEngine:
@@ -35,50 +50,81 @@ class HipEngine:
         self.pipe.init_ref(ref_img)
         return self
 
-    def partial(self, comp_imgs):
-        """Packed accumulators [2, sH, sW, 3] of this rank's frames (+ accumulated robustness or None)."""
+    def output_shape(self):
+        return (*self.pipe.output_size(), 3)
+
+    def partial(self, comp_imgs, bounds=None):
+        """This rank's frames merged into slab-major accumulators: a flat float32 buffer holding, for each
+        slab j, [2][rows_j][sW][3] (bounds=None: one slab = the whole output).  Returns (flat, acc_r)."""
         from .merge import merge_burst, can_fuse_acc_r
 
         pipe = self.pipe
         sH, sW = pipe.output_size()
-        acc = torch.empty((2, sH, sW, 3), dtype=torch.float32, device=pipe.device)
+        bounds = bounds or [0, sH]
+        flat = torch.empty(2 * sH * sW * 3, dtype=torch.float32, device=pipe.device)
         acc_r = torch.zeros(tuple(pipe.ref.shape), dtype=torch.float32, device=pipe.device) if self.accumulate_r else None
         fuse_acc = acc_r is not None and can_fuse_acc_r(self.config) and len(comp_imgs) > 0
         frames = pipe.process_frames(list(comp_imgs), None if fuse_acc else acc_r)
-        if frames:
-            merge_burst(frames, None, None, acc[0], acc[1], pipe.cfa, self.config, do_ref=False, divide=False,
-                        store_den=True, acc_r=acc_r if fuse_acc else None)
-        else:
-            acc.zero_()
-        return acc, acc_r
+        if not frames:
+            flat.zero_()
+            return flat, acc_r
+        off = 0
+        for j in range(len(bounds) - 1):
+            r0, r1 = bounds[j], bounds[j + 1]
+            n = (r1 - r0) * sW * 3
+            if r1 > r0:
+                slab = flat[off:off + 2 * n].view(2, r1 - r0, sW, 3)
+                merge_burst(frames, None, None, slab[0], slab[1], pipe.cfa, self.config, do_ref=False, divide=False,
+                            store_den=True, acc_r=acc_r if fuse_acc else None, rows=(r0, r1 - r0), out_height=sH,
+                            load_acc=False)
+            off += 2 * n
+        return flat, acc_r
 
-    def finish(self, acc, acc_r):
-        """Rank 0: reference-frame merge + normalisation on the reduced accumulators."""
+    def finish_slab(self, acc, row0, acc_r=None):
+        """acc [2][rows][sW][3] (summed over ranks) -> finished output slab: reference frame + normalise."""
         from .kernels import estimate_kernels
         from .merge import merge_burst, merge_ref
         from .utils import divide
 
         pipe = self.pipe
-        ref_covs = estimate_kernels(pipe.ref, self.config)
-        if self.denoiser_on:
-            merge_ref(pipe.ref, ref_covs, acc[0], acc[1], pipe.cfa, self.config, acc_r)
+        sH, _ = pipe.output_size()
+        if not hasattr(self, "_ref_covs"):
+            self._ref_covs = estimate_kernels(pipe.ref, self.config)
+        if acc.shape[1] == 0:
+            return acc[0]
+        if self.denoiser_on:  # whole image only (row0 == 0 and all rows)
+            assert row0 == 0 and acc.shape[1] == sH
+            merge_ref(pipe.ref, self._ref_covs, acc[0], acc[1], pipe.cfa, self.config, acc_r)
             divide(acc[0], acc[1])
         else:
-            merge_burst([], pipe.ref, ref_covs, acc[0], acc[1], pipe.cfa, self.config, load_acc=True, do_ref=True,
-                        divide=True)
+            merge_burst([], pipe.ref, self._ref_covs, acc[0], acc[1], pipe.cfa, self.config, load_acc=True, do_ref=True,
+                        divide=True, rows=(row0, acc.shape[1]), out_height=sH)
         return acc[0]
 
 
+def _staged(t, group):
+    """Host-only backends (gloo, used by the CPU tests) get CPU copies of device tensors."""
+    return t.is_cuda and dist.get_backend(group) != "nccl"
+
+
 def _reduce_sum(t, dst, group):
-    """Sum-reduce to `dst`.  RCCL ("nccl") reduces device tensors in place over xGMI; a host-only backend
-    (gloo, used by the CPU tests) gets a staged copy."""
-    if t.is_cuda and dist.get_backend(group) != "nccl":
+    """Sum-reduce to `dst`.  RCCL ("nccl") reduces device tensors in place over xGMI."""
+    if _staged(t, group):
         h = t.cpu()
         dist.reduce(h, dst=dst, op=dist.ReduceOp.SUM, group=group)
         t.copy_(h)
         return t
     dist.reduce(t, dst=dst, op=dist.ReduceOp.SUM, group=group)
     return t
+
+
+def _all_to_all(recv, send, out_splits, in_splits, group):
+    if _staged(send, group):
+        hr, hs = torch.empty(recv.shape, dtype=recv.dtype), send.cpu()
+        dist.all_to_all_single(hr, hs, out_splits, in_splits, group=group)
+        recv.copy_(hr)
+    else:
+        dist.all_to_all_single(recv, send, out_splits, in_splits, group=group)
 
 
 def main_sharded(ref_img, comp_imgs, config, group=None, engine=None):
@@ -89,16 +135,61 @@ def main_sharded(ref_img, comp_imgs, config, group=None, engine=None):
     eng = engine if engine is not None else HipEngine(config)
     eng.init_ref(ref_img)
     mine = [comp_imgs[i] for i in shard_indices(len(comp_imgs), rank, world)]
-    acc, acc_r = eng.partial(mine)
-    if world > 1:
-        dst = dist.get_global_rank(group, 0) if group is not None else 0
-        acc = _reduce_sum(acc, dst, group)
-        if acc_r is not None:
-            acc_r = _reduce_sum(acc_r, dst, group)
-    if rank != 0:
-        return None, {}
-    out = eng.finish(acc, acc_r)
+    sH, sW, _ = eng.output_shape()
+    root = dist.get_global_rank(group, 0) if (world > 1 and group is not None) else 0
     debug = {"robustness": [], "flow": []}
+
+    if world == 1 or getattr(eng, "denoiser_on", False):
+        # single exchange of the whole accumulators, finish on rank 0
+        flat, acc_r = eng.partial(mine)
+        if world > 1:
+            flat = _reduce_sum(flat, root, group)
+            if acc_r is not None:
+                acc_r = _reduce_sum(acc_r, root, group)
+        if rank != 0:
+            return None, {}
+        out = eng.finish_slab(flat.view(2, sH, sW, 3), 0, acc_r)
+        if acc_r is not None:
+            debug["accumulated robustness"] = acc_r
+        return out, debug
+
+    bounds = slab_bounds(sH, world)
+    flat, acc_r = eng.partial(mine, bounds)
+    rows_me = bounds[rank + 1] - bounds[rank]
+    n_me = 2 * rows_me * sW * 3
+    recv = torch.empty(world * n_me, dtype=torch.float32, device=flat.device)
+    in_splits = [2 * (bounds[j + 1] - bounds[j]) * sW * 3 for j in range(world)]
+    _all_to_all(recv, flat, [n_me] * world, in_splits, group)
+    del flat
+    summed = recv.view(world, 2, rows_me, sW, 3).sum(dim=0) if rows_me > 0 else recv.view(2, 0, sW, 3)
+    del recv
+    out_slab = eng.finish_slab(summed, bounds[rank])
     if acc_r is not None:
-        debug["accumulated robustness"] = acc_r
-    return out, debug
+        acc_r = _reduce_sum(acc_r, root, group)
+
+    # finished slabs -> rank 0
+    staged = _staged(out_slab, group)
+    if rank == 0:
+        out = torch.empty((sH, sW, 3), dtype=torch.float32, device=out_slab.device)
+        out[bounds[0]:bounds[1]] = out_slab
+        ops, bufs = [], []
+        for j in range(1, world):
+            r0, r1 = bounds[j], bounds[j + 1]
+            if r1 > r0:
+                buf = torch.empty((r1 - r0, sW, 3), dtype=torch.float32) if staged else out[r0:r1]
+                bufs.append((r0, r1, buf))
+                ops.append(dist.P2POp(dist.irecv, buf, dist.get_global_rank(group, j) if group is not None else j, group))
+        if ops:
+            for req in dist.batch_isend_irecv(ops):
+                req.wait()
+        if staged:
+            for r0, r1, buf in bufs:
+                out[r0:r1] = buf.to(out.device)
+        if acc_r is not None:
+            debug["accumulated robustness"] = acc_r
+        return out, debug
+    if rows_me > 0:
+        buf = out_slab.cpu() if staged else out_slab.contiguous()
+        for req in dist.batch_isend_irecv([dist.P2POp(dist.isend, buf, root, group)]):
+            req.wait()
+    return None, {}

@@ -50,18 +50,23 @@ def can_fuse_acc_r(config):
 
 
 def merge_burst(frames, ref_img, ref_kernels, num, den, cfa_pattern, config, load_acc=False, do_ref=True,
-                divide=True, store_den=False, acc_r=None):
+                divide=True, store_den=False, acc_r=None, rows=None, out_height=None):
     """Fused merge of a whole (shard of a) burst: `frames` is a list of (raw, flow, covs, r).  Per output
     pixel the frames are summed in list order with the accumulators in registers — the same float32
     order as successive merge() calls — then the reference frame is added and the result normalised,
     writing `num` once.  Not usable with the accumulated-robustness denoiser (its
     overwrite rule needs the sequential merge_ref).  `acc_r` (float32 [H, W], integer scales) receives the sum
-    of the frames' robustness maps in the same pass."""
+    of the frames' robustness maps in the same pass.  `rows = (row0, nrows)` restricts the launch to a slab of
+    output rows; `num` / `den` are then [nrows, sW, 3] slabs and `out_height` the full output height."""
     scale, kflags = _common(config)
     if do_ref and config.accumulated_robustness_denoiser.enabled:
         raise ValueError("merge_burst cannot apply the accumulated robustness denoiser; use merge_ref")
     ts = config.block_matching.tuning.tile_size
     sH, sW, _ = num.shape
+    row0, nrows = (0, sH) if rows is None else rows
+    if rows is not None:
+        assert num.shape[0] == nrows and out_height is not None
+        sH = int(out_height)
     flags = (1 if load_acc else 0) | (2 if do_ref else 0) | (4 if divide else 0) | (8 if store_den else 0)
     if frames:
         H, W = frames[0][0].shape
@@ -82,4 +87,4 @@ def merge_burst(frames, ref_img, ref_kernels, num, den, cfa_pattern, config, loa
                   _lib.ptr_array([c[2] for c in chunk]), _lib.ptr_array([c[3] for c in chunk]), len(chunk),
                   H, W, W, ny, nx, int(ts), _lib.ptr(ref_img if (f & 2) else None),
                   _lib.ptr(ref_kernels if (f & 2) else None), cfa, scale, kflags, f, _lib.ptr(num), _lib.ptr(den),
-                  _lib.ptr(acc_r if chunk else None), sH, sW, _lib.stream())
+                  _lib.ptr(acc_r if chunk else None), sH, sW, int(row0), int(nrows), _lib.stream())

@@ -165,6 +165,8 @@ int hhsr_add(float* A, const float* B, int64_t n, void* stream);          /* A +
 /* Fused burst merge: for every HR pixel, sum the contributions of `n_frames` comp frames with the
  * accumulators held in registers (same left-to-right float32 order as n calls of hhsr_accumulate),
  * then optionally add the reference frame and normalise.  HOST arrays of device pointers.
+ * Output rows [row0, row0 + nrows) are processed and num / den point at row0 (slabs for the multi-GPU
+ * reduce-scatter; row0 = 0, nrows = sH for the whole image).
  * acc_r (optional, float32 [H][W], integer scales only) receives sum_n r_n — the accumulated robustness of
  * super_resolution.py:158-159 — at no extra HBM traffic (+= with HHSR_MERGE_LOAD_ACC).
  * flags: */
@@ -176,7 +178,7 @@ int hhsr_merge_burst(const float* const* raws, const float* const* flows, const 
                      const float* const* rs, int n_frames, int H, int W, int pitch,
                      int ny, int nx, int ts, const float* ref_raw, const float* ref_covs,
                      const uint8_t cfa[4], double scale, int kflags, int flags,
-                     float* num, float* den, float* acc_r, int sH, int sW, void* stream);
+                     float* num, float* den, float* acc_r, int sH, int sW, int row0, int nrows, void* stream);
 
 #ifdef __cplusplus
 }

@@ -17,7 +17,9 @@ from handheld_super_resolution import synthetic as synth
 
 
 class OracleEngine:
-    """Test double for distributed.HipEngine with the same three methods."""
+    """Test double for distributed.HipEngine with the same methods (NumPy oracle as the compute)."""
+
+    denoiser_on = False
 
     def __init__(self, config):
         self.cfg = config
@@ -32,23 +34,34 @@ class OracleEngine:
         self.stats = oracle.init_robustness(self.ref, self.cfa, self.wb, self.cfg)
         return self
 
-    def partial(self, comps):
+    def output_shape(self):
         H, W = self.ref.shape
         s = self.cfg.scale
-        acc = np.zeros((2, round(s * H), round(s * W), 3), np.float32)
+        return (round(s * H), round(s * W), 3)
+
+    def partial(self, comps, bounds=None):
+        H, W = self.ref.shape
+        sH, sW, _ = self.output_shape()
+        bounds = bounds or [0, sH]
+        acc = np.zeros((2, sH, sW, 3), np.float32)
         acc_r = np.zeros((H, W), np.float32)
         for img in comps:
             flow = oracle.align(*self.al, oracle.compute_grey_images(img, "FFT"), self.cfg)
             r = oracle.compute_robustness(img, *self.stats, flow, self.cfa, self.wb, self.curves, self.cfg)
             acc_r += r
             oracle.merge(img, flow, oracle.estimate_kernels(img, self.cfg), r, acc[0], acc[1], self.cfa, self.cfg)
-        return torch.from_numpy(acc), torch.from_numpy(acc_r)
+        flat = np.concatenate([acc[:, bounds[j]:bounds[j + 1]].ravel() for j in range(len(bounds) - 1)])
+        return torch.from_numpy(flat), torch.from_numpy(acc_r)
 
-    def finish(self, acc, acc_r):
+    def finish_slab(self, acc, row0, acc_r=None):
+        sH, sW, _ = self.output_shape()
         a = acc.numpy()
-        oracle.merge_ref(self.ref, oracle.estimate_kernels(self.ref, self.cfg), a[0], a[1], self.cfa, self.cfg)
-        oracle.divide(a[0], a[1])
-        return torch.from_numpy(a[0])
+        rows = a.shape[1]
+        full = np.zeros((2, sH, sW, 3), np.float32)
+        full[:, row0:row0 + rows] = a
+        oracle.merge_ref(self.ref, oracle.estimate_kernels(self.ref, self.cfg), full[0], full[1], self.cfa, self.cfg)
+        oracle.divide(full[0], full[1])
+        return torch.from_numpy(np.ascontiguousarray(full[0, row0:row0 + rows]))
 
 
 def _burst():
@@ -79,6 +92,12 @@ def _free_port():
         return s.getsockname()[1]
 
 
+def test_slab_bounds():
+    b = hdist.slab_bounds(6000, 8)
+    assert b[0] == 0 and b[-1] == 6000 and all(x % 16 == 0 for x in b[:-1]) and b == sorted(b)
+    assert hdist.slab_bounds(100, 8) == [0, 16, 32, 48, 64, 80, 96, 100, 100]  # trailing slabs may be empty
+
+
 def test_shard_indices():
     assert hdist.shard_indices(19, 0, 8) == [0, 8, 16]
     assert hdist.shard_indices(19, 7, 8) == [7, 15]
@@ -87,9 +106,11 @@ def test_shard_indices():
 
 
 @pytest.mark.timeout(300)
-def test_sharded_equals_sequential_world2(tmp_path):
+@pytest.mark.parametrize("world", [2, 3])
+def test_sharded_equals_sequential(tmp_path, world):
+    """world 3: uneven slabs (256 output rows -> 96 + 96 + 64) and uneven frame shards (3 frames)."""
     out_path = str(tmp_path / "out.npz")
-    mp.spawn(_worker, args=(2, _free_port(), out_path), nprocs=2, join=True)
+    mp.spawn(_worker, args=(world, _free_port(), out_path), nprocs=world, join=True)
     got = np.load(out_path)
     ref, comp, cfg = _burst()
     want, dbg = oracle.main(ref, comp, cfg)
