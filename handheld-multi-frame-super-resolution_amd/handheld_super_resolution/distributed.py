@@ -28,10 +28,16 @@ def shard_indices(n_frames, rank, world):
     return list(range(rank, n_frames, world))
 
 
-def slab_bounds(sH, world):
-    """Row slabs [b[j], b[j+1]) of the output, one per rank, starts aligned to SLAB_ALIGN."""
+def slab_rows(sH, world):
+    """Rows per slab: ceil(sH / world) rounded up to SLAB_ALIGN.  All slabs have this (padded) size so that
+    every collective moves equal chunks; slab j covers output rows [j*rows, min((j+1)*rows, sH))."""
     rows = -(-sH // world)
-    rows = -(-rows // SLAB_ALIGN) * SLAB_ALIGN
+    return -(-rows // SLAB_ALIGN) * SLAB_ALIGN
+
+
+def slab_bounds(sH, world):
+    """Valid (un-padded) row range [b[j], b[j+1]) of every slab."""
+    rows = slab_rows(sH, world)
     return [min(j * rows, sH) for j in range(world + 1)]
 
 
@@ -53,32 +59,31 @@ class HipEngine:
     def output_shape(self):
         return (*self.pipe.output_size(), 3)
 
-    def partial(self, comp_imgs, bounds=None):
-        """This rank's frames merged into slab-major accumulators: a flat float32 buffer holding, for each
-        slab j, [2][rows_j][sW][3] (bounds=None: one slab = the whole output).  Returns (flat, acc_r)."""
+    def partial(self, comp_imgs, world=1):
+        """This rank's frames merged into slab-major accumulators: float32 [world][2][rows][sW][3] with
+        rows = slab_rows(sH, world) (num | den per slab; rows past the image stay zero).  world = 1: one slab =
+        the whole output.  Returns (acc, acc_r)."""
         from .merge import merge_burst, can_fuse_acc_r
 
         pipe = self.pipe
         sH, sW = pipe.output_size()
-        bounds = bounds or [0, sH]
-        flat = torch.empty(2 * sH * sW * 3, dtype=torch.float32, device=pipe.device)
+        rows = slab_rows(sH, world) if world > 1 else sH
+        bounds = slab_bounds(sH, world) if world > 1 else [0, sH]
+        padded = world * rows != sH
+        alloc = torch.zeros if (padded or not comp_imgs) else torch.empty
+        acc = alloc((world, 2, rows, sW, 3), dtype=torch.float32, device=pipe.device)
         acc_r = torch.zeros(tuple(pipe.ref.shape), dtype=torch.float32, device=pipe.device) if self.accumulate_r else None
         fuse_acc = acc_r is not None and can_fuse_acc_r(self.config) and len(comp_imgs) > 0
         frames = pipe.process_frames(list(comp_imgs), None if fuse_acc else acc_r)
         if not frames:
-            flat.zero_()
-            return flat, acc_r
-        off = 0
-        for j in range(len(bounds) - 1):
+            return acc, acc_r
+        for j in range(world):
             r0, r1 = bounds[j], bounds[j + 1]
-            n = (r1 - r0) * sW * 3
             if r1 > r0:
-                slab = flat[off:off + 2 * n].view(2, r1 - r0, sW, 3)
-                merge_burst(frames, None, None, slab[0], slab[1], pipe.cfa, self.config, do_ref=False, divide=False,
-                            store_den=True, acc_r=acc_r if fuse_acc else None, rows=(r0, r1 - r0), out_height=sH,
-                            load_acc=False)
-            off += 2 * n
-        return flat, acc_r
+                merge_burst(frames, None, None, acc[j, 0, : r1 - r0], acc[j, 1, : r1 - r0], pipe.cfa, self.config,
+                            do_ref=False, divide=False, store_den=True, acc_r=acc_r if fuse_acc else None,
+                            rows=(r0, r1 - r0), out_height=sH)
+        return acc, acc_r
 
     def finish_slab(self, acc, row0, acc_r=None):
         """acc [2][rows][sW][3] (summed over ranks) -> finished output slab: reference frame + normalise."""
@@ -118,13 +123,26 @@ def _reduce_sum(t, dst, group):
     return t
 
 
-def _all_to_all(recv, send, out_splits, in_splits, group):
+def _all_to_all(recv, send, group):
+    """Equal-split all-to-all: chunk j of `send` goes to rank j."""
     if _staged(send, group):
         hr, hs = torch.empty(recv.shape, dtype=recv.dtype), send.cpu()
-        dist.all_to_all_single(hr, hs, out_splits, in_splits, group=group)
+        dist.all_to_all_single(hr, hs, group=group)
         recv.copy_(hr)
     else:
-        dist.all_to_all_single(recv, send, out_splits, in_splits, group=group)
+        dist.all_to_all_single(recv, send, group=group)
+
+
+def _gather(t, dst, world, group):
+    """Equal-size gather of `t` to global rank `dst`; returns the stacked tensor there, None elsewhere."""
+    me = dist.get_rank()
+    staged = _staged(t, group)
+    src = t.cpu() if staged else t.contiguous()
+    out = torch.empty((world, *src.shape), dtype=src.dtype, device=src.device) if me == dst else None
+    dist.gather(src, list(out.unbind(0)) if me == dst else None, dst=dst, group=group)  # received in place
+    if me != dst:
+        return None
+    return out.to(t.device) if staged else out
 
 
 def main_sharded(ref_img, comp_imgs, config, group=None, engine=None):
@@ -141,55 +159,36 @@ def main_sharded(ref_img, comp_imgs, config, group=None, engine=None):
 
     if world == 1 or getattr(eng, "denoiser_on", False):
         # single exchange of the whole accumulators, finish on rank 0
-        flat, acc_r = eng.partial(mine)
+        acc, acc_r = eng.partial(mine, 1)
         if world > 1:
-            flat = _reduce_sum(flat, root, group)
+            acc = _reduce_sum(acc, root, group)
             if acc_r is not None:
                 acc_r = _reduce_sum(acc_r, root, group)
         if rank != 0:
             return None, {}
-        out = eng.finish_slab(flat.view(2, sH, sW, 3), 0, acc_r)
+        out = eng.finish_slab(acc[0], 0, acc_r)
         if acc_r is not None:
             debug["accumulated robustness"] = acc_r
         return out, debug
 
+    rows = slab_rows(sH, world)
     bounds = slab_bounds(sH, world)
-    flat, acc_r = eng.partial(mine, bounds)
-    rows_me = bounds[rank + 1] - bounds[rank]
-    n_me = 2 * rows_me * sW * 3
-    recv = torch.empty(world * n_me, dtype=torch.float32, device=flat.device)
-    in_splits = [2 * (bounds[j + 1] - bounds[j]) * sW * 3 for j in range(world)]
-    _all_to_all(recv, flat, [n_me] * world, in_splits, group)
-    del flat
-    summed = recv.view(world, 2, rows_me, sW, 3).sum(dim=0) if rows_me > 0 else recv.view(2, 0, sW, 3)
+    acc, acc_r = eng.partial(mine, world)              # [world][2][rows][sW][3]
+    recv = torch.empty_like(acc)
+    _all_to_all(recv, acc, group)                        # recv[k] = rank k's partial of MY slab
+    del acc
+    summed = recv.sum(dim=0)                             # [2][rows][sW][3]
     del recv
-    out_slab = eng.finish_slab(summed, bounds[rank])
+    valid = bounds[rank + 1] - bounds[rank]
+    out_slab = torch.zeros((rows, sW, 3), dtype=torch.float32, device=summed.device)
+    if valid > 0:
+        out_slab[:valid] = eng.finish_slab(summed[:, :valid].contiguous() if valid != rows else summed, bounds[rank])
     if acc_r is not None:
         acc_r = _reduce_sum(acc_r, root, group)
-
-    # finished slabs -> rank 0
-    staged = _staged(out_slab, group)
-    if rank == 0:
-        out = torch.empty((sH, sW, 3), dtype=torch.float32, device=out_slab.device)
-        out[bounds[0]:bounds[1]] = out_slab
-        ops, bufs = [], []
-        for j in range(1, world):
-            r0, r1 = bounds[j], bounds[j + 1]
-            if r1 > r0:
-                buf = torch.empty((r1 - r0, sW, 3), dtype=torch.float32) if staged else out[r0:r1]
-                bufs.append((r0, r1, buf))
-                ops.append(dist.P2POp(dist.irecv, buf, dist.get_global_rank(group, j) if group is not None else j, group))
-        if ops:
-            for req in dist.batch_isend_irecv(ops):
-                req.wait()
-        if staged:
-            for r0, r1, buf in bufs:
-                out[r0:r1] = buf.to(out.device)
-        if acc_r is not None:
-            debug["accumulated robustness"] = acc_r
-        return out, debug
-    if rows_me > 0:
-        buf = out_slab.cpu() if staged else out_slab.contiguous()
-        for req in dist.batch_isend_irecv([dist.P2POp(dist.isend, buf, root, group)]):
-            req.wait()
-    return None, {}
+    gathered = _gather(out_slab, root, world, group)     # [world][rows][sW][3] on rank 0
+    if rank != 0:
+        return None, {}
+    out = gathered.view(world * rows, sW, 3)[:sH]
+    if acc_r is not None:
+        debug["accumulated robustness"] = acc_r
+    return out, debug

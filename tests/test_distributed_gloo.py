@@ -39,19 +39,19 @@ class OracleEngine:
         s = self.cfg.scale
         return (round(s * H), round(s * W), 3)
 
-    def partial(self, comps, bounds=None):
+    def partial(self, comps, world=1):
         H, W = self.ref.shape
         sH, sW, _ = self.output_shape()
-        bounds = bounds or [0, sH]
-        acc = np.zeros((2, sH, sW, 3), np.float32)
+        rows = hdist.slab_rows(sH, world) if world > 1 else sH
+        acc = np.zeros((2, world * rows, sW, 3), np.float32)
         acc_r = np.zeros((H, W), np.float32)
         for img in comps:
             flow = oracle.align(*self.al, oracle.compute_grey_images(img, "FFT"), self.cfg)
             r = oracle.compute_robustness(img, *self.stats, flow, self.cfa, self.wb, self.curves, self.cfg)
             acc_r += r
-            oracle.merge(img, flow, oracle.estimate_kernels(img, self.cfg), r, acc[0], acc[1], self.cfa, self.cfg)
-        flat = np.concatenate([acc[:, bounds[j]:bounds[j + 1]].ravel() for j in range(len(bounds) - 1)])
-        return torch.from_numpy(flat), torch.from_numpy(acc_r)
+            oracle.merge(img, flow, oracle.estimate_kernels(img, self.cfg), r, acc[0, :sH], acc[1, :sH], self.cfa, self.cfg)
+        slabs = np.ascontiguousarray(acc.reshape(2, world, rows, sW, 3).transpose(1, 0, 2, 3, 4))
+        return torch.from_numpy(slabs), torch.from_numpy(acc_r)
 
     def finish_slab(self, acc, row0, acc_r=None):
         sH, sW, _ = self.output_shape()
@@ -95,6 +95,7 @@ def _free_port():
 def test_slab_bounds():
     b = hdist.slab_bounds(6000, 8)
     assert b[0] == 0 and b[-1] == 6000 and all(x % 16 == 0 for x in b[:-1]) and b == sorted(b)
+    assert hdist.slab_rows(6000, 8) == 752 and hdist.slab_rows(256, 3) == 96
     assert hdist.slab_bounds(100, 8) == [0, 16, 32, 48, 64, 80, 96, 100, 100]  # trailing slabs may be empty
 
 
