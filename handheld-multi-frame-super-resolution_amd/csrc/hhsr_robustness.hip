@@ -192,30 +192,34 @@ extern "C" int hhsr_rob_s(const float* flow, int ny, int nx, float Mt, float s1,
 // then reads 4 raw-resolution planes (3 means + sigma^2) instead of 6.
 __global__ void __launch_bounds__(256) k_rob_sigma(const float* __restrict__ rmean, const float* __restrict__ rvar,
                                                     const double* __restrict__ stdc, int ncurve,
-                                                    float* __restrict__ ssq, size_t n) {
+                                                    float* __restrict__ ssq, uint32_t* __restrict__ idx, size_t n) {
     const size_t o = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (o >= n) return;
     double s_sq = 0.0;
+    uint32_t packed = 0;
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
         const float b = rmean[c * n + o];
         int id = 0;
         const double bb = 1000.0 * (double)b;
         if (isfinite(bb)) id = clampi((int)rint(bb), 0, ncurve - 1);  // non-finite (D6 border): see k_rob_frame
+        packed |= (uint32_t)id << (10 * c);
         const double s_t = stdc[id];
         const double sp = (double)rvar[c * n + o];
         const double st2 = s_t * s_t;
         s_sq += (st2 > sp) ? st2 : sp;  // Python max(sigma_p_sq, sigma_t^2)
     }
     ssq[o] = (float)s_sq;
+    if (idx) idx[o] = packed;
 }
 
 extern "C" int hhsr_rob_sigma(const float* ref_means, const float* ref_vars, int H, int W, const double* std_curve,
-                              int ncurve, float* sigma_sq, void* stream) {
+                              int ncurve, float* sigma_sq, uint32_t* curve_index, void* stream) {
     HHSR_ARG(ref_means && ref_vars && std_curve && sigma_sq && H > 0 && W > 0 && ncurve > 0);
+    HHSR_ARG(!curve_index || ncurve <= 1024);  // three 10-bit indices per word
     const size_t n = (size_t)H * W;
     hipLaunchKernelGGL(k_rob_sigma, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, ref_means,
-                       ref_vars, std_curve, ncurve, sigma_sq, n);
+                       ref_vars, std_curve, ncurve, sigma_sq, curve_index, n);
     HHSR_LAUNCHED();
 }
 
@@ -264,114 +268,206 @@ __global__ void __launch_bounds__(256) k_rob_frame(const float* __restrict__ cm,
 // pixels are displaced by the same flow vector and read the same <= 11x11 window of the frame's guide means.
 // The window (3 channels, clamp-to-edge coordinates as in robustness.py:403-409) is staged in LDS with
 // coalesced loads; the 27 taps of every pixel come from LDS: ~8 vector loads per pixel instead of 41.
-constexpr int RF_T = 16, RF_W = 12;
+constexpr int RF_T = 16;               // a 16-column group lies inside one flow tile (ts % 16 == 0)
+constexpr int RF_BX = 32, RF_BY = 32;  // raw pixels per workgroup (2 x 2 sub-tiles of 16 x 16)
+constexpr int RF_NK = 4;               // pixels per thread (rows ly + 8k)
+constexpr int RF_WN = 11;              // guide window per sub-tile: 16/2 + 3 rows and columns
+
+// One axis of the guide-image position of raw pixel p displaced by the tile's flow f:
+//     l = (p + f + 0.5) / 2 - 0.5      (robustness.py:380-383, float64 in the reference).
+// Split f = fi + ff (fi = floor(f), 0 <= ff < 1, exact in float64) and n = p + fi:  2 l = n + ff - 0.5.  The
+// in-image test, round-half-even centre and the centre offset then follow from the integer n and three
+// per-tile predicates on ff — the same decisions as the float64 expression without per-pixel float64.
+struct RobAxis {
+    int fi;       // floor(f)
+    float h;      // ff / 2
+    bool lt, eq;  // ff < 0.5, ff == 0.5
+    bool ok;      // finite, sane flow
+};
+__device__ __forceinline__ RobAxis rob_axis(float f) {
+    const double fd = (double)f, fl = floor(fd), ff = fd - fl;
+    RobAxis a;
+    a.ok = fabs(fd) < 1.0e9;  // false for NaN: such a pixel is "outside" like in the reference
+    a.fi = a.ok ? (int)fl : 0;
+    a.h = (float)(0.5 * ff);
+    a.lt = ff < 0.5;
+    a.eq = ff == 0.5;
+    return a;
+}
+// centre c = rint(l) and r = c - l for pixel p; returns whether 0 <= l < len
+__device__ __forceinline__ bool rob_centre(const RobAxis& a, int p, int len, int& c, float& r) {
+    const int n = p + a.fi, m = n >> 1, odd = n & 1;
+    const bool up = odd && !a.lt && (!a.eq || (m & 1));  // l = m + 0.25 + ff/2 on odd n: tie goes to the even centre
+    c = m + (up ? 1 : 0);
+    const float base = odd ? 0.25f + a.h : a.h - 0.25f;  // l - m
+    r = (up ? 1.0f : 0.0f) - base;
+    return a.ok && (n >= 1 || (n == 0 && !a.lt)) && (n < 2 * len || (n == 2 * len && a.lt));
+}
+// Dodgson weights of the 3 taps c-1, c, c+1 at offsets r-1, r, r+1 (|r| <= 0.5): the centre is on the inner
+// branch, the neighbours on the outer one; a tap clamped to the image border coincides with the centre and
+// takes the centre's weight (robustness.py:407-413).
+__device__ __forceinline__ void dodgson3(float r, int c, int len, float w[3]) {
+    const float inner = fmaf(-2.0f * r, r, 1.0f);
+    const float am = fabsf(r - 1.0f), ap = fabsf(r + 1.0f);
+    const float om = fmaf(am, am, fmaf(-2.5f, am, 1.5f)), op = fmaf(ap, ap, fmaf(-2.5f, ap, 1.5f));
+    w[0] = c - 1 >= 0 ? om : inner;
+    w[1] = inner;
+    w[2] = c + 1 <= len - 1 ? op : inner;
+}
 
 // Arithmetic of this fused kernel (vs the reference's Numba typing):
-//   * guide positions, the in/out-of-image test, the window centre (round-half-even) and the clamped tap
-//     coordinates: float64, identical decisions to the reference;
+//   * the in/out-of-image test, the window centre (round-half-even) and the clamped taps: exact integer /
+//     predicate form of the reference's float64 expressions (rob_axis / rob_centre) — identical decisions;
 //   * Dodgson weights and the weighted mean: float32 FMAs.  The reference evaluates the weights in
 //     float64 but rounds its float32 buffer after every tap (robustness.py:414-415), so its means already
-//     carry ~1e-7 relative rounding noise; float32 weights stay within that (this replaces ~150 fp64
-//     operations and 54 float<->double conversions per pixel, which bounded the kernel);
-//   * the noise-curve index is taken in float64 (exact same index as the reference); the shrink
-//     d^2/(d^2 + d_t^2) and sigma^2 sums are float32 (relative error 1e-7 on values that feed
-//     exp(-d^2/sigma^2));
+//     carry ~1e-7 relative rounding noise; float32 weights stay within that;
+//   * the noise-curve indices round(1000 b_c) only depend on the reference frame: hhsr_rob_sigma takes them in
+//     float64 once per burst (exact same index as the reference) and packs the three 10-bit indices in one word;
+//   * the shrink d^2/(d^2 + d_t^2), the sigma^2 ratio and the exponential are float32 with v_rcp_f32 / v_exp_f32
+//     (1 ulp each; relative error ~2e-7 on values that feed exp(-d^2/sigma^2)); Inf / NaN propagate like the
+//     IEEE divisions they replace, so the D6 border and out-of-image pixels still end at R = 0.
 // Net effect on R: <= 1e-4 absolute on the few pixels in the transition band 0 < R < 1 (tests: 1e-4).
+// The kernel is VALU-bound (it was ~550 instructions per pixel, 69 of them float64, before this form).
+// Workgroup = 32 x 32 raw pixels = 2 x 2 sub-tiles of 16 x 16 (each inside one flow tile, own guide window);
+// a thread owns 4 pixels (rows ly, ly+8, ly+16, ly+24).  One short dependent chain (flow -> window origin ->
+// guide loads -> LDS) per 1024 pixels and 20 independent plane loads in flight per thread: with one pixel per
+// thread the kernel was bound by that chain's latency (3 TB/s of plane traffic at 8 workgroups per CU).
 __global__ void __launch_bounds__(256) k_rob_frame_tile(const float* __restrict__ cm, int lh, int lw,
                                                          const float* __restrict__ rmean,
                                                          const float* __restrict__ ssq,
+                                                         const uint32_t* __restrict__ cidx,
                                                          const float2* __restrict__ flow, int nx, int ts,
                                                          const float* __restrict__ S,
-                                                         const double* __restrict__ difc, int ncurve, double t,
+                                                         const double* __restrict__ difc, double t,
                                                          float* __restrict__ R, int H, int W) {
-    __shared__ float s_g[3][RF_W][RF_W + 1];
-    const int bx = blockIdx.x * RF_T, by = blockIdx.y * RF_T;
-    const int lx_ = threadIdx.x & (RF_T - 1), ly_ = threadIdx.x >> 4;
-    const int x = bx + lx_, y = by + ly_;
-    const int tix = bx / ts, tiy = by / ts;  // uniform
-    const float2 f = flow[(size_t)tiy * nx + tix];
-    const double fx = (double)f.x, fy = (double)f.y;
-    // window origin from the block's first pixel (LR position is monotone in the pixel coordinate)
-    const double ly0 = ((double)by + fy + 0.5) / 2.0 - 0.5, lx0 = ((double)bx + fx + 0.5) / 2.0 - 0.5;
-    const int wy0 = (int)rint(fmin(fmax(ly0, -4.0), (double)lh + 4.0)) - 1;
-    const int wx0 = (int)rint(fmin(fmax(lx0, -4.0), (double)lw + 4.0)) - 1;
-    const size_t gplane = (size_t)lh * lw;
-    for (int p = threadIdx.x; p < 3 * RF_W * RF_W; p += 256) {
-        const int c = p / (RF_W * RF_W), q = p - c * RF_W * RF_W;
-        const int i = q / RF_W, j = q - i * RF_W;
-        const int gy = clampi(wy0 + i, 0, lh - 1), gx = clampi(wx0 + j, 0, lw - 1);
-        s_g[c][i][j] = cm[c * gplane + (size_t)gy * lw + gx];
+    __shared__ float s_g[2][2][3][RF_WN][RF_WN + 2];
+    const int lx_ = threadIdx.x & (RF_BX - 1), ly_ = threadIdx.x >> 5;
+    const int grp = lx_ >> 4;  // 16-column group
+    const int bx = blockIdx.x * RF_BX + grp * RF_T, by = blockIdx.y * RF_BY;
+    const int x = blockIdx.x * RF_BX + lx_;
+    const int tix = min(bx, W - 1) / ts;
+    RobAxis ay[2], ax[2];
+    int wy0[2], wx0[2];
+    float Sv[2];
+#pragma unroll
+    for (int v = 0; v < 2; ++v) {  // the two sub-tiles of this column group
+        const int tiy = min(by + RF_T * v, H - 1) / ts;
+        const float2 f = flow[(size_t)tiy * nx + tix];
+        Sv[v] = S[(size_t)tiy * nx + tix];
+        ay[v] = rob_axis(f.y);
+        ax[v] = rob_axis(f.x);
+        // window origin from the sub-tile's first pixel (the centre is monotone in the pixel coordinate and
+        // 16 pixels advance it by at most 8, so centre-1 .. centre+1 stays inside 11 x 11 entries)
+        float r_;
+        rob_centre(ay[v], by + RF_T * v, lh, wy0[v], r_);
+        rob_centre(ax[v], bx, lw, wx0[v], r_);
+        wy0[v] = clampi(wy0[v], -4, lh + 4) - 1;
+        wx0[v] = clampi(wx0[v], -4, lw + 4) - 1;
     }
-    // the reference-frame operands do not depend on the LDS window: issue their loads before the barrier
-    const bool live = x < W && y < H;
-    const size_t plane = (size_t)H * W, o = live ? (size_t)y * W + x : 0;
-    float rb[3];
+    const size_t gplane = (size_t)lh * lw;
+    const int tg = (lx_ & (RF_T - 1)) + RF_T * ly_;  // 0..127 within the column group
+    constexpr int WSZ = 3 * RF_WN * RF_WN, NST = (WSZ + 127) / 128;
+    float st[2][NST];
 #pragma unroll
-    for (int c = 0; c < 3; ++c) rb[c] = rmean[c * plane + o];
-    const float s_sq = ssq[o];
-    const float Sv = S[(size_t)tiy * nx + tix];
-    __syncthreads();
-    if (!live) return;
-    const double ly = ((double)y + fy + 0.5) / 2.0 - 0.5;
-    const double lx = ((double)x + fx + 0.5) / 2.0 - 0.5;
-    float cmu[3] = {INFINITY, INFINITY, INFINITY};
-    if (ly >= 0.0 && ly < (double)lh && lx >= 0.0 && lx < (double)lw) {
-        const int cy = (int)rint(ly), cx = (int)rint(lx);  // round-half-even
-        const float ry = (float)((double)cy - ly), rx = (float)((double)cx - lx);  // in [-0.5, 0.5]
-        float wxv[3], b0 = 0.f, b1 = 0.f, b2 = 0.f, wacc = 0.f;
+    for (int v = 0; v < 2; ++v)
 #pragma unroll
-        for (int j = -1; j <= 1; ++j)  // tap coordinate clamped to the guide image (robustness.py:407)
-            wxv[j + 1] = dodgsonf(rx + (float)(clampi(cx + j, 0, lw - 1) - cx));
-#pragma unroll
-        for (int i = -1; i <= 1; ++i) {
-            const float wy = dodgsonf(ry + (float)(clampi(cy + i, 0, lh - 1) - cy));
-            const int wi = cy + i - wy0;
-#pragma unroll
-            for (int j = -1; j <= 1; ++j) {
-                const float w = wy * wxv[j + 1];
-                const int wj = cx + j - wx0;
-                b0 = fmaf(s_g[0][wi][wj], w, b0);
-                b1 = fmaf(s_g[1][wi][wj], w, b1);
-                b2 = fmaf(s_g[2][wi][wj], w, b2);
-                wacc += w;
+        for (int u = 0; u < NST; ++u) {
+            const int p = tg + 128 * u;
+            if (p < WSZ) {
+                const int c = p / (RF_WN * RF_WN), q = p - c * (RF_WN * RF_WN);
+                const int i = q / RF_WN, j = q - i * RF_WN;
+                const int gy = clampi(wy0[v] + i, 0, lh - 1), gx = clampi(wx0[v] + j, 0, lw - 1);
+                st[v][u] = cm[c * gplane + (size_t)gy * lw + gx];
             }
         }
-        const float iw = 1.0f / wacc;
-        cmu[0] = b0 * iw;
-        cmu[1] = b1 * iw;
-        cmu[2] = b2 * iw;
-    }
-    float d_sq = 0.f;
+    // the reference-frame operands do not depend on the LDS window: issue their loads before the barrier
+    const size_t plane = (size_t)H * W;
+    bool live[RF_NK];
+    size_t o[RF_NK];
+    float rb[RF_NK][3], s_sq[RF_NK];
+    uint32_t ci[RF_NK];
 #pragma unroll
-    for (int c = 0; c < 3; ++c) {
-        const float b = rb[c];
-        const float dp = fabsf(b - cmu[c]);
-        int id = 0;
-        const double bb = 1000.0 * (double)b;  // index decided in float64 like the reference
-        if (isfinite(bb)) id = clampi((int)rint(bb), 0, ncurve - 1);
-        const float d_t = (float)difc[id];
-        const float dp2 = dp * dp;
-        const float shrink = dp2 / (dp2 + d_t * d_t);
-        d_sq += dp2 * shrink * shrink;
+    for (int k = 0; k < RF_NK; ++k) {
+        const int y = by + ly_ + 8 * k;
+        live[k] = x < W && y < H;
+        o[k] = live[k] ? (size_t)y * W + x : 0;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) rb[k][c] = rmean[c * plane + o[k]];
+        s_sq[k] = ssq[o[k]];
+        ci[k] = cidx[o[k]];
     }
-    const float e = expf(-d_sq / s_sq);
-    double v = (double)(Sv * e) - t;
-    v = v > 0.0 ? v : 0.0;
-    v = v < 1.0 ? v : 1.0;
-    R[o] = (float)v;
+#pragma unroll
+    for (int v = 0; v < 2; ++v)
+#pragma unroll
+        for (int u = 0; u < NST; ++u) {
+            const int p = tg + 128 * u;
+            if (p < WSZ) {
+                const int c = p / (RF_WN * RF_WN), q = p - c * (RF_WN * RF_WN);
+                const int i = q / RF_WN, j = q - i * RF_WN;
+                s_g[grp][v][c][i][j] = st[v][u];
+            }
+        }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < RF_NK; ++k) {
+        if (!live[k]) continue;
+        const int v = k >> 1, y = by + ly_ + 8 * k;
+        float d_t[3];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) d_t[c] = (float)difc[(ci[k] >> (10 * c)) & 1023u];
+        int cy, cx;
+        float ry, rx;
+        const bool iny = rob_centre(ay[v], y, lh, cy, ry), inx = rob_centre(ax[v], x, lw, cx, rx);
+        float cmu[3] = {INFINITY, INFINITY, INFINITY};
+        if (iny && inx) {
+            float wxv[3], wyv[3], b0 = 0.f, b1 = 0.f, b2 = 0.f, wacc = 0.f;
+            dodgson3(rx, cx, lw, wxv);
+            dodgson3(ry, cy, lh, wyv);
+            const int wi0 = cy - 1 - wy0[v], wj0 = cx - 1 - wx0[v];
+#pragma unroll
+            for (int i = 0; i < 3; ++i) {
+#pragma unroll
+                for (int j = 0; j < 3; ++j) {
+                    const float w = wyv[i] * wxv[j];
+                    b0 = fmaf(s_g[grp][v][0][wi0 + i][wj0 + j], w, b0);
+                    b1 = fmaf(s_g[grp][v][1][wi0 + i][wj0 + j], w, b1);
+                    b2 = fmaf(s_g[grp][v][2][wi0 + i][wj0 + j], w, b2);
+                    wacc += w;
+                }
+            }
+            const float iw = __builtin_amdgcn_rcpf(wacc);
+            cmu[0] = b0 * iw;
+            cmu[1] = b1 * iw;
+            cmu[2] = b2 * iw;
+        }
+        float d_sq = 0.f;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const float dp = fabsf(rb[k][c] - cmu[c]);
+            const float dp2 = dp * dp;
+            const float shrink = dp2 * __builtin_amdgcn_rcpf(dp2 + d_t[c] * d_t[c]);
+            d_sq += dp2 * shrink * shrink;
+        }
+        const float e = __builtin_amdgcn_exp2f((-d_sq * __builtin_amdgcn_rcpf(s_sq[k])) * 1.44269504088896341f);
+        double r = (double)(Sv[v] * e) - t;
+        r = r > 0.0 ? r : 0.0;
+        r = r < 1.0 ? r : 1.0;
+        R[o[k]] = (float)r;
+    }
 }
 
 extern "C" int hhsr_rob_frame(const float* comp_means, int lh, int lw, const float* ref_means,
-                              const float* ref_sigma_sq, const float* flow, int ny, int nx, int ts, const float* S,
-                              const double* diff_curve, int ncurve, double t, float* R, void* stream) {
+                              const float* ref_sigma_sq, const uint32_t* ref_curve_index, const float* flow, int ny,
+                              int nx, int ts, const float* S, const double* diff_curve, int ncurve, double t, float* R,
+                              void* stream) {
     HHSR_ARG(comp_means && ref_means && ref_sigma_sq && flow && S && diff_curve && R);
     HHSR_ARG(lh > 0 && lw > 0 && ts > 0 && ncurve > 0);
     const int H = 2 * lh, W = 2 * lw;
     HHSR_ARG(ny * ts >= H && nx * ts >= W);
-    if (ts % RF_T == 0)
-        hipLaunchKernelGGL(k_rob_frame_tile, dim3(hhsr_cdiv(W, RF_T), hhsr_cdiv(H, RF_T)), dim3(256), 0,
-                           (hipStream_t)stream, comp_means, lh, lw, ref_means, ref_sigma_sq,
-                           reinterpret_cast<const float2*>(flow), nx, ts, S, diff_curve, ncurve, t, R, H, W);
+    if (ts % RF_T == 0 && ref_curve_index && ncurve <= 1024)
+        hipLaunchKernelGGL(k_rob_frame_tile, dim3(hhsr_cdiv(W, RF_BX), hhsr_cdiv(H, RF_BY)), dim3(256), 0,
+                           (hipStream_t)stream, comp_means, lh, lw, ref_means, ref_sigma_sq, ref_curve_index,
+                           reinterpret_cast<const float2*>(flow), nx, ts, S, diff_curve, t, R, H, W);
     else
         hipLaunchKernelGGL(k_rob_frame, dim3(hhsr_cdiv(W, 64), hhsr_cdiv(H, 4)), dim3(256), 0, (hipStream_t)stream,
                            comp_means, lh, lw, ref_means, ref_sigma_sq, reinterpret_cast<const float2*>(flow), nx, ts,

@@ -79,12 +79,15 @@ def noise_curves_to_device(std_curve, diff_curve, device):
 
 def noise_sigma_sq(ref_local_means, ref_local_stds, std_curve):
     """sigma^2 = sum_c max(var_c, sigma_t(mu_c)^2) of the reference frame (robustness.py:505-528): it does
-    not depend on the compared frame, so a burst computes it once."""
+    not depend on the compared frame, so a burst computes it once.
+    Returns (sigma_sq float32 [H, W], curve_index int32 [H, W] or None): the second plane holds the three
+    noise-curve indices round(1000 mu_c) of every pixel (10 bits each), equally frame-independent."""
     _, H, W = ref_local_means.shape
     out = torch.empty((H, W), dtype=torch.float32, device=ref_local_means.device)
+    idx = torch.empty((H, W), dtype=torch.int32, device=out.device) if std_curve.numel() <= 1024 else None
     _lib.call("hhsr_rob_sigma", _lib.ptr(ref_local_means), _lib.ptr(ref_local_stds), H, W, _lib.ptr(std_curve),
-              int(std_curve.numel()), _lib.ptr(out), _lib.stream())
-    return out
+              int(std_curve.numel()), _lib.ptr(out), _lib.ptr(idx), _lib.stream())
+    return out, idx
 
 
 def compute_robustness(comp_img, ref_local_means, ref_local_stds, flows, cfa_pattern, white_balance, noise_model,
@@ -110,8 +113,9 @@ def compute_robustness(comp_img, ref_local_means, ref_local_stds, flows, cfa_pat
     cm, _ = compute_local_stats_from_raw(comp_img, cfa_pattern, white_balance)
     S = compute_s(flows, t.Mt, t.s1, t.s2)
     R = torch.empty((H, W), dtype=torch.float32, device=comp_img.device)
-    _lib.call("hhsr_rob_frame", _lib.ptr(cm), H // 2, W // 2, _lib.ptr(ref_local_means), _lib.ptr(ref_sigma_sq),
-              _lib.ptr(flows), ny, nx, int(ts), _lib.ptr(S), _lib.ptr(diff_curve), int(diff_curve.numel()),
+    sigma_sq, curve_index = ref_sigma_sq
+    _lib.call("hhsr_rob_frame", _lib.ptr(cm), H // 2, W // 2, _lib.ptr(ref_local_means), _lib.ptr(sigma_sq),
+              _lib.ptr(curve_index), _lib.ptr(flows), ny, nx, int(ts), _lib.ptr(S), _lib.ptr(diff_curve), int(diff_curve.numel()),
               float(t.t), _lib.ptr(R), _lib.stream())
     r = local_min(R, accumulate_into)
     return (r, R) if return_R else r

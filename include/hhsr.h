@@ -129,15 +129,18 @@ int hhsr_rob_upscale(const float* stats, int lh, int lw, const float* flow, int 
                      float* out, void* stream);
 /* Per-tile flow-irregularity map S (robustness.py:570-612). */
 int hhsr_rob_s(const float* flow, int ny, int nx, float Mt, float s1, float s2, float* S, void* stream);
-/* Frame-independent noise-model term (robustness.py:505-528, once per burst):
- * sigma_sq[p] = sum_c max(ref_vars[c][p], std_curve[round(1000 ref_means[c][p])]^2), float32 [H][W]. */
+/* Frame-independent noise-model terms (robustness.py:505-528, once per burst):
+ * sigma_sq[p] = sum_c max(ref_vars[c][p], std_curve[round(1000 ref_means[c][p])]^2), float32 [H][W];
+ * curve_index[p] (optional, NULL to skip; needs ncurve <= 1024) = the three curve indices
+ * round(1000 ref_means[c][p]) packed 10 bits each (c = 0 in the low bits), uint32 [H][W]. */
 int hhsr_rob_sigma(const float* ref_means, const float* ref_vars, int H, int W,
-                   const double* std_curve, int ncurve, float* sigma_sq, void* stream);
+                   const double* std_curve, int ncurve, float* sigma_sq, uint32_t* curve_index, void* stream);
 /* Fused warp-upsample of the frame's guide means + colour distance + noise-model shrink + threshold
  * (robustness.py:359-421, 453-461, 505-528, 627-639) -> R float32 [2lh][2lw].
- * ref_sigma_sq from hhsr_rob_sigma; diff_curve: device double[ncurve]. */
+ * ref_sigma_sq / ref_curve_index from hhsr_rob_sigma (index plane NULL = look the curve up per frame on
+ * the slower generic kernel); diff_curve: device double[ncurve]. */
 int hhsr_rob_frame(const float* comp_means, int lh, int lw, const float* ref_means, const float* ref_sigma_sq,
-                   const float* flow, int ny, int nx, int ts, const float* S,
+                   const uint32_t* ref_curve_index, const float* flow, int ny, int nx, int ts, const float* S,
                    const double* diff_curve, int ncurve, double t, float* R, void* stream);
 /* 5x5 clamp-border minimum (robustness.py:670-686).  acc_r != NULL additionally does acc_r += r
  * (the accumulated robustness of super_resolution.py:158-159, fused to save a pass). */
