@@ -556,6 +556,19 @@ extern "C" int hhsr_ica(const float* ref, const float* gx, const float* gy, int 
 // with the block-matching border rule (L2: clamp-to-edge, L1: zero-fill); ICA's own rule (zero outside /
 // clamped coordinates for TS = 8) differs only where the window leaves the moving level, and there
 // (wave-uniform test) the ICA taps are read from global memory with the exact rule.
+// Instruction diet (the level-0 launch is VALU-issue bound: 47k tiles x ~1000 VALU instructions before):
+//   * the wave index is made scalar (readfirstlane), so tile coordinates, window origins, flows and every
+//     border test live in SGPRs and branch on the scalar unit;
+//   * windows are staged through a 2-D lane mapping (lane -> column, 64/CW rows per pass): no per-element
+//     divisions, and for tiles whose windows lie inside their level (wave-uniform test) no per-element bounds
+//     logic either — one 64-bit add per load, LDS stores at immediate offsets;
+//   * the waves of a workgroup never share LDS data: a wave-level fence replaces __syncthreads();
+//   * the (2r+1)^2 <= 9 candidate loop is unrolled (immediate LDS offsets).
+template <int N, int CW>
+struct Stage2D {  // N x N window, lane -> (row lane / CW + k * (64 / CW), column lane % CW)
+    static constexpr int RPP = HHSR_WAVE / CW, NK = (N + RPP - 1) / RPP;
+};
+
 template <int TS, int R, bool L1>
 __global__ void __launch_bounds__(256) k_align_wave(const float* __restrict__ ref, int rh, int rw, int ref_pitch,
                                                      const float* __restrict__ hess, const float* __restrict__ mov,
@@ -566,7 +579,7 @@ __global__ void __launch_bounds__(256) k_align_wave(const float* __restrict__ re
     constexpr int M = ICA_M;
     constexpr int RS = TS + 2, RP = RS | 1;            // reference tile + halo
     constexpr int PPT = TS * TS / HHSR_WAVE > 0 ? TS * TS / HHSR_WAVE : 1;
-    const int wave = threadIdx.x / HHSR_WAVE, lane = threadIdx.x & (HHSR_WAVE - 1);
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x / HHSR_WAVE), lane = threadIdx.x & (HHSR_WAVE - 1);
     constexpr int n1 = 2 * r + 1, n = n1 * n1, nparts = 4 * n;
     constexpr int WS = TS + 2 * r + 2 * M + 1, WP = WS | 1;  // moving window
     constexpr int slice = (RS * RP + WS * WP + nparts + 3) & ~3;
@@ -574,45 +587,75 @@ __global__ void __launch_bounds__(256) k_align_wave(const float* __restrict__ re
     float* s_win = s_ref + RS * RP;
     float* s_part = s_win + WS * WP;
     const int tile = blockIdx.x * 4 + wave;
-    bool active = tile < ntiles;
-    const int tsafe = active ? tile : 0;
-    const int ty = tsafe / nx, tx = tsafe - ty * nx;
-    float* fl = flow + (size_t)tsafe * 2;
-    const float f0 = fl[0], f1 = fl[1];
+    if (tile >= ntiles) return;  // wave-uniform; no workgroup barrier below
+    const int ty = tile / nx, tx = tile - ty * nx;
+    float* fl = flow + (size_t)tile * 2;
+    const float f0 = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, fl[0])));
+    const float f1 = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, fl[1])));
     const float r0 = rintf(f0), r1 = rintf(f1);  // round-half-even
     const int ox = tx * TS + (int)r0 - r - M, oy = ty * TS + (int)r1 - r - M;  // window origin in the moving level
-    if (active) {
+    {
         // all global loads of the two windows are issued back to back into registers, then stored to LDS
         // (a load -> store loop serialises on memory latency: 14-40 round trips per tile)
-        constexpr int NR = (RS * RS + HHSR_WAVE - 1) / HHSR_WAVE, NW = (WS * WS + HHSR_WAVE - 1) / HHSR_WAVE;
-        float vr[NR], vw[NW];
+        constexpr int CWR = RS <= 32 ? 32 : 64, CWW = WS <= 32 ? 32 : 64;
+        using SR = Stage2D<RS, CWR>;
+        using SW = Stage2D<WS, CWW>;
+        float vr[SR::NK], vw[SW::NK];
+        const int jr = lane % CWR, ir = lane / CWR, jw = lane % CWW, iw = lane / CWW;
+        const int rx0 = tx * TS - 1, ry0 = ty * TS - 1;
+        const bool ref_in = rx0 >= 0 && ry0 >= 0 && rx0 + RS <= rw && ry0 + RS <= rh;
+        const bool win_in = ox >= 0 && oy >= 0 && ox + WS <= mw && oy + WS <= mh;
+        if (ref_in) {  // columns past the window re-read its last column (never stored)
+            const float* q = ref + (size_t)(ry0 + ir) * ref_pitch + rx0 + min(jr, RS - 1);
 #pragma unroll
-        for (int k = 0; k < NR; ++k) {
-            const int p = lane + k * HHSR_WAVE;
-            const int i = p / RS, j = p - i * RS;
-            const int y = ty * TS + i - 1, x = tx * TS + j - 1;
-            vr[k] = (p < RS * RS && y >= 0 && y < rh && x >= 0 && x < rw) ? ref[(size_t)y * ref_pitch + x] : 0.f;
+            for (int k = 0; k < SR::NK; ++k) {
+                const bool tail = (k + 1) * SR::RPP > RS;  // compile time: this pass can run past the last row
+                vr[k] = (!tail || ir + k * SR::RPP < RS) ? q[(size_t)k * SR::RPP * ref_pitch] : 0.f;
+            }
+        } else {
+#pragma unroll
+            for (int k = 0; k < SR::NK; ++k) {
+                const int y = ry0 + ir + k * SR::RPP, x = rx0 + jr;
+                vr[k] = (jr < RS && ir + k * SR::RPP < RS && y >= 0 && y < rh && x >= 0 && x < rw)
+                            ? ref[(size_t)y * ref_pitch + x] : 0.f;
+            }
         }
+        if (win_in) {
+            const float* q = mov + (size_t)(oy + iw) * mov_pitch + ox + min(jw, WS - 1);
 #pragma unroll
-        for (int k = 0; k < NW; ++k) {
-            const int p = lane + k * HHSR_WAVE;
-            const int i = p / WS, j = p - i * WS;
-            const int y = oy + i, x = ox + j;
-            if (L1) vw[k] = (p < WS * WS && y >= 0 && y < mh && x >= 0 && x < mw) ? mov[(size_t)y * mov_pitch + x] : 0.f;
-            else vw[k] = p < WS * WS ? mov[(size_t)clampi(y, 0, mh - 1) * mov_pitch + clampi(x, 0, mw - 1)] : 0.f;
+            for (int k = 0; k < SW::NK; ++k) {
+                const bool tail = (k + 1) * SW::RPP > WS;
+                vw[k] = (!tail || iw + k * SW::RPP < WS) ? q[(size_t)k * SW::RPP * mov_pitch] : 0.f;
+            }
+        } else {
+#pragma unroll
+            for (int k = 0; k < SW::NK; ++k) {
+                const int y = oy + iw + k * SW::RPP, x = ox + jw;
+                const bool inw = jw < WS && iw + k * SW::RPP < WS;
+                if (L1) vw[k] = (inw && y >= 0 && y < mh && x >= 0 && x < mw) ? mov[(size_t)y * mov_pitch + x] : 0.f;
+                else vw[k] = inw ? mov[(size_t)clampi(y, 0, mh - 1) * mov_pitch + clampi(x, 0, mw - 1)] : 0.f;
+            }
         }
+        if (jr < RS) {
+            float* d = s_ref + ir * RP + jr;
 #pragma unroll
-        for (int k = 0; k < NR; ++k) {
-            const int p = lane + k * HHSR_WAVE;
-            if (p < RS * RS) s_ref[(p / RS) * RP + p % RS] = vr[k];
+            for (int k = 0; k < SR::NK; ++k)
+                if ((k + 1) * SR::RPP <= RS || ir + k * SR::RPP < RS) d[k * SR::RPP * RP] = vr[k];
         }
+        if (jw < WS) {
+            float* d = s_win + iw * WP + jw;
 #pragma unroll
-        for (int k = 0; k < NW; ++k) {
-            const int p = lane + k * HHSR_WAVE;
-            if (p < WS * WS) s_win[(p / WS) * WP + p % WS] = vw[k];
+            for (int k = 0; k < SW::NK; ++k)
+                if ((k + 1) * SW::RPP <= WS || iw + k * SW::RPP < WS) d[k * SW::RPP * WP] = vw[k];
         }
     }
-    __syncthreads();
+    // LDS operations of one wave complete in order; the slice is private to the wave
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    // lane's pixels p = lane + 64k: row lane / TS + k * (64 / TS), column lane % TS
+    constexpr int RSTEP = HHSR_WAVE / TS > 0 ? HHSR_WAVE / TS : 1;
+    const int li = lane / TS, lj = lane % TS;
     // ---------------- block matching ----------------
     float nfx = f0, nfy = f1;  // flow after block matching
     if (L1 && mode == 1) {     // "L1_ref_effective": flow <- round(flow)
@@ -620,60 +663,55 @@ __global__ void __launch_bounds__(256) k_align_wave(const float* __restrict__ re
         nfy = r1;
     } else {
         CostIdx best{INFINITY, 0};
-        if (n <= 16) {
-            if (active) {
-                float rv[PPT];
+        if (n <= 16 && TS * TS >= HHSR_WAVE) {
+            float rv[PPT];
+            const float* rb = s_ref + (li + 1) * RP + lj + 1;
+            const float* wb = s_win + (li + M) * WP + lj + M;
+#pragma unroll
+            for (int k = 0; k < PPT; ++k) rv[k] = rb[k * RSTEP * RP];
+#pragma unroll
+            for (int c = 0; c < n; ++c) {
+                const int dy = c / n1, dx = c - dy * n1;
+                float acc = 0.f;
 #pragma unroll
                 for (int k = 0; k < PPT; ++k) {
-                    const int p = lane + k * HHSR_WAVE;
-                    rv[k] = s_ref[(p / TS + 1) * RP + p % TS + 1];
+                    const float d = rv[k] - wb[(k * RSTEP + dy) * WP + dx];
+                    acc += L1 ? fabsf(d) : d * d;
                 }
-                for (int c = 0; c < n; ++c) {
-                    const int dy = c / n1, dx = c - dy * n1;
-                    float acc = 0.f;
-#pragma unroll
-                    for (int k = 0; k < PPT; ++k) {
-                        const int p = lane + k * HHSR_WAVE;
-                        const float d = rv[k] - s_win[(p / TS + dy + M) * WP + p % TS + dx + M];
-                        acc += L1 ? fabsf(d) : d * d;
-                    }
-                    acc = wave_sum_uniform(acc);
-                    if (acc < best.c) {
-                        best.c = acc;
-                        best.i = c;
-                    }
+                acc = wave_sum_uniform(acc);
+                if (acc < best.c) {
+                    best.c = acc;
+                    best.i = c;
                 }
             }
         } else {
-            if (active) {
-                constexpr int QR = TS / 4;
-                for (int it = lane; it < nparts; it += HHSR_WAVE) {
-                    const int c = it >> 2, q = it & 3;
-                    const int dy = c / n1, dx = c - dy * n1;
-                    float acc = 0.f;
-                    for (int i = q * QR; i < (q + 1) * QR; ++i) {
-                        const float* wrow = s_win + (i + dy + M) * WP + dx + M;
-                        const float* rrow = s_ref + (i + 1) * RP + 1;
+            constexpr int QR = TS / 4;
+            for (int it = lane; it < nparts; it += HHSR_WAVE) {
+                const int c = it >> 2, q = it & 3;
+                const int dy = c / n1, dx = c - dy * n1;
+                float acc = 0.f;
+                for (int i = q * QR; i < (q + 1) * QR; ++i) {
+                    const float* wrow = s_win + (i + dy + M) * WP + dx + M;
+                    const float* rrow = s_ref + (i + 1) * RP + 1;
 #pragma unroll
-                        for (int j = 0; j < TS; ++j) {
-                            const float d = rrow[j] - wrow[j];
-                            acc += L1 ? fabsf(d) : d * d;
-                        }
-                    }
-                    s_part[it] = acc;
-                }
-            }
-            __syncthreads();
-            if (active) {
-                for (int c = lane; c < n; c += HHSR_WAVE) {
-                    const float tot = (s_part[4 * c] + s_part[4 * c + 1]) + (s_part[4 * c + 2] + s_part[4 * c + 3]);
-                    if (tot < best.c) {
-                        best.c = tot;
-                        best.i = c;
+                    for (int j = 0; j < TS; ++j) {
+                        const float d = rrow[j] - wrow[j];
+                        acc += L1 ? fabsf(d) : d * d;
                     }
                 }
-                best = wave_argmin(best);
+                s_part[it] = acc;
             }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            for (int c = lane; c < n; c += HHSR_WAVE) {
+                const float tot = (s_part[4 * c] + s_part[4 * c + 1]) + (s_part[4 * c + 2] + s_part[4 * c + 3]);
+                if (tot < best.c) {
+                    best.c = tot;
+                    best.i = c;
+                }
+            }
+            best = wave_argmin(best);
         }
         const int dy = best.i / n1 - r, dx = best.i % n1 - r;
         if (L1) {  // flow <- round(flow) + shift
@@ -684,7 +722,6 @@ __global__ void __launch_bounds__(256) k_align_wave(const float* __restrict__ re
             nfy = f1 + (float)dy;
         }
     }
-    if (!active) return;
     // ---------------- ICA ----------------
     const float* h = hess + (size_t)tile * 4;
     const float A00 = h[0], A01 = h[1], A10 = h[2], A11 = h[3];
@@ -712,13 +749,14 @@ __global__ void __launch_bounds__(256) k_align_wave(const float* __restrict__ re
                                 tx * TS + ix >= 0 && ty * TS + iy >= 0 && tx * TS + ix + TS < mw &&
                                 ty * TS + iy + TS < mh;
             float B0 = 0.f, B1 = 0.f;
+            const float* wl = s_win + (li + sy) * WP + (lj + sx);
 #pragma unroll
             for (int k = 0; k < PPT; ++k) {
                 const int p = lane + k * HHSR_WAVE;
                 const int i = p / TS, j = p % TS;
                 float m00, m01, m10, m11;
                 if (in_lds) {
-                    const float* w = s_win + (i + sy) * WP + (j + sx);
+                    const float* w = TS * TS >= HHSR_WAVE ? wl + k * RSTEP * WP : s_win + (i + sy) * WP + (j + sx);
                     m00 = w[0];
                     m01 = w[1];
                     m10 = w[WP];
