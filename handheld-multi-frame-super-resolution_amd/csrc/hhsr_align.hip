@@ -564,6 +564,19 @@ extern "C" int hhsr_ica(const float* ref, const float* gx, const float* gy, int 
 //     logic either — one 64-bit add per load, LDS stores at immediate offsets;
 //   * the waves of a workgroup never share LDS data: a wave-level fence replaces __syncthreads();
 //   * the (2r+1)^2 <= 9 candidate loop is unrolled (immediate LDS offsets).
+// a <- [a.lo + a.hi | b.lo + b.hi] over the two 32-lane halves (v_permlane32_swap: vdst[32..63] <-> src[0..31])
+__device__ __forceinline__ float swap32_add(float a, float b) {
+    const auto t = __builtin_amdgcn_permlane32_swap(__float_as_uint(a), __float_as_uint(b), false, false);
+    const unsigned x = t[0], y = t[1];  // (a bit_cast of the vector elements themselves is mis-compiled: x + x)
+    return __uint_as_float(x) + __uint_as_float(y);
+}
+// rows [a.r0 + a.r1, b.r0 + b.r1, a.r2 + a.r3, b.r2 + b.r3] (v_permlane16_swap: odd rows of vdst <-> even rows of src)
+__device__ __forceinline__ float swap16_add(float a, float b) {
+    const auto t = __builtin_amdgcn_permlane16_swap(__float_as_uint(a), __float_as_uint(b), false, false);
+    const unsigned x = t[0], y = t[1];
+    return __uint_as_float(x) + __uint_as_float(y);
+}
+
 template <int N, int CW>
 struct Stage2D {  // N x N window, lane -> (row lane / CW + k * (64 / CW), column lane % CW)
     static constexpr int RPP = HHSR_WAVE / CW, NK = (N + RPP - 1) / RPP;
@@ -580,12 +593,11 @@ __global__ void __launch_bounds__(256) k_align_wave(const float* __restrict__ re
     constexpr int RS = TS + 2, RP = RS | 1;            // reference tile + halo
     constexpr int PPT = TS * TS / HHSR_WAVE > 0 ? TS * TS / HHSR_WAVE : 1;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x / HHSR_WAVE), lane = threadIdx.x & (HHSR_WAVE - 1);
-    constexpr int n1 = 2 * r + 1, n = n1 * n1, nparts = 4 * n;
+    constexpr int n1 = 2 * r + 1, n = n1 * n1;
     constexpr int WS = TS + 2 * r + 2 * M + 1, WP = WS | 1;  // moving window
-    constexpr int slice = (RS * RP + WS * WP + nparts + 3) & ~3;
+    constexpr int slice = (RS * RP + WS * WP + 3) & ~3;
     float* s_ref = lds + (size_t)wave * slice;
     float* s_win = s_ref + RS * RP;
-    float* s_part = s_win + WS * WP;
     const int tile = blockIdx.x * 4 + wave;
     if (tile >= ntiles) return;  // wave-uniform; no workgroup barrier below
     const int ty = tile / nx, tx = tile - ty * nx;
@@ -685,30 +697,52 @@ __global__ void __launch_bounds__(256) k_align_wave(const float* __restrict__ re
                 }
             }
         } else {
-            constexpr int QR = TS / 4;
-            for (int it = lane; it < nparts; it += HHSR_WAVE) {
-                const int c = it >> 2, q = it & 3;
-                const int dy = c / n1, dx = c - dy * n1;
-                float acc = 0.f;
-                for (int i = q * QR; i < (q + 1) * QR; ++i) {
-                    const float* wrow = s_win + (i + dy + M) * WP + dx + M;
-                    const float* rrow = s_ref + (i + 1) * RP + 1;
+            // (2r+1)^2 = 25 or 81 candidates.  A lane owns PPT vertically adjacent pixels of one column, so a
+            // window value serves up to PPT (pixel, dy) pairs from a register: (PPT + 2r)(2r + 1) LDS reads per
+            // lane instead of 2 per difference, every candidate's partial cost in its own VGPR.
+            constexpr int NQ = (n + 3) / 4;
+            float acc[4 * NQ];
 #pragma unroll
-                    for (int j = 0; j < TS; ++j) {
-                        const float d = rrow[j] - wrow[j];
-                        acc += L1 ? fabsf(d) : d * d;
+            for (int c = 0; c < 4 * NQ; ++c) acc[c] = 0.f;
+            const int lc = lane % TS, lr = (lane / TS) * PPT;
+            float rv[PPT];
+            const float* rb = s_ref + (lr + 1) * RP + lc + 1;
+            const float* wb = s_win + (lr + M) * WP + lc + M;
+#pragma unroll
+            for (int k = 0; k < PPT; ++k) rv[k] = rb[k * RP];
+#pragma unroll
+            for (int rr = 0; rr < PPT + 2 * r; ++rr) {
+#pragma unroll
+                for (int dx = 0; dx < n1; ++dx) {
+                    const float w = wb[rr * WP + dx];
+#pragma unroll
+                    for (int k = 0; k < PPT; ++k) {
+                        const int dy = rr - k;
+                        if (dy >= 0 && dy < n1) {
+                            const float d = rv[k] - w;
+                            acc[dy * n1 + dx] = L1 ? acc[dy * n1 + dx] + fabsf(d) : fmaf(d, d, acc[dy * n1 + dx]);
+                        }
                     }
                 }
-                s_part[it] = acc;
             }
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-            for (int c = lane; c < n; c += HHSR_WAVE) {
-                const float tot = (s_part[4 * c] + s_part[4 * c + 1]) + (s_part[4 * c + 2] + s_part[4 * c + 3]);
-                if (tot < best.c) {
-                    best.c = tot;
-                    best.i = c;
+            // 4 candidates per step: the lane-half and row swaps of gfx950 fold the 64 partials of candidates
+            // (4q, 4q+1, 4q+2, 4q+3) into the 16-lane rows (0, 2, 1, 3) of ONE register, a 4-step DPP row
+            // reduction finishes all four at once (10 instructions per 4 candidates, fixed association).
+            const int roff = ((lane >> 4) & 1) * 2 + (lane >> 5);  // rows 0..3 hold candidates 4q + {0, 2, 1, 3}
+#pragma unroll
+            for (int q = 0; q < NQ; ++q) {
+                const float s01 = swap32_add(acc[4 * q], acc[4 * q + 1]);      // [c0 | c1]
+                const float s23 = swap32_add(acc[4 * q + 2], acc[4 * q + 3]);  // [c2 | c3]
+                float v = swap16_add(s01, s23);                                // rows [c0, c2, c1, c3]
+                v += HHSR_DPP(v, 0xB1, 0xf);
+                v += HHSR_DPP(v, 0x4E, 0xf);
+                v += HHSR_DPP(v, 0x141, 0xf);
+                v += HHSR_DPP(v, 0x140, 0xf);
+                const int idx = 4 * q + roff;
+                const float cost = idx < n ? v : INFINITY;
+                if (cost < best.c) {  // idx grows with q: strict < keeps the first minimum of this row
+                    best.c = cost;
+                    best.i = idx;
                 }
             }
             best = wave_argmin(best);
@@ -796,8 +830,8 @@ __global__ void __launch_bounds__(256) k_align_wave(const float* __restrict__ re
 }
 
 static size_t align_wave_lds(int ts, int r) {
-    const int RS = ts + 2, RP = RS | 1, WS = ts + 2 * r + 2 * ICA_M + 1, WP = WS | 1, n = (2 * r + 1) * (2 * r + 1);
-    return (size_t)4 * ((RS * RP + WS * WP + 4 * n + 3) & ~3) * sizeof(float);
+    const int RS = ts + 2, RP = RS | 1, WS = ts + 2 * r + 2 * ICA_M + 1, WP = WS | 1;
+    return (size_t)4 * ((RS * RP + WS * WP + 3) & ~3) * sizeof(float);
 }
 
 extern "C" int hhsr_align_level(const float* ref, int rh, int rw, int ref_pitch, const float* hess, const float* mov,
