@@ -3,7 +3,7 @@
 // The library route (hhsr_grey.hip) spends 9 full passes over the image per frame (row FFT, real-FFT
 // post-processing + transpose, column FFT, transpose, mask, and the same backwards).  The mask keeps only
 // |kx| <= W/4, |ky| <= H/4, so this file does the round trip in THREE kernels, each keeping a whole 1-D
-// transform in LDS (Stockham autosort, radices 5/4/3/2, twiddles from an LDS table):
+// transform in LDS (in-place Stockham passes through registers, radices 2..16, per-pass twiddles from an LDS table):
 //   k_rows_fwd   2 rows per workgroup (simultaneously): real row -> half-length complex FFT -> real-FFT
 //                post-processing; only the Wk = W/4 + 1 kept x-bins are written, blocked-transposed
 //                (x-bins in blocks of 8, 64-byte runs);
@@ -12,9 +12,10 @@
 //   k_rows_inv   2 rows per workgroup: gather the kept bins, rebuild the half-length spectrum, inverse
 //                FFT, write the real row.
 // HBM / MALL traffic per 12 MP frame: 48 + 24 | 24 + 24 | 24 + 48 = 192 MB (library route: ~860 MB).
-// Measured at 3000x4000: 171 us (library plans: 222 us); max abs error 4.8e-7 vs float64 (library 5.4e-7).
-// The kernels are latency-bound on their ~16 barrier phases; fewer, fatter passes (radix 10/16 butterflies
-// in registers) are the next step.
+// Measured at 3000x4000: 146 us (44 + 58 + 43; library plans: 222 us); error vs float64 at the library's level.
+// The kernels are bound by the latency of their barrier phases, not by HBM: composite radices (4 passes for 2000
+// and 3000 points instead of 5 and 6) and in-place passes (half the LDS: 3 / 2 resident workgroups per CU for the
+// row / column kernels instead of 2 / 1) brought them from 171 us.
 // Supported when W is even and W/2 and H factor into {2, 3, 5} and the LDS budgets fit; the caller falls
 // back to the library plans otherwise.  Numerics: float32 butterflies, float64-computed twiddle tables.
 #include "hhsr_common.h"
@@ -73,62 +74,173 @@ __device__ __forceinline__ void dft5(float2* v) {
     v[3] = csub(m2, n2);
 }
 
-__constant__ int g_dbg_skip = 0;  // experiment knob: skip the last n passes (wrong results, timing only)
+// ---- composite radices: R = A * B point DFTs in registers ----------------------------------------------------
+// Cooley-Tukey inside the butterfly: n = n1 B + n2, k = k1 + A k2:
+//   X[k1 + A k2] = sum_n2 w_B^(n2 k2) [ w_R^(n2 k1) sum_n1 v[n1 B + n2] w_A^(n1 k1) ].
+// The inner twiddles w_R^m are compile-time constants (float64 Taylor series, constexpr), trivial ones
+// (1, -i, -1, +i) cost no multiplication.  Three passes of radix 10-25 replace the five to six passes of radix
+// <= 5: half the LDS round trips and workgroup barriers of kernels that are bound by exactly those.
+constexpr double hhsr_pi = 3.14159265358979323846264338327950288;
+constexpr double c_sin_small(double x) {  // |x| <= pi/4
+    double term = x, sum = x;
+    for (int n = 1; n < 12; ++n) {
+        term *= -x * x / ((2.0 * n) * (2.0 * n + 1.0));
+        sum += term;
+    }
+    return sum;
+}
+constexpr double c_cos_small(double x) {
+    double term = 1.0, sum = 1.0;
+    for (int n = 1; n < 12; ++n) {
+        term *= -x * x / ((2.0 * n - 1.0) * (2.0 * n));
+        sum += term;
+    }
+    return sum;
+}
+// cos / sin of 2 pi m / R through octant reduction (exact on the axes)
+constexpr double c_cos2pi(int m, int R) {
+    m %= R;
+    if (8 * m <= R) return c_cos_small(2.0 * hhsr_pi * m / R);
+    if (8 * m <= 3 * R) return -c_sin_small(2.0 * hhsr_pi * (4 * m - R) / (4.0 * R));       // cos(pi/2 + d) = -sin d
+    if (8 * m <= 5 * R) return -c_cos_small(2.0 * hhsr_pi * (2 * m - R) / (2.0 * R));       // cos(pi + d) = -cos d
+    if (8 * m <= 7 * R) return c_sin_small(2.0 * hhsr_pi * (4 * m - 3 * R) / (4.0 * R));    // cos(3pi/2 + d) = sin d
+    return c_cos_small(2.0 * hhsr_pi * (m - R) / (double)R);
+}
+constexpr double c_sin2pi(int m, int R) {
+    m %= R;
+    if (8 * m <= R) return c_sin_small(2.0 * hhsr_pi * m / R);
+    if (8 * m <= 3 * R) return c_cos_small(2.0 * hhsr_pi * (4 * m - R) / (4.0 * R));
+    if (8 * m <= 5 * R) return -c_sin_small(2.0 * hhsr_pi * (2 * m - R) / (2.0 * R));
+    if (8 * m <= 7 * R) return -c_cos_small(2.0 * hhsr_pi * (4 * m - 3 * R) / (4.0 * R));
+    return c_sin_small(2.0 * hhsr_pi * (m - R) / (double)R);
+}
+template <int R>
+struct TwTab {  // w_R^m = exp(-2 pi i m / R)
+    float c[R], s[R];
+    constexpr TwTab() : c(), s() {
+        for (int m = 0; m < R; ++m) {
+            c[m] = (float)c_cos2pi(m, R);
+            s[m] = (float)(-c_sin2pi(m, R));
+        }
+    }
+};
 
-// One Stockham pass of radix R over NB independent length-N transforms stored `bstride` elements apart.
+template <int R>
+__device__ __forceinline__ void dft_reg(float2* v);
+template <> __device__ __forceinline__ void dft_reg<2>(float2* v) { dft2(v); }
+template <> __device__ __forceinline__ void dft_reg<3>(float2* v) { dft3(v); }
+template <> __device__ __forceinline__ void dft_reg<4>(float2* v) { dft4(v); }
+template <> __device__ __forceinline__ void dft_reg<5>(float2* v) { dft5(v); }
+
+template <int A, int B>
+__device__ __forceinline__ void dft_comp(float2* v) {
+    constexpr int R = A * B;
+    constexpr TwTab<R> tab{};
+    float2 y[B][A];
+#pragma unroll
+    for (int n2 = 0; n2 < B; ++n2) {
+        float2 t[A];
+#pragma unroll
+        for (int n1 = 0; n1 < A; ++n1) t[n1] = v[n1 * B + n2];
+        dft_reg<A>(t);
+#pragma unroll
+        for (int k1 = 0; k1 < A; ++k1) {
+            const int m = (n2 * k1) % R;
+            if (m == 0) y[n2][k1] = t[k1];
+            else if (4 * m == R) y[n2][k1] = mul_mi(t[k1]);
+            else if (2 * m == R) y[n2][k1] = make_float2(-t[k1].x, -t[k1].y);
+            else if (4 * m == 3 * R) y[n2][k1] = mul_pi(t[k1]);
+            else y[n2][k1] = cmul(t[k1], make_float2(tab.c[m], tab.s[m]));
+        }
+    }
+#pragma unroll
+    for (int k1 = 0; k1 < A; ++k1) {
+        float2 t[B];
+#pragma unroll
+        for (int n2 = 0; n2 < B; ++n2) t[n2] = y[n2][k1];
+        dft_reg<B>(t);
+#pragma unroll
+        for (int k2 = 0; k2 < B; ++k2) v[k1 + A * k2] = t[k2];
+    }
+}
+template <> __device__ __forceinline__ void dft_reg<6>(float2* v) { dft_comp<3, 2>(v); }
+template <> __device__ __forceinline__ void dft_reg<8>(float2* v) { dft_comp<4, 2>(v); }
+template <> __device__ __forceinline__ void dft_reg<9>(float2* v) { dft_comp<3, 3>(v); }
+template <> __device__ __forceinline__ void dft_reg<10>(float2* v) { dft_comp<5, 2>(v); }
+template <> __device__ __forceinline__ void dft_reg<12>(float2* v) { dft_comp<4, 3>(v); }
+template <> __device__ __forceinline__ void dft_reg<15>(float2* v) { dft_comp<5, 3>(v); }
+template <> __device__ __forceinline__ void dft_reg<16>(float2* v) { dft_comp<4, 4>(v); }
+
+// Butterflies one thread may hold between the read and the write phase of a pass (2 R VGPRs each)
+__host__ __device__ constexpr int fft_maxit(int R) { return R <= 3 ? 4 : R <= 5 ? 3 : R <= 12 ? 2 : 1; }
+
+// One Stockham pass of radix R over NB independent length-N transforms stored `bstride` elements apart, IN PLACE:
+// every thread reads the inputs of its (up to MAXIT) butterflies into registers, the workgroup synchronises, and
+// the autosorted outputs overwrite the same buffer (a second barrier ends the pass).  Half the LDS of the usual
+// ping-pong — twice the resident workgroups for kernels that are bound by barrier / memory latency.
 // twp: this pass's twiddles, twp[(r-1)*Ns + k] = exp(-2 pi i r k / (Ns R)) — contiguous in k, so the lanes of
 // a wave (consecutive butterflies -> consecutive k) read consecutive LDS words (no bank conflicts).
 template <int R>
-__device__ __forceinline__ void stockham_pass(const float2* __restrict__ in, float2* __restrict__ out, int bstride,
-                                              int NB, const float2* __restrict__ twp, int N, int Ns, int tid,
-                                              int nt) {
-    const int L = N / R;
+__device__ __forceinline__ void stockham_pass(float2* __restrict__ buf, int bstride, int NB,
+                                              const float2* __restrict__ twp, int N, int Ns, int tid, int nt) {
+    constexpr int MAXIT = fft_maxit(R);
+    const int L = N / R, total = NB * L;
     const float rNs = 1.0f / (float)Ns, rL = 1.0f / (float)L;
-    for (int jj = tid; jj < NB * L; jj += nt) {
-        const int bidx = (int)(((float)jj + 0.5f) * rL);  // exact floor for jj < 2^16 ... guarded by the host
-        const int j = jj - bidx * L;
-        const int q = (int)(((float)j + 0.5f) * rNs);
-        const int k = j - q * Ns;
-        const float2* ib = in + (size_t)bidx * bstride;
-        float2* ob = out + (size_t)bidx * bstride;
-        float2 v[R];
+    float2 v[MAXIT][R];
+    int dst[MAXIT];
 #pragma unroll
-        for (int r = 0; r < R; ++r) v[r] = ib[j + r * L];
-        if (Ns > 1) {
+    for (int it = 0; it < MAXIT; ++it) {
+        const int jj = tid + it * nt;
+        if (jj < total) {
+            const int bidx = (int)(((float)jj + 0.5f) * rL);  // exact floor for jj < 2^16 ... guarded by the host
+            const int j = jj - bidx * L;
+            const int q = (int)(((float)j + 0.5f) * rNs);
+            const int k = j - q * Ns;
+            const float2* ib = buf + (size_t)bidx * bstride;
 #pragma unroll
-            for (int r = 1; r < R; ++r) v[r] = cmul(v[r], twp[(r - 1) * Ns + k]);
+            for (int r = 0; r < R; ++r) v[it][r] = ib[j + r * L];
+            if (Ns > 1) {
+#pragma unroll
+                for (int r = 1; r < R; ++r) v[it][r] = cmul(v[it][r], twp[(r - 1) * Ns + k]);
+            }
+            dft_reg<R>(v[it]);
+            dst[it] = bidx * bstride + q * Ns * R + k;
         }
-        if (R == 2) dft2(v);
-        else if (R == 3) dft3(v);
-        else if (R == 4) dft4(v);
-        else dft5(v);
-        const int d = q * Ns * R + k;
-#pragma unroll
-        for (int r = 0; r < R; ++r) ob[d + r * Ns] = v[r];
     }
+    __syncthreads();
+#pragma unroll
+    for (int it = 0; it < MAXIT; ++it) {
+        const int jj = tid + it * nt;
+        if (jj < total) {
+#pragma unroll
+            for (int r = 0; r < R; ++r) buf[dst[it] + r * Ns] = v[it][r];
+        }
+    }
+    __syncthreads();
 }
 
-// Forward FFTs of NB length-N sequences: sequence b lives at buf + b*bstride in half `src_half` (0/1) of a
-// double buffer whose halves are N elements apart.  Returns the half (0/1) holding the results.
-// Every thread of the workgroup calls it; it starts and ends with a barrier.
-__device__ __forceinline__ int fft_lds(float2* buf, int bstride, int NB, int src_half, const float2* tw, int N,
-                                       const HhsrRadices& rad, int tid, int nt) {
-    int Ns = 1, half = src_half, toff = 0;
+// Forward FFTs, in place, of NB length-N sequences (sequence b at buf + b*bstride).  Every thread of the
+// workgroup calls it; it starts and ends with a barrier.
+__device__ __forceinline__ void fft_lds(float2* buf, int bstride, int NB, const float2* tw, int N,
+                                        const HhsrRadices& rad, int tid, int nt) {
+    int Ns = 1, toff = 0;
     __syncthreads();
-    for (int p = 0; p < rad.n - g_dbg_skip; ++p) {
+    for (int p = 0; p < rad.n; ++p) {
         const int R = rad.r[p];
-        const float2* in = buf + half * N;
-        float2* out = buf + (half ^ 1) * N;
-        if (R == 5) stockham_pass<5>(in, out, bstride, NB, tw + toff, N, Ns, tid, nt);
-        else if (R == 4) stockham_pass<4>(in, out, bstride, NB, tw + toff, N, Ns, tid, nt);
-        else if (R == 3) stockham_pass<3>(in, out, bstride, NB, tw + toff, N, Ns, tid, nt);
-        else stockham_pass<2>(in, out, bstride, NB, tw + toff, N, Ns, tid, nt);
-        __syncthreads();
-        half ^= 1;
+        // opaque copy of N: keeps the per-radix invariants (N / R, reciprocals, ...) of ALL switch arms from being
+        // hoisted out of the pass loop, where they stay live together and spill
+        int Np = N;
+        asm volatile("" : "+s"(Np));
+        switch (R) {
+#define HHSR_PASS(RR) case RR: stockham_pass<RR>(buf, bstride, NB, tw + toff, Np, Ns, tid, nt); break;
+            HHSR_PASS(2) HHSR_PASS(3) HHSR_PASS(4) HHSR_PASS(5) HHSR_PASS(6) HHSR_PASS(8) HHSR_PASS(9) HHSR_PASS(10)
+            HHSR_PASS(12) HHSR_PASS(15) HHSR_PASS(16)
+#undef HHSR_PASS
+            default: break;  // the host only schedules the radices above
+        }
         toff += (R - 1) * Ns;
         Ns *= R;
     }
-    return half;
 }
 
 __device__ __forceinline__ bool fft_kept(int u, int n) {
@@ -142,47 +254,45 @@ __device__ __forceinline__ bool fft_kept(int u, int n) {
 // whose cache lines are shared by the 8 columns of its block (placed on one XCD, see k_cols).
 __device__ __forceinline__ size_t t_index(int kx, int y, int H) { return ((size_t)(kx >> 3) * H + y) * 8 + (kx & 7); }
 
-constexpr int FFT_NT = 512;   // threads per workgroup, row kernels
+constexpr int FFT_NT = 512;          // threads per workgroup
+constexpr int FFT_ROWS_WPE = 6;     // row kernels: 48 KB of LDS -> three workgroups per CU need <= 85 VGPRs
+constexpr int FFT_COLS_WPE = 4;     // column kernel: 72 KB of LDS -> two workgroups per CU (<= 128 VGPRs)
 
 // Row kernels: RB rows per workgroup, transformed SIMULTANEOUSLY (RB x fewer barriers, RB x more independent
-// butterflies per thread).  LDS: tw[twlen] | RB x { half0[M] | half1[M] }  (float2 each).
+// butterflies per thread).  LDS: tw[twlen] | RB x row[M]  (float2 each).
 template <int RB>
-__global__ void __launch_bounds__(FFT_NT) k_rows_fwd(const float* __restrict__ src, int H, int W, float2* __restrict__ T,
-                                                      int Wk, HhsrRadices rad, const float2* __restrict__ twM,
-                                                      int twlen, const float2* __restrict__ twW) {
+__global__ void __launch_bounds__(FFT_NT, FFT_ROWS_WPE) k_rows_fwd(const float* __restrict__ src, int H, int W,
+                                                                        float2* __restrict__ T, int Wk, HhsrRadices rad,
+                                                                        const float2* __restrict__ twM, int twlen,
+                                                                        const float2* __restrict__ twW) {
     extern __shared__ __attribute__((aligned(16))) float2 fl[];
     const int M = W / 2, tid = threadIdx.x;
     float2* tw = fl;
     float2* buf = tw + twlen;
-    const int bstride = 2 * M;
     for (int k = tid; k < twlen; k += FFT_NT) tw[k] = twM[k];
     const int y0 = blockIdx.x * RB;
     const int nrows = min(RB, H - y0);
     for (int idx = tid; idx < nrows * M; idx += FFT_NT) {  // z[n] = x[2n] + i x[2n+1]
         const int rb = idx / M, n = idx - rb * M;
-        buf[rb * bstride + n] = reinterpret_cast<const float2*>(src + (size_t)(y0 + rb) * W)[n];
+        buf[rb * M + n] = reinterpret_cast<const float2*>(src + (size_t)(y0 + rb) * W)[n];
     }
-    const int h = fft_lds(buf, bstride, nrows, 0, tw, M, rad, tid, FFT_NT);
+    fft_lds(buf, M, nrows, tw, M, rad, tid, FFT_NT);
     // X[k] = 1/2 [(Z[k] + conj Z[M-k]) - i w_k (Z[k] - conj Z[M-k])],  w_k = exp(-2 pi i k / W); kept bins only,
-    // written into the other half of the row's double buffer
+    // straight from LDS to the blocked-transposed spectrum (8 consecutive lanes = one 64-byte run)
     for (int idx = tid; idx < nrows * Wk; idx += FFT_NT) {
         const int rb = idx / Wk, k = idx - rb * Wk;
-        const float2* Z = buf + rb * bstride + h * M;
+        const float2* Z = buf + rb * M;
         const float2 zk = Z[k == M ? 0 : k], zm = cconj(Z[k == 0 ? 0 : M - k]);
         const float2 s = cadd(zk, zm), d = mul_mi(cmul(twW[k], csub(zk, zm)));
-        buf[rb * bstride + (h ^ 1) * M + k] = cscale(cadd(s, d), 0.5f);
-    }
-    __syncthreads();
-    for (int idx = tid; idx < nrows * Wk; idx += FFT_NT) {  // blocked-transposed store, 64-byte runs
-        const int rb = idx / Wk, k = idx - rb * Wk;
-        T[t_index(k, y0 + rb, H)] = buf[rb * bstride + (h ^ 1) * M + k];
+        T[t_index(k, y0 + rb, H)] = cscale(cadd(s, d), 0.5f);
     }
 }
 
 // Column kernel: TWO adjacent kept columns per workgroup (one 16-byte load per row serves both), transformed
-// simultaneously.  LDS: tw[twlen] | 2 x { half0[H] | half1[H] }
-__global__ void __launch_bounds__(FFT_NT) k_cols(float2* __restrict__ T, int H, int W, int Wk, HhsrRadices rad,
-                                                  const float2* __restrict__ twH, int twlen, float norm) {
+// simultaneously.  LDS: tw[twlen] | 2 x col[H]
+__global__ void __launch_bounds__(FFT_NT, FFT_COLS_WPE) k_cols(float2* __restrict__ T, int H, int W, int Wk,
+                                                                    HhsrRadices rad, const float2* __restrict__ twH,
+                                                                    int twlen, float norm) {
     extern __shared__ __attribute__((aligned(16))) float2 fl[];
     const int tid = threadIdx.x;
     // workgroup b runs on XCD b % 8 (observed; locality only): give the 4 column pairs of one 64-byte block to
@@ -192,77 +302,104 @@ __global__ void __launch_bounds__(FFT_NT) k_cols(float2* __restrict__ T, int H, 
     if (kx >= Wk) return;
     float2* tw = fl;
     float2* buf = tw + twlen;
-    const int bstride = 2 * H;
     float4* col = reinterpret_cast<float4*>(T + ((size_t)(kx >> 3) * H) * 8 + (kx & 7));  // row y at col[4 y]
     for (int k = tid; k < twlen; k += FFT_NT) tw[k] = twH[k];
     for (int k = tid; k < H; k += FFT_NT) {
         const float4 v = col[(size_t)4 * k];
         buf[k] = make_float2(v.x, v.y);
-        buf[bstride + k] = make_float2(v.z, v.w);
+        buf[H + k] = make_float2(v.z, v.w);
     }
-    const int h = fft_lds(buf, bstride, 2, 0, tw, H, rad, tid, FFT_NT);
+    fft_lds(buf, H, 2, tw, H, rad, tid, FFT_NT);
     for (int idx = tid; idx < 2 * H; idx += FFT_NT) {
         const int c = idx >= H, ky = idx - c * H;
         const int x = kx + c, nx = x == 0 ? 0 : W - x;
         const int nky = ky == 0 ? 0 : H - ky;
         const int m = x < Wk ? (int)(fft_kept(ky, H) && fft_kept(x, W)) + (int)(fft_kept(nky, H) && fft_kept(nx, W)) : 0;
         // masked, normalised and conjugated: the inverse is conj(FFT(conj(.)))
-        buf[c * bstride + (h ^ 1) * H + ky] = cconj(cscale(buf[c * bstride + h * H + ky], 0.5f * (float)m * norm));
+        buf[idx] = cconj(cscale(buf[idx], 0.5f * (float)m * norm));
     }
-    const int h2 = fft_lds(buf, bstride, 2, h ^ 1, tw, H, rad, tid, FFT_NT);
+    fft_lds(buf, H, 2, tw, H, rad, tid, FFT_NT);
     for (int y = tid; y < H; y += FFT_NT) {
-        const float2 a = cconj(buf[h2 * H + y]), b2 = cconj(buf[bstride + h2 * H + y]);
+        const float2 a = cconj(buf[y]), b2 = cconj(buf[H + y]);
         col[(size_t)4 * y] = make_float4(a.x, a.y, b2.x, b2.y);
     }
 }
 
 template <int RB>
-__global__ void __launch_bounds__(FFT_NT) k_rows_inv(const float2* __restrict__ T, int H, int W, int Wk,
-                                                      float* __restrict__ dst, HhsrRadices rad,
-                                                      const float2* __restrict__ twM, int twlen,
-                                                      const float2* __restrict__ twW) {
+__global__ void __launch_bounds__(FFT_NT, FFT_ROWS_WPE) k_rows_inv(const float2* __restrict__ T, int H, int W, int Wk,
+                                                                        float* __restrict__ dst, HhsrRadices rad,
+                                                                        const float2* __restrict__ twM, int twlen,
+                                                                        const float2* __restrict__ twW) {
     extern __shared__ __attribute__((aligned(16))) float2 fl[];
     const int M = W / 2, tid = threadIdx.x;
     float2* tw = fl;
     float2* buf = tw + twlen;
-    const int bstride = 2 * M;
     for (int k = tid; k < twlen; k += FFT_NT) tw[k] = twM[k];
     const int y0 = blockIdx.x * RB;
     const int nrows = min(RB, H - y0);
-    for (int idx = tid; idx < nrows * Wk; idx += FFT_NT) {  // kept bins -> half 1
-        const int rb = idx / Wk, k = idx - rb * Wk;
-        buf[rb * bstride + M + k] = T[t_index(k, y0 + rb, H)];
-    }
-    __syncthreads();
-    // Z[k] = 1/2 [(X[k] + conj X[M-k]) + i conj(w_k) (X[k] - conj X[M-k])], X = 0 above the kept band; stored
-    // conjugated (half 0) for the conj(FFT(conj(.))) inverse
+    // Z[k] = 1/2 [(X[k] + conj X[M-k]) + i conj(w_k) (X[k] - conj X[M-k])] with X = 0 above the kept band, built
+    // straight from the spectrum in global memory (each kept bin is read by the threads of k and M-k; the second
+    // read hits L1/L2) and stored conjugated for the conj(FFT(conj(.))) inverse
     for (int idx = tid; idx < nrows * M; idx += FFT_NT) {
         const int rb = idx / M, k = idx - rb * M;
-        const float2* X = buf + rb * bstride + M;
         const int mk = M - k;  // in 1..M
-        const float2 xk = k < Wk ? X[k] : make_float2(0.f, 0.f);
-        const float2 xm = mk < Wk ? cconj(X[mk]) : make_float2(0.f, 0.f);
+        const float2 xk = k < Wk ? T[t_index(k, y0 + rb, H)] : make_float2(0.f, 0.f);
+        const float2 xm = mk < Wk ? cconj(T[t_index(mk, y0 + rb, H)]) : make_float2(0.f, 0.f);
         const float2 s = cadd(xk, xm), d = mul_pi(cmul(cconj(twW[k]), csub(xk, xm)));
-        buf[rb * bstride + k] = cconj(cscale(cadd(s, d), 0.5f));
+        buf[rb * M + k] = cconj(cscale(cadd(s, d), 0.5f));
     }
-    const int h = fft_lds(buf, bstride, nrows, 0, tw, M, rad, tid, FFT_NT);
+    fft_lds(buf, M, nrows, tw, M, rad, tid, FFT_NT);
     for (int idx = tid; idx < nrows * M; idx += FFT_NT) {  // x[2n] = Re z[n], x[2n+1] = Im z[n]
         const int rb = idx / M, n = idx - rb * M;
-        reinterpret_cast<float2*>(dst + (size_t)(y0 + rb) * W)[n] = cconj(buf[rb * bstride + h * M + n]);
+        reinterpret_cast<float2*>(dst + (size_t)(y0 + rb) * W)[n] = cconj(buf[rb * M + n]);
     }
 }
 
 // ---- host side --------------------------------------------------------------------------------------------
-static bool factorize(int n, HhsrRadices& out) {
-    out.n = 0;
-    const int cand[4] = {5, 4, 3, 2};
-    for (int c = 0; c < 4; ++c)
-        while (n % cand[c] == 0 && n > 1) {
-            if (out.n >= HHSR_MAX_RADICES) return false;
-            out.r[out.n++] = cand[c];
-            n /= cand[c];
+// Radix schedule: fewest passes over the supported radices, then the smallest maximum radix (registers, idle
+// lanes), then an odd / small first radix (the Ns = 1 pass stores with stride R: even R collide on LDS banks).
+// HHSR_FFT_RADIX_MAX (experiments) caps the radix; 5 reproduces the original 5/4/3/2 schedule.
+static const int k_radices[] = {16, 15, 12, 10, 9, 8, 6, 5, 4, 3, 2};
+
+static void radix_search(int n, int rmax, int cap, int depth, int* cur, int& best_n, int* best, int& best_max) {
+    if (n == 1) {
+        int mx = 0;
+        for (int i = 0; i < depth; ++i) mx = cur[i] > mx ? cur[i] : mx;
+        if (depth < best_n || (depth == best_n && mx < best_max)) {
+            best_n = depth;
+            best_max = mx;
+            for (int i = 0; i < depth; ++i) best[i] = cur[i];
         }
-    return n == 1 && out.n > 0;
+        return;
+    }
+    if (depth + 1 > best_n || depth >= HHSR_MAX_RADICES) return;
+    for (int r : k_radices) {
+        if (r > rmax || n % r) continue;
+        if (depth > 0 && r > cur[depth - 1]) continue;  // non-increasing: each multiset once
+        if (cap / r > fft_maxit(r) * FFT_NT) continue;  // butterflies of this pass must fit the threads' registers
+        cur[depth] = r;
+        radix_search(n / r, rmax, cap, depth + 1, cur, best_n, best, best_max);
+    }
+}
+
+// nb: sequences transformed together by one workgroup (every pass runs nb * n / R butterflies)
+static bool factorize(int n, int nb, HhsrRadices& out) {
+    const char* e = getenv("HHSR_FFT_RADIX_MAX");
+    const int rmax = e ? atoi(e) : 16;  // (radix 20 / 25 butterflies would exceed the 128-VGPR budget)
+    int cur[HHSR_MAX_RADICES], best[HHSR_MAX_RADICES], best_n = HHSR_MAX_RADICES + 1, best_max = 1 << 30;
+    radix_search(n, rmax, nb * n, 0, cur, best_n, best, best_max);
+    if (best_n > HHSR_MAX_RADICES) return false;
+    // order: the radix with the fewest bank collisions at stride R first, then descending
+    auto collide = [](int r) { int g = 2 * r, b = 64; while (b) { int t = g % b; g = b; b = t; } return g; };
+    int first = 0;
+    for (int i = 1; i < best_n; ++i)
+        if (collide(best[i]) < collide(best[first]) || (collide(best[i]) == collide(best[first]) && best[i] > best[first]))
+            first = i;
+    out.n = 0;
+    out.r[out.n++] = best[first];
+    for (int i = 0; i < best_n; ++i)
+        if (i != first) out.r[out.n++] = best[i];
+    return out.n > 0;
 }
 
 static bool host_kept_fft(int u, int n) {
@@ -310,13 +447,19 @@ static std::vector<float2> pass_twiddles(const HhsrRadices& rad) {
     return h;
 }
 
-static int pick_rb(int M, int twlen) {
-    const char* e = getenv("HHSR_FFT_RB");
-    if (e) return atoi(e);
-    const int cands[3] = {2, 1, 4};  // measured at 3000x4000: 2 rows per workgroup is the fastest
-    for (int c = 0; c < 3; ++c)
-        if (sizeof(float2) * ((size_t)twlen + (size_t)cands[c] * 2 * M) <= 150 * 1024 && cands[c] * (M / 2) < 65536)
-            return cands[c];
+// rows per workgroup of the row kernels: the first candidate whose LDS footprint leaves room for two workgroups
+// per CU and whose passes fit the per-thread butterfly capacity
+static int pick_rb(int M, HhsrRadices& rad) {
+    const char* e = getenv("HHSR_FFT_RB");  // experiments
+    const int forced = e ? atoi(e) : 0;
+    const int cands[3] = {2, 4, 1};
+    for (int c = 0; c < 3; ++c) {
+        const int rb = cands[c];
+        if (forced && rb != forced) continue;
+        if (sizeof(float2) * ((size_t)M + (size_t)rb * M) > 76 * 1024 && rb > 1) continue;
+        if (rb * (M / 2) >= 65536) continue;
+        if (factorize(M, rb, rad)) return rb;
+    }
     return 0;
 }
 
@@ -325,7 +468,8 @@ bool hhsr_fft_create(HhsrFft& f, int H, int W) {
     if (W % 2 || H < 2 || W < 4) return false;
     const int M = W / 2;
     if (M >= 65536 || H >= 65536) return false;
-    if (!factorize(M, f.radM) || !factorize(H, f.radH)) return false;
+    f.rb = pick_rb(M, f.radM);
+    if (!f.rb || !factorize(H, 2, f.radH)) return false;
     int Wk = 0;
     for (int x = 0; x <= M; ++x)
         if (host_kept_fft(x, W) || host_kept_fft(x == 0 ? 0 : W - x, W)) Wk = x + 1;
@@ -336,11 +480,9 @@ bool hhsr_fft_create(HhsrFft& f, int H, int W) {
     const std::vector<float2> hM = pass_twiddles(f.radM), hH = pass_twiddles(f.radH);
     f.twlenM = (int)hM.size();
     f.twlenH = (int)hH.size();
-    f.rb = pick_rb(M, f.twlenM);
-    if (!f.rb) return false;
-    f.lds_rows = sizeof(float2) * ((size_t)f.twlenM + (size_t)f.rb * 2 * M);
-    f.lds_cols = sizeof(float2) * ((size_t)f.twlenH + (size_t)4 * H);
-    if (f.lds_cols > 150 * 1024) return false;
+    f.lds_rows = sizeof(float2) * ((size_t)f.twlenM + (size_t)f.rb * M);
+    f.lds_cols = sizeof(float2) * ((size_t)f.twlenH + (size_t)2 * H);
+    if (f.lds_cols > 150 * 1024 || f.lds_rows > 150 * 1024) return false;
     const void* kf = f.rb == 4 ? (const void*)k_rows_fwd<4> : f.rb == 2 ? (const void*)k_rows_fwd<2> : (const void*)k_rows_fwd<1>;
     const void* ki = f.rb == 4 ? (const void*)k_rows_inv<4> : f.rb == 2 ? (const void*)k_rows_inv<2> : (const void*)k_rows_inv<1>;
     if (hipFuncSetAttribute(kf, hipFuncAttributeMaxDynamicSharedMemorySize, (int)f.lds_rows) != hipSuccess ||
@@ -370,12 +512,6 @@ void hhsr_fft_destroy(HhsrFft& f) {
 }
 
 int hhsr_fft_lowpass(const HhsrFft& f, const float* src, float* dst, hipStream_t s) {
-    static int dbg = -1;
-    if (dbg < 0) {
-        const char* e = getenv("HHSR_FFT_SKIP");
-        dbg = e ? atoi(e) : 0;
-        if (dbg) (void)hipMemcpyToSymbol(HIP_SYMBOL(g_dbg_skip), &dbg, sizeof(int));
-    }
     const int nrb = hhsr_cdiv(f.H, f.rb);
     // unnormalised inverse transforms multiply by (W/2) and H
     const float norm = (float)(1.0 / ((double)(f.W / 2) * (double)f.H));
