@@ -9,7 +9,6 @@
 // and the tensor sums are float32.
 #include "hhsr_common.h"
 
-constexpr int CV_TX = 32, CV_TY = 8;  // quads per 256-thread workgroup
 
 struct CovParams {
     double alpha, beta, k_detail, k_denoise, D_th, D_tr, k_stretch, k_shrink;
@@ -23,31 +22,11 @@ __device__ __forceinline__ float gat1(float v, double alpha, double c0, double t
     return (float)(two_over_alpha * sqrt(t));
 }
 
-__global__ void __launch_bounds__(256) k_cov_from_raw(const float* __restrict__ raw, int H, int W, int pitch,
-                                                       float4* __restrict__ covs, int gh, int gw, CovParams P) {
-    // grey tile with a halo of one quad on the top/left and one on the bottom/right
-    __shared__ float s_g[CV_TY + 2][CV_TX + 2 + 1];
-    const int qx0 = blockIdx.x * CV_TX, qy0 = blockIdx.y * CV_TY;
-    const double c0 = 3.0 / 8.0 * P.alpha * P.alpha + P.beta;
-    const double toa = 2.0 / P.alpha;
-    for (int p = threadIdx.x; p < (CV_TY + 2) * (CV_TX + 2); p += 256) {
-        const int i = p / (CV_TX + 2), j = p - i * (CV_TX + 2);
-        const int qy = qy0 + i - 1, qx = qx0 + j - 1;
-        float g = 0.f;
-        if (qy >= 0 && qy < gh && qx >= 0 && qx < gw) {
-            const float2 a = *reinterpret_cast<const float2*>(raw + (size_t)(2 * qy) * pitch + 2 * qx);
-            const float2 b = *reinterpret_cast<const float2*>(raw + (size_t)(2 * qy + 1) * pitch + 2 * qx);
-            // decimate: float64 sum of the four float32 VST values, /4 (utils_image.py:346-357)
-            const double s = (double)gat1(a.x, P.alpha, c0, toa) + (double)gat1(a.y, P.alpha, c0, toa) +
-                             (double)gat1(b.x, P.alpha, c0, toa) + (double)gat1(b.y, P.alpha, c0, toa);
-            g = (float)(s / 4.0);
-        }
-        s_g[i][j] = g;
-    }
-    __syncthreads();
-    const int lx = threadIdx.x % CV_TX, ly = threadIdx.x / CV_TX;
-    const int qx = qx0 + lx, qy = qy0 + ly;
-    if (qx >= gw || qy >= gh) return;
+// Per-quad kernel covariance from the variance-stabilised quad means `sg` (LDS tile with a one-quad halo,
+// pitch SGP; (ly, lx) = the quad's position inside the tile without the halo).
+template <int SGP>
+__device__ __forceinline__ float4 quad_cov(const float* __restrict__ sg, int ly, int lx, int qy, int qx, int gh, int gw,
+                                           const CovParams& P) {
     // structure tensor over the gradient samples (y-1..y, x-1..x) that exist in the [gh-1][gw-1] grid
     float T00 = 0.f, T01 = 0.f, T11 = 0.f;
 #pragma unroll
@@ -56,8 +35,8 @@ __global__ void __launch_bounds__(256) k_cov_from_raw(const float* __restrict__ 
         for (int j = 0; j < 2; ++j) {
             const int gy_ = qy - 1 + i, gx_ = qx - 1 + j;
             if (gy_ >= 0 && gy_ < gh - 1 && gx_ >= 0 && gx_ < gw - 1) {
-                const float g00 = s_g[ly + i][lx + j], g01 = s_g[ly + i][lx + j + 1];
-                const float g10 = s_g[ly + i + 1][lx + j], g11 = s_g[ly + i + 1][lx + j + 1];
+                const float g00 = sg[(ly + i) * SGP + lx + j], g01 = sg[(ly + i) * SGP + lx + j + 1];
+                const float g10 = sg[(ly + i + 1) * SGP + lx + j], g11 = sg[(ly + i + 1) * SGP + lx + j + 1];
                 // two chained float32 convs (kernels.py:97-116)
                 const float t0a = -0.5f * g00 + 0.5f * g01, t0b = -0.5f * g10 + 0.5f * g11;
                 const float t1a = 0.5f * g00 + 0.5f * g01, t1b = 0.5f * g10 + 0.5f * g11;
@@ -130,7 +109,131 @@ __global__ void __launch_bounds__(256) k_cov_from_raw(const float* __restrict__ 
     o.y = k1s * e1x * e1y + k2s * e2x * e2y;
     o.z = o.y;
     o.w = k1s * e1y * e1y + k2s * e2y * e2y;
-    covs[(size_t)qy * gw + qx] = o;
+    return o;
+}
+
+// ---- fused per-frame pass over the raw image -----------------------------------------------------------------
+// Both per-frame consumers of the raw Bayer image at quad resolution — the guide-image local statistics of the
+// robustness (Alg. 7-8) and the kernel covariances (Alg. 5) — work on a quad tile with a one-quad halo.  One
+// kernel stages the tile once (4 B/pixel read instead of 8), each thread owns two quads (rows ly and ly + 8 of a
+// 32 x 16 tile: 19 % halo overhead instead of 33 %), and outputs that the caller does not need (the variances of
+// comp frames) are not written.  The stand-alone entry points hhsr_rob_stats / hhsr_cov_from_raw run the same
+// kernel with one half compiled out.
+constexpr int FS_TX = 32, FS_TY = 16, FS_P = FS_TX + 2 + 1, FS_N = (FS_TY + 2) * (FS_TX + 2);
+constexpr int FS_IT = (FS_N + 255) / 256;
+
+struct FsCfa {
+    uint8_t c[4];
+};
+struct FrameStatsArgs {
+    const float* raw;
+    int pitch, gh, gw;
+    FsCfa cfa;
+    double rwb[3];  // 1 / white balance
+    float* means;   // [3][gh][gw] or NULL
+    float* vars;    // [3][gh][gw] or NULL
+    float4* covs;   // [gh][gw] or NULL
+    CovParams P;
+};
+
+template <bool STATS, bool COV>
+__global__ void __launch_bounds__(256) k_frame_stats(FrameStatsArgs A) {
+    __shared__ float s_ch[STATS ? 3 : 1][STATS ? FS_TY + 2 : 1][FS_P];
+    __shared__ float s_g[COV ? (FS_TY + 2) * FS_P : 1];
+    const int qx0 = blockIdx.x * FS_TX, qy0 = blockIdx.y * FS_TY;
+    const int gh = A.gh, gw = A.gw;
+    const double c0 = 3.0 / 8.0 * A.P.alpha * A.P.alpha + A.P.beta;
+    const double toa = 2.0 / A.P.alpha;
+    // all loads of the tile first, then the float64 maths (a load -> compute -> store loop would serialise on
+    // memory latency); out-of-image quads read the clamped quad (the statistics' border rule) and are zeroed for
+    // the covariance tile (its border rule)
+    float2 va[FS_IT], vb[FS_IT];
+#pragma unroll
+    for (int u = 0; u < FS_IT; ++u) {
+        const int p = min(threadIdx.x + 256 * u, FS_N - 1);
+        const int i = p / (FS_TX + 2), j = p - i * (FS_TX + 2);
+        const int qy = clampi(qy0 + i - 1, 0, gh - 1), qx = clampi(qx0 + j - 1, 0, gw - 1);
+        va[u] = *reinterpret_cast<const float2*>(A.raw + (size_t)(2 * qy) * A.pitch + 2 * qx);
+        vb[u] = *reinterpret_cast<const float2*>(A.raw + (size_t)(2 * qy + 1) * A.pitch + 2 * qx);
+    }
+#pragma unroll
+    for (int u = 0; u < FS_IT; ++u) {
+        const int p = threadIdx.x + 256 * u;
+        if (p < FS_N) {
+            const int i = p / (FS_TX + 2), j = p - i * (FS_TX + 2);
+            const float v[4] = {va[u].x, va[u].y, vb[u].x, vb[u].y};
+            if (STATS) {
+                double g = 0.0;
+                float ch[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {  // robustness.py:215-225: raw / wb[c] in float64
+                    const int c = A.cfa.c[k];
+                    const double x = (double)v[k] * A.rwb[c];
+                    if (c == 1) g += x;
+                    else ch[c] = (float)x;
+                }
+                ch[1] = (float)(g / 2.0);
+                s_ch[0][i][j] = ch[0];
+                s_ch[1][i][j] = ch[1];
+                s_ch[2][i][j] = ch[2];
+            }
+            if (COV) {
+                const int qy = qy0 + i - 1, qx = qx0 + j - 1;
+                float g = 0.f;
+                if (qy >= 0 && qy < gh && qx >= 0 && qx < gw) {
+                    // decimate: float64 sum of the four float32 VST values, /4 (utils_image.py:346-357)
+                    const double s = (double)gat1(v[0], A.P.alpha, c0, toa) + (double)gat1(v[1], A.P.alpha, c0, toa) +
+                                     (double)gat1(v[2], A.P.alpha, c0, toa) + (double)gat1(v[3], A.P.alpha, c0, toa);
+                    g = (float)(s / 4.0);
+                }
+                s_g[i * FS_P + j] = g;
+            }
+        }
+    }
+    __syncthreads();
+    const int lx = threadIdx.x % FS_TX, ly0 = threadIdx.x / FS_TX;
+    const int gx = qx0 + lx;
+    if (gx >= gw) return;
+    const size_t plane = (size_t)gh * gw;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        const int ly = ly0 + 8 * h, gy = qy0 + ly;
+        if (gy >= gh) break;
+        const size_t o = (size_t)gy * gw + gx;
+        if (STATS) {
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                float s0 = 0.f, s1 = 0.f;  // float32 running sums in (i, j) order (robustness.py:280-288)
+#pragma unroll
+                for (int i = 0; i < 3; ++i)
+#pragma unroll
+                    for (int j = 0; j < 3; ++j) {
+                        const float v = s_ch[c][ly + i][lx + j];
+                        s0 += v;
+                        s1 += v * v;
+                    }
+                const double m = (double)s0 / 9.0;
+                A.means[c * plane + o] = (float)m;
+                if (A.vars) A.vars[c * plane + o] = (float)((double)s1 / 9.0 - m * m);
+            }
+        }
+        if (COV) A.covs[o] = quad_cov<FS_P>(s_g, ly, lx, gy, gx, gh, gw, A.P);
+    }
+}
+
+static int frame_stats_launch(const float* raw, int H, int W, int pitch, const uint8_t* cfa, const double* wb,
+                              float* means, float* vars, float* covs, const CovParams& P, void* stream) {
+    FrameStatsArgs A;
+    A.raw = raw; A.pitch = pitch; A.gh = H / 2; A.gw = W / 2;
+    for (int k = 0; k < 4; ++k) A.cfa.c[k] = cfa ? cfa[k] : 0;
+    for (int k = 0; k < 3; ++k) A.rwb[k] = wb ? 1.0 / wb[k] : 1.0;
+    A.means = means; A.vars = vars; A.covs = reinterpret_cast<float4*>(covs); A.P = P;
+    const dim3 grid(hhsr_cdiv(A.gw, FS_TX), hhsr_cdiv(A.gh, FS_TY)), block(256);
+    hipStream_t s = (hipStream_t)stream;
+    if (means && covs) hipLaunchKernelGGL((k_frame_stats<true, true>), grid, block, 0, s, A);
+    else if (means) hipLaunchKernelGGL((k_frame_stats<true, false>), grid, block, 0, s, A);
+    else hipLaunchKernelGGL((k_frame_stats<false, true>), grid, block, 0, s, A);
+    return hhsr_launch_status("hhsr_frame_stats");
 }
 
 extern "C" int hhsr_cov_from_raw(const float* raw, int H, int W, int pitch, float* covs, double alpha, double beta,
@@ -140,9 +243,29 @@ extern "C" int hhsr_cov_from_raw(const float* raw, int H, int W, int pitch, floa
     HHSR_ARG((pitch & 1) == 0 && ((uintptr_t)raw & 7) == 0 && ((uintptr_t)covs & 15) == 0);
     HHSR_ARG(alpha > 0.0);  // utils_image.py:141: the VST is ill-defined otherwise
     HHSR_ARG(law == 0 || law == 1);
-    const int gh = H / 2, gw = W / 2;
     CovParams P{alpha, beta, k_detail, k_denoise, D_th, D_tr, k_stretch, k_shrink, law};
-    hipLaunchKernelGGL(k_cov_from_raw, dim3(hhsr_cdiv(gw, CV_TX), hhsr_cdiv(gh, CV_TY)), dim3(256), 0,
-                       (hipStream_t)stream, raw, H, W, pitch, reinterpret_cast<float4*>(covs), gh, gw, P);
-    HHSR_LAUNCHED();
+    return frame_stats_launch(raw, H, W, pitch, nullptr, nullptr, nullptr, nullptr, covs, P, stream);
+}
+
+extern "C" int hhsr_rob_stats(const float* raw, int H, int W, int pitch, const uint8_t cfa[4], const double* wb,
+                              float* means, float* vars, void* stream) {
+    HHSR_ARG(raw && cfa && wb && means && H >= 2 && W >= 2 && pitch >= W);
+    HHSR_ARG((pitch & 1) == 0 && ((uintptr_t)raw & 7) == 0);
+    for (int k = 0; k < 4; ++k) HHSR_ARG(cfa[k] <= 2);
+    for (int k = 0; k < 3; ++k) HHSR_ARG(wb[k] != 0.0);
+    CovParams P{1.0, 0.0, 0, 0, 0, 1.0, 0, 1.0, 0};
+    return frame_stats_launch(raw, H, W, pitch, cfa, wb, means, vars, nullptr, P, stream);
+}
+
+extern "C" int hhsr_frame_stats(const float* raw, int H, int W, int pitch, const uint8_t cfa[4], const double* wb,
+                                float* means, float* vars, float* covs, double alpha, double beta, double k_detail,
+                                double k_denoise, double D_th, double D_tr, double k_stretch, double k_shrink, int law,
+                                void* stream) {
+    HHSR_ARG(raw && cfa && wb && means && covs && H >= 2 && W >= 2 && pitch >= W);
+    HHSR_ARG((pitch & 1) == 0 && ((uintptr_t)raw & 7) == 0 && ((uintptr_t)covs & 15) == 0);
+    HHSR_ARG(alpha > 0.0 && (law == 0 || law == 1));
+    for (int k = 0; k < 4; ++k) HHSR_ARG(cfa[k] <= 2);
+    for (int k = 0; k < 3; ++k) HHSR_ARG(wb[k] != 0.0);
+    CovParams P{alpha, beta, k_detail, k_denoise, D_th, D_tr, k_stretch, k_shrink, law};
+    return frame_stats_launch(raw, H, W, pitch, cfa, wb, means, vars, covs, P, stream);
 }

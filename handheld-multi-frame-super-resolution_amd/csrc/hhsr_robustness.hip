@@ -1,7 +1,7 @@
 // Alg. 6-9 robustness (reference robustness.py; Dodgson kernel utils_image.py:395-406).
 //
 // The reference runs 8 launches and ~600 MB of raw-resolution temporaries per frame.  Here:
-//   k_rob_stats   raw -> guide (LDS tile) -> 3x3 mean/variance at guide resolution        (1 read of raw)
+//   k_frame_stats raw -> guide (LDS tile) -> 3x3 mean/variance at guide resolution        (hhsr_kernels.hip)
 //   k_rob_frame   fused: Dodgson warp-upsample of the frame's means, |d mu|, noise-model shrink,
 //                 S lookup, threshold -> R at raw resolution                               (no temporaries)
 //   k_local_min5  5x5 minimum through an LDS tile
@@ -9,79 +9,8 @@
 // maths, float32 storage and float32 running sums that are rounded after every tap.
 #include "hhsr_common.h"
 
-// ---- guide image + local statistics -----------------------------------------------------------
-constexpr int RS_TX = 32, RS_TY = 8;
-
-struct Cfa {
-    uint8_t c[4];
-};
-struct Wb {
-    double w[3];
-};
-
-__global__ void __launch_bounds__(256) k_rob_stats(const float* __restrict__ raw, int pitch, Cfa cfa, Wb wb,
-                                                    float* __restrict__ means, float* __restrict__ vars, int gh,
-                                                    int gw) {
-    __shared__ float s_g[3][RS_TY + 2][RS_TX + 2 + 1];
-    const int gx0 = blockIdx.x * RS_TX, gy0 = blockIdx.y * RS_TY;
-    for (int p = threadIdx.x; p < (RS_TY + 2) * (RS_TX + 2); p += 256) {
-        const int i = p / (RS_TX + 2), j = p - i * (RS_TX + 2);
-        // clamp-border neighbourhood (robustness.py:284-286)
-        const int gy = clampi(gy0 + i - 1, 0, gh - 1), gx = clampi(gx0 + j - 1, 0, gw - 1);
-        const float2 a = *reinterpret_cast<const float2*>(raw + (size_t)(2 * gy) * pitch + 2 * gx);
-        const float2 b = *reinterpret_cast<const float2*>(raw + (size_t)(2 * gy + 1) * pitch + 2 * gx);
-        const float v[4] = {a.x, a.y, b.x, b.y};
-        double g = 0.0;
-        float ch[3] = {0.f, 0.f, 0.f};
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {  // robustness.py:215-225: raw / wb[c] in float64
-            const int c = cfa.c[k];
-            const double x = (double)v[k] / wb.w[c];
-            if (c == 1) g += x;
-            else ch[c] = (float)x;
-        }
-        ch[1] = (float)(g / 2.0);
-        s_g[0][i][j] = ch[0];
-        s_g[1][i][j] = ch[1];
-        s_g[2][i][j] = ch[2];
-    }
-    __syncthreads();
-    const int lx = threadIdx.x % RS_TX, ly = threadIdx.x / RS_TX;
-    const int gx = gx0 + lx, gy = gy0 + ly;
-    if (gx >= gw || gy >= gh) return;
-    const size_t plane = (size_t)gh * gw, o = (size_t)gy * gw + gx;
-#pragma unroll
-    for (int c = 0; c < 3; ++c) {
-        float s0 = 0.f, s1 = 0.f;  // float32 running sums in (i, j) order (robustness.py:280-288)
-#pragma unroll
-        for (int i = 0; i < 3; ++i)
-#pragma unroll
-            for (int j = 0; j < 3; ++j) {
-                const float v = s_g[c][ly + i][lx + j];
-                s0 += v;
-                s1 += v * v;
-            }
-        const double m = (double)s0 / 9.0;
-        means[c * plane + o] = (float)m;
-        vars[c * plane + o] = (float)((double)s1 / 9.0 - m * m);
-    }
-}
-
-extern "C" int hhsr_rob_stats(const float* raw, int H, int W, int pitch, const uint8_t cfa[4], const double* wb,
-                              float* means, float* vars, void* stream) {
-    HHSR_ARG(raw && cfa && wb && means && vars && H >= 2 && W >= 2 && pitch >= W);
-    HHSR_ARG((pitch & 1) == 0 && ((uintptr_t)raw & 7) == 0);
-    for (int k = 0; k < 4; ++k) HHSR_ARG(cfa[k] <= 2);
-    Cfa c;
-    Wb w;
-    for (int k = 0; k < 4; ++k) c.c[k] = cfa[k];
-    for (int k = 0; k < 3; ++k) w.w[k] = wb[k];
-    const int gh = H / 2, gw = W / 2;
-    hipLaunchKernelGGL(k_rob_stats, dim3(hhsr_cdiv(gw, RS_TX), hhsr_cdiv(gh, RS_TY)), dim3(256), 0,
-                       (hipStream_t)stream, raw, pitch, c, w, means, vars, gh, gw);
-    HHSR_LAUNCHED();
-}
-
+// (the guide image + local statistics pass lives in hhsr_kernels.hip: it shares its raw tile with the kernel
+// covariances, k_frame_stats)
 // ---- Dodgson quadratic warp-upsample ------------------------------------------------------------
 __device__ __forceinline__ double dodgson(double x) {  // utils_image.py:399-406
     const double a = fabs(x);

@@ -36,6 +36,7 @@ _SIGS = {
     "hhsr_flow_upscale_nearest": [P, I, I, P, I, I, I, F, P],
     "hhsr_cov_from_raw": [P, I, I, I, P, D, D, D, D, D, D, D, D, I, P],
     "hhsr_rob_stats": [P, I, I, I, U8P, DP, P, P, P],
+    "hhsr_frame_stats": [P, I, I, I, U8P, DP, P, P, P, D, D, D, D, D, D, D, D, I, P],
     "hhsr_rob_upscale": [P, I, I, P, I, I, I, P, P],
     "hhsr_rob_s": [P, I, I, F, F, F, P, P],
     "hhsr_rob_sigma": [P, P, I, I, P, I, P, P, P],

@@ -87,14 +87,12 @@ class HipEngine:
 
     def finish_slab(self, acc, row0, acc_r=None):
         """acc [2][rows][sW][3] (summed over ranks) -> finished output slab: reference frame + normalise."""
-        from .kernels import estimate_kernels
         from .merge import merge_burst, merge_ref
         from .utils import divide
 
         pipe = self.pipe
         sH, _ = pipe.output_size()
-        if not hasattr(self, "_ref_covs"):
-            self._ref_covs = estimate_kernels(pipe.ref, self.config)
+        self._ref_covs = pipe.ref_covs
         if acc.shape[1] == 0:
             return acc[0]
         if self.denoiser_on:  # whole image only (row0 == 0 and all rows)

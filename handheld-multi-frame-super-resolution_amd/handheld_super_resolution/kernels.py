@@ -7,9 +7,7 @@ SEL_HARD_THRESHOLD = 0
 SEL_LINEAR = 1
 
 
-def estimate_kernels(img, config):
-    """covs float32[H/2, W/2, 2, 2] sampled at the centre of every Bayer quad (kernels.py:29-137).
-    GAT, 2x2 decimation, the two gradient convolutions and the per-quad kernel are ONE HIP kernel."""
+def _kernel_params(config):
     if config.mode != "bayer":
         raise NotImplementedError("grey mode is outside the MI355X hot path (bayer only)")
     law = config.merging.selection_law
@@ -22,12 +20,38 @@ def estimate_kernels(img, config):
     t = config.merging.tuning
     alpha, beta = config.noise_model.alpha, config.noise_model.beta
     assert alpha > 0, f"alpha should be positive, got {alpha} (VST is ill defined and kernels would be wrong)"
+    return (float(alpha), float(beta), float(t.k_detail), float(t.k_denoise), float(t.D_th), float(t.D_tr),
+            float(t.k_stretch), float(t.k_shrink), sel)
+
+
+def estimate_kernels(img, config):
+    """covs float32[H/2, W/2, 2, 2] sampled at the centre of every Bayer quad (kernels.py:29-137).
+    GAT, 2x2 decimation, the two gradient convolutions and the per-quad kernel are ONE HIP kernel."""
+    params = _kernel_params(config)
     img = _lib.f32c(img)
     H, W = img.shape
     if H % 2 or W % 2:
         raise ValueError(f"bayer frames need even dimensions, got {(H, W)}")
     covs = torch.empty((H // 2, W // 2, 2, 2), dtype=torch.float32, device=img.device)
-    _lib.call("hhsr_cov_from_raw", _lib.ptr(img), H, W, W, _lib.ptr(covs), float(alpha), float(beta),
-              float(t.k_detail), float(t.k_denoise), float(t.D_th), float(t.D_tr), float(t.k_stretch),
-              float(t.k_shrink), sel, _lib.stream())
+    _lib.call("hhsr_cov_from_raw", _lib.ptr(img), H, W, W, _lib.ptr(covs), *params, _lib.stream())
     return covs
+
+
+def frame_stats(img, cfa_pattern, white_balance, config, want_vars=False):
+    """One pass over the raw frame for both of its per-frame consumers: the guide-image local means (and,
+    for the reference frame, variances) of robustness.py:207-294 and the kernel covariances of kernels.py:29-137.
+    Returns (means [3, H/2, W/2], vars or None, covs [H/2, W/2, 2, 2])."""
+    from .robustness import _wb3
+
+    params = _kernel_params(config)
+    img = _lib.f32c(img)
+    H, W = img.shape
+    if H % 2 or W % 2:
+        raise ValueError(f"bayer frames need even dimensions, got {(H, W)}")
+    means = torch.empty((3, H // 2, W // 2), dtype=torch.float32, device=img.device)
+    vars_ = torch.empty_like(means) if want_vars else None
+    covs = torch.empty((H // 2, W // 2, 2, 2), dtype=torch.float32, device=img.device)
+    _lib.call("hhsr_frame_stats", _lib.ptr(img), H, W, W, _lib.cfa_bytes(cfa_pattern),
+              _lib.doubles(_wb3(white_balance)), _lib.ptr(means), _lib.ptr(vars_), _lib.ptr(covs), *params,
+              _lib.stream())
+    return means, vars_, covs

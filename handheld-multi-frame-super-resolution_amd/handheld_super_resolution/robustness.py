@@ -12,15 +12,16 @@ def _wb3(white_balance):
     return wb[:3]
 
 
-def compute_local_stats_from_raw(raw_img, cfa_pattern, white_balance):
+def compute_local_stats_from_raw(raw_img, cfa_pattern, white_balance, want_vars=True):
     """Guide image (Alg. 7, robustness.py:207-225) and its 3x3 local mean / variance (Alg. 8,
-    :269-294) at guide resolution in one pass over the raw frame.  Returns (means, vars) [3, H/2, W/2]."""
+    :269-294) at guide resolution in one pass over the raw frame.  Returns (means, vars) [3, H/2, W/2]
+    (vars = None when not wanted: comp frames only use their means)."""
     raw_img = _lib.f32c(raw_img)
     H, W = raw_img.shape
     if H % 2 or W % 2:
         raise ValueError(f"bayer frames need even dimensions, got {(H, W)}")
     means = torch.empty((3, H // 2, W // 2), dtype=torch.float32, device=raw_img.device)
-    vars_ = torch.empty_like(means)
+    vars_ = torch.empty_like(means) if want_vars else None
     _lib.call("hhsr_rob_stats", _lib.ptr(raw_img), H, W, W, _lib.cfa_bytes(cfa_pattern), _lib.doubles(_wb3(white_balance)),
               _lib.ptr(means), _lib.ptr(vars_), _lib.stream())
     return means, vars_
@@ -91,7 +92,7 @@ def noise_sigma_sq(ref_local_means, ref_local_stds, std_curve):
 
 
 def compute_robustness(comp_img, ref_local_means, ref_local_stds, flows, cfa_pattern, white_balance, noise_model,
-                       config, return_R=False, accumulate_into=None, ref_sigma_sq=None):
+                       config, return_R=False, accumulate_into=None, ref_sigma_sq=None, comp_means=None):
     """Alg. 6 (robustness.py:79-170): r float32 [H, W].  3 kernels instead of the reference's 8:
     guide + local stats; fused warp-upsample / colour distance / noise model / threshold; 5x5 min."""
     comp_img = _lib.f32c(comp_img)
@@ -110,7 +111,9 @@ def compute_robustness(comp_img, ref_local_means, ref_local_stds, flows, cfa_pat
     ny, nx, _ = flows.shape
     if ref_sigma_sq is None:  # a BurstPipeline passes the per-burst map; stand-alone callers get it here
         ref_sigma_sq = noise_sigma_sq(ref_local_means, ref_local_stds, std_curve)
-    cm, _ = compute_local_stats_from_raw(comp_img, cfa_pattern, white_balance)
+    cm = comp_means  # a BurstPipeline gets them from the fused per-frame pass (kernels.frame_stats)
+    if cm is None:
+        cm, _ = compute_local_stats_from_raw(comp_img, cfa_pattern, white_balance, want_vars=False)
     S = compute_s(flows, t.Mt, t.s1, t.s2)
     R = torch.empty((H, W), dtype=torch.float32, device=comp_img.device)
     sigma_sq, curve_index = ref_sigma_sq

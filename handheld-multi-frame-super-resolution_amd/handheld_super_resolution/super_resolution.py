@@ -20,8 +20,9 @@ from .utils_image import compute_grey_images
 from .utils import divide, add, getTime
 from .alignment import align, init_alignment
 from .params import sanitize_config, update_snr_config
-from .robustness import init_robustness, compute_robustness, noise_curves_to_device, noise_sigma_sq
-from .kernels import estimate_kernels
+from .robustness import (init_robustness, compute_robustness, noise_curves_to_device, noise_sigma_sq,
+                         upscale_warp_stats)
+from .kernels import estimate_kernels, frame_stats
 from .merge import merge, merge_ref, merge_burst, can_fuse_acc_r
 
 
@@ -70,7 +71,12 @@ class BurstPipeline:
         sanitize_config(cfg, tuple(self.ref.shape))
         grey = compute_grey_images(self.ref, self.grey_method)
         self.align_state = init_alignment(grey, cfg)
-        self.ref_means, self.ref_vars = init_robustness(self.ref, self.cfa, self.wb, cfg)
+        if cfg.robustness.enabled:  # init_robustness + the reference frame's kernels from one raw pass
+            m, v, self.ref_covs = frame_stats(self.ref, self.cfa, self.wb, cfg, want_vars=True)
+            self.ref_means, self.ref_vars = upscale_warp_stats(m), upscale_warp_stats(v)
+        else:
+            self.ref_means, self.ref_vars = init_robustness(self.ref, self.cfa, self.wb, cfg)
+            self.ref_covs = estimate_kernels(self.ref, cfg)
         self.ref_sigma_sq = (noise_sigma_sq(self.ref_means, self.ref_vars, self.curves[0])
                              if cfg.robustness.enabled else None)
         self.grey_ref = grey
@@ -83,9 +89,12 @@ class BurstPipeline:
         raw = _lib.f32c(img, self.device)
         grey = compute_grey_images(raw, self.grey_method)
         flow = align(*self.align_state, grey, cfg)
+        if cfg.robustness.enabled:  # guide means + kernel covariances from one pass over the raw frame
+            means, _, covs = frame_stats(raw, self.cfa, self.wb, cfg)
+        else:
+            means, covs = None, estimate_kernels(raw, cfg)
         r = compute_robustness(raw, self.ref_means, self.ref_vars, flow, self.cfa, self.wb, self.curves, cfg,
-                               accumulate_into=accumulate_r, ref_sigma_sq=self.ref_sigma_sq)
-        covs = estimate_kernels(raw, cfg)
+                               accumulate_into=accumulate_r, ref_sigma_sq=self.ref_sigma_sq, comp_means=means)
         return raw, flow, covs, r
 
     def process_frames(self, comp_imgs, accumulate_r=None, n_streams=None):
@@ -183,7 +192,7 @@ def main(ref_img, comp_imgs, config):
             torch.cuda.synchronize()
             getTime(im_time, "\nImage processed (Total)")
 
-    ref_covs = estimate_kernels(pipe.ref, config)
+    ref_covs = pipe.ref_covs
     if fused:
         merge_burst(frames, pipe.ref, ref_covs, num, None, pipe.cfa, config, do_ref=True, divide=True,
                     acc_r=accumulated_r if fuse_acc else None)

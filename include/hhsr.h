@@ -120,9 +120,15 @@ int hhsr_cov_from_raw(const float* raw, int H, int W, int pitch, float* covs,
 
 /* ---- robustness, Alg. 6-9 (robustness.py) -----------------------------------------------------*/
 /* Guide image + 3x3 local mean / variance at guide resolution [3][H/2][W/2]
- * (robustness.py:207-225, 269-294).  wb: HOST double[3]. */
+ * (robustness.py:207-225, 269-294).  wb: HOST double[3].  vars may be NULL (comp frames only need the means). */
 int hhsr_rob_stats(const float* raw, int H, int W, int pitch, const uint8_t cfa[4],
                    const double* wb, float* means, float* vars, void* stream);
+/* hhsr_rob_stats + hhsr_cov_from_raw in one pass over the raw frame (both work on the same Bayer-quad tile):
+ * what super_resolution.py:137-163 computes per frame from the raw image alone.  vars may be NULL. */
+int hhsr_frame_stats(const float* raw, int H, int W, int pitch, const uint8_t cfa[4], const double* wb,
+                     float* means, float* vars, float* covs, double alpha, double beta, double k_detail,
+                     double k_denoise, double D_th, double D_tr, double k_stretch, double k_shrink, int law,
+                     void* stream);
 /* Dodgson-quadratic x2 upsampling of a [3][lh][lw] map to [3][2lh][2lw], optionally warped by the
  * per-tile flow (NULL = reference frame; robustness.py:359-421).  +inf outside. */
 int hhsr_rob_upscale(const float* stats, int lh, int lw, const float* flow, int ny, int nx, int ts,
