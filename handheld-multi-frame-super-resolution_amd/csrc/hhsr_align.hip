@@ -586,7 +586,9 @@ template <int TS, int R, bool L1>
 __global__ void __launch_bounds__(256) k_align_wave(const float* __restrict__ ref, int rh, int rw, int ref_pitch,
                                                      const float* __restrict__ hess, const float* __restrict__ mov,
                                                      int mh, int mw, int mov_pitch, float* __restrict__ flow, int nx,
-                                                     int ntiles, int mode, int n_iter) {
+                                                     int ntiles, int mode, int n_iter,
+                                                     const float2* __restrict__ coarse, int cny, int cnx, int rep,
+                                                     float mult) {
     constexpr int r = R;
     extern __shared__ __attribute__((aligned(16))) float lds[];
     constexpr int M = ICA_M;
@@ -602,8 +604,22 @@ __global__ void __launch_bounds__(256) k_align_wave(const float* __restrict__ re
     if (tile >= ntiles) return;  // wave-uniform; no workgroup barrier below
     const int ty = tile / nx, tx = tile - ty * nx;
     float* fl = flow + (size_t)tile * 2;
-    const float f0 = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, fl[0])));
-    const float f1 = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, fl[1])));
+    // incoming flow: this level's array, or (fused nearest-neighbour upscaling, alignment.py:150-172) the coarser
+    // level's flow of tile (ty/rep, tx/rep) times the level factor — zero past the coarse grid — or zero (rep < 0)
+    float fin0 = 0.f, fin1 = 0.f;
+    if (coarse) {
+        const int sy = ty / rep, sx = tx / rep;
+        if (sy < cny && sx < cnx) {
+            const float2 c = coarse[(size_t)sy * cnx + sx];
+            fin0 = c.x * mult;
+            fin1 = c.y * mult;
+        }
+    } else if (rep >= 0) {
+        fin0 = fl[0];
+        fin1 = fl[1];
+    }
+    const float f0 = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, fin0)));
+    const float f1 = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, fin1)));
     const float r0 = rintf(f0), r1 = rintf(f1);  // round-half-even
     const int ox = tx * TS + (int)r0 - r - M, oy = ty * TS + (int)r1 - r - M;  // window origin in the moving level
     {
@@ -836,13 +852,15 @@ static size_t align_wave_lds(int ts, int r) {
 
 extern "C" int hhsr_align_level(const float* ref, int rh, int rw, int ref_pitch, const float* hess, const float* mov,
                                 int mh, int mw, int mov_pitch, float* flow, int ny, int nx, int ts, int r, int metric,
-                                int n_iter, void* stream) {
+                                int n_iter, const float* coarse_flow, int cny, int cnx, int rep, float mult,
+                                void* stream) {
     HHSR_ARG(ref && hess && mov && flow && rh > 0 && rw > 0 && mh > 0 && mw > 0 && ny > 0 && nx > 0);
     HHSR_ARG(r >= 0 && n_iter > 0 && metric >= 0 && metric <= 2);  // 0 = L2, 1 = L1 (intended), 2 = L1_ref_effective
     HHSR_ARG(ts == 8 || ts == 16 || ts == 32);
     HHSR_ARG(metric == 0 || ts >= 16);  // block_matching.py:87: no L1 search for 8-pixel tiles
     HHSR_ARG(ny * ts <= rh && nx * ts <= rw);
     HHSR_ARG(r == 1 || r == 2 || r == 4);  // compiled search radii (other radii: hhsr_bm_* + hhsr_ica)
+    HHSR_ARG(!coarse_flow || (cny > 0 && cnx > 0 && rep > 0));
     const size_t l = align_wave_lds(ts, r);
     HHSR_ARG(l <= 64 * 1024);
     const int ntiles = nx * ny;
@@ -850,7 +868,8 @@ extern "C" int hhsr_align_level(const float* ref, int rh, int rw, int ref_pitch,
     hipStream_t s = (hipStream_t)stream;
     const int mode = metric == 2 ? 1 : 0;
 #define ALW(TS, R, L1) hipLaunchKernelGGL((k_align_wave<TS, R, L1>), g, b, l, s, ref, rh, rw, ref_pitch, hess, mov, mh, \
-                                          mw, mov_pitch, flow, nx, ntiles, mode, n_iter)
+                                          mw, mov_pitch, flow, nx, ntiles, mode, n_iter, \
+                                          reinterpret_cast<const float2*>(coarse_flow), cny, cnx, rep, mult)
 #define ALW_R(TS, L1) do { if (r == 1) ALW(TS, 1, L1); else if (r == 2) ALW(TS, 2, L1); else ALW(TS, 4, L1); } while (0)
     if (metric == 0) {
         if (ts == 8) ALW_R(8, false);

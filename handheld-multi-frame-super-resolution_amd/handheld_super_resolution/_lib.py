@@ -32,7 +32,7 @@ _SIGS = {
     "hhsr_bm_l2": [P, I, P, I, I, I, P, I, I, I, I, P],
     "hhsr_bm_l1": [P, I, P, I, I, I, P, I, I, I, I, I, P],
     "hhsr_ica": [P, P, P, I, P, P, I, I, I, P, I, I, I, I, I, P],
-    "hhsr_align_level": [P, I, I, I, P, P, I, I, I, P, I, I, I, I, I, I, P],
+    "hhsr_align_level": [P, I, I, I, P, P, I, I, I, P, I, I, I, I, I, I, P, I, I, I, F, P],
     "hhsr_flow_upscale_nearest": [P, I, I, P, I, I, I, F, P],
     "hhsr_cov_from_raw": [P, I, I, I, P, D, D, D, D, D, D, D, D, I, P],
     "hhsr_rob_stats": [P, I, I, I, U8P, DP, P, P, P],

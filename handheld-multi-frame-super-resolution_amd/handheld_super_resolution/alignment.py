@@ -75,25 +75,46 @@ def upscale_lvl(alignments, npatchs, l, config):
     return ups[: npatchs[0], : npatchs[1]].contiguous()
 
 
-def align_lvl(ref_lvl, tyled_pyr_lvl, ref_fft_lvl, ref_gradx_lvl, ref_grady_lvl, ref_hessian_lvl, moving_lvl,
-              alignments, l, config):
-    """Block matching then ICA on one level (alignment.py:125-147).  For tiles up to 32 pixels both steps
-    run in ONE fused kernel (hhsr_align_level; config.hip.fused_align: false selects the two-kernel path,
-    which is also what 64-pixel tiles use)."""
-    metric = config.block_matching.tuning.metrics[l]
+def _fused_level(l, config):
+    """(metric code, ts, r) when level l runs on the fused block-matching + ICA kernel, else None."""
     bm = config.block_matching.tuning
     ts, r = bm.tile_sizes[l], bm.search_radii[l]
     hip = config.get("hip", None) if hasattr(config, "get") else None
     fused = True if hip is None else bool(hip.get("fused_align", True))
-    code = {"L2": 0, "L1": 1, "L1_ref_effective": 2}.get(metric)
+    code = {"L2": 0, "L1": 1, "L1_ref_effective": 2}.get(bm.metrics[l])
     if fused and code is not None and ts in (8, 16, 32) and r in (1, 2, 4) and not (code != 0 and ts == 8):
+        return code, ts, r
+    return None
+
+
+def align_lvl(ref_lvl, tyled_pyr_lvl, ref_fft_lvl, ref_gradx_lvl, ref_grady_lvl, ref_hessian_lvl, moving_lvl,
+              alignments, l, config, coarse=None):
+    """Block matching then ICA on one level (alignment.py:125-147).  For tiles up to 32 pixels both steps
+    run in ONE fused kernel (hhsr_align_level; config.hip.fused_align: false selects the two-kernel path,
+    which is also what 64-pixel tiles use).  `coarse` (fused kernel only): where the incoming flow comes from
+    instead of `alignments` — "zero" or (coarser_flow, rep, mult) for the nearest-neighbour upscaling of
+    upscale_lvl() fused into the launch; `alignments` then only receives the result."""
+    metric = config.block_matching.tuning.metrics[l]
+    fl = _fused_level(l, config)
+    if fl is not None:
+        code, ts, r = fl
         ny, nx, _ = alignments.shape
         mh, mw = moving_lvl.shape
         rh, rw = ref_lvl.shape
         assert ref_lvl.is_contiguous() and moving_lvl.is_contiguous() and alignments.is_contiguous()
+        if coarse is None:
+            cptr, cny, cnx, rep, mult = None, 0, 0, 0, 1.0
+        elif isinstance(coarse, str):
+            cptr, cny, cnx, rep, mult = None, 0, 0, -1, 1.0
+        else:
+            cf, rep, mult = coarse
+            assert cf.is_contiguous() and cf.dtype == torch.float32
+            cptr, (cny, cnx) = cf, cf.shape[:2]
         _lib.call("hhsr_align_level", _lib.ptr(ref_lvl), rh, rw, rw, _lib.ptr(ref_hessian_lvl), _lib.ptr(moving_lvl),
-                  mh, mw, mw, _lib.ptr(alignments), ny, nx, ts, r, code, int(config.ica.tuning.n_iter), _lib.stream())
+                  mh, mw, mw, _lib.ptr(alignments), ny, nx, ts, r, code, int(config.ica.tuning.n_iter),
+                  _lib.ptr(cptr), int(cny), int(cnx), int(rep), float(mult), _lib.stream())
         return
+    assert coarse is None, "fused flow upscaling needs the fused level kernel"
     if metric == "L2":
         align_lvl_block_matching_L2(ref_lvl, ref_fft_lvl, moving_lvl, alignments, l, config)
     elif metric == "L1":
@@ -118,10 +139,23 @@ def align(ref_pyramid, tyled_pyr, ref_tiled_fft, ref_gradx, ref_grady, ref_hessi
         l = n - i - 1
         ts = config.block_matching.tuning.tile_sizes[l]
         grid = (ref_pyramid[i].shape[0] // ts, ref_pyramid[i].shape[1] // ts)
-        if alignments is None:
+        bm = config.block_matching.tuning
+        coarse = None
+        q = bm.tile_sizes[l] // bm.tile_sizes[l + 1] if alignments is not None else 1
+        rep = bm.factors[l + 1] // q if (alignments is not None and q > 0) else 1
+        if (_fused_level(l, config) is not None and rep > 0 and
+                (alignments is None or bm.flow_upscale_mode == "nearest")):
+            # the level kernel takes its incoming flow straight from the coarser level (or zero): no separate
+            # upscaling / memset launch
+            if alignments is None:
+                coarse = "zero"
+            else:
+                coarse = (alignments, rep, float(bm.factors[l + 1]))
+            alignments = torch.empty((*grid, 2), dtype=torch.float32, device=img.device)
+        elif alignments is None:
             alignments = torch.zeros((*grid, 2), dtype=torch.float32, device=img.device)
         else:
             alignments = upscale_lvl(alignments, grid, l, config)
         align_lvl(ref_pyramid[i], tyled_pyr[i], ref_tiled_fft[i], ref_gradx[i], ref_grady[i], ref_hessian[i],
-                  moving_pyramid[i], alignments, l, config)
+                  moving_pyramid[i], alignments, l, config, coarse=coarse)
     return alignments

@@ -100,10 +100,14 @@ int hhsr_ica(const float* ref, const float* gx, const float* gy, int ref_pitch, 
 /* ---- one pyramid level in one launch: block matching then ICA (alignment.py:125-147), ts in {8, 16, 32}.
  * metric: 0 = L2, 1 = L1 (intended semantics), 2 = L1_ref_effective.  Gradients are taken from the
  * reference level itself (rh x rw) — bit-identical to hhsr_grad_hessian's — `hess` from hhsr_grad_hessian.
- * Same results as hhsr_bm_* followed by hhsr_ica (flags bit 0 is irrelevant below ts = 64). */
+ * Same results as hhsr_bm_* followed by hhsr_ica (flags bit 0 is irrelevant below ts = 64).
+ * Incoming flow: `flow` itself (coarse_flow NULL, rep >= 0); or the nearest-neighbour upscaling of the coarser
+ * level fused in (alignment.py:150-172): mult * coarse_flow[ty/rep][tx/rep] ([cny][cnx][2], zero past it); or
+ * zero (coarse_flow NULL, rep < 0: the coarsest level).  `flow` is always the output. */
 int hhsr_align_level(const float* ref, int rh, int rw, int ref_pitch, const float* hess,
                      const float* mov, int mh, int mw, int mov_pitch,
-                     float* flow, int ny, int nx, int ts, int r, int metric, int n_iter, void* stream);
+                     float* flow, int ny, int nx, int ts, int r, int metric, int n_iter,
+                     const float* coarse_flow, int cny, int cnx, int rep, float mult, void* stream);
 
 /* ---- flow upscaling, nearest mode (alignment.py:150-172): dst[y][x] = mult*src[y/rep][x/rep],
  * zero where y/rep >= sny or x/rep >= snx. */

@@ -233,7 +233,41 @@ def test_upscale(golden, mode):
     assert_close(N(alignment.upscale_lvl(T(g["flow"]), (21, 29), 1, cfg)), g[mode + "_l1"], tol, tol, mode + " l1")
 
 
+def test_align_fused_upscale_equals_separate_launches():
+    """align(): the level kernel taking its incoming flow from the coarser level (fused nearest-neighbour
+    upscaling, zero start) == separate memset / hhsr_flow_upscale_nearest launches == two-kernel levels."""
+    ref, comp, _ = synth.make_burst(200, 264, 2, seed=21)
+    cfg = base_config(ts=16)
+    cfg.block_matching.tuning.factors = [1, 2, 2, 2]
+    grey_r, grey_c = utils_image.compute_grey_images(T(ref), "FFT"), utils_image.compute_grey_images(T(comp[0]), "FFT")
+    state = alignment.init_alignment(grey_r, cfg)
+    f_fused = N(alignment.align(*state, grey_c, cfg))
+    cfg.hip = {"fused_align": False}
+    f_sep = N(alignment.align(*state, grey_c, cfg))
+    assert_close(f_fused, f_sep, 0, 2e-5, "fused upscaling vs separate launches")
+    assert np.abs(f_fused).max() > 0.5  # the burst really moves
+
+
 # ------------------------------------------------------------------------------------------ kernels
+def test_frame_stats_equals_separate_passes():
+    """hhsr_frame_stats (one raw pass) == hhsr_rob_stats + hhsr_cov_from_raw, bit for bit."""
+    ref, _, _ = synth.make_burst(134, 202, 1, seed=8)
+    cfg = base_config(snr=12.0, ts=16)
+    cfa, wb = [[2, 1], [1, 0]], [1.9, 1.0, 1.6]
+    m, v, c = kernels.frame_stats(T(ref), cfa, wb, cfg, want_vars=True)
+    m2, v2 = robustness.compute_local_stats_from_raw(T(ref), cfa, wb)
+    c2 = kernels.estimate_kernels(T(ref), cfg)
+    assert_close(N(m), N(m2), 0, 0, "fused means")
+    assert_close(N(v), N(v2), 0, 0, "fused vars")
+    assert_close(N(c), N(c2), 0, 0, "fused covs")
+    m3, v3, _ = kernels.frame_stats(T(ref), cfa, wb, cfg)
+    assert v3 is None
+    assert_close(N(m3), N(m2), 0, 0, "means without vars")
+    om, ov = oracle.local_stats(oracle.guide_image(ref, cfa, wb))
+    assert_close(N(m), om, 1e-6, 1e-7, "means vs oracle")
+    assert_close(N(v), ov, 1e-5, 1e-7, "vars vs oracle")
+
+
 @pytest.mark.parametrize("law", ["linear", "hard_threshold"])
 def test_cov_golden(golden, law):
     g = golden("kernels")
