@@ -63,7 +63,7 @@ def main():
     ap.add_argument("--scale", type=float, default=2)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-crop", type=int, default=512)
-    ap.add_argument("--streams", type=int, default=None, help="HIP streams for the frame pipeline (default: config, 2)")
+    ap.add_argument("--streams", type=int, default=None, help="HIP streams for the frame pipeline (default: config, 3)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))

@@ -13,6 +13,7 @@
 // tap.  `WT` selects the type of the weight chain: double = the reference's typing (validation mode,
 // HHSR_WEIGHT_F64), float = the default fast path (comp_accum_fast).
 #include "hhsr_common.h"
+#include <type_traits>
 
 struct Cfa4 {
     uint8_t c[4];
@@ -224,22 +225,29 @@ __device__ __forceinline__ void taps_accum(const FrameGeo& q, const Geo& g, cons
     const int ci = q.ci, cj = q.cj;
     const bool interior = ci >= 1 && ci + 1 < g.H && cj >= 1 && cj + 1 < g.W;
     const float dxm = dx0 - 1.f, dxp = dx0 + 1.f;
+    // the 9 taps; CHECK = window crosses the frame border (taps outside are skipped, merge.py:404-405).  Two
+    // copies so that the common interior case is straight-line code without per-tap exec-mask branches.
+    auto taps = [&](auto check) {
+        constexpr bool CHECK = decltype(check)::value;
 #pragma unroll
-    for (int di = -1; di <= 1; ++di) {
-        const float dy = dy0 + (float)di;
-        const float a = iyy * dy * dy, b = ixy * dy;
+        for (int di = -1; di <= 1; ++di) {
+            const float dy = dy0 + (float)di;
+            const float a = iyy * dy * dy, b = ixy * dy;
 #pragma unroll
-        for (int dj = -1; dj <= 1; ++dj) {
-            if (!interior && (cj + dj < 0 || cj + dj >= g.W || ci + di < 0 || ci + di >= g.H)) continue;
-            const float c = rawAt(di, dj);
-            const float dx = dj < 0 ? dxm : (dj > 0 ? dxp : dx0);
-            const float z = fminf(fmaf(fmaf(ixx, dx, b), dx, a), 0.f);
-            const float e = __builtin_amdgcn_exp2f(z);
-            const float w = e * e;
-            sv[di & 1][dj & 1] = fmaf(w, c, sv[di & 1][dj & 1]);
-            sa[di & 1][dj & 1] += w;
+            for (int dj = -1; dj <= 1; ++dj) {
+                if (CHECK && (cj + dj < 0 || cj + dj >= g.W || ci + di < 0 || ci + di >= g.H)) continue;
+                const float c = rawAt(di, dj);
+                const float dx = dj < 0 ? dxm : (dj > 0 ? dxp : dx0);
+                const float z = fminf(fmaf(fmaf(ixx, dx, b), dx, a), 0.f);
+                const float e = __builtin_amdgcn_exp2f(z);
+                const float w = e * e;
+                sv[di & 1][dj & 1] = fmaf(w, c, sv[di & 1][dj & 1]);
+                sa[di & 1][dj & 1] += w;
+            }
         }
-    }
+    };
+    if (interior) taps(std::false_type{});
+    else taps(std::true_type{});
     // offset parity -> absolute raw-coordinate parity: swap columns / rows when the centre is odd
     const bool oj = cj & 1, oi = ci & 1;
 #pragma unroll
