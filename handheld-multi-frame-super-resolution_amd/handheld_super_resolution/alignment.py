@@ -126,13 +126,16 @@ def align_lvl(ref_lvl, tyled_pyr_lvl, ref_fft_lvl, ref_gradx_lvl, ref_grady_lvl,
     align_lvl_ica(ref_lvl, ref_gradx_lvl, ref_grady_lvl, ref_hessian_lvl, moving_lvl, alignments, l, config)
 
 
-def align(ref_pyramid, tyled_pyr, ref_tiled_fft, ref_gradx, ref_grady, ref_hessian, img, config):
+def align(ref_pyramid, tyled_pyr, ref_tiled_fft, ref_gradx, ref_grady, ref_hessian, img, config,
+          moving_pyramid=None):
     """Coarse-to-fine alignment of one grey frame (alignment.py:84-123).  Everything is enqueued on
     torch's current stream: no host synchronisation between levels (the reference needs a
-    cuda.synchronize() per level to order its torch and Numba streams)."""
+    cuda.synchronize() per level to order its torch and Numba streams).  `moving_pyramid`: the frame's
+    pyramid when the caller already built it (it does not depend on the reference frame)."""
     img = _lib.f32c(img)
     factors = config.block_matching.tuning.factors
-    moving_pyramid = build_gaussian_pyramid(img, factors)
+    if moving_pyramid is None:
+        moving_pyramid = build_gaussian_pyramid(img, factors)
     alignments = None
     n = len(ref_pyramid)
     for i in range(n):

@@ -18,7 +18,7 @@ import torch
 from . import _lib
 from .utils_image import compute_grey_images
 from .utils import divide, add, getTime
-from .alignment import align, init_alignment
+from .alignment import align, init_alignment, build_gaussian_pyramid
 from .params import sanitize_config, update_snr_config
 from .robustness import (init_robustness, compute_robustness, noise_curves_to_device, noise_sigma_sq,
                          upscale_warp_stats)
@@ -68,6 +68,9 @@ class BurstPipeline:
 
     def init_ref(self, ref_img):
         cfg = self.config
+        main = torch.cuda.current_stream(self.device)
+        self._entry = torch.cuda.Event()  # everything the caller enqueued before (e.g. the frames' upload) is done
+        self._entry.record(main)
         self.ref = _lib.f32c(ref_img, self.device)
         sanitize_config(cfg, tuple(self.ref.shape))
         grey = compute_grey_images(self.ref, self.grey_method)
@@ -81,15 +84,23 @@ class BurstPipeline:
         self.ref_sigma_sq = (noise_sigma_sq(self.ref_means, self.ref_vars, self.curves[0])
                              if cfg.robustness.enabled else None)
         self.grey_ref = grey
+        self._ref_ready = torch.cuda.Event()
+        self._ref_ready.record(main)
         return self
 
-    def process_frame(self, img, accumulate_r=None):
-        """grey -> align -> robustness -> kernels for one comp frame; returns (raw, flow, covs, r).
-        `accumulate_r`: optional float32 [H, W] that receives += r (fused into the local-min pass)."""
+    def process_frame(self, img, accumulate_r=None, wait_ref=None):
+        """grey -> kernels -> align -> robustness for one comp frame; returns (raw, flow, covs, r).
+        `accumulate_r`: optional float32 [H, W] that receives += r (fused into the local-min pass).
+        `wait_ref`: event after which the reference-frame state is complete — the frame's own grey image and
+        pyramid do not need it and are enqueued before the wait, so on a side stream they overlap the
+        (latency-bound) reference precompute."""
         cfg = self.config
         raw = _lib.f32c(img, self.device)
         grey = compute_grey_images(raw, self.grey_method)
-        flow = align(*self.align_state, grey, cfg)
+        pyramid = build_gaussian_pyramid(grey, cfg.block_matching.tuning.factors)
+        if wait_ref is not None:
+            torch.cuda.current_stream(self.device).wait_event(wait_ref)
+        flow = align(*self.align_state, grey, cfg, moving_pyramid=pyramid)
         if cfg.robustness.enabled:  # guide means + kernel covariances from one pass over the raw frame
             means, _, covs = frame_stats(raw, self.cfa, self.wb, cfg)
         else:
@@ -114,15 +125,13 @@ class BurstPipeline:
         if len(self._streams) < n_streams:
             self._streams += [torch.cuda.Stream(self.device) for _ in range(n_streams - len(self._streams))]
         pool = self._streams[:n_streams]
-        ready = torch.cuda.Event()
-        ready.record(main)
         frames = []
         for i in range(n):
             s = pool[i % n_streams]
             if i < n_streams:
-                s.wait_event(ready)  # reference-frame state was produced on the caller's stream
+                s.wait_event(self._entry)  # the caller's earlier work (frame upload, previous burst) is done
             with torch.cuda.stream(s):
-                f = self.process_frame(comp_imgs[i])
+                f = self.process_frame(comp_imgs[i], wait_ref=self._ref_ready)
             for t in f[1:]:
                 t.record_stream(main)  # consumed by the merge on the caller's stream
             frames.append(f)
