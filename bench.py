@@ -31,6 +31,7 @@ import numpy as np  # noqa: E402
 import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
+VALU_PEAK_TLANEOPS = 78.6  # 256 CUs x 4 SIMD-32 x 2.4 GHz: one wave64 VALU instruction per 2 cycles (MI355X_MICROARCH.md)
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec (6.3 TB/s achievable)
 
 
@@ -149,18 +150,24 @@ def main():
         n_local = len(hdist.shard_indices(NF - 1, rank, world))
         nbytes = merge_burst_bytes(n_local, P, S, with_ref=(world == 1), partial=(world > 1))
         achieved = nbytes / (avg_ms * 1e-3) / 1e9
-        traffic = None
-        try:  # HBM bytes per launch from the committed rocprofv3 --pmc passes of this exact workload
+        traffic, valu = None, None
+        try:  # HBM bytes / VALU instructions per launch from the committed rocprofv3 --pmc passes of this exact workload
             with open(os.path.join(ROOT, "profiles", "r01_pmc_merge.json")) as f:
                 pm = json.load(f)
             if pm.get("workload") == f"{H}x{W}x{NF} x{scale}" and world == 1:
                 traffic = pm["traffic_bytes_per_launch"]
+                # VALU lane-operations per second against the issue peak (157.3 TFLOP/s fp32 vector / 2)
+                insts = pm["valu_wave_insts_per_launch"]
+                lane_ops = insts * 64 / (avg_ms * 1e-3)
+                valu = {"wave_insts_per_launch": insts, "achieved_Tlaneops": round(lane_ops / 1e12, 2),
+                        "peak_Tlaneops": VALU_PEAK_TLANEOPS, "frac": round(lane_ops / 1e12 / VALU_PEAK_TLANEOPS, 3)}
         except Exception:
             pass
         roof = {"kernel": "k_merge_burst_tile (hhsr_merge_burst)", "bound": "hbm", "achieved": round(achieved, 1),
                 "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
-                "avg_launch_ms": round(avg_ms, 4), "bytes_per_launch": nbytes,
-                "note": "fused burst merge keeps the accumulators in registers: VALU-issue bound, not HBM bound"}
+                "avg_launch_ms": round(avg_ms, 4), "bytes_per_launch": nbytes, "valu_issue": valu,
+                "note": "fused burst merge keeps the accumulators in registers: bound by VALU issue (see valu_issue), "
+                        "not by HBM"}
 
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
