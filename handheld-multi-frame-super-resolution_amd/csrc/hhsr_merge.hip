@@ -657,6 +657,136 @@ __global__ void __launch_bounds__(256) k_merge_burst_tile(BurstArgs a, Geo g, Cf
     }
 }
 
+// ---- x2 variant: one thread = one LR pixel = its 2 x 2 HR pixels ----------------------------------------------
+// At scale 2 the four HR pixels of an LR pixel share the robustness sample, the flow vector, the staged windows
+// and most of the geometry (their centres differ by at most one raw pixel, decided by wave-uniform comparisons
+// of frac(flow) with 0.25 / 0.75).  A 16 x 16 LR workgroup (32 x 32 HR, inside one flow tile for ts % 16 == 0)
+// stages a 19 x 19 raw window and an 11 x 11 covariance window per frame — the per-frame staging, prefetch
+// address arithmetic and the two workgroup barriers are paid once per FOUR output pixels, and every thread owns
+// exactly one accumulated-robustness sample.  Same arithmetic per HR pixel as k_merge_burst_tile (frame_geom /
+// taps_accum are shared), so results are bit-identical to it.
+constexpr int QT = 16;  // LR workgroup edge
+
+template <bool ISO>
+__global__ void __launch_bounds__(256) k_merge_burst_quad(BurstArgs a, Geo g, Cfa4 cfa, float* __restrict__ num,
+                                                           float* __restrict__ den) {
+    __shared__ float s_raw[RWIN * RPITCH];
+    __shared__ float4 s_cov[CWIN * CWIN];
+    const int tx = threadIdx.x & (QT - 1), ty = threadIdx.x >> 4;
+    const int nbx = gridDim.x, nblk = gridDim.x * gridDim.y;
+    int bid = blockIdx.y * nbx + blockIdx.x;
+    {   // XCD-aware tile order, see k_merge_burst_tile
+        const int xcd = bid & 7, loc = bid >> 3, q = nblk >> 3, rem = nblk & 7;
+        bid = xcd * q + min(xcd, rem) + loc;
+    }
+    const int lx0 = (bid % nbx) * QT, ly0 = (g.row0 >> 1) + (bid / nbx) * QT;  // LR origin of the workgroup
+    const int lx = lx0 + tx, ly = ly0 + ty;
+    const bool live = lx < g.W && 2 * ly < g.row1;
+    const int lxc = min(lx, g.W - 1), lyc = min(ly, (g.row1 >> 1) - 1);
+    const Pix p0 = make_pix(g, 2 * min(ly0, (g.row1 >> 1) - 1), 2 * min(lx0, g.W - 1));  // smallest centre of the tile
+    Pix pq[2][2];
+#pragma unroll
+    for (int sa = 0; sa < 2; ++sa)
+#pragma unroll
+        for (int sb = 0; sb < 2; ++sb) pq[sa][sb] = make_pix(g, 2 * lyc + sa, 2 * lxc + sb);
+    const int tile = p0.tile, ridx = pq[0][0].ridx;
+    float n4[2][2][2][2], d4[2][2][2][2];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+        (&n4[0][0][0][0])[k] = 0.f;
+        (&d4[0][0][0][0])[k] = 0.f;
+    }
+    float racc = 0.f;
+
+    constexpr int rwin = QT + 3, cwin = QT / 2 + 3;  // 19 raw pixels, 11 covariance cells
+    static_assert(rwin <= RWIN && cwin <= CWIN, "window buffers");
+    const int e0 = threadIdx.x, e1 = threadIdx.x + 256;
+    const int e0y = e0 / rwin, e0x = e0 - e0y * rwin, e1y = e1 / rwin, e1x = e1 - e1y * rwin;
+    const int cey = threadIdx.x / cwin, cex = threadIdx.x - cey * cwin;
+    const bool has1 = e1 < rwin * rwin, hasc = threadIdx.x < cwin * cwin;
+
+    float pr0 = 0.f, pr1 = 0.f, plr = 0.f;
+    float4 pc = make_float4(0.f, 0.f, 0.f, 0.f);
+    float2 pfl = make_float2(0.f, 0.f);
+    TileWin pw{0, 0, 0, 0};
+    auto prefetch = [&](int n) {
+        const FramePtr f = a.f[n];
+        pfl = f.flow[tile];
+        const FrameGeo qc = frame_geom<GEOM_P2, ISO>(pfl, g, p0);
+        pw.rx0 = qc.cj - 1; pw.ry0 = qc.ci - 1;
+        pw.cx0 = qc.cj >= 1 ? (qc.cj - 1) >> 1 : 0;
+        pw.cy0 = qc.ci >= 1 ? (qc.ci - 1) >> 1 : 0;
+        {
+            const int y = pw.ry0 + e0y, x = pw.rx0 + e0x;
+            pr0 = (y >= 0 && y < g.H && x >= 0 && x < g.W) ? f.raw[(size_t)y * g.pitch + x] : 0.f;
+        }
+        if (has1) {
+            const int y = pw.ry0 + e1y, x = pw.rx0 + e1x;
+            pr1 = (y >= 0 && y < g.H && x >= 0 && x < g.W) ? f.raw[(size_t)y * g.pitch + x] : 0.f;
+        }
+        if (!ISO && hasc) {
+            const int y = min(max(pw.cy0 + cey, 0), g.gh - 1), x = min(max(pw.cx0 + cex, 0), g.gw - 1);
+            pc = f.cov[(size_t)y * g.gw + x];
+        }
+        plr = f.r[ridx];
+    };
+
+    if (a.n > 0) prefetch(0);
+    for (int n = 0; n < a.n; ++n) {
+        __syncthreads();  // the previous frame's taps are done with the LDS windows
+        s_raw[e0y * RPITCH + e0x] = pr0;
+        if (has1) s_raw[e1y * RPITCH + e1x] = pr1;
+        if (!ISO && hasc) s_cov[cey * CWIN + cex] = pc;
+        const float2 fl = pfl;
+        const TileWin w = pw;
+        const float local_r = plr;
+        __syncthreads();
+        if (n + 1 < a.n) prefetch(n + 1);  // in flight while this frame's taps are evaluated
+        racc += local_r;
+        if (live && local_r != 0.f) {
+#pragma unroll
+            for (int sa = 0; sa < 2; ++sa)
+#pragma unroll
+                for (int sb = 0; sb < 2; ++sb) {
+                    const FrameGeo q = frame_geom<GEOM_P2, ISO>(fl, g, pq[sa][sb]);
+                    if (q.valid) {
+                        const float* __restrict__ rc = s_raw + (q.ci - w.ry0) * RPITCH + (q.cj - w.rx0);
+                        const int cx0 = q.x0 - w.cx0, cy0 = q.y0 - w.cy0;
+                        const int cx1 = min(q.x0 + 1, g.gw - 1) - w.cx0, cy1 = min(q.y0 + 1, g.gh - 1) - w.cy0;
+                        taps_accum<ISO, false>(
+                            q, g, local_r, [=](int di, int dj) { return rc[di * RPITCH + dj]; },
+                            [=](int k) { return s_cov[(k & 2 ? cy1 : cy0) * CWIN + (k & 1 ? cx1 : cx0)]; },
+                            n4[sa][sb], d4[sa][sb]);
+                    }
+                }
+        }
+    }
+    if (!live) return;
+    if (a.acc_r) a.acc_r[ridx] = ((a.flags & HHSR_MERGE_LOAD_ACC) ? a.acc_r[ridx] : 0.f) + racc;
+#pragma unroll
+    for (int sa = 0; sa < 2; ++sa)
+#pragma unroll
+        for (int sb = 0; sb < 2; ++sb) {
+            const int hi = 2 * ly + sa, hj = 2 * lx + sb;
+            const size_t o = ((size_t)(hi - g.row0) * g.sW + hj) * 3;
+            float n3[3] = {0.f, 0.f, 0.f}, d3[3] = {0.f, 0.f, 0.f};
+            if (a.flags & HHSR_MERGE_LOAD_ACC) {
+#pragma unroll
+                for (int k = 0; k < 3; ++k) {
+                    n3[k] = num[o + k];
+                    d3[k] = den[o + k];
+                }
+            }
+            if (a.flags & HHSR_MERGE_DO_REF) ref_accum_fast<ISO>(a.ref_raw, a.ref_cov, g, hi, hj, n4[sa][sb], d4[sa][sb]);
+            classes_to_rgb(cfa, n4[sa][sb], d4[sa][sb], n3, d3);
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                num[o + k] = (a.flags & HHSR_MERGE_DIVIDE) ? n3[k] / d3[k] : n3[k];
+                if (a.flags & HHSR_MERGE_STORE_DEN) den[o + k] = d3[k];
+            }
+        }
+}
+
 static bool scale_is_pow2(double s) {  // 1, 2, 4, 8: (h + 0.5)/s is exact in float32
     return s == 1.0 || s == 2.0 || s == 4.0 || s == 8.0;
 }
@@ -761,6 +891,15 @@ extern "C" int hhsr_merge_burst(const float* const* raws, const float* const* fl
     const int iscale = (int)scale;
     const bool tiled = !f64 && (double)iscale == scale && iscale >= 1 && ((int64_t)ts * iscale) % MT == 0 &&
                        n_frames > 0 && row0 % MT == 0 && !getenv("HHSR_MERGE_NO_LDS");
+    // x2: one thread per LR pixel (4 HR pixels), 32 x 32 HR workgroups inside one flow tile
+    const bool quad = tiled && p2 && iscale == 2 && ts % QT == 0 && sW == 2 * W && sH == 2 * H && row0 % (2 * QT) == 0 &&
+                      nrows % 2 == 0 && !getenv("HHSR_MERGE_NO_QUAD");
+    if (quad) {
+        const dim3 qgrid(hhsr_cdiv(W, QT), hhsr_cdiv(nrows / 2, QT));
+        if (iso) hipLaunchKernelGGL((k_merge_burst_quad<true>), qgrid, block, 0, s, a, g, c, num, den);
+        else hipLaunchKernelGGL((k_merge_burst_quad<false>), qgrid, block, 0, s, a, g, c, num, den);
+        HHSR_LAUNCHED();
+    }
     if (tiled) {
         const dim3 tgrid(hhsr_cdiv(sW, MT), hhsr_cdiv(nrows, MT));
 #define HHSR_MT(GEOM, ISO) hipLaunchKernelGGL((k_merge_burst_tile<GEOM, ISO>), tgrid, block, 0, s, a, g, c, num, den)
