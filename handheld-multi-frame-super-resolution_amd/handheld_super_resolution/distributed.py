@@ -20,7 +20,7 @@ so that the sharding / exchange logic can be exercised without a GPU (tests run 
 import torch
 import torch.distributed as dist
 
-SLAB_ALIGN = 16  # slabs start on the 16-pixel tile grid of the fused merge kernel
+SLAB_ALIGN = 32  # slabs start on the 32-row workgroup grid of the x2 merge kernel (16-row grid of the generic one)
 
 
 def shard_indices(n_frames, rank, world):

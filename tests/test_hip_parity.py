@@ -391,6 +391,34 @@ def _frames(H, W, n, ts, seed, cfg):
     return ref, fr
 
 
+@pytest.mark.parametrize("kern", ["handheld", "iso"])
+def test_merge_x2_quad_kernel_equals_tile_kernel(monkeypatch, kern):
+    """scale 2: the one-thread-per-LR-pixel kernel (k_merge_burst_quad) == the 16x16 HR tile kernel, bit for bit,
+    including the fused accumulated robustness, partial launches and an image that is not a tile multiple."""
+    H, W, ts = 72, 104, 16
+    cfg = base_config(ts=ts, scale=2)
+    cfg.merging.kernel = kern
+    ref, fr = _frames(H, W, 4, ts, 77, cfg)
+    fr[1] = (fr[1][0], fr[1][1] + 9.5, fr[1][2], fr[1][3])  # a frame pushed partly out of the image
+    cfa = [[2, 1], [1, 0]]
+    tf = [tuple(T(a) for a in f) for f in fr]
+    rc = T(oracle.estimate_kernels(ref, cfg))
+
+    def run():
+        out, den = torch.empty(2 * H, 2 * W, 3, device=DEV), torch.empty(2 * H, 2 * W, 3, device=DEV)
+        acc = torch.zeros(H, W, device=DEV)
+        merge.merge_burst(tf[:2], None, None, out, den, cfa, cfg, do_ref=False, divide=False, store_den=True, acc_r=acc)
+        merge.merge_burst(tf[2:], T(ref), rc, out, den, cfa, cfg, load_acc=True, acc_r=acc)
+        return N(out), N(acc)
+
+    out_q, acc_q = run()
+    monkeypatch.setenv("HHSR_MERGE_NO_QUAD", "1")
+    out_t, acc_t = run()
+    assert_close(out_q, out_t, 0, 0, "quad vs tile kernel")
+    assert_close(acc_q, acc_t, 0, 0, "quad vs tile accumulated robustness")
+    assert_close(acc_q, sum(f[3] for f in fr), 1e-6, 1e-6, "accumulated robustness")
+
+
 @pytest.mark.parametrize("scale", [1, 2, 3])
 def test_merge_burst_equals_sequential(scale):
     H, W, ts = 64, 96, 16
