@@ -667,11 +667,12 @@ __global__ void __launch_bounds__(256) k_merge_burst_tile(BurstArgs a, Geo g, Cf
 // taps_accum are shared), so results are bit-identical to it.
 constexpr int QT = 16;  // LR workgroup edge
 
-template <bool ISO>
+template <bool ISO, bool LMIN>
 __global__ void __launch_bounds__(256) k_merge_burst_quad(BurstArgs a, Geo g, Cfa4 cfa, float* __restrict__ num,
                                                            float* __restrict__ den) {
     __shared__ float s_raw[RWIN * RPITCH];
     __shared__ float4 s_cov[CWIN * CWIN];
+    __shared__ float s_R[LMIN ? QT + 4 : 1][QT + 4 + 1];  // LMIN: un-filtered robustness of the tile + 2-pixel border
     const int tx = threadIdx.x & (QT - 1), ty = threadIdx.x >> 4;
     const int nbx = gridDim.x, nblk = gridDim.x * gridDim.y;
     int bid = blockIdx.y * nbx + blockIdx.x;
@@ -705,7 +706,15 @@ __global__ void __launch_bounds__(256) k_merge_burst_quad(BurstArgs a, Geo g, Cf
     const int cey = threadIdx.x / cwin, cex = threadIdx.x - cey * cwin;
     const bool has1 = e1 < rwin * rwin, hasc = threadIdx.x < cwin * cwin;
 
-    float pr0 = 0.f, pr1 = 0.f, plr = 0.f;
+    // LMIN: the frames carry the thresholded map R; r = its 5x5 clamp-border minimum (robustness.py:641-686) is
+    // taken here from a (QT+4)^2 window — the separate local-minimum pass and its 8 B/pixel disappear
+    constexpr int RW = QT + 4;
+    const int m0y = threadIdx.x / RW, m0x = threadIdx.x - m0y * RW;
+    const int m1 = threadIdx.x + 256, m1y = m1 / RW, m1x = m1 - m1y * RW;
+    const bool hasm1 = LMIN && m1 < RW * RW;
+    const int moff0 = clampi(ly0 - 2 + m0y, 0, g.H - 1) * g.W + clampi(lx0 - 2 + m0x, 0, g.W - 1);
+    const int moff1 = clampi(ly0 - 2 + m1y, 0, g.H - 1) * g.W + clampi(lx0 - 2 + m1x, 0, g.W - 1);
+    float pr0 = 0.f, pr1 = 0.f, plr = 0.f, plr1 = 0.f;
     float4 pc = make_float4(0.f, 0.f, 0.f, 0.f);
     float2 pfl = make_float2(0.f, 0.f);
     TileWin pw{0, 0, 0, 0};
@@ -728,7 +737,12 @@ __global__ void __launch_bounds__(256) k_merge_burst_quad(BurstArgs a, Geo g, Cf
             const int y = min(max(pw.cy0 + cey, 0), g.gh - 1), x = min(max(pw.cx0 + cex, 0), g.gw - 1);
             pc = f.cov[(size_t)y * g.gw + x];
         }
-        plr = f.r[ridx];
+        if (LMIN) {
+            plr = f.r[moff0];
+            if (hasm1) plr1 = f.r[moff1];
+        } else {
+            plr = f.r[ridx];
+        }
     };
 
     if (a.n > 0) prefetch(0);
@@ -737,11 +751,22 @@ __global__ void __launch_bounds__(256) k_merge_burst_quad(BurstArgs a, Geo g, Cf
         s_raw[e0y * RPITCH + e0x] = pr0;
         if (has1) s_raw[e1y * RPITCH + e1x] = pr1;
         if (!ISO && hasc) s_cov[cey * CWIN + cex] = pc;
+        if (LMIN) {
+            s_R[m0y][m0x] = plr;
+            if (hasm1) s_R[m1y][m1x] = plr1;
+        }
         const float2 fl = pfl;
         const TileWin w = pw;
-        const float local_r = plr;
+        float local_r = plr;
         __syncthreads();
         if (n + 1 < a.n) prefetch(n + 1);  // in flight while this frame's taps are evaluated
+        if (LMIN) {
+            local_r = s_R[ty][tx];
+#pragma unroll
+            for (int i = 0; i < 5; ++i)
+#pragma unroll
+                for (int j = 0; j < 5; ++j) local_r = fminf(local_r, s_R[ty + i][tx + j]);
+        }
         racc += local_r;
         if (live && local_r != 0.f) {
 #pragma unroll
@@ -892,13 +917,24 @@ extern "C" int hhsr_merge_burst(const float* const* raws, const float* const* fl
     const bool tiled = !f64 && (double)iscale == scale && iscale >= 1 && ((int64_t)ts * iscale) % MT == 0 &&
                        n_frames > 0 && row0 % MT == 0 && !getenv("HHSR_MERGE_NO_LDS");
     // x2: one thread per LR pixel (4 HR pixels), 32 x 32 HR workgroups inside one flow tile
+    const bool lmin = (flags & HHSR_MERGE_LOCAL_MIN) != 0;
     const bool quad = tiled && p2 && iscale == 2 && ts % QT == 0 && sW == 2 * W && sH == 2 * H && row0 % (2 * QT) == 0 &&
                       nrows % 2 == 0 && !getenv("HHSR_MERGE_NO_QUAD");
     if (quad) {
         const dim3 qgrid(hhsr_cdiv(W, QT), hhsr_cdiv(nrows / 2, QT));
-        if (iso) hipLaunchKernelGGL((k_merge_burst_quad<true>), qgrid, block, 0, s, a, g, c, num, den);
-        else hipLaunchKernelGGL((k_merge_burst_quad<false>), qgrid, block, 0, s, a, g, c, num, den);
+        if (lmin) {
+            if (iso) hipLaunchKernelGGL((k_merge_burst_quad<true, true>), qgrid, block, 0, s, a, g, c, num, den);
+            else hipLaunchKernelGGL((k_merge_burst_quad<false, true>), qgrid, block, 0, s, a, g, c, num, den);
+        } else {
+            if (iso) hipLaunchKernelGGL((k_merge_burst_quad<true, false>), qgrid, block, 0, s, a, g, c, num, den);
+            else hipLaunchKernelGGL((k_merge_burst_quad<false, false>), qgrid, block, 0, s, a, g, c, num, den);
+        }
         HHSR_LAUNCHED();
+    }
+    if (lmin) {
+        hhsr_set_error("hhsr_merge_burst: HHSR_MERGE_LOCAL_MIN needs the x2 kernel (scale 2, ts %% 16 == 0, "
+                       "sH = 2 H, sW = 2 W, row0 %% 32 == 0, float32 weights)");
+        return -3;
     }
     if (tiled) {
         const dim3 tgrid(hhsr_cdiv(sW, MT), hhsr_cdiv(nrows, MT));

@@ -74,7 +74,8 @@ class HipEngine:
         acc = alloc((world, 2, rows, sW, 3), dtype=torch.float32, device=pipe.device)
         acc_r = torch.zeros(tuple(pipe.ref.shape), dtype=torch.float32, device=pipe.device) if self.accumulate_r else None
         fuse_acc = acc_r is not None and can_fuse_acc_r(self.config) and len(comp_imgs) > 0
-        frames = pipe.process_frames(list(comp_imgs), None if fuse_acc else acc_r)
+        fuse_min = pipe.fuses_local_min() and (fuse_acc or acc_r is None)  # 5x5 local minimum inside the merge
+        frames = pipe.process_frames(list(comp_imgs), None if fuse_acc else acc_r, fuse_local_min=fuse_min)
         if not frames:
             return acc, acc_r
         for j in range(world):
@@ -82,7 +83,7 @@ class HipEngine:
             if r1 > r0:
                 merge_burst(frames, None, None, acc[j, 0, : r1 - r0], acc[j, 1, : r1 - r0], pipe.cfa, self.config,
                             do_ref=False, divide=False, store_den=True, acc_r=acc_r if fuse_acc else None,
-                            rows=(r0, r1 - r0), out_height=sH)
+                            rows=(r0, r1 - r0), out_height=sH, local_min=fuse_min)
         return acc, acc_r
 
     def finish_slab(self, acc, row0, acc_r=None):

@@ -49,15 +49,29 @@ def can_fuse_acc_r(config):
     return float(config.scale).is_integer()
 
 
+def can_fuse_local_min(config, shape):
+    """merge_burst can take the thresholded maps R and apply the 5x5 local minimum itself (the x2 kernel:
+    scale 2, tile size a multiple of 16, float32 weights) — mirrors the test in hhsr_merge_burst."""
+    import os
+
+    scale, kflags = _common(config)
+    H, W = shape
+    return (scale == 2.0 and not (kflags & 2) and int(config.block_matching.tuning.tile_size) % 16 == 0 and
+            H % 2 == 0 and W % 2 == 0 and not os.environ.get("HHSR_MERGE_NO_QUAD") and
+            not os.environ.get("HHSR_MERGE_NO_LDS"))
+
+
 def merge_burst(frames, ref_img, ref_kernels, num, den, cfa_pattern, config, load_acc=False, do_ref=True,
-                divide=True, store_den=False, acc_r=None, rows=None, out_height=None):
+                divide=True, store_den=False, acc_r=None, rows=None, out_height=None, local_min=False):
     """Fused merge of a whole (shard of a) burst: `frames` is a list of (raw, flow, covs, r).  Per output
     pixel the frames are summed in list order with the accumulators in registers — the same float32
     order as successive merge() calls — then the reference frame is added and the result normalised,
     writing `num` once.  Not usable with the accumulated-robustness denoiser (its
     overwrite rule needs the sequential merge_ref).  `acc_r` (float32 [H, W], integer scales) receives the sum
     of the frames' robustness maps in the same pass.  `rows = (row0, nrows)` restricts the launch to a slab of
-    output rows; `num` / `den` are then [nrows, sW, 3] slabs and `out_height` the full output height."""
+    output rows; `num` / `den` are then [nrows, sW, 3] slabs and `out_height` the full output height.
+    `local_min`: the frames carry the thresholded maps R (compute_robustness(..., fuse_local_min=True)) and the
+    5x5 minimum of Alg. 9 is taken inside the merge (see can_fuse_local_min)."""
     scale, kflags = _common(config)
     if do_ref and config.accumulated_robustness_denoiser.enabled:
         raise ValueError("merge_burst cannot apply the accumulated robustness denoiser; use merge_ref")
@@ -68,6 +82,8 @@ def merge_burst(frames, ref_img, ref_kernels, num, den, cfa_pattern, config, loa
         assert num.shape[0] == nrows and out_height is not None
         sH = int(out_height)
     flags = (1 if load_acc else 0) | (2 if do_ref else 0) | (4 if divide else 0) | (8 if store_den else 0)
+    if local_min and frames:
+        flags |= 16
     if frames:
         H, W = frames[0][0].shape
         ny, nx, _ = frames[0][1].shape

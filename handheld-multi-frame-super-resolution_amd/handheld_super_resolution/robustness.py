@@ -92,7 +92,8 @@ def noise_sigma_sq(ref_local_means, ref_local_stds, std_curve):
 
 
 def compute_robustness(comp_img, ref_local_means, ref_local_stds, flows, cfa_pattern, white_balance, noise_model,
-                       config, return_R=False, accumulate_into=None, ref_sigma_sq=None, comp_means=None):
+                       config, return_R=False, accumulate_into=None, ref_sigma_sq=None, comp_means=None,
+                       fuse_local_min=False):
     """Alg. 6 (robustness.py:79-170): r float32 [H, W].  3 kernels instead of the reference's 8:
     guide + local stats; fused warp-upsample / colour distance / noise model / threshold; 5x5 min."""
     comp_img = _lib.f32c(comp_img)
@@ -120,5 +121,8 @@ def compute_robustness(comp_img, ref_local_means, ref_local_stds, flows, cfa_pat
     _lib.call("hhsr_rob_frame", _lib.ptr(cm), H // 2, W // 2, _lib.ptr(ref_local_means), _lib.ptr(sigma_sq),
               _lib.ptr(curve_index), _lib.ptr(flows), ny, nx, int(ts), _lib.ptr(S), _lib.ptr(diff_curve), int(diff_curve.numel()),
               float(t.t), _lib.ptr(R), _lib.stream())
+    if fuse_local_min:  # the caller's merge applies Alg. 9 itself (merge_burst(..., local_min=True))
+        assert accumulate_into is None and not return_R
+        return R
     r = local_min(R, accumulate_into)
     return (r, R) if return_R else r

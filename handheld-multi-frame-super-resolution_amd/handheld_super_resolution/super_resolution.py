@@ -23,7 +23,7 @@ from .params import sanitize_config, update_snr_config
 from .robustness import (init_robustness, compute_robustness, noise_curves_to_device, noise_sigma_sq,
                          upscale_warp_stats)
 from .kernels import estimate_kernels, frame_stats
-from .merge import merge, merge_ref, merge_burst, can_fuse_acc_r
+from .merge import merge, merge_ref, merge_burst, can_fuse_acc_r, can_fuse_local_min
 
 
 def denoiser_enabled(config):
@@ -88,7 +88,7 @@ class BurstPipeline:
         self._ref_ready.record(main)
         return self
 
-    def process_frame(self, img, accumulate_r=None, wait_ref=None):
+    def process_frame(self, img, accumulate_r=None, wait_ref=None, fuse_local_min=False):
         """grey -> kernels -> align -> robustness for one comp frame; returns (raw, flow, covs, r).
         `accumulate_r`: optional float32 [H, W] that receives += r (fused into the local-min pass).
         `wait_ref`: event after which the reference-frame state is complete — the frame's own grey image and
@@ -106,10 +106,15 @@ class BurstPipeline:
         else:
             means, covs = None, estimate_kernels(raw, cfg)
         r = compute_robustness(raw, self.ref_means, self.ref_vars, flow, self.cfa, self.wb, self.curves, cfg,
-                               accumulate_into=accumulate_r, ref_sigma_sq=self.ref_sigma_sq, comp_means=means)
+                               accumulate_into=accumulate_r, ref_sigma_sq=self.ref_sigma_sq, comp_means=means,
+                               fuse_local_min=fuse_local_min and cfg.robustness.enabled)
         return raw, flow, covs, r
 
-    def process_frames(self, comp_imgs, accumulate_r=None, n_streams=None):
+    def fuses_local_min(self):
+        """True when the fused merge can take the un-filtered robustness maps (see merge.can_fuse_local_min)."""
+        return bool(self.config.robustness.enabled) and can_fuse_local_min(self.config, tuple(self.ref.shape))
+
+    def process_frames(self, comp_imgs, accumulate_r=None, n_streams=None, fuse_local_min=False):
         """process_frame() over a list of frames.  Frames are independent until the merge, so they are
         issued round-robin on `n_streams` HIP streams (config.hip.streams, default 3): the launch-latency-
         bound coarse pyramid levels of one frame overlap the bandwidth-bound kernels of another.  The caller's
@@ -120,7 +125,7 @@ class BurstPipeline:
             hip = self.config.get("hip", None) if hasattr(self.config, "get") else None
             n_streams = int(hip.get("streams", DEFAULT_STREAMS)) if hip is not None else DEFAULT_STREAMS
         if n_streams <= 1 or accumulate_r is not None or n < 2:
-            return [self.process_frame(img, accumulate_r) for img in comp_imgs]
+            return [self.process_frame(img, accumulate_r, fuse_local_min=fuse_local_min) for img in comp_imgs]
         main = torch.cuda.current_stream(self.device)
         if len(self._streams) < n_streams:
             self._streams += [torch.cuda.Stream(self.device) for _ in range(n_streams - len(self._streams))]
@@ -131,7 +136,7 @@ class BurstPipeline:
             if i < n_streams:
                 s.wait_event(self._entry)  # the caller's earlier work (frame upload, previous burst) is done
             with torch.cuda.stream(s):
-                f = self.process_frame(comp_imgs[i], wait_ref=self._ref_ready)
+                f = self.process_frame(comp_imgs[i], wait_ref=self._ref_ready, fuse_local_min=fuse_local_min)
             for t in f[1:]:
                 t.record_stream(main)  # consumed by the merge on the caller's stream
             frames.append(f)
@@ -182,8 +187,13 @@ def main(ref_img, comp_imgs, config):
 
     frames = []
     n_images = len(comp_imgs)
+    fuse_min = False
     if fused and not verbose and not debug_mode:
-        frames = pipe.process_frames([comp_imgs[i] for i in range(n_images)], None if fuse_acc else accumulated_r)
+        # the x2 merge kernel takes the 5x5 local minimum of the robustness itself (one pass and 8 B/pixel less per
+        # frame); a separately accumulated robustness map needs the filtered maps
+        fuse_min = pipe.fuses_local_min() and (fuse_acc or not accumulate_r)
+        frames = pipe.process_frames([comp_imgs[i] for i in range(n_images)], None if fuse_acc else accumulated_r,
+                                     fuse_local_min=fuse_min)
         n_images = 0  # the per-frame loop below is the verbose / debug / sequential-merge path
     for im_id in range(n_images):
         if verbose:
@@ -205,7 +215,7 @@ def main(ref_img, comp_imgs, config):
     ref_covs = pipe.ref_covs
     if fused:
         merge_burst(frames, pipe.ref, ref_covs, num, None, pipe.cfa, config, do_ref=True, divide=True,
-                    acc_r=accumulated_r if fuse_acc else None)
+                    acc_r=accumulated_r if fuse_acc else None, local_min=fuse_min)
     else:
         merge_ref(pipe.ref, ref_covs, num, den, pipe.cfa, config, accumulated_r if denoiser_on else None)
         divide(num, den)

@@ -187,6 +187,10 @@ int hhsr_add(float* A, const float* B, int64_t n, void* stream);          /* A +
 #define HHSR_MERGE_DO_REF 2     /* add the reference frame (ref_raw/ref_covs) after the comps */
 #define HHSR_MERGE_DIVIDE 4     /* write num/den into num                                    */
 #define HHSR_MERGE_STORE_DEN 8  /* also store den                                            */
+#define HHSR_MERGE_LOCAL_MIN 16 /* rs[] hold the thresholded maps R of hhsr_rob_frame; their 5x5 clamp-border minimum
+                                   (robustness.py:641-686, hhsr_local_min5) is taken inside the merge.  Only with the
+                                   x2 kernel: scale 2, ts % 16 == 0, sH = 2 H, sW = 2 W, row0 % 32 == 0, float32
+                                   weights, HHSR_MERGE_NO_QUAD unset; error -3 otherwise.                        */
 int hhsr_merge_burst(const float* const* raws, const float* const* flows, const float* const* covs,
                      const float* const* rs, int n_frames, int H, int W, int pitch,
                      int ny, int nx, int ts, const float* ref_raw, const float* ref_covs,

@@ -417,6 +417,20 @@ def test_merge_x2_quad_kernel_equals_tile_kernel(monkeypatch, kern):
     assert_close(out_q, out_t, 0, 0, "quad vs tile kernel")
     assert_close(acc_q, acc_t, 0, 0, "quad vs tile accumulated robustness")
     assert_close(acc_q, sum(f[3] for f in fr), 1e-6, 1e-6, "accumulated robustness")
+    # 5x5 local minimum of the robustness taken inside the merge == hhsr_local_min5 followed by the merge
+    monkeypatch.delenv("HHSR_MERGE_NO_QUAD")
+    assert merge.can_fuse_local_min(cfg, (H, W))
+    tf_min = [(f[0], f[1], f[2], robustness.local_min(f[3])) for f in tf]
+    want, acc_w = torch.empty(2 * H, 2 * W, 3, device=DEV), torch.zeros(H, W, device=DEV)
+    merge.merge_burst(tf_min, T(ref), rc, want, None, cfa, cfg, acc_r=acc_w)
+    got, acc_g = torch.empty(2 * H, 2 * W, 3, device=DEV), torch.zeros(H, W, device=DEV)
+    merge.merge_burst(tf, T(ref), rc, got, None, cfa, cfg, acc_r=acc_g, local_min=True)
+    assert_close(N(got), N(want), 0, 0, "fused local minimum")
+    assert_close(N(acc_g), N(acc_w), 0, 0, "fused local minimum, accumulated robustness")
+    cfg3 = base_config(ts=ts, scale=3)
+    assert not merge.can_fuse_local_min(cfg3, (H, W))
+    with pytest.raises(RuntimeError):
+        merge.merge_burst(tf, T(ref), rc, torch.empty(3 * H, 3 * W, 3, device=DEV), None, cfa, cfg3, local_min=True)
 
 
 @pytest.mark.parametrize("scale", [1, 2, 3])
