@@ -163,7 +163,7 @@ def main():
                         "peak_Tlaneops": VALU_PEAK_TLANEOPS, "frac": round(lane_ops / 1e12 / VALU_PEAK_TLANEOPS, 3)}
         except Exception:
             pass
-        roof = {"kernel": "k_merge_burst_tile (hhsr_merge_burst)", "bound": "hbm", "achieved": round(achieved, 1),
+        roof = {"kernel": "k_merge_burst_quad (hhsr_merge_burst)" if float(scale) == 2.0 else "k_merge_burst_tile (hhsr_merge_burst)", "bound": "hbm", "achieved": round(achieved, 1),
                 "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                 "avg_launch_ms": round(avg_ms, 4), "bytes_per_launch": nbytes, "valu_issue": valu,
                 "note": "fused burst merge keeps the accumulators in registers: bound by VALU issue (see valu_issue), "
