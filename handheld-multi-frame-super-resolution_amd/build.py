@@ -24,6 +24,7 @@ SOURCES = {
     "hhsr_merge.hip": [],
     "hhsr_grey.hip": ["-ffp-contract=off"],
     "hhsr_fft.hip": [],
+    "hhsr_io.hip": ["-ffp-contract=off"],
 }
 
 

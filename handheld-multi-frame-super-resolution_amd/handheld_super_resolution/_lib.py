@@ -37,6 +37,7 @@ _SIGS = {
     "hhsr_cov_from_raw": [P, I, I, I, P, D, D, D, D, D, D, D, D, I, P],
     "hhsr_rob_stats": [P, I, I, I, U8P, DP, P, P, P],
     "hhsr_frame_stats": [P, I, I, I, U8P, DP, P, P, P, D, D, D, D, D, D, D, D, I, P],
+    "hhsr_normalize_raw_u16": [P, I, I, I, I, U8P, DP, D, DP, P, P],
     "hhsr_rob_upscale": [P, I, I, P, I, I, I, P, P],
     "hhsr_rob_s": [P, I, I, F, F, F, P, P],
     "hhsr_rob_sigma": [P, P, I, I, P, I, P, P, P],

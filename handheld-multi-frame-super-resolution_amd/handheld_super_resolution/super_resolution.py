@@ -229,7 +229,7 @@ def main(ref_img, comp_imgs, config):
 
 
 def prepare_config(config, ref_raw, alpha=None, beta=None, cfa_pattern=None, white_balance=None, iso=100,
-                   std_curve=None, diff_curve=None):
+                   std_curve=None, diff_curve=None, shape=None):
     """The parameter derivation process() performs between loading the burst and calling main()
     (reference super_resolution.py:227-296): noise model, SNR -> tile size / merge tunings, sanity
     checks, exif block, denoiser switch.  Mutates `config` in place like the reference."""
@@ -244,7 +244,7 @@ def prepare_config(config, ref_raw, alpha=None, beta=None, cfa_pattern=None, whi
         # the reference draws these by an unseeded Monte-Carlo (fast_monte_carlo.py); here: its analytic
         # un-clipped limit (synthetic.noise_curves) unless the caller supplies curves
         std_curve, diff_curve = noise_curves(float(alpha), float(beta))
-    brightness = float(np.mean(ref_raw))
+    brightness = float(ref_raw.mean()) if torch.is_tensor(ref_raw) else float(np.mean(ref_raw))
     id_noise = min(max(round(1000 * brightness), 0), len(std_curve) - 1)
     SNR = brightness / float(std_curve[id_noise])
     if config.verbose >= 1:
@@ -254,7 +254,7 @@ def prepare_config(config, ref_raw, alpha=None, beta=None, cfa_pattern=None, whi
         print("|expected noise std : {:.2e}".format(float(std_curve[id_noise])))
         print("|Estimated SNR : {:.2f}".format(SNR))
     update_snr_config(config, SNR)
-    sanitize_config(config, tuple(ref_raw.shape))
+    sanitize_config(config, tuple(shape if shape is not None else ref_raw.shape))
     config.exif = {"cfa_pattern": np.asarray(cfa_pattern).tolist(), "iso": iso,
                    "white_balance": [float(v) for v in white_balance]}
     config.noise_model.update({"std_curve": np.asarray(std_curve).tolist(), "diff_curve": np.asarray(diff_curve).tolist()})
@@ -267,29 +267,51 @@ def process(burst_path, config):
     """process(burst_path, config) -> (float32 ndarray [sH, sW, 3], debug_dict)   (reference :203-360).
 
     `burst_path` is either a burst held in memory / in an .npz file — a mapping with keys ``ref`` [H,W],
-    ``comp`` [N-1,H,W] (normalised, white-balanced RAW), ``cfa_pattern`` [2,2], ``white_balance`` [>=3],
-    ``alpha``, ``beta`` and optionally ``iso``, ``std_curve``, ``diff_curve`` — or a folder of .dng files,
-    which needs rawpy + exifread like the reference (absent from this image: ImportError).  The CPU-side
+    ``comp`` [N-1,H,W], ``cfa_pattern`` [2,2], ``white_balance`` [>=3], ``alpha``, ``beta`` and optionally
+    ``iso``, ``std_curve``, ``diff_curve``; ref / comp are either normalised white-balanced float RAW or integer
+    sensor counts with ``black_levels`` and ``white_level`` (normalised on the GPU like utils_dng.py:149-160) —
+    or a folder of .dng files, which needs rawpy + exifread like the reference (absent from this image:
+    ImportError).  Noise curves: given, or ``config.noise_model.estimator``: "analytic" (default) /
+    "monte_carlo" (the reference's estimator, seeded by ``config.noise_model.seed``).  The CPU-side
     ISP after the hot path (colour matrix, gamma, sharpening, orientation; raw2rgb.py) is out of scope:
     the un-post-processed linear RGB image is returned, as with ``postprocessing.enabled: false``."""
     import os
 
+    from .utils_dng import load_dng_burst, normalize_burst
+
     if isinstance(burst_path, (str, os.PathLike)) and str(burst_path).endswith(".npz"):
         burst = dict(np.load(burst_path))
     elif isinstance(burst_path, (str, os.PathLike)):
-        try:
-            import rawpy  # noqa: F401
-            import exifread  # noqa: F401
-        except ImportError as e:
-            raise ImportError("reading .dng bursts needs rawpy and exifread (not installed); pass an in-memory burst "
-                              "or an .npz file instead") from e
-        raise NotImplementedError("DNG decoding is outside the MI355X hot path (SURVEY.md §8f-3)")
+        ref_raw, raw_comp, iso, tags, cfa, _, white_balance, _ = load_dng_burst(burst_path)  # needs rawpy + exifread
+        nm = tags["Image Tag 0xC761"].values  # DNG NoiseProfile, already scaled for the ISO (reference :232-238)
+        burst = {"ref": ref_raw, "comp": raw_comp, "iso": iso, "cfa_pattern": cfa, "white_balance": white_balance,
+                 "alpha": sum(x[0] for x in nm[::2]) / 3, "beta": sum(x[0] for x in nm[1::2]) / 3}
     else:
         burst = burst_path
-    ref_raw = np.asarray(burst["ref"], dtype=np.float32)
-    raw_comp = np.asarray(burst["comp"], dtype=np.float32)
-    prepare_config(config, ref_raw, burst.get("alpha"), burst.get("beta"), burst["cfa_pattern"],
-                   burst["white_balance"], int(burst.get("iso", 100)), burst.get("std_curve"), burst.get("diff_curve"))
+    ref_raw, raw_comp = burst["ref"], burst["comp"]
+    if not torch.is_tensor(ref_raw) and np.issubdtype(np.asarray(ref_raw).dtype, np.integer):
+        # sensor counts + metadata: the normalisation / white balance of utils_dng.py:149-160, on the GPU
+        stack = normalize_burst(np.concatenate([np.asarray(ref_raw)[None], np.asarray(raw_comp)]),
+                                burst["black_levels"], burst["white_level"], burst["white_balance"],
+                                burst["cfa_pattern"])
+        ref_raw, raw_comp = stack[0], stack[1:]
+        brightness_src = ref_raw.mean().item()
+    else:
+        ref_raw = np.asarray(ref_raw, dtype=np.float32) if not torch.is_tensor(ref_raw) else ref_raw
+        raw_comp = np.asarray(raw_comp, dtype=np.float32) if not torch.is_tensor(raw_comp) else raw_comp
+        brightness_src = None
+    std_curve, diff_curve = burst.get("std_curve"), burst.get("diff_curve")
+    alpha, beta = burst.get("alpha"), burst.get("beta")
+    if (std_curve is None or diff_curve is None) and config.noise_model.get("estimator", "analytic") == "monte_carlo":
+        from .fast_monte_carlo import run_fast_MC  # the reference's estimator (super_resolution.py:252), seeded
+
+        if config.noise_model.get("alpha", None) is not None:
+            alpha, beta = config.noise_model.alpha, config.noise_model.beta
+        std_curve, diff_curve = run_fast_MC(float(alpha), float(beta), seed=int(config.noise_model.get("seed", 0)))
+    ref_for_stats = ref_raw if brightness_src is None else np.full((1, 1), brightness_src, np.float32)
+    prepare_config(config, ref_for_stats, alpha, beta, burst["cfa_pattern"], burst["white_balance"],
+                   int(burst.get("iso", 100)), std_curve, diff_curve,
+                   shape=tuple(ref_raw.shape))
     den = config.accumulated_robustness_denoiser
     if den.median.enabled or den.gauss.enabled:
         raise NotImplementedError("post-hoc median / gauss frame-count denoisers are out of scope (SURVEY.md §2a)")

@@ -197,6 +197,15 @@ int hhsr_merge_burst(const float* const* raws, const float* const* flows, const 
                      const uint8_t cfa[4], double scale, int kflags, int flags,
                      float* num, float* den, float* acc_r, int sH, int sW, int row0, int nrows, void* stream);
 
+/* ---- burst front end (utils_dng.py:149-160) ------------------------------------------------
+ * Sensor counts uint16 [n_frames][H][pitch] -> normalised, white-balanced float32 [n_frames][H][W]:
+ * v = (float32(count) - black[c]) / (white - black[c]); v *= wb[c] / wb[1], c = cfa[(y&1)*2 + (x&1)], in the
+ * reference's float32 arithmetic (bit-identical to its NumPy expression).  black_levels / white_balance: HOST
+ * double[3] indexed by colour (R, G, B); raw and out 16-byte aligned. */
+int hhsr_normalize_raw_u16(const uint16_t* raw, int n_frames, int H, int W, int pitch, const uint8_t cfa[4],
+                           const double* black_levels, double white_level, const double* white_balance,
+                           float* out, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

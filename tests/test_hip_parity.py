@@ -594,6 +594,72 @@ def test_process_facade():
     assert_close(img, N(out), 0, 0, "process == main")
 
 
+# ------------------------------------------------------------------------------------------ burst front end
+@pytest.mark.parametrize("shape", [(3, 64, 96), (2, 50, 70)])
+def test_normalize_raw_bit_exact(shape):
+    """hhsr_normalize_raw_u16 == the NumPy expression of utils_dng.py:149-160, bit for bit (incl. a width that is
+    not a multiple of the 8-pixel vector path)."""
+    from handheld_super_resolution import utils_dng
+
+    rng = np.random.default_rng(9)
+    raw = rng.integers(0, 16384, shape, dtype=np.uint16)
+    cfa, bl, wl, wb = [[2, 1], [1, 0]], [63, 64, 66], 16383, [1.91, 1.0, 1.57, 1.0]
+    got = N(utils_dng.normalize_burst(raw, bl, wl, wb, cfa))
+    want = oracle.frontend.normalize_burst(raw, bl, wl, wb, cfa)
+    assert got.dtype == np.float32 and np.array_equal(got, want)
+    assert np.array_equal(N(utils_dng.normalize_burst(raw[0], bl, wl, wb, cfa)), want[0])
+    with pytest.raises(TypeError):
+        utils_dng.normalize_burst(raw.astype(np.float32), bl, wl, wb, cfa)
+
+
+def test_monte_carlo_noise_curves_gpu():
+    from handheld_super_resolution import fast_monte_carlo as mc
+
+    a, b = synth.ALPHA_ISO100 * 4, synth.BETA_ISO100 * 4
+    s1, d1 = mc.run_fast_MC(a, b, seed=5)
+    s2, d2 = mc.run_fast_MC(a, b, seed=5)
+    assert np.array_equal(s1, s2) and np.array_equal(d1, d2)  # seeded: reproducible
+    sa, da = synth.noise_curves(a, b)
+    assert np.abs(s1[100:900] / sa[100:900] - 1).max() < 0.005 and np.abs(d1[100:900] / da[100:900] - 1).max() < 0.01
+    rng = np.random.default_rng(1)
+    for i in (0, 2, 999):
+        dm, sm = oracle.frontend.unitary_mc(a, b, i / 1000, 50000, rng)
+        assert abs(s1[i] / sm - 1) < 0.02 and abs(d1[i] / dm - 1) < 0.03
+
+
+def test_process_integer_burst_and_monte_carlo_estimator():
+    """process() on sensor counts + metadata (normalised on the GPU) == process() on the normalised floats; the
+    Monte-Carlo estimator option produces curves and runs."""
+    ref, comp, _ = synth.make_burst(256, 256, 3, seed=4)
+    wb, bl, wl = [1.8, 1.0, 1.4], [64, 64, 64], 4095
+    cfa = [[0, 1], [1, 2]]
+    # counts whose normalisation is NOT the identity on the synthetic floats: build counts first
+    gains = np.array([[wb[cfa[i][j]] / wb[1] for j in range(2)] for i in range(2)], np.float64)
+    g = np.tile(gains, (128, 128))
+    to_counts = lambda x: np.clip(np.rint(x / g * (wl - 64) + 64), 0, wl).astype(np.uint16)  # noqa: E731
+    ref_c, comp_c = to_counts(ref), to_counts(comp)
+    stack = oracle.frontend.normalize_burst(np.concatenate([ref_c[None], comp_c]), bl, wl, wb, cfa)
+
+    def cfg0():
+        c = hsr.default_config()
+        c.verbose = 0
+        c.block_matching.tuning.tile_size = 16
+        c.block_matching.tuning.factors = [1, 2, 2, 2]
+        c.block_matching.tuning.metrics = ["L2"] * 4
+        return c
+
+    meta = {"cfa_pattern": cfa, "white_balance": wb, "alpha": synth.ALPHA_ISO100, "beta": synth.BETA_ISO100}
+    img_i, _ = hsr.process({"ref": ref_c, "comp": comp_c, "black_levels": bl, "white_level": wl, **meta}, cfg0())
+    img_f, _ = hsr.process({"ref": stack[0], "comp": stack[1:], **meta}, cfg0())
+    assert_close(img_i, img_f, 0, 0, "integer burst == normalised burst")
+    c = cfg0()
+    c.noise_model.estimator = "monte_carlo"
+    c.noise_model.seed = 7
+    img_m, _ = hsr.process({"ref": stack[0], "comp": stack[1:], **meta}, c)
+    assert len(c.noise_model.std_curve) == 1001 and np.isfinite(img_m[8:-8, 8:-8]).all()
+    assert np.abs(img_m[8:-8, 8:-8] - img_f[8:-8, 8:-8]).max() < 0.05  # clipped-regime curves only move r slightly
+
+
 def test_full_size_properties():
     """BASELINE config C2 geometry (3000x4000, x2): size-independent properties on the GPU path."""
     H, W = 3000, 4000

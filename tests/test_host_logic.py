@@ -93,3 +93,35 @@ def test_prepare_config_derives_like_process():
     assert cfg.merging.tuning.k_detail == 0.25 and cfg.merging.tuning.D_tr == 1.0  # SNR clipped to 30
     assert cfg.accumulated_robustness_denoiser.enabled is False
     assert len(cfg.noise_model.std_curve) == 1001 and cfg.exif.white_balance[0] == 2.0
+
+
+# ------------------------------------------------------------------------------------------ burst front end
+def test_oracle_normalize_known_answers():
+    """utils_dng.py:149-160 on a 2x2 CFA cell with hand-computed float32 results."""
+    raw = np.array([[[1088, 4159], [64, 2112]]], dtype=np.uint16)
+    cfa = [[0, 1], [1, 2]]
+    out = oracle.frontend.normalize_burst(raw, [64, 64, 64], 4159, [2.0, 1.0, 1.5], cfa)
+    f = np.float32
+    want = np.array([[[(f(1088) - f(64)) / f(4095) * f(2.0), f(1.0)], [f(0.0), (f(2112) - f(64)) / f(4095) * f(1.5)]]])
+    assert out.dtype == np.float32 and np.array_equal(out, want.astype(np.float32))
+
+
+def test_monte_carlo_noise_curves_cpu():
+    """Seeded Monte-Carlo estimator (torch, here on the CPU): reproducible, equals the analytic un-clipped limits
+    where no clipping occurs, agrees with the NumPy restatement of the reference's unitary_MC where it does."""
+    from handheld_super_resolution import fast_monte_carlo as mc, synthetic as synth
+
+    a, b = synth.ALPHA_ISO100 * 8, synth.BETA_ISO100 * 8
+    s1, d1 = mc.run_fast_MC(a, b, seed=3, device="cpu", n_patches=20000)
+    s2, d2 = mc.run_fast_MC(a, b, seed=3, device="cpu", n_patches=20000)
+    assert s1.shape == (1001,) and np.array_equal(s1, s2) and np.array_equal(d1, d2)
+    sa, da = synth.noise_curves(a, b)
+    xmin, xmax = mc.get_non_linearity_bound(a, b)
+    assert (xmin, xmax) == oracle.frontend.non_linearity_bound(a, b)
+    lo, hi = int(np.ceil(xmin * 1000)) + 2, int(np.floor(xmax * 1000)) - 2
+    assert np.abs(s1[lo:hi] / sa[lo:hi] - 1).max() < 0.01 and np.abs(d1[lo:hi] / da[lo:hi] - 1).max() < 0.02
+    assert s1[0] < 0.75 * sa[0] and s1[1000] < 0.75 * sa[1000]  # clipping at 0 / 1 shrinks the spread
+    rng = np.random.default_rng(0)
+    for i in (0, 3, 998, 1000):
+        dm, sm = oracle.frontend.unitary_mc(a, b, i / 1000, 20000, rng)
+        assert abs(s1[i] / sm - 1) < 0.03 and abs(d1[i] / dm - 1) < 0.05
