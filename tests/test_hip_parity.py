@@ -577,6 +577,26 @@ def test_e2e_ragged_sizes_and_scales(shape, scale):
     assert_close(N(dbg["accumulated robustness"]), wdbg["accumulated robustness"], 0, 4e-3, "acc r", max_bad_frac=0.02)
 
 
+@pytest.mark.parametrize("n_comp", [0, 1, 2])
+def test_e2e_few_frames_and_foreign_inputs(n_comp):
+    """Bursts of 1-3 frames (0 comp frames = the reference frame alone) against the oracle; strided float64 /
+    host-tensor inputs give the same result as contiguous float32 arrays."""
+    ref, comp, _ = synth.make_burst(128, 160, 3, seed=2)
+
+    def cfg0():
+        c = base_config(ts=16, scale=2)
+        c.block_matching.tuning.factors = [1, 2, 2, 2]
+        return c
+
+    out, _ = hsr.main(ref, comp[:n_comp], cfg0())
+    want, _ = oracle.main(ref, comp[:n_comp], cfg0())
+    assert_close(N(out), want, 2e-5, 1e-5, f"{n_comp} comp frames")
+    wide = np.zeros((128, 320), np.float64)
+    wide[:, ::2] = ref
+    out2, _ = hsr.main(wide[:, ::2], torch.from_numpy(comp[:n_comp]), cfg0())
+    assert_close(N(out2), N(out), 0, 0, "strided float64 / host tensor inputs")
+
+
 def test_process_facade():
     ref, comp, _ = synth.make_burst(512, 512, 3, seed=3)
     cfg = hsr.default_config()
