@@ -268,13 +268,21 @@ __global__ void __launch_bounds__(FFT_NT, FFT_ROWS_WPE) k_rows_fwd(const float* 
     extern __shared__ __attribute__((aligned(16))) float2 fl[];
     const int M = W / 2, tid = threadIdx.x;
     float2* tw = fl;
-    float2* buf = tw + twlen;
+    float2* buf = tw + ((twlen + 1) & ~1);  // 16-byte aligned
     for (int k = tid; k < twlen; k += FFT_NT) tw[k] = twM[k];
     const int y0 = blockIdx.x * RB;
     const int nrows = min(RB, H - y0);
-    for (int idx = tid; idx < nrows * M; idx += FFT_NT) {  // z[n] = x[2n] + i x[2n+1]
-        const int rb = idx / M, n = idx - rb * M;
-        buf[rb * M + n] = reinterpret_cast<const float2*>(src + (size_t)(y0 + rb) * W)[n];
+    if ((M & 1) == 0 && (W & 3) == 0) {  // two complex samples (16 bytes) per lane
+        const int Mh = M / 2;
+        for (int idx = tid; idx < nrows * Mh; idx += FFT_NT) {
+            const int rb = idx / Mh, n = idx - rb * Mh;
+            reinterpret_cast<float4*>(buf + rb * M)[n] = reinterpret_cast<const float4*>(src + (size_t)(y0 + rb) * W)[n];
+        }
+    } else {
+        for (int idx = tid; idx < nrows * M; idx += FFT_NT) {  // z[n] = x[2n] + i x[2n+1]
+            const int rb = idx / M, n = idx - rb * M;
+            buf[rb * M + n] = reinterpret_cast<const float2*>(src + (size_t)(y0 + rb) * W)[n];
+        }
     }
     fft_lds(buf, M, nrows, tw, M, rad, tid, FFT_NT);
     // X[k] = 1/2 [(Z[k] + conj Z[M-k]) - i w_k (Z[k] - conj Z[M-k])],  w_k = exp(-2 pi i k / W); kept bins only,
@@ -301,7 +309,7 @@ __global__ void __launch_bounds__(FFT_NT, FFT_COLS_WPE) k_cols(float2* __restric
     const int kx = 8 * (xcd + 8 * (loc >> 2)) + 2 * (loc & 3);
     if (kx >= Wk) return;
     float2* tw = fl;
-    float2* buf = tw + twlen;
+    float2* buf = tw + ((twlen + 1) & ~1);  // 16-byte aligned
     float4* col = reinterpret_cast<float4*>(T + ((size_t)(kx >> 3) * H) * 8 + (kx & 7));  // row y at col[4 y]
     for (int k = tid; k < twlen; k += FFT_NT) tw[k] = twH[k];
     for (int k = tid; k < H; k += FFT_NT) {
@@ -333,7 +341,7 @@ __global__ void __launch_bounds__(FFT_NT, FFT_ROWS_WPE) k_rows_inv(const float2*
     extern __shared__ __attribute__((aligned(16))) float2 fl[];
     const int M = W / 2, tid = threadIdx.x;
     float2* tw = fl;
-    float2* buf = tw + twlen;
+    float2* buf = tw + ((twlen + 1) & ~1);  // 16-byte aligned
     for (int k = tid; k < twlen; k += FFT_NT) tw[k] = twM[k];
     const int y0 = blockIdx.x * RB;
     const int nrows = min(RB, H - y0);
@@ -349,9 +357,18 @@ __global__ void __launch_bounds__(FFT_NT, FFT_ROWS_WPE) k_rows_inv(const float2*
         buf[rb * M + k] = cconj(cscale(cadd(s, d), 0.5f));
     }
     fft_lds(buf, M, nrows, tw, M, rad, tid, FFT_NT);
-    for (int idx = tid; idx < nrows * M; idx += FFT_NT) {  // x[2n] = Re z[n], x[2n+1] = Im z[n]
-        const int rb = idx / M, n = idx - rb * M;
-        reinterpret_cast<float2*>(dst + (size_t)(y0 + rb) * W)[n] = cconj(buf[rb * M + n]);
+    if ((M & 1) == 0 && (W & 3) == 0) {
+        const int Mh = M / 2;
+        for (int idx = tid; idx < nrows * Mh; idx += FFT_NT) {  // x[2n] = Re z[n], x[2n+1] = -Im conj-stored z[n]
+            const int rb = idx / Mh, n = idx - rb * Mh;
+            const float4 z = reinterpret_cast<const float4*>(buf + rb * M)[n];
+            reinterpret_cast<float4*>(dst + (size_t)(y0 + rb) * W)[n] = make_float4(z.x, -z.y, z.z, -z.w);
+        }
+    } else {
+        for (int idx = tid; idx < nrows * M; idx += FFT_NT) {  // x[2n] = Re z[n], x[2n+1] = Im z[n]
+            const int rb = idx / M, n = idx - rb * M;
+            reinterpret_cast<float2*>(dst + (size_t)(y0 + rb) * W)[n] = cconj(buf[rb * M + n]);
+        }
     }
 }
 
@@ -480,8 +497,8 @@ bool hhsr_fft_create(HhsrFft& f, int H, int W) {
     const std::vector<float2> hM = pass_twiddles(f.radM), hH = pass_twiddles(f.radH);
     f.twlenM = (int)hM.size();
     f.twlenH = (int)hH.size();
-    f.lds_rows = sizeof(float2) * ((size_t)f.twlenM + (size_t)f.rb * M);
-    f.lds_cols = sizeof(float2) * ((size_t)f.twlenH + (size_t)2 * H);
+    f.lds_rows = sizeof(float2) * ((size_t)((f.twlenM + 1) & ~1) + (size_t)f.rb * M);
+    f.lds_cols = sizeof(float2) * ((size_t)((f.twlenH + 1) & ~1) + (size_t)2 * H);
     if (f.lds_cols > 150 * 1024 || f.lds_rows > 150 * 1024) return false;
     const void* kf = f.rb == 4 ? (const void*)k_rows_fwd<4> : f.rb == 2 ? (const void*)k_rows_fwd<2> : (const void*)k_rows_fwd<1>;
     const void* ki = f.rb == 4 ? (const void*)k_rows_inv<4> : f.rb == 2 ? (const void*)k_rows_inv<2> : (const void*)k_rows_inv<1>;
