@@ -518,6 +518,28 @@ def test_e2e_golden_128(golden):
     assert_close(N(out2), o, 2e-5, 1e-6, "sequential == fused")
 
 
+def test_e2e_golden_x1_denoiser(golden):
+    """The reference's own result for x1 / BGGR / white balance / accumulated-robustness merge denoiser."""
+    from test_oracle_golden import x1_config
+
+    g = golden("e2e_x1")
+    cfa, wb = ((2, 1), (1, 0)), (1.9, 1.0, 1.6)
+    ref, comp, _ = synth.make_burst(128, 160, 3, seed=int(g["seed"]), max_shift=2.0, occluder=True, cfa=cfa, wb=wb)
+    cfg = x1_config(cfa, wb)
+    cfg.debug = True
+    out, dbg = hsr.main(ref, comp, cfg)
+    assert_close(np.stack(dbg["flow"]), g["flow"], 0, 2e-3, "flow", max_bad_frac=0.02)
+    assert_close(np.stack(dbg["robustness"]), g["r"], 0, 1e-3, "r", max_bad_frac=0.01)
+    assert_close(N(dbg["accumulated robustness"]), g["acc_r"], 0, 2e-3, "acc r", max_bad_frac=0.01)
+    o = N(out)
+    assert_close(o, g["out"], 0, 1e-3, "output", max_bad_frac=0.005)
+    with np.errstate(all="ignore"):
+        assert np.nanpercentile(np.abs(o - g["out"]), 99) < 1e-4
+    cfg2 = x1_config(cfa, wb)  # non-debug (multi-stream) path
+    out2, _ = hsr.main(ref, comp, cfg2)
+    assert_close(N(out2), o, 0, 0, "debug path == fast path")
+
+
 @pytest.mark.parametrize("metric0", ["L1", "L2", "L1_ref_effective"])
 def test_e2e_c1_512(metric0):
     """BASELINE config C1: 512x512, 3 frames, x1 (demosaick only), Ts=16."""

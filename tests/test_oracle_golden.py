@@ -153,6 +153,15 @@ def test_merge_ref_denoiser(golden):
     assert_close(den, g["den_denref"], 1e-5, 1e-7, "denoiser denref")
 
 
+def x1_config(cfa, wb):
+    cfg = base_config(ts=16, scale=1)
+    cfg.block_matching.tuning.factors = [1, 2, 2, 2]
+    cfg.exif = {"cfa_pattern": [list(r) for r in cfa], "iso": 100, "white_balance": list(wb)}
+    cfg.accumulated_robustness_denoiser.enabled = True
+    cfg.accumulated_robustness_denoiser.merge.enabled = True
+    return cfg
+
+
 def test_e2e_128(golden):
     """main() on the 128x128 x3 burst the reference itself processed (x2, Ts=16, all-L2)."""
     from handheld_super_resolution import synthetic as synth
@@ -176,3 +185,23 @@ def test_e2e_128(golden):
     with np.errstate(all="ignore"):
         d = np.abs(out - g["out"])
     assert np.nanpercentile(d, 99) < 1e-4
+
+
+def test_e2e_x1_denoiser(golden):
+    """main() in BASELINE config C1's regime as the reference itself computed it: x1, BGGR CFA, white balance
+    (1.9, 1, 1.6), accumulated-robustness merge denoiser on; 128x160, 3 frames."""
+    from handheld_super_resolution import synthetic as synth
+
+    g = golden("e2e_x1")
+    cfa, wb = ((2, 1), (1, 0)), (1.9, 1.0, 1.6)
+    ref, comp, shifts = synth.make_burst(128, 160, 3, seed=int(g["seed"]), max_shift=2.0, occluder=True, cfa=cfa, wb=wb)
+    np.testing.assert_array_equal(shifts, g["shifts"])
+    cfg = x1_config(cfa, wb)
+    cap = {}
+    out, dbg = oracle.main(ref, comp, cfg, capture=cap)
+    assert_close(np.stack(cap["flow"]), g["flow"], 0, 2e-3, "flow", max_bad_frac=0.02)
+    assert_close(np.stack(cap["r"]), g["r"], 0, 1e-3, "r", max_bad_frac=0.01)
+    assert_close(dbg["accumulated robustness"], g["acc_r"], 0, 2e-3, "acc r", max_bad_frac=0.01)
+    assert_close(out, g["out"], 0, 1e-3, "output", max_bad_frac=0.005)
+    with np.errstate(all="ignore"):
+        assert np.nanpercentile(np.abs(out - g["out"]), 99) < 1e-4

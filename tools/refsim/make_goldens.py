@@ -383,10 +383,45 @@ def stage_e2e():
          out=npy(out), acc_r=np.asarray(dbg["accumulated robustness"], dtype=np.float32))
 
 
+def stage_e2e_x1():
+    """main() end to end in BASELINE config C1's regime: x1 (demosaicking only), BGGR CFA, white balance != 1,
+    accumulated-robustness merge denoiser on (merge_ref widens / overwrites where few frames were merged),
+    128x160, 3 frames, Ts=16, factors [1,2,2,2], all-L2."""
+    sr = loader.ref("super_resolution")
+    H, W = 128, 160
+    cfa, wb = ((2, 1), (1, 0)), (1.9, 1.0, 1.6)
+    ref, comp, shifts = synth.make_burst(H, W, 3, seed=77, max_shift=2.0, occluder=True, cfa=cfa, wb=wb)
+    cfg = base_config(ts=16, scale=1)
+    cfg.block_matching.tuning.factors = [1, 2, 2, 2]
+    cfg.exif = {"cfa_pattern": [list(r) for r in cfa], "iso": 100, "white_balance": list(wb)}
+    cfg.accumulated_robustness_denoiser.enabled = True
+    cfg.accumulated_robustness_denoiser.merge.enabled = True
+    cap = {"flow": [], "r": []}
+
+    def wrap(name, key):
+        f = getattr(sr, name)
+
+        def g(*a, **k):
+            o = f(*a, **k)
+            cap[key].append(npy(o))
+            return o
+
+        setattr(sr, name, g)
+
+    wrap("align", "flow")
+    wrap("compute_robustness", "r")
+    t0 = time.time()
+    with np.errstate(all="ignore"):
+        out, dbg = sr.main(ref, comp, cfg)
+    print(f"    main(): {time.time() - t0:.1f}s")
+    save("e2e_x1", shifts=shifts, seed=np.array(77), flow=np.stack(cap["flow"]), r=np.stack(cap["r"]),
+         out=npy(out), acc_r=np.asarray(dbg["accumulated robustness"], dtype=np.float32))
+
+
 STAGES = {
     "grey": stage_grey, "downsample": stage_downsample, "hessian": stage_hessian, "bm_l2": stage_bm_l2,
     "ica": stage_ica, "upscale": stage_upscale, "kernels": stage_kernels, "robustness": stage_robustness,
-    "merge": stage_merge, "params": stage_params, "e2e": stage_e2e,
+    "merge": stage_merge, "params": stage_params, "e2e": stage_e2e, "e2e_x1": stage_e2e_x1,
 }
 
 
