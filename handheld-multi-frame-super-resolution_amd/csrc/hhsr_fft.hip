@@ -16,7 +16,7 @@
 // The kernels are bound by the latency of their barrier phases, not by HBM: composite radices (4 passes for 2000
 // and 3000 points instead of 5 and 6) and in-place passes (half the LDS: 3 / 2 resident workgroups per CU for the
 // row / column kernels instead of 2 / 1) brought them from 171 us.
-// Supported when W is even and W/2 and H factor into {2, 3, 5} and the LDS budgets fit; the caller falls
+// Supported when W is even and W/2 and H factor into {2, 3, 5, 7} and the LDS budgets fit; the caller falls
 // back to the library plans otherwise.  Numerics: float32 butterflies, float64-computed twiddle tables.
 #include "hhsr_common.h"
 #include "hhsr_fft.h"
@@ -72,6 +72,30 @@ __device__ __forceinline__ void dft5(float2* v) {
     v[4] = csub(m1, n1);
     v[2] = cadd(m2, n2);
     v[3] = csub(m2, n2);
+}
+
+// 7-point DFT: a_j = x_j + x_{7-j}, b_j = x_j - x_{7-j};  X_k = x_0 + sum_j a_j cos(2 pi j k / 7) -+ i sum_j b_j
+// sin(2 pi j k / 7) for k and 7 - k.  (4032 x 3024 sensors: 2016 = 2^5 3^2 7, 3024 = 2^4 3^3 7.)
+__device__ __forceinline__ void dft7(float2* v) {
+    const float c1 = 0.62348980185873353053f, c2 = -0.22252093395631440429f, c3 = -0.90096886790241912624f;
+    const float s1 = 0.78183148246802980871f, s2 = 0.97492791218182360702f, s3 = 0.43388373911755812048f;
+    const float2 x0 = v[0];
+    const float2 a1 = cadd(v[1], v[6]), a2 = cadd(v[2], v[5]), a3 = cadd(v[3], v[4]);
+    const float2 b1 = csub(v[1], v[6]), b2 = csub(v[2], v[5]), b3 = csub(v[3], v[4]);
+    // cos / sin of 2 pi j k / 7 for (j, k) in 1..3: index j*k mod 7 folded to 1..3 (sin changes sign past 3)
+    const float2 m1 = make_float2(x0.x + c1 * a1.x + c2 * a2.x + c3 * a3.x, x0.y + c1 * a1.y + c2 * a2.y + c3 * a3.y);
+    const float2 m2 = make_float2(x0.x + c2 * a1.x + c3 * a2.x + c1 * a3.x, x0.y + c2 * a1.y + c3 * a2.y + c1 * a3.y);
+    const float2 m3 = make_float2(x0.x + c3 * a1.x + c1 * a2.x + c2 * a3.x, x0.y + c3 * a1.y + c1 * a2.y + c2 * a3.y);
+    const float2 n1 = mul_mi(make_float2(s1 * b1.x + s2 * b2.x + s3 * b3.x, s1 * b1.y + s2 * b2.y + s3 * b3.y));
+    const float2 n2 = mul_mi(make_float2(s2 * b1.x - s3 * b2.x - s1 * b3.x, s2 * b1.y - s3 * b2.y - s1 * b3.y));
+    const float2 n3 = mul_mi(make_float2(s3 * b1.x - s1 * b2.x + s2 * b3.x, s3 * b1.y - s1 * b2.y + s2 * b3.y));
+    v[0] = cadd(x0, cadd(a1, cadd(a2, a3)));
+    v[1] = cadd(m1, n1);
+    v[6] = csub(m1, n1);
+    v[2] = cadd(m2, n2);
+    v[5] = csub(m2, n2);
+    v[3] = cadd(m3, n3);
+    v[4] = csub(m3, n3);
 }
 
 // ---- composite radices: R = A * B point DFTs in registers ----------------------------------------------------
@@ -131,6 +155,7 @@ template <> __device__ __forceinline__ void dft_reg<2>(float2* v) { dft2(v); }
 template <> __device__ __forceinline__ void dft_reg<3>(float2* v) { dft3(v); }
 template <> __device__ __forceinline__ void dft_reg<4>(float2* v) { dft4(v); }
 template <> __device__ __forceinline__ void dft_reg<5>(float2* v) { dft5(v); }
+template <> __device__ __forceinline__ void dft_reg<7>(float2* v) { dft7(v); }
 
 template <int A, int B>
 __device__ __forceinline__ void dft_comp(float2* v) {
@@ -168,6 +193,7 @@ template <> __device__ __forceinline__ void dft_reg<8>(float2* v) { dft_comp<4, 
 template <> __device__ __forceinline__ void dft_reg<9>(float2* v) { dft_comp<3, 3>(v); }
 template <> __device__ __forceinline__ void dft_reg<10>(float2* v) { dft_comp<5, 2>(v); }
 template <> __device__ __forceinline__ void dft_reg<12>(float2* v) { dft_comp<4, 3>(v); }
+template <> __device__ __forceinline__ void dft_reg<14>(float2* v) { dft_comp<7, 2>(v); }
 template <> __device__ __forceinline__ void dft_reg<15>(float2* v) { dft_comp<5, 3>(v); }
 template <> __device__ __forceinline__ void dft_reg<16>(float2* v) { dft_comp<4, 4>(v); }
 
@@ -233,8 +259,8 @@ __device__ __forceinline__ void fft_lds(float2* buf, int bstride, int NB, const 
         asm volatile("" : "+s"(Np));
         switch (R) {
 #define HHSR_PASS(RR) case RR: stockham_pass<RR>(buf, bstride, NB, tw + toff, Np, Ns, tid, nt); break;
-            HHSR_PASS(2) HHSR_PASS(3) HHSR_PASS(4) HHSR_PASS(5) HHSR_PASS(6) HHSR_PASS(8) HHSR_PASS(9) HHSR_PASS(10)
-            HHSR_PASS(12) HHSR_PASS(15) HHSR_PASS(16)
+            HHSR_PASS(2) HHSR_PASS(3) HHSR_PASS(4) HHSR_PASS(5) HHSR_PASS(6) HHSR_PASS(7) HHSR_PASS(8) HHSR_PASS(9)
+            HHSR_PASS(10) HHSR_PASS(12) HHSR_PASS(14) HHSR_PASS(15) HHSR_PASS(16)
 #undef HHSR_PASS
             default: break;  // the host only schedules the radices above
         }
@@ -376,7 +402,7 @@ __global__ void __launch_bounds__(FFT_NT, FFT_ROWS_WPE) k_rows_inv(const float2*
 // Radix schedule: fewest passes over the supported radices, then the smallest maximum radix (registers, idle
 // lanes), then an odd / small first radix (the Ns = 1 pass stores with stride R: even R collide on LDS banks).
 // HHSR_FFT_RADIX_MAX (experiments) caps the radix; 5 reproduces the original 5/4/3/2 schedule.
-static const int k_radices[] = {16, 15, 12, 10, 9, 8, 6, 5, 4, 3, 2};
+static const int k_radices[] = {16, 15, 14, 12, 10, 9, 8, 7, 6, 5, 4, 3, 2};
 
 static void radix_search(int n, int rmax, int cap, int depth, int* cur, int& best_n, int* best, int& best_max) {
     if (n == 1) {

@@ -36,7 +36,7 @@ def smooth(rng, h, w, sigma=2.0):
 
 
 # ------------------------------------------------------------------------------------------ grey / pyramid
-@pytest.mark.parametrize("shape", [(48, 40), (50, 42), (31, 45), (512, 384)])
+@pytest.mark.parametrize("shape", [(48, 40), (50, 42), (31, 45), (512, 384), (56, 84), (126, 196), (378, 504)])
 def test_grey_fft(shape):
     img = np.random.default_rng(1).random(shape, dtype=np.float32)
     want = oracle.grey_fft(img)
@@ -58,6 +58,24 @@ def test_grey_fused_vs_library_plans(monkeypatch):
         assert_close(outs[mode], want, 0, 3e-6, "plan " + mode)
     utils_image._grey_plans.clear()
     assert np.abs(outs["4"] - outs["0"]).max() < 2e-6
+
+
+def test_grey_fused_radix7_sensor_size(monkeypatch):
+    """4032 x 3024 (the common 12 MP sensor; 2016 = 2^5 3^2 7, 3024 = 2^4 3^3 7) runs on the fused FFT kernels
+    (radix 7 / 14 butterflies) and agrees with the library plans."""
+    img = torch.rand((3024, 4032), device=DEV, generator=torch.Generator(device=DEV).manual_seed(5))
+    outs = {}
+    for mode in ("4", "0"):
+        monkeypatch.setenv("HHSR_GREY_PLAN", mode)
+        utils_image._grey_plans.clear()
+        outs[mode] = utils_image.compute_grey_images(img, "FFT").clone()
+    utils_image._grey_plans.clear()
+    assert float((outs["4"] - outs["0"]).abs().max()) < 3e-6
+    # constant image in -> same constant out (DC bin only), any size
+    flat = torch.full((3024, 4032), 0.37, device=DEV)
+    monkeypatch.setenv("HHSR_GREY_PLAN", "4")
+    assert float((utils_image.compute_grey_images(flat, "FFT") - 0.37).abs().max()) < 2e-6
+    utils_image._grey_plans.clear()
 
 
 def test_grey_golden(golden):
