@@ -92,6 +92,8 @@ def merge_burst(frames, ref_img, ref_kernels, num, den, cfa_pattern, config, loa
         ny = nx = 0
     cfa = _lib.cfa_bytes(cfa_pattern)
     chunks = [frames[i:i + _lib.MAX_FRAMES] for i in range(0, len(frames), _lib.MAX_FRAMES)] or [[]]
+    if len(chunks) > 1 and den is None:  # bursts longer than one launch holds chain through num / den
+        den = torch.empty_like(num)
     for ci, chunk in enumerate(chunks):
         last = ci == len(chunks) - 1
         f = flags

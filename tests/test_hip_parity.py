@@ -451,6 +451,33 @@ def test_merge_x2_quad_kernel_equals_tile_kernel(monkeypatch, kern):
         merge.merge_burst(tf, T(ref), rc, torch.empty(3 * H, 3 * W, 3, device=DEV), None, cfa, cfg3, local_min=True)
 
 
+def test_merge_burst_more_frames_than_one_launch_holds():
+    """70 frames > HHSR_MAX_FRAMES (64): merge_burst chains two launches through the accumulators (with the fused
+    local minimum and accumulated robustness) == per-frame merges."""
+    H, W, ts, n = 32, 48, 16, 70
+    cfg = base_config(ts=ts, scale=2)
+    rng = np.random.default_rng(12)
+    ref, comp, _ = synth.make_burst(H, W, 3, seed=5)
+    covs = T(oracle.estimate_kernels(comp[0], cfg))
+    tf = []
+    for k in range(n):
+        flow = T(rng.uniform(-1.5, 1.5, (H // ts, W // ts, 2)).astype(np.float32))
+        tf.append((T(comp[k % 2]), flow, covs, T(rng.random((H, W), dtype=np.float32))))
+    cfa = [[0, 1], [1, 2]]
+    rc = T(oracle.estimate_kernels(ref, cfg))
+    got, acc = torch.empty(2 * H, 2 * W, 3, device=DEV), torch.zeros(H, W, device=DEV)
+    merge.merge_burst(tf, T(ref), rc, got, None, cfa, cfg, acc_r=acc, local_min=True)
+    num, den = torch.zeros(2 * H, 2 * W, 3, device=DEV), torch.zeros(2 * H, 2 * W, 3, device=DEV)
+    want_acc = torch.zeros(H, W, device=DEV)
+    for f in tf:
+        r = robustness.local_min(f[3], want_acc)
+        merge.merge(f[0], f[1], f[2], r, num, den, cfa, cfg)
+    merge.merge_ref(T(ref), rc, num, den, cfa, cfg)
+    utils.divide(num, den)
+    assert_close(N(got), N(num), 2e-5, 1e-6, "70-frame burst")
+    assert_close(N(acc), N(want_acc), 1e-6, 1e-5, "70-frame accumulated robustness")
+
+
 @pytest.mark.parametrize("scale", [1, 2, 3])
 def test_merge_burst_equals_sequential(scale):
     H, W, ts = 64, 96, 16
