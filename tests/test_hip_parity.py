@@ -644,6 +644,66 @@ def test_e2e_ragged_sizes_and_scales(shape, scale):
     assert_close(N(dbg["accumulated robustness"]), wdbg["accumulated robustness"], 0, 4e-3, "acc r", max_bad_frac=0.02)
 
 
+def _opt_robustness_off(c):
+    c.robustness.enabled = False
+    c.robustness.save_mask = False  # (the reference's sanitize_config refuses the combination)
+
+
+def _opt_bilinear(c):
+    c.block_matching.tuning.flow_upscale_mode = "bilinear"
+
+
+def _opt_bicubic(c):
+    c.block_matching.tuning.flow_upscale_mode = "bicubic"
+
+
+def _opt_iso(c):
+    c.merging.kernel = "iso"
+
+
+def _opt_law(c):
+    c.merging.selection_law = "hard_threshold" if c.merging.selection_law == "linear" else "linear"
+
+
+def _opt_save_mask(c):
+    c.robustness.save_mask = True
+
+
+def _opt_fp64(c):
+    c.hip = {"weight_fp64": True}
+
+
+def _opt_one_stream(c):
+    c.hip = {"streams": 1}
+
+
+@pytest.mark.parametrize("opt", [_opt_robustness_off, _opt_bilinear, _opt_bicubic, _opt_iso, _opt_law, _opt_save_mask,
+                                 _opt_fp64, _opt_one_stream], ids=lambda f: f.__name__[5:])
+def test_e2e_config_matrix(opt, capsys):
+    """One option at a time away from the base configuration, HIP main() vs the oracle; plus verbose = 2 (timers,
+    host synchronisation, per-frame path) giving the same image as the quiet pipelined path."""
+    ref, comp, _ = synth.make_burst(128, 160, 3, seed=6, max_shift=2.0, occluder=True)
+
+    def cfg0(verbose=0):
+        c = base_config(ts=16, scale=2)
+        c.block_matching.tuning.factors = [1, 2, 2, 2]
+        opt(c)
+        c.verbose = verbose
+        return c
+
+    out, dbg = hsr.main(ref, comp, cfg0())
+    want, wdbg = oracle.main(ref, comp, cfg0())
+    o = N(out)
+    assert_close(o, want, 0, 1e-3, "output", max_bad_frac=0.005)
+    with np.errstate(all="ignore"):
+        assert np.nanpercentile(np.abs(o - want), 99) < 1e-4
+    if "accumulated robustness" in wdbg:
+        assert_close(N(dbg["accumulated robustness"]), wdbg["accumulated robustness"], 0, 2e-3, "acc r", max_bad_frac=0.01)
+    out_v, _ = hsr.main(ref, comp, cfg0(verbose=2))
+    assert "Total ellapsed time" in capsys.readouterr().out
+    assert_close(N(out_v), o, 2e-5, 1e-6, "verbose (sequential) == quiet (fused, pipelined)")
+
+
 @pytest.mark.parametrize("n_comp", [0, 1, 2])
 def test_e2e_few_frames_and_foreign_inputs(n_comp):
     """Bursts of 1-3 frames (0 comp frames = the reference frame alone) against the oracle; strided float64 /
