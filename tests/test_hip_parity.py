@@ -849,19 +849,26 @@ def test_full_size_properties():
 
 
 # ------------------------------------------------------------------------------------------ frame sharding
-def _shard_worker(rank, world, port, out_path):
+def _shard_cfg(scale, denoiser):
+    cfg = base_config(ts=16, scale=scale)
+    if denoiser:
+        cfg.accumulated_robustness_denoiser.enabled = True
+        cfg.accumulated_robustness_denoiser.merge.enabled = True
+    return cfg
+
+
+def _shard_worker(rank, world, port, out_path, scale=2, denoiser=False, n_frames=4):
     import os
     import torch.distributed as dist
     from handheld_super_resolution import distributed as hdist
 
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
-    dist.init_process_group("gloo", rank=rank, world_size=world)  # 2 processes share the one GPU of the test box
+    dist.init_process_group("gloo", rank=rank, world_size=world)  # the processes share the one GPU of the test box
     try:
         torch.cuda.set_device(0)
-        ref, comp, _ = synth.make_burst(512, 512, 4, seed=17, max_shift=2.0)
-        cfg = base_config(ts=16, scale=2)
-        out, dbg = hdist.main_sharded(ref, comp, cfg)
+        ref, comp, _ = synth.make_burst(512, 512, n_frames, seed=17, max_shift=2.0)
+        out, dbg = hdist.main_sharded(ref, comp, _shard_cfg(scale, denoiser))
         if rank == 0:
             np.savez(out_path, out=out.cpu().numpy(), acc_r=dbg["accumulated robustness"].cpu().numpy())
         else:
@@ -870,8 +877,7 @@ def _shard_worker(rank, world, port, out_path):
         dist.destroy_process_group()
 
 
-def test_sharded_hip_engine_world2(tmp_path):
-    """The HIP engine behind main_sharded(): 2 ranks (gloo rendezvous, both on cuda:0) == single process."""
+def _spawn_sharded(tmp_path, world, **kw):
     import socket
     import torch.multiprocessing as mp
 
@@ -879,8 +885,25 @@ def test_sharded_hip_engine_world2(tmp_path):
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
     out_path = str(tmp_path / "o.npz")
-    mp.spawn(_shard_worker, args=(2, port, out_path), nprocs=2, join=True)
-    got = np.load(out_path)
+    mp.spawn(_shard_worker, args=(world, port, out_path, kw.get("scale", 2), kw.get("denoiser", False),
+                                  kw.get("n_frames", 4)), nprocs=world, join=True)
+    return np.load(out_path)
+
+
+@pytest.mark.parametrize("world,scale,denoiser,n_frames", [(3, 3, False, 5), (3, 1, True, 3)])
+def test_sharded_hip_engine_variants(tmp_path, world, scale, denoiser, n_frames):
+    """3 ranks on the one GPU: x3 (generic tile merge kernel, padded slabs, a rank without frames when the burst
+    has 2 comp frames) and the accumulated-robustness denoiser (whole-accumulator reduce + rank-0 finish)."""
+    got = _spawn_sharded(tmp_path, world, scale=scale, denoiser=denoiser, n_frames=n_frames)
+    ref, comp, _ = synth.make_burst(512, 512, n_frames, seed=17, max_shift=2.0)
+    want, dbg = hsr.main(ref, comp, _shard_cfg(scale, denoiser))
+    assert_close(got["out"], N(want), 2e-5, 1e-6, "sharded == single", max_bad_frac=1e-5)
+    assert_close(got["acc_r"], N(dbg["accumulated robustness"]), 0, 1e-6, "acc_r")
+
+
+def test_sharded_hip_engine_world2(tmp_path):
+    """The HIP engine behind main_sharded(): 2 ranks (gloo rendezvous, both on cuda:0) == single process."""
+    got = _spawn_sharded(tmp_path, 2)
     ref, comp, _ = synth.make_burst(512, 512, 4, seed=17, max_shift=2.0)
     cfg = base_config(ts=16, scale=2)
     want, dbg = hsr.main(ref, comp, cfg)
