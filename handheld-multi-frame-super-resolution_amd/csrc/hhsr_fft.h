@@ -19,6 +19,7 @@ struct HhsrFft {
     size_t lds_rows = 0, lds_cols = 0;
     int twlenM = 0, twlenH = 0;     // lengths of the per-pass twiddle tables
     int rb = 0;                     // rows per workgroup of the row kernels (4, 2 or 1 by LDS budget)
+    int nc = 0;                     // kept columns per workgroup of the column kernel (2 or 1)
 };
 
 bool hhsr_fft_create(HhsrFft& f, int H, int W);   // false: sizes unsupported (caller uses the library plans)

@@ -324,6 +324,7 @@ __global__ void __launch_bounds__(FFT_NT, FFT_ROWS_WPE) k_rows_fwd(const float* 
 
 // Column kernel: TWO adjacent kept columns per workgroup (one 16-byte load per row serves both), transformed
 // simultaneously.  LDS: tw[twlen] | 2 x col[H]
+template <int NC>  // kept columns per workgroup: 2 (one 16-byte load per row serves both) or 1 (long columns)
 __global__ void __launch_bounds__(FFT_NT, FFT_COLS_WPE) k_cols(float2* __restrict__ T, int H, int W, int Wk,
                                                                     HhsrRadices rad, const float2* __restrict__ twH,
                                                                     int twlen, float norm) {
@@ -332,19 +333,25 @@ __global__ void __launch_bounds__(FFT_NT, FFT_COLS_WPE) k_cols(float2* __restric
     // workgroup b runs on XCD b % 8 (observed; locality only): give the 4 column pairs of one 64-byte block to
     // 4 consecutive workgroups of ONE XCD so that its L2 serves each cache line to all of them
     const int xcd = blockIdx.x & 7, loc = blockIdx.x >> 3;
-    const int kx = 8 * (xcd + 8 * (loc >> 2)) + 2 * (loc & 3);
+    const int per = 8 / NC;  // workgroups per 8-column block
+    const int kx = 8 * (xcd + 8 * (loc / per)) + NC * (loc % per);
     if (kx >= Wk) return;
     float2* tw = fl;
     float2* buf = tw + ((twlen + 1) & ~1);  // 16-byte aligned
-    float4* col = reinterpret_cast<float4*>(T + ((size_t)(kx >> 3) * H) * 8 + (kx & 7));  // row y at col[4 y]
+    float2* colb = T + ((size_t)(kx >> 3) * H) * 8 + (kx & 7);  // row y at colb[8 y]
+    float4* col = reinterpret_cast<float4*>(colb);               // NC = 2: row y at col[4 y]
     for (int k = tid; k < twlen; k += FFT_NT) tw[k] = twH[k];
     for (int k = tid; k < H; k += FFT_NT) {
-        const float4 v = col[(size_t)4 * k];
-        buf[k] = make_float2(v.x, v.y);
-        buf[H + k] = make_float2(v.z, v.w);
+        if (NC == 2) {
+            const float4 v = col[(size_t)4 * k];
+            buf[k] = make_float2(v.x, v.y);
+            buf[H + k] = make_float2(v.z, v.w);
+        } else {
+            buf[k] = colb[(size_t)8 * k];
+        }
     }
-    fft_lds(buf, H, 2, tw, H, rad, tid, FFT_NT);
-    for (int idx = tid; idx < 2 * H; idx += FFT_NT) {
+    fft_lds(buf, H, NC, tw, H, rad, tid, FFT_NT);
+    for (int idx = tid; idx < NC * H; idx += FFT_NT) {
         const int c = idx >= H, ky = idx - c * H;
         const int x = kx + c, nx = x == 0 ? 0 : W - x;
         const int nky = ky == 0 ? 0 : H - ky;
@@ -352,10 +359,14 @@ __global__ void __launch_bounds__(FFT_NT, FFT_COLS_WPE) k_cols(float2* __restric
         // masked, normalised and conjugated: the inverse is conj(FFT(conj(.)))
         buf[idx] = cconj(cscale(buf[idx], 0.5f * (float)m * norm));
     }
-    fft_lds(buf, H, 2, tw, H, rad, tid, FFT_NT);
+    fft_lds(buf, H, NC, tw, H, rad, tid, FFT_NT);
     for (int y = tid; y < H; y += FFT_NT) {
-        const float2 a = cconj(buf[y]), b2 = cconj(buf[H + y]);
-        col[(size_t)4 * y] = make_float4(a.x, a.y, b2.x, b2.y);
+        if (NC == 2) {
+            const float2 a = cconj(buf[y]), b2 = cconj(buf[H + y]);
+            col[(size_t)4 * y] = make_float4(a.x, a.y, b2.x, b2.y);
+        } else {
+            colb[(size_t)8 * y] = cconj(buf[y]);
+        }
     }
 }
 
@@ -512,7 +523,12 @@ bool hhsr_fft_create(HhsrFft& f, int H, int W) {
     const int M = W / 2;
     if (M >= 65536 || H >= 65536) return false;
     f.rb = pick_rb(M, f.radM);
-    if (!f.rb || !factorize(H, 2, f.radH)) return false;
+    if (!f.rb) return false;
+    f.nc = 0;
+    const char* enc = getenv("HHSR_FFT_NC");  // experiments / tests: force the columns-per-workgroup choice
+    for (int nc = enc ? atoi(enc) : 2; nc >= 1 && !f.nc; --nc)  // two columns per workgroup unless their passes / LDS do not fit
+        if (sizeof(float2) * ((size_t)H + (size_t)nc * H) <= 150 * 1024 && factorize(H, nc, f.radH)) f.nc = nc;
+    if (!f.nc) return false;
     int Wk = 0;
     for (int x = 0; x <= M; ++x)
         if (host_kept_fft(x, W) || host_kept_fft(x == 0 ? 0 : W - x, W)) Wk = x + 1;
@@ -524,13 +540,14 @@ bool hhsr_fft_create(HhsrFft& f, int H, int W) {
     f.twlenM = (int)hM.size();
     f.twlenH = (int)hH.size();
     f.lds_rows = sizeof(float2) * ((size_t)((f.twlenM + 1) & ~1) + (size_t)f.rb * M);
-    f.lds_cols = sizeof(float2) * ((size_t)((f.twlenH + 1) & ~1) + (size_t)2 * H);
+    f.lds_cols = sizeof(float2) * ((size_t)((f.twlenH + 1) & ~1) + (size_t)f.nc * H);
     if (f.lds_cols > 150 * 1024 || f.lds_rows > 150 * 1024) return false;
     const void* kf = f.rb == 4 ? (const void*)k_rows_fwd<4> : f.rb == 2 ? (const void*)k_rows_fwd<2> : (const void*)k_rows_fwd<1>;
     const void* ki = f.rb == 4 ? (const void*)k_rows_inv<4> : f.rb == 2 ? (const void*)k_rows_inv<2> : (const void*)k_rows_inv<1>;
     if (hipFuncSetAttribute(kf, hipFuncAttributeMaxDynamicSharedMemorySize, (int)f.lds_rows) != hipSuccess ||
         hipFuncSetAttribute(ki, hipFuncAttributeMaxDynamicSharedMemorySize, (int)f.lds_rows) != hipSuccess ||
-        hipFuncSetAttribute((const void*)k_cols, hipFuncAttributeMaxDynamicSharedMemorySize, (int)f.lds_cols) != hipSuccess) {
+        hipFuncSetAttribute(f.nc == 2 ? (const void*)k_cols<2> : (const void*)k_cols<1>,
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)f.lds_cols) != hipSuccess) {
         (void)hipGetLastError();
         return false;
     }
@@ -563,8 +580,12 @@ int hhsr_fft_lowpass(const HhsrFft& f, const float* src, float* dst, hipStream_t
 #define ROWS_INV(RB) hipLaunchKernelGGL(k_rows_inv<RB>, dim3(nrb), dim3(FFT_NT), f.lds_rows, s, f.T, f.H, f.W, f.Wk, dst, \
                                         f.radM, f.twM, f.twlenM, f.twW)
     if (f.rb == 4) ROWS_FWD(4); else if (f.rb == 2) ROWS_FWD(2); else ROWS_FWD(1);
-    hipLaunchKernelGGL(k_cols, dim3(((f.Wk + 63) / 64) * 32), dim3(FFT_NT), f.lds_cols, s, f.T, f.H, f.W, f.Wk, f.radH, f.twH,
-                       f.twlenH, norm);
+    if (f.nc == 2)
+        hipLaunchKernelGGL(k_cols<2>, dim3(((f.Wk + 63) / 64) * 32), dim3(FFT_NT), f.lds_cols, s, f.T, f.H, f.W, f.Wk,
+                           f.radH, f.twH, f.twlenH, norm);
+    else
+        hipLaunchKernelGGL(k_cols<1>, dim3(((f.Wk + 63) / 64) * 64), dim3(FFT_NT), f.lds_cols, s, f.T, f.H, f.W, f.Wk,
+                           f.radH, f.twH, f.twlenH, norm);
     if (f.rb == 4) ROWS_INV(4); else if (f.rb == 2) ROWS_INV(2); else ROWS_INV(1);
 #undef ROWS_FWD
 #undef ROWS_INV

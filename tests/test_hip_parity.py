@@ -60,6 +60,21 @@ def test_grey_fused_vs_library_plans(monkeypatch):
     assert np.abs(outs["4"] - outs["0"]).max() < 2e-6
 
 
+def test_grey_fused_one_column_per_workgroup(monkeypatch):
+    """Long columns (e.g. 6000 rows at 48 MP) run the column kernel with one column per workgroup; forced here
+    on a small image and checked against the two-column schedule and the float64 oracle."""
+    img = np.random.default_rng(4).random((240, 400), dtype=np.float32)
+    want = oracle.grey_fft(img)
+    outs = {}
+    for nc in ("2", "1"):
+        monkeypatch.setenv("HHSR_FFT_NC", nc)
+        utils_image._grey_plans.clear()
+        outs[nc] = N(utils_image.compute_grey_images(T(img), "FFT"))
+        assert_close(outs[nc], want, 0, 3e-6, "columns per workgroup " + nc)
+    utils_image._grey_plans.clear()
+    assert np.array_equal(outs["1"], outs["2"])
+
+
 def test_grey_fused_radix7_sensor_size(monkeypatch):
     """4032 x 3024 (the common 12 MP sensor; 2016 = 2^5 3^2 7, 3024 = 2^4 3^3 7) runs on the fused FFT kernels
     (radix 7 / 14 butterflies) and agrees with the library plans."""
