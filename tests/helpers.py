@@ -1,4 +1,6 @@
 """Shared test helpers (config construction mirrors tools/refsim/make_goldens.py)."""
+import os
+
 import numpy as np
 
 from handheld_super_resolution.config import default_config
@@ -45,6 +47,21 @@ def assert_close(a, b, rtol, atol, what="", max_bad_frac=0.0):
         ok = np.abs(a - b) <= atol + rtol * np.abs(b)
     ok = ok | both_nan | same_inf
     bad = (~ok).sum()
+    log = os.environ.get("HHSR_PARITY_LOG")
+    if log:  # tools/parity_report.py: measured errors next to the tolerances, one JSON line per comparison
+        import json
+
+        with np.errstate(all="ignore"):
+            d = np.abs(a - b)
+            d[both_nan | same_inf] = 0
+            fin = np.isfinite(d)
+            p99 = float(np.percentile(d[fin], 99.9)) if fin.any() else 0.0
+            rec = {"test": os.environ.get("PYTEST_CURRENT_TEST", "").split(" ")[0], "what": what, "n": int(ok.size),
+                   "max_abs": float(np.nanmax(np.where(fin, d, 0))) if d.size else 0.0, "p999_abs": p99,
+                   "rtol": rtol, "atol": atol, "outliers": int(bad), "allowed_frac": max_bad_frac,
+                   "scale": float(np.nanmax(np.abs(np.where(np.isfinite(b), b, 0)))) if b.size else 0.0}
+        with open(log, "a") as f:
+            f.write(json.dumps(rec) + "\n")
     if bad > max_bad_frac * ok.size:
         with np.errstate(all="ignore"):
             err = np.where(ok, 0, np.abs(a - b))
