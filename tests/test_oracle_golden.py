@@ -176,15 +176,13 @@ def test_e2e_128(golden):
     out, dbg = oracle.main(ref, comp, cfg, capture=cap)
     assert_close(cap["grey_ref"], g["grey_ref"], 0, 2e-6, "grey ref")
     flow = np.stack(cap["flow"])
-    assert_close(flow, g["flow"], 0, 2e-3, "flow", max_bad_frac=0.02)
-    assert_close(np.stack(cap["r"]), g["r"], 0, 1e-3, "r", max_bad_frac=0.01)
+    # measured: flow 4e-6 px, r 3e-6, output 5e-6 (the sim accumulates in a different float64/float32 mix than
+    # NumPy in a few places) — asserted with a 10x margin, no outliers allowed
+    assert_close(flow, g["flow"], 0, 5e-5, "flow")
+    assert_close(np.stack(cap["r"]), g["r"], 0, 5e-5, "r")
     assert_close(cap["covs"][-1], g["covs_last"], 1e-4, 1e-6, "ref covs")
-    assert_close(dbg["accumulated robustness"], g["acc_r"], 0, 2e-3, "acc r", max_bad_frac=0.01)
-    assert_close(out, g["out"], 0, 1e-3, "output", max_bad_frac=0.005)
-    # and the bulk is much tighter than the outlier allowance
-    with np.errstate(all="ignore"):
-        d = np.abs(out - g["out"])
-    assert np.nanpercentile(d, 99) < 1e-4
+    assert_close(dbg["accumulated robustness"], g["acc_r"], 0, 5e-5, "acc r")
+    assert_close(out, g["out"], 0, 5e-5, "output")
 
 
 def test_e2e_x1_denoiser(golden):
@@ -199,9 +197,7 @@ def test_e2e_x1_denoiser(golden):
     cfg = x1_config(cfa, wb)
     cap = {}
     out, dbg = oracle.main(ref, comp, cfg, capture=cap)
-    assert_close(np.stack(cap["flow"]), g["flow"], 0, 2e-3, "flow", max_bad_frac=0.02)
-    assert_close(np.stack(cap["r"]), g["r"], 0, 1e-3, "r", max_bad_frac=0.01)
-    assert_close(dbg["accumulated robustness"], g["acc_r"], 0, 2e-3, "acc r", max_bad_frac=0.01)
-    assert_close(out, g["out"], 0, 1e-3, "output", max_bad_frac=0.005)
-    with np.errstate(all="ignore"):
-        assert np.nanpercentile(np.abs(out - g["out"]), 99) < 1e-4
+    assert_close(np.stack(cap["flow"]), g["flow"], 0, 5e-5, "flow")
+    assert_close(np.stack(cap["r"]), g["r"], 0, 5e-5, "r")
+    assert_close(dbg["accumulated robustness"], g["acc_r"], 0, 5e-5, "acc r")
+    assert_close(out, g["out"], 0, 5e-5, "output")
