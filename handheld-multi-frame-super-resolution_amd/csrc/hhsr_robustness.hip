@@ -54,6 +54,12 @@ __device__ __forceinline__ bool dodgson_sample(const float* __restrict__ LR, int
             wacc += w;
         }
     }
+    if (wacc == 1.0) {  // interior, un-warped or not: the Dodgson weights sum to exactly 1 there and x / 1.0 == x
+        out[0] = b0;
+        out[1] = b1;
+        out[2] = b2;
+        return true;
+    }
     out[0] = (float)((double)b0 / wacc);
     out[1] = (float)((double)b1 / wacc);
     out[2] = (float)((double)b2 / wacc);
