@@ -159,6 +159,90 @@ extern "C" int hhsr_rob_sigma(const float* ref_means, const float* ref_vars, int
     HHSR_LAUNCHED();
 }
 
+// ---- reference-frame planes in one pass (once per burst) ----------------------------------------------------------
+// hhsr_rob_upscale(means) + hhsr_rob_upscale(vars) + hhsr_rob_sigma fused: the un-warped Dodgson upsampling of the
+// reference frame's guide means and variances, the noise-model sigma^2 and the packed curve indices, from guide
+// tiles staged in LDS.  The upsampled variances (144 MB at 12 MP) are never written.  Same arithmetic as the
+// three kernels (float64 weights, float32 buffers rounded after every tap, float64 sigma^2 sum): bit-identical.
+constexpr int RP_T = 32, RP_W = RP_T / 2 + 2;  // 32 x 32 raw pixels per workgroup, 18 x 18 guide window
+
+__global__ void __launch_bounds__(256) k_ref_planes(const float* __restrict__ gm, const float* __restrict__ gv, int lh,
+                                                     int lw, const double* __restrict__ stdc, int ncurve,
+                                                     float* __restrict__ rmean, float* __restrict__ ssq,
+                                                     uint32_t* __restrict__ idx, int H, int W) {
+    __shared__ float s_w[6][RP_W][RP_W + 1];
+    const int bx = blockIdx.x * RP_T, by = blockIdx.y * RP_T;
+    const int wx0 = bx / 2 - 1, wy0 = by / 2 - 1;  // centre (y >> 1) - 1 of the first pixel
+    const size_t gplane = (size_t)lh * lw;
+    for (int p = threadIdx.x; p < 6 * RP_W * RP_W; p += 256) {
+        const int c = p / (RP_W * RP_W), q = p - c * (RP_W * RP_W);
+        const int i = q / RP_W, j = q - i * RP_W;
+        const int gy = clampi(wy0 + i, 0, lh - 1), gx = clampi(wx0 + j, 0, lw - 1);
+        s_w[c][i][j] = (c < 3 ? gm + c * gplane : gv + (c - 3) * gplane)[(size_t)gy * lw + gx];
+    }
+    __syncthreads();
+    const size_t plane = (size_t)H * W;
+    const int lx_ = threadIdx.x & 31, ly_ = threadIdx.x >> 5;
+#pragma unroll 1
+    for (int k = 0; k < 4; ++k) {
+        const int x = bx + lx_, y = by + ly_ + 8 * k;
+        if (x >= W || y >= H) continue;
+        const size_t o = (size_t)y * W + x;
+        // un-warped position l = (p + 0.5) / 2 - 0.5 (robustness.py:380-383): outside for p = 0 (D6)
+        const double ly = ((double)y + 0.5) / 2.0 - 0.5, lx = ((double)x + 0.5) / 2.0 - 0.5;
+        float v[6];
+        if (!(ly >= 0.0 && ly < (double)lh && lx >= 0.0 && lx < (double)lw)) {
+#pragma unroll
+            for (int c = 0; c < 6; ++c) v[c] = INFINITY;
+        } else {
+            const int cy = (int)rint(ly), cx = (int)rint(lx);
+            float b[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+            double wacc = 0.0;
+#pragma unroll
+            for (int i = -1; i <= 1; ++i) {
+                const int y_ = clampi(cy + i, 0, lh - 1);
+                const double wy = dodgson((double)y_ - ly);
+#pragma unroll
+                for (int j = -1; j <= 1; ++j) {
+                    const int x_ = clampi(cx + j, 0, lw - 1);
+                    const double w = wy * dodgson((double)x_ - lx);
+#pragma unroll
+                    for (int c = 0; c < 6; ++c)  // float32 buffer += float32 * float64, rounded after every tap
+                        b[c] = (float)((double)b[c] + (double)s_w[c][cy + i - wy0][cx + j - wx0] * w);
+                    wacc += w;
+                }
+            }
+#pragma unroll
+            for (int c = 0; c < 6; ++c) v[c] = wacc == 1.0 ? b[c] : (float)((double)b[c] / wacc);
+        }
+        double s_sq = 0.0;
+        uint32_t packed = 0;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            rmean[c * plane + o] = v[c];
+            int id = 0;
+            const double bb = 1000.0 * (double)v[c];
+            if (isfinite(bb)) id = clampi((int)rint(bb), 0, ncurve - 1);
+            packed |= (uint32_t)id << (10 * c);
+            const double s_t = stdc[id], st2 = s_t * s_t, sp = (double)v[3 + c];
+            s_sq += (st2 > sp) ? st2 : sp;
+        }
+        ssq[o] = (float)s_sq;
+        if (idx) idx[o] = packed;
+    }
+}
+
+extern "C" int hhsr_ref_planes(const float* guide_means, const float* guide_vars, int lh, int lw,
+                               const double* std_curve, int ncurve, float* ref_means, float* sigma_sq,
+                               uint32_t* curve_index, void* stream) {
+    HHSR_ARG(guide_means && guide_vars && std_curve && ref_means && sigma_sq && lh > 0 && lw > 0 && ncurve > 0);
+    HHSR_ARG(!curve_index || ncurve <= 1024);
+    const int H = 2 * lh, W = 2 * lw;
+    hipLaunchKernelGGL(k_ref_planes, dim3(hhsr_cdiv(W, RP_T), hhsr_cdiv(H, RP_T)), dim3(256), 0, (hipStream_t)stream,
+                       guide_means, guide_vars, lh, lw, std_curve, ncurve, ref_means, sigma_sq, curve_index, H, W);
+    HHSR_LAUNCHED();
+}
+
 // ---- fused per-frame robustness -> R (generic tile sizes) ---------------------------------------------
 __global__ void __launch_bounds__(256) k_rob_frame(const float* __restrict__ cm, int lh, int lw,
                                                     const float* __restrict__ rmean, const float* __restrict__ ssq,

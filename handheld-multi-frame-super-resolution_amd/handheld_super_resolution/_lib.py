@@ -41,6 +41,7 @@ _SIGS = {
     "hhsr_rob_upscale": [P, I, I, P, I, I, I, P, P],
     "hhsr_rob_s": [P, I, I, F, F, F, P, P],
     "hhsr_rob_sigma": [P, P, I, I, P, I, P, P, P],
+    "hhsr_ref_planes": [P, P, I, I, P, I, P, P, P, P],
     "hhsr_rob_frame": [P, I, I, P, P, P, P, I, I, I, P, P, I, D, P, P],
     "hhsr_local_min5": [P, I, I, P, P, P],
     "hhsr_accumulate": [P, I, I, I, P, I, I, I, P, P, U8P, D, I, P, P, I, I, P],

@@ -91,6 +91,21 @@ def noise_sigma_sq(ref_local_means, ref_local_stds, std_curve):
     return out, idx
 
 
+def ref_planes(guide_means, guide_vars, std_curve):
+    """Reference-frame state of the robustness in one pass (once per burst): the upsampled local means
+    [3, H, W] (init_robustness, robustness.py:23-76) and noise_sigma_sq()'s (sigma_sq, curve_index) — bit-identical
+    to upscale_warp_stats() x 2 + noise_sigma_sq(), without materialising the upsampled variances."""
+    guide_means, guide_vars = _lib.f32c(guide_means), _lib.f32c(guide_vars)
+    _, lh, lw = guide_means.shape
+    dev = guide_means.device
+    means = torch.empty((3, 2 * lh, 2 * lw), dtype=torch.float32, device=dev)
+    sig = torch.empty((2 * lh, 2 * lw), dtype=torch.float32, device=dev)
+    idx = torch.empty((2 * lh, 2 * lw), dtype=torch.int32, device=dev) if std_curve.numel() <= 1024 else None
+    _lib.call("hhsr_ref_planes", _lib.ptr(guide_means), _lib.ptr(guide_vars), lh, lw, _lib.ptr(std_curve),
+              int(std_curve.numel()), _lib.ptr(means), _lib.ptr(sig), _lib.ptr(idx), _lib.stream())
+    return means, (sig, idx)
+
+
 def compute_robustness(comp_img, ref_local_means, ref_local_stds, flows, cfa_pattern, white_balance, noise_model,
                        config, return_R=False, accumulate_into=None, ref_sigma_sq=None, comp_means=None,
                        fuse_local_min=False):

@@ -20,8 +20,7 @@ from .utils_image import compute_grey_images
 from .utils import divide, add, getTime
 from .alignment import align, init_alignment, build_gaussian_pyramid
 from .params import sanitize_config, update_snr_config
-from .robustness import (init_robustness, compute_robustness, noise_curves_to_device, noise_sigma_sq,
-                         upscale_warp_stats)
+from .robustness import init_robustness, compute_robustness, noise_curves_to_device, ref_planes
 from .kernels import estimate_kernels, frame_stats
 from .merge import merge, merge_ref, merge_burst, can_fuse_acc_r, can_fuse_local_min
 
@@ -75,14 +74,15 @@ class BurstPipeline:
         sanitize_config(cfg, tuple(self.ref.shape))
         grey = compute_grey_images(self.ref, self.grey_method)
         self.align_state = init_alignment(grey, cfg)
-        if cfg.robustness.enabled:  # init_robustness + the reference frame's kernels from one raw pass
+        if cfg.robustness.enabled:  # init_robustness + the reference frame's kernels from one raw pass, then the
+            # upsampled means, sigma^2 and curve indices from one pass over the guide statistics
             m, v, self.ref_covs = frame_stats(self.ref, self.cfa, self.wb, cfg, want_vars=True)
-            self.ref_means, self.ref_vars = upscale_warp_stats(m), upscale_warp_stats(v)
+            self.ref_means, self.ref_sigma_sq = ref_planes(m, v, self.curves[0])
+            self.ref_vars = None  # only needed for sigma^2, which is already there
         else:
             self.ref_means, self.ref_vars = init_robustness(self.ref, self.cfa, self.wb, cfg)
             self.ref_covs = estimate_kernels(self.ref, cfg)
-        self.ref_sigma_sq = (noise_sigma_sq(self.ref_means, self.ref_vars, self.curves[0])
-                             if cfg.robustness.enabled else None)
+            self.ref_sigma_sq = None
         self.grey_ref = grey
         self._ref_ready = torch.cuda.Event()
         self._ref_ready.record(main)

@@ -145,6 +145,13 @@ int hhsr_rob_s(const float* flow, int ny, int nx, float Mt, float s1, float s2, 
  * round(1000 ref_means[c][p]) packed 10 bits each (c = 0 in the low bits), uint32 [H][W]. */
 int hhsr_rob_sigma(const float* ref_means, const float* ref_vars, int H, int W,
                    const double* std_curve, int ncurve, float* sigma_sq, uint32_t* curve_index, void* stream);
+/* hhsr_rob_upscale(means) + hhsr_rob_upscale(vars) + hhsr_rob_sigma in one pass over the reference frame's guide
+ * statistics [3][lh][lw] (robustness.py:23-76 and 505-528, once per burst): ref_means float32 [3][2lh][2lw],
+ * sigma_sq [2lh][2lw], curve_index (optional) — bit-identical to the three calls; the upsampled variances are
+ * never written. */
+int hhsr_ref_planes(const float* guide_means, const float* guide_vars, int lh, int lw,
+                    const double* std_curve, int ncurve, float* ref_means, float* sigma_sq,
+                    uint32_t* curve_index, void* stream);
 /* Fused warp-upsample of the frame's guide means + colour distance + noise-model shrink + threshold
  * (robustness.py:359-421, 453-461, 505-528, 627-639) -> R float32 [2lh][2lw].
  * ref_sigma_sq / ref_curve_index from hhsr_rob_sigma (index plane NULL = look the curve up per frame on

@@ -352,6 +352,22 @@ def test_robustness_golden(golden):
     assert (N(ones) == 1).all()
 
 
+def test_ref_planes_equal_separate_kernels():
+    """hhsr_ref_planes == hhsr_rob_upscale x 2 + hhsr_rob_sigma, bit for bit (incl. the D6 +inf border and a size
+    that is not a multiple of the 32-pixel tile)."""
+    ref, _, _ = synth.make_burst(138, 202, 1, seed=9)
+    cfa, wb = [[0, 1], [1, 2]], [1.7, 1.0, 1.3]
+    m, v = robustness.compute_local_stats_from_raw(T(ref), cfa, wb)
+    std, _ = robustness.noise_curves_to_device(*synth.noise_curves(synth.ALPHA_ISO100, synth.BETA_ISO100), DEV)
+    means, (sig, idx) = robustness.ref_planes(m, v, std)
+    means2, vars2 = robustness.upscale_warp_stats(m), robustness.upscale_warp_stats(v)
+    sig2, idx2 = robustness.noise_sigma_sq(means2, vars2, std)
+    assert_close(N(means), N(means2), 0, 0, "ref means")
+    assert_close(N(sig), N(sig2), 0, 0, "sigma^2")
+    assert np.array_equal(N(idx), N(idx2))
+    assert np.isinf(N(means)[:, 0, :]).all() and np.isinf(N(means)[:, :, 0]).all()  # D6
+
+
 def test_robustness_random():
     rng = np.random.default_rng(7)
     H, W, ts = 96, 144, 32
