@@ -18,9 +18,14 @@ Parity pinning: the reference has no tests or golden vectors of its own
 own code executed in the build container (``tools/refsim``: the reference's
 kernel bodies run under a CPU stand-in for ``numba.cuda``).  The captured
 vectors live in ``tests/golden/*.npz``; ``tests/test_oracle_golden.py`` checks
-every stage and one end-to-end burst against them.  The level-0 ``L1`` search
-is undefined behaviour upstream (App. A D1) and is therefore *unpinned*: the
-oracle defines its intended semantics.
+every stage and two end-to-end bursts (x2 RGGB; x1 BGGR with white balance and
+the accumulated-robustness denoiser) against them — measured end-to-end
+difference to the reference's own output 5e-6.  The level-0 ``L1`` search is
+undefined behaviour upstream (App. A D1) and is therefore *unpinned*: the
+oracle defines its intended semantics.  ``frontend`` (burst normalisation,
+Monte-Carlo noise curves — SURVEY.md §8f-3) restates code whose reference
+counterpart needs rawpy / draws unseeded random numbers: the normalisation is
+pinned by hand-computed known answers, the Monte-Carlo only statistically.
 """
 from .params import update_snr_config, sanitize_config, lerp  # noqa: F401
 from .grey import compute_grey_images, grey_fft, decimate_to_grey  # noqa: F401
