@@ -57,7 +57,7 @@ int hhsr_lowpass_mask_r2c(float* spec, int H, int W, int64_t stride_y, int64_t s
  * Returns 1000 + hipfftResult on a hipFFT error. */
 #define HHSR_GREY_PRUNED 1   /* batched row plans + strided column plans on the kept x-bins only (experiment) */
 #define HHSR_GREY_FUSED 4    /* three in-LDS kernels (rows, columns + mask, rows) when W is even and W/2, H factor
-                                into {2,3,5} and fit LDS; otherwise the library plans are used */
+                                into {2,3,5,7} and fit LDS; otherwise the library plans are used */
 #define HHSR_GREY_TPRUNED 2  /* row plans with a transposed spectrum + contiguous column plans on the kept bins */
 int hhsr_grey_plan_create(int H, int W, int flags, void** plan_out);
 int hhsr_grey_lowpass(void* plan, const float* src, float* dst, void* stream);
