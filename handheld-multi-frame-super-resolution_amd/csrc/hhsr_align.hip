@@ -600,7 +600,7 @@ __global__ void __launch_bounds__(256) k_align_wave(const float* __restrict__ re
     constexpr int slice = (RS * RP + WS * WP + 3) & ~3;
     float* s_ref = lds + (size_t)wave * slice;
     float* s_win = s_ref + RS * RP;
-    const int tile = blockIdx.x * 4 + wave;
+    const int tile = xcd_remap(blockIdx.x, gridDim.x) * 4 + wave;  // neighbouring tiles share window halos: same L2
     if (tile >= ntiles) return;  // wave-uniform; no workgroup barrier below
     const int ty = tile / nx, tx = tile - ty * nx;
     float* fl = flow + (size_t)tile * 2;

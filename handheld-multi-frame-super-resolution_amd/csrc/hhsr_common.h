@@ -102,6 +102,14 @@ __device__ __forceinline__ int wave_argmin_first(float cost, int idx, float* min
     return best;
 }
 
+// XCD-aware workgroup order.  The dispatcher places workgroup b on XCD b % 8 (observed; used for locality
+// only, never for correctness): neighbouring workgroups, which share tile halos, land on different XCDs and
+// each 4 MB L2 fetches the halo again.  This bijection gives every XCD one contiguous range of logical ids.
+__device__ __forceinline__ int xcd_remap(int bid, int nblk) {
+    const int xcd = bid & 7, loc = bid >> 3, q = nblk >> 3, rem = nblk & 7;
+    return xcd * q + min(xcd, rem) + loc;
+}
+
 __device__ __forceinline__ int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
 
 // Python/Numba `max(0, z)`: returns z only when z > 0, so NaN -> 0 (reference quirk D10).

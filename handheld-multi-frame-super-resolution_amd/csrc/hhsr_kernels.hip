@@ -149,7 +149,8 @@ template <bool STATS, bool COV>
 __global__ void __launch_bounds__(256) k_frame_stats(FrameStatsArgs A) {
     __shared__ float s_ch[STATS ? 3 : 1][STATS ? FS_TY + 2 : 1][FS_P];
     __shared__ float s_g[COV ? (FS_TY + 2) * FS_P : 1];
-    const int qx0 = blockIdx.x * FS_TX, qy0 = blockIdx.y * FS_TY;
+    const int bid = xcd_remap(blockIdx.y * gridDim.x + blockIdx.x, gridDim.x * gridDim.y);  // bands of tile rows per XCD
+    const int qx0 = (bid % gridDim.x) * FS_TX, qy0 = (bid / gridDim.x) * FS_TY;
     const int gh = A.gh, gw = A.gw;
     const double c0 = 3.0 / 8.0 * A.P.alpha * A.P.alpha + A.P.beta;
     const double toa = 2.0 / A.P.alpha;

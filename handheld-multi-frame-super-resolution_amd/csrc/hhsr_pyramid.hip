@@ -93,7 +93,8 @@ __global__ void __launch_bounds__(256) k_gauss_decimate(const float* __restrict_
     constexpr int IWp = IW | 1;  // odd pitch: the strided column reads below stay <= 2-way conflicted
     float* s_in = lds;                  // [IH][IWp]
     float* s_tmp = lds + IH * IWp;      // [GD_TY][IWp]
-    const int ox0 = blockIdx.x * GD_TX, oy0 = blockIdx.y * GD_TY;
+    const int bid = xcd_remap(blockIdx.y * gridDim.x + blockIdx.x, gridDim.x * gridDim.y);  // bands of tile rows per XCD
+    const int ox0 = (bid % gridDim.x) * GD_TX, oy0 = (bid / gridDim.x) * GD_TY;
     const int ix0 = ox0 * f, iy0 = oy0 * f;
     const int tid = threadIdx.x;
     constexpr int NL = (IH * IW + 255) / 256;

@@ -491,8 +491,10 @@ __global__ void __launch_bounds__(256) k_rob_frame_row4(const float* __restrict_
     __shared__ float s_g[2][2][3][RF_WN][RF_WN + 2];
     const int lx4 = threadIdx.x & 7, ly_ = threadIdx.x >> 3;  // 8 threads x 4 pixels per row, 32 rows
     const int grp = lx4 >> 2, v = ly_ >> 4;                   // the thread's 16 x 16 sub-tile
-    const int sx0 = blockIdx.x * RF_BX + grp * RF_T, sy0 = blockIdx.y * RF_BY + v * RF_T;
-    const int x0 = blockIdx.x * RF_BX + 4 * lx4, y = blockIdx.y * RF_BY + ly_;
+    const int bid = xcd_remap(blockIdx.y * gridDim.x + blockIdx.x, gridDim.x * gridDim.y);  // bands of tile rows per XCD
+    const int bxi = bid % gridDim.x, byi = bid / gridDim.x;
+    const int sx0 = bxi * RF_BX + grp * RF_T, sy0 = byi * RF_BY + v * RF_T;
+    const int x0 = bxi * RF_BX + 4 * lx4, y = byi * RF_BY + ly_;
     const int tix = min(sx0, W - 1) / ts, tiy = min(sy0, H - 1) / ts;
     const float2 f = flow[(size_t)tiy * nx + tix];
     const float Sv = S[(size_t)tiy * nx + tix];
