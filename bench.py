@@ -56,8 +56,8 @@ def merge_burst_bytes(n_comp, P, S, with_ref=True, partial=False):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--height", type=int, default=3000)
     ap.add_argument("--width", type=int, default=4000)
     ap.add_argument("--frames", type=int, default=20, help="burst length including the reference frame")

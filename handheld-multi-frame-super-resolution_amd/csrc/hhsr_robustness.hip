@@ -171,7 +171,8 @@ __global__ void __launch_bounds__(256) k_ref_planes(const float* __restrict__ gm
                                                      float* __restrict__ rmean, float* __restrict__ ssq,
                                                      uint32_t* __restrict__ idx, int H, int W) {
     __shared__ float s_w[6][RP_W][RP_W + 1];
-    const int bx = blockIdx.x * RP_T, by = blockIdx.y * RP_T;
+    const int bid = xcd_remap(blockIdx.y * gridDim.x + blockIdx.x, gridDim.x * gridDim.y);
+    const int bx = (bid % gridDim.x) * RP_T, by = (bid / gridDim.x) * RP_T;
     const int wx0 = bx / 2 - 1, wy0 = by / 2 - 1;  // centre (y >> 1) - 1 of the first pixel
     const size_t gplane = (size_t)lh * lw;
     for (int p = threadIdx.x; p < 6 * RP_W * RP_W; p += 256) {
