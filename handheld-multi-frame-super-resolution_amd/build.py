@@ -19,8 +19,8 @@ SOURCES = {
     "hhsr_api.hip": ["-ffp-contract=off"],
     "hhsr_pyramid.hip": ["-ffp-contract=off"],
     "hhsr_align.hip": ["-ffp-contract=off"],
-    "hhsr_kernels.hip": ["-ffp-contract=off"],
-    "hhsr_robustness.hip": ["-ffp-contract=off"],
+    "hhsr_kernels.hip": ["-ffp-contract=off", "-fno-slp-vectorize"],
+    "hhsr_robustness.hip": ["-ffp-contract=off", "-fno-slp-vectorize"],
     "hhsr_merge.hip": [],
     "hhsr_grey.hip": ["-ffp-contract=off"],
     "hhsr_fft.hip": [],
