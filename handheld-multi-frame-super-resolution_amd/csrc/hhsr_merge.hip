@@ -25,8 +25,32 @@ struct Geo {
     int ny, nx, ts;     // flow tile grid
     int sH, sW;         // output
     int row0, row1;     // output rows [row0, row1) handled by this launch (merge_burst slabs); num/den point at row0
+    int bt, bb, bl, br; // border bands: output rows < bt / >= sH - bb and columns < bl / >= sW - br are the pixels whose
+                        // reference-frame window centre lies on the outermost raw row / column (see border_pixel)
     double scale;
 };
+
+// Border pixels.  A colour can be missing from the reference frame's 3x3 window only when that window is centred on
+// the outermost raw row / column; such a pixel's channel sum may then consist of nothing but far-off samples whose
+// weights sit at the float32 denormal limit (or below it).  The reference evaluates those weights in float64 and
+// rounds the products into float32 accumulators (merge.py:419-434), so 1e-40 / 1e-40 is a colour there and the
+// float32 weight chain cannot reproduce it.  The float32 kernels therefore leave the border bands alone and
+// k_merge_border computes them with the reference's float64 chain (a few rows / columns: ~0.2 % of the pixels).
+__device__ __forceinline__ bool border_pixel(const Geo& g, int hi, int hj) {
+    return hi < g.bt || hi >= g.sH - g.bb || hj < g.bl || hj >= g.sW - g.br;
+}
+
+// Robustness of the raw pixel (i_r, j_r): the map itself, or (LMIN maps hold the thresholded R) its 5x5
+// clamp-border minimum (robustness.py:641-686).
+__device__ __forceinline__ float robustness_at(const float* __restrict__ r, const Geo& g, int i_r, int j_r, bool lmin) {
+    if (!lmin) return r[(size_t)i_r * g.W + j_r];
+    float m = r[(size_t)i_r * g.W + j_r];
+    for (int di = -2; di <= 2; ++di) {
+        const float* row = r + (size_t)min(max(i_r + di, 0), g.H - 1) * g.W;
+        for (int dj = -2; dj <= 2; ++dj) m = fminf(m, row[min(max(j_r + dj, 0), g.W - 1)]);
+    }
+    return m;
+}
 
 struct FramePtr {
     const float* raw;
@@ -38,7 +62,7 @@ struct FramePtr {
 // ---- one comp frame's contribution to HR pixel (hi, hj)  (merge.py:291-434) -----------------------
 template <typename WT, bool ISO>
 __device__ __forceinline__ void comp_contrib(const FramePtr f, const Geo& g, const Cfa4 cfa, int hi, int hj,
-                                             float val[3], float acc[3]) {
+                                             float val[3], float acc[3], bool lmin = false) {
     const double lr_x = ((double)hj + 0.5) / g.scale;
     const double lr_y = ((double)hi + 0.5) / g.scale;
     const int px = (int)lr_x / g.ts, py = (int)lr_y / g.ts;  // == int(lr // tile_size) for lr >= 0
@@ -46,7 +70,7 @@ __device__ __forceinline__ void comp_contrib(const FramePtr f, const Geo& g, con
     const int i_r = min((int)lr_y, g.H - 1), j_r = min((int)lr_x, g.W - 1);
     const double mx = lr_x + (double)fl.x, my = lr_y + (double)fl.y;
     if (!(mx >= 0.0 && mx < (double)g.W && my >= 0.0 && my < (double)g.H)) return;
-    const WT local_r = (WT)f.r[(size_t)i_r * g.W + j_r];
+    const WT local_r = (WT)robustness_at(f.r, g, i_r, j_r, lmin);
     WT ixx = 0, ixy = 0, iyy = 0;
     if (!ISO) {
         const double kj = mx / 2.0 - 0.5, ki = my / 2.0 - 0.5;
@@ -411,13 +435,13 @@ __global__ void __launch_bounds__(256) k_accumulate(FramePtr f, Geo g, Cfa4 cfa,
     const int hj = blockIdx.x * 64 + (threadIdx.x & 63), hi = blockIdx.y * 4 + (threadIdx.x >> 6);
     if (hj >= g.sW || hi >= g.sH) return;
     float val[3] = {0.f, 0.f, 0.f}, acc[3] = {0.f, 0.f, 0.f};
-    if (sizeof(WT) == 4) {
+    if (sizeof(WT) == 4 && !border_pixel(g, hi, hj)) {
         const Pix p = make_pix(g, hi, hj);
         float n4[2][2] = {{0.f, 0.f}, {0.f, 0.f}}, d4[2][2] = {{0.f, 0.f}, {0.f, 0.f}};
         comp_accum_fast<GEOM, ISO>(f, g, p, n4, d4);
         classes_to_rgb(cfa, n4, d4, val, acc);
-    } else {
-        comp_contrib<WT, ISO>(f, g, cfa, hi, hj, val, acc);
+    } else {  // float64 weight chain: validation mode, and always on the border bands (see border_pixel)
+        comp_contrib<double, ISO>(f, g, cfa, hi, hj, val, acc);
     }
     const size_t o = ((size_t)hi * g.sW + hj) * 3;
 #pragma unroll
@@ -468,12 +492,12 @@ __device__ __forceinline__ bool owns_lr_pixel(const BurstArgs& a, int hi, int hj
     return a.acc_r != nullptr && (hi % a.iscale) == 0 && (hj % a.iscale) == 0;
 }
 
+// All frames + reference frame + normalisation of ONE output pixel, operands from global memory.
 template <typename WT, int GEOM, bool ISO>
-__global__ void __launch_bounds__(256) k_merge_burst(BurstArgs a, Geo g, Cfa4 cfa, float* __restrict__ num,
-                                                      float* __restrict__ den) {
-    const int hj = blockIdx.x * 64 + (threadIdx.x & 63), hi = g.row0 + blockIdx.y * 4 + (threadIdx.x >> 6);
-    if (hj >= g.sW || hi >= g.row1) return;
+__device__ __forceinline__ void merge_pixel(const BurstArgs& a, const Geo& g, const Cfa4 cfa, int hi, int hj,
+                                            float* __restrict__ num, float* __restrict__ den) {
     const size_t o = ((size_t)(hi - g.row0) * g.sW + hj) * 3;
+    const bool lmin = (a.flags & HHSR_MERGE_LOCAL_MIN) != 0;
     float n3[3] = {0.f, 0.f, 0.f}, d3[3] = {0.f, 0.f, 0.f};
     if (a.flags & HHSR_MERGE_LOAD_ACC) {
 #pragma unroll
@@ -481,12 +505,6 @@ __global__ void __launch_bounds__(256) k_merge_burst(BurstArgs a, Geo g, Cfa4 cf
             n3[k] = num[o + k];
             d3[k] = den[o + k];
         }
-    }
-    if (owns_lr_pixel(a, hi, hj)) {
-        const Pix p = make_pix(g, hi, hj);
-        float racc = (a.flags & HHSR_MERGE_LOAD_ACC) ? a.acc_r[p.ridx] : 0.f;
-        for (int n = 0; n < a.n; ++n) racc += a.f[n].r[p.ridx];
-        a.acc_r[p.ridx] = racc;
     }
     if (sizeof(WT) == 4) {
         // fast path: parity-class sums over all frames, mapped to R/G/B once
@@ -497,7 +515,7 @@ __global__ void __launch_bounds__(256) k_merge_burst(BurstArgs a, Geo g, Cfa4 cf
     } else {
         for (int n = 0; n < a.n; ++n) {
             float val[3] = {0.f, 0.f, 0.f}, acc[3] = {0.f, 0.f, 0.f};
-            comp_contrib<WT, ISO>(a.f[n], g, cfa, hi, hj, val, acc);
+            comp_contrib<WT, ISO>(a.f[n], g, cfa, hi, hj, val, acc, lmin);
 #pragma unroll
             for (int k = 0; k < 3; ++k) {  // same float32 order as successive `num += val`
                 n3[k] += val[k];
@@ -519,6 +537,44 @@ __global__ void __launch_bounds__(256) k_merge_burst(BurstArgs a, Geo g, Cfa4 cf
         num[o + k] = (a.flags & HHSR_MERGE_DIVIDE) ? n3[k] / d3[k] : n3[k];
         if (a.flags & HHSR_MERGE_STORE_DEN) den[o + k] = d3[k];
     }
+}
+
+template <typename WT, int GEOM, bool ISO>
+__global__ void __launch_bounds__(256) k_merge_burst(BurstArgs a, Geo g, Cfa4 cfa, float* __restrict__ num,
+                                                      float* __restrict__ den) {
+    const int hj = blockIdx.x * 64 + (threadIdx.x & 63), hi = g.row0 + blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (hj >= g.sW || hi >= g.row1) return;
+    if (owns_lr_pixel(a, hi, hj)) {
+        const Pix p = make_pix(g, hi, hj);
+        float racc = (a.flags & HHSR_MERGE_LOAD_ACC) ? a.acc_r[p.ridx] : 0.f;
+        for (int n = 0; n < a.n; ++n) racc += a.f[n].r[p.ridx];
+        a.acc_r[p.ridx] = racc;
+    }
+    if (sizeof(WT) == 4 && border_pixel(g, hi, hj)) return;  // k_merge_border's
+    merge_pixel<WT, GEOM, ISO>(a, g, cfa, hi, hj, num, den);
+}
+
+// The border bands (see border_pixel) with the reference's float64 weight chain.  Threads enumerate the bt + bb full
+// rows first, then the bl + br columns of the rows in between (no pixel twice: LOAD_ACC reads what it overwrites).
+template <bool ISO>
+__global__ void __launch_bounds__(256) k_merge_border(BurstArgs a, Geo g, Cfa4 cfa, float* __restrict__ num,
+                                                       float* __restrict__ den) {
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    const int nrow = g.bt + g.bb, ncol = g.bl + g.br, mid = g.sH - nrow;
+    int hi, hj;
+    if (t < nrow * g.sW) {
+        const int r = t / g.sW;
+        hj = t - r * g.sW;
+        hi = r < g.bt ? r : g.sH - g.bb + (r - g.bt);
+    } else {
+        const int u = t - nrow * g.sW;
+        if (ncol == 0 || u >= mid * ncol) return;
+        const int r = u / ncol, c = u - r * ncol;
+        hi = g.bt + r;
+        hj = c < g.bl ? c : g.sW - g.br + (c - g.bl);
+    }
+    if (hi < g.row0 || hi >= g.row1) return;
+    merge_pixel<double, GEOM_F64, ISO>(a, g, cfa, hi, hj, num, den);
 }
 
 // ---- host entry points ----------------------------------------------------------------------------------
@@ -639,6 +695,7 @@ __global__ void __launch_bounds__(256) k_merge_burst_tile(BurstArgs a, Geo g, Cf
     if (!live) return;
     if (owns_lr_pixel(a, hi, hj))
         a.acc_r[p.ridx] = ((a.flags & HHSR_MERGE_LOAD_ACC) ? a.acc_r[p.ridx] : 0.f) + racc;
+    if (border_pixel(g, hi, hj)) return;  // k_merge_border's
     const size_t o = ((size_t)(hi - g.row0) * g.sW + hj) * 3;
     float n3[3] = {0.f, 0.f, 0.f}, d3[3] = {0.f, 0.f, 0.f};
     if (a.flags & HHSR_MERGE_LOAD_ACC) {
@@ -667,12 +724,13 @@ __global__ void __launch_bounds__(256) k_merge_burst_tile(BurstArgs a, Geo g, Cf
 // taps_accum are shared), so results are bit-identical to it.
 constexpr int QT = 16;  // LR workgroup edge
 
+// Body of the first-generation x2 kernel: general per-pixel geometry, any window position.  s_raw: >= RWIN * RPITCH
+// floats, s_cov: >= CWIN * CWIN float4, s_R: >= (QT + 4) * (QT + 5) floats (LMIN).
 template <bool ISO, bool LMIN>
-__global__ void __launch_bounds__(256) k_merge_burst_quad(BurstArgs a, Geo g, Cfa4 cfa, float* __restrict__ num,
-                                                           float* __restrict__ den) {
-    __shared__ float s_raw[RWIN * RPITCH];
-    __shared__ float4 s_cov[CWIN * CWIN];
-    __shared__ float s_R[LMIN ? QT + 4 : 1][QT + 4 + 1];  // LMIN: un-filtered robustness of the tile + 2-pixel border
+__device__ __forceinline__ void quad_tile_body(const BurstArgs& a, const Geo& g, const Cfa4 cfa, float* __restrict__ num,
+                                               float* __restrict__ den, float* __restrict__ s_raw,
+                                               float4* __restrict__ s_cov, float* __restrict__ s_Rf) {
+    float (*s_R)[QT + 4 + 1] = reinterpret_cast<float (*)[QT + 4 + 1]>(s_Rf);
     const int tx = threadIdx.x & (QT - 1), ty = threadIdx.x >> 4;
     const int nbx = gridDim.x, nblk = gridDim.x * gridDim.y;
     int bid = blockIdx.y * nbx + blockIdx.x;
@@ -793,6 +851,7 @@ __global__ void __launch_bounds__(256) k_merge_burst_quad(BurstArgs a, Geo g, Cf
 #pragma unroll
         for (int sb = 0; sb < 2; ++sb) {
             const int hi = 2 * ly + sa, hj = 2 * lx + sb;
+            if (border_pixel(g, hi, hj)) continue;  // k_merge_border's
             const size_t o = ((size_t)(hi - g.row0) * g.sW + hj) * 3;
             float n3[3] = {0.f, 0.f, 0.f}, d3[3] = {0.f, 0.f, 0.f};
             if (a.flags & HHSR_MERGE_LOAD_ACC) {
@@ -812,6 +871,354 @@ __global__ void __launch_bounds__(256) k_merge_burst_quad(BurstArgs a, Geo g, Cf
         }
 }
 
+template <bool ISO, bool LMIN>
+__global__ void __launch_bounds__(256) k_merge_burst_quad(BurstArgs a, Geo g, Cfa4 cfa, float* __restrict__ num,
+                                                           float* __restrict__ den) {
+    __shared__ float s_raw[RWIN * RPITCH];
+    __shared__ float4 s_cov[CWIN * CWIN];
+    __shared__ float s_R[LMIN ? (QT + 4) * (QT + 4 + 1) : 1];  // LMIN: un-filtered robustness of the tile + 2-pixel border
+    quad_tile_body<ISO, LMIN>(a, g, cfa, num, den, s_raw, s_cov, s_R);
+}
+
+// ---- x2, second generation: one WAVE per Bayer parity class --------------------------------------------------------
+// Same tile as k_merge_burst_quad (16 x 16 LR = 32 x 32 HR pixels inside one flow tile, one thread per LR pixel = its
+// 2 x 2 HR pixels), but wave w of the workgroup owns the 8 x 8 LR pixels of ONE parity class (row parity w >> 1, column
+// parity w & 1).  With the flow shared by the tile, everything that depends on sub-pixel position and parity is then
+// wave-uniform per frame — window-centre offsets, tap distances dx / dy, the covariance cell offset and its bilinear
+// weights, the CFA class of every tap — and the per-pixel work shrinks to: 3 rows of the raw window (aligned
+// ds_read_b64 pairs), 4 covariance cells blended with uniform weights, one inverse, 9 x (2 FMA + min + v_exp_f32 + FMA
+// + add), and 8 FMAs into the parity-class accumulators behind a uniform 4-way branch: 216 -> ~110 VALU instructions
+// per output pixel and frame.  The reference frame (Alg. 11) runs through the same code as one more "frame" with its own
+// uniform geometry (position idx / scale without the half pixel, D7; round-half-even centre; identity fallback of the
+// inverse).  Tiles in which ANY window leaves the image (the image perimeter, or flows larger than the distance to it)
+// run the general per-pixel body of the first-generation kernel instead — decided once per tile by a lane-parallel
+// scan of the frames' flow vectors.
+//   * weights are exp2 of the -0.5 log2(e)-scaled quadratic form in ONE v_exp_f32 (no e * e: the border bands, where
+//     denormal weights matter, belong to k_merge_border);
+//   * the raw window is staged twice, the second copy shifted by one column, so that every sub-pixel of every parity
+//     class reads 8-byte aligned pairs (stride-2 dword reads would be 2-way bank conflicts);
+//   * the finished 32 x 32 x 3 tile goes through LDS and leaves as whole 16-byte vectors in 384-byte row segments
+//     (the per-thread dword stores of the first kernel wrote 1.42 x the output bytes).
+constexpr int X2_RP = 24;   // raw / R window pitch in floats: rows are read with stride 2 -> 48 dwords = 16 (mod 32) banks
+constexpr int X2_CP = 24;   // covariance window pitch in float4: 96 dwords = 32 (mod 64) banks for ds_read_b128
+constexpr int X2_OP = 100;  // output tile pitch in floats (96 + 4: rows stay 16-byte aligned)
+constexpr float X2_KEXP = -0.72134752044448170368f;  // -0.5 * log2(e)
+constexpr int X2_WIN = QT + 3;                        // 19 x 19 raw window
+
+// LDS reads as exactly the instruction written: the compiler narrows a float4 whose .z is unused into ds_read2_b32
+// (cells are 4 dwords apart: 4-way bank conflicts), narrows a half-used pair to a stride-2 ds_read_b32 (2-way) and
+// merges neighbouring pairs into ds_read2_b64 (8 LDS cycles instead of 2 x 2) — measured with tools/ubench/lds_patterns:
+// 444 LDS cycles per wave and frame instead of ~200, more than half of them bank conflicts.  Volatile keeps the access
+// width; the loads are still scheduled and waited for by the compiler (unlike inline asm).
+typedef float hhsr_v2f __attribute__((ext_vector_type(2)));
+typedef float hhsr_v4f __attribute__((ext_vector_type(4)));
+#define HHSR_LDS __attribute__((address_space(3)))
+__device__ __forceinline__ float2 lds_pair(const float* p) {  // p: 8-byte aligned LDS address
+    const hhsr_v2f v = *(const volatile HHSR_LDS hhsr_v2f*)p;
+    return make_float2(v.x, v.y);
+}
+__device__ __forceinline__ float4 lds_quad(const float4* p) {  // p: LDS address
+    const hhsr_v4f v = *(const volatile HHSR_LDS hhsr_v4f*)p;
+    return make_float4(v.x, v.y, v.z, v.w);
+}
+
+struct X2Axis {       // wave-uniform geometry of one axis of one frame
+    int org;          // raw coordinate of window index 0
+    int e[2];         // first tap of sub-pixel s sits at window index t + e[s] (t = the LR pixel's index in the tile)
+    float d0[2];      // centre tap minus sampling position (taps_accum's dx0 / dy0)
+    int oc[2];        // covariance cell of sub-pixel s = l + oc[s] in the staged cell window (l = lj or li)
+    float f[2];       // its bilinear fraction
+};
+
+// comp frame (merge.py:319-361): position (h + 0.5)/2 + flow; frame_geom<GEOM_P2> per sub-pixel, bit for bit
+__device__ __forceinline__ int x2_comp_org(float fl, int l0) {
+    const float fi = floorf(fl);
+    return l0 + (int)fi + (int)(fl >= fi + 0.75f) - 1;
+}
+__device__ __forceinline__ X2Axis x2_comp_axis(float fl, int l0, int p) {
+    X2Axis u;
+    const float fi = floorf(fl);
+    const int c0 = fl >= fi + 0.75f, c1 = fl >= fi + 0.25f;  // exact, see frame_geom<GEOM_P2>
+    u.org = l0 + (int)fi + c0 - 1;
+    u.e[0] = 0;
+    u.e[1] = c1 - c0;
+    const float fr0 = (fl - fi) + (0.25f - (float)c0), fr1 = (fl - fi) + (0.75f - (float)c1);
+    u.d0[0] = 0.5f - fr0;
+    u.d0[1] = 0.5f - fr1;
+    // covariance cell x0 = (cj - 1) >> 1, fraction 0.5 ((cj - 1) & 1 + fr), cj - 1 = org + t + e; window origin org >> 1
+    const int m0 = (u.org & 1) + p, m1 = m0 + u.e[1];
+    u.oc[0] = m0 >> 1;
+    u.oc[1] = m1 >> 1;
+    u.f[0] = 0.5f * ((float)(m0 & 1) + fr0);
+    u.f[1] = 0.5f * ((float)(m1 & 1) + fr1);
+    return u;
+}
+// reference frame (merge.py:113-114, 179-202; ref_accum_fast): position h / 2 = l + s / 2, centre = round-half-even,
+// covariance position (pos - 0.5) / 2 with floor + signed fraction; staged with org = l0 - 1, cell origin (l0 - 1) >> 1
+__device__ __forceinline__ X2Axis x2_ref_axis(int l0, int p) {
+    X2Axis u;
+    u.org = l0 - 1;
+    u.e[0] = 0;
+    u.e[1] = p;                      // l + 0.5 rounds to the even neighbour: l (even l) or l + 1 (odd l)
+    u.d0[0] = 0.f;
+    u.d0[1] = p ? 0.5f : -0.5f;
+    u.oc[0] = p;                     // cell of (l - 0.5) / 2:       l even: l/2 - 1 (f 0.75), l odd: (l-1)/2 (f 0.25)
+    u.oc[1] = 1;                     // cell of l / 2:               l even: l/2 (f 0),        l odd: (l-1)/2 (f 0.5)
+    u.f[0] = p ? 0.25f : 0.75f;
+    u.f[1] = p ? 0.5f : 0.f;
+    return u;
+}
+
+template <bool ISO, bool LMIN>
+__global__ void __launch_bounds__(256, 4) k_merge_x2(BurstArgs a, Geo g, Cfa4 cfa, float* __restrict__ num,
+                                                   float* __restrict__ den) {
+    __shared__ __align__(16) float s_rawA[20 * X2_RP];              // window[y][x]
+    __shared__ __align__(16) float s_rawB[20 * X2_RP];              // window[y][x + 1]
+    __shared__ float4 s_cov[CWIN * X2_CP];
+    __shared__ __align__(16) float s_R[20 * X2_RP];                 // LMIN: un-filtered robustness, tile + 2-pixel border
+    __shared__ __align__(16) float s_out[32 * X2_OP];
+    const int tid = threadIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;  // readfirstlane: known wave-uniform
+    const int nbx = gridDim.x, nblk = gridDim.x * gridDim.y;
+    const int bid = xcd_remap(blockIdx.y * nbx + blockIdx.x, nblk);
+    const int lx0 = (bid % nbx) * QT, ly0 = (g.row0 >> 1) + (bid / nbx) * QT;  // LR origin of the workgroup
+    const int lrow1 = g.row1 >> 1;
+    const int tile = (ly0 / g.ts) * g.nx + lx0 / g.ts;
+
+    // ---- can the whole tile take the uniform path?  every window of every frame inside the image -------------------
+    bool ok = lx0 + QT <= g.W && ly0 + QT <= lrow1;
+    if ((a.flags & HHSR_MERGE_DO_REF) && !(lx0 >= 1 && lx0 + QT + 2 <= g.W && ly0 >= 1 && ly0 + QT + 2 <= g.H)) ok = false;
+    if (ok && lane < a.n) {
+        const float2 fl = a.f[lane].flow[tile];
+        const int ox = x2_comp_org(fl.x, lx0), oy = x2_comp_org(fl.y, ly0);
+        ok = ox >= 0 && ox + X2_WIN <= g.W && oy >= 0 && oy + X2_WIN <= g.H;  // NaN flow: (int) of NaN is checked too
+        ok = ok && fl.x == fl.x && fl.y == fl.y;
+    }
+    if (!__all(ok)) {  // wave-uniform, identical in the four waves
+        quad_tile_body<ISO, LMIN>(a, g, cfa, num, den, s_rawA, s_cov, s_R);
+        return;
+    }
+
+    const int py = wave >> 1, px = wave & 1;                        // this wave's parity class
+    const int li = lane >> 3, lj = lane & 7;
+    const int ty = 2 * li + py, tx = 2 * lj + px;                   // LR pixel inside the tile
+    const int ridx = (ly0 + ty) * g.W + lx0 + tx;
+    float n4[2][2][2][2], d4[2][2][2][2];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+        (&n4[0][0][0][0])[k] = 0.f;
+        (&d4[0][0][0][0])[k] = 0.f;
+    }
+    float racc = 0.f;
+
+    // staging slots (by thread id, independent of the pixel mapping)
+    constexpr int rwin = X2_WIN, cwin = QT / 2 + 3;  // 19 raw pixels, 11 covariance cells
+    const int e0 = tid, e1 = tid + 256;
+    const int e0y = e0 / rwin, e0x = e0 - e0y * rwin, e1y = e1 / rwin, e1x = e1 - e1y * rwin;
+    const int cey = tid / cwin, cex = tid - cey * cwin;
+    const bool has1 = e1 < rwin * rwin, hasc = tid < cwin * cwin;
+    constexpr int RW = QT + 4;
+    const int m0y = tid / RW, m0x = tid - m0y * RW;
+    const int m1 = tid + 256, m1y = m1 / RW, m1x = m1 - m1y * RW;
+    const bool hasm1 = LMIN && m1 < RW * RW;
+    const int moff0 = clampi(ly0 - 2 + m0y, 0, g.H - 1) * g.W + clampi(lx0 - 2 + m0x, 0, g.W - 1);
+    const int moff1 = clampi(ly0 - 2 + m1y, 0, g.H - 1) * g.W + clampi(lx0 - 2 + m1x, 0, g.W - 1);
+    const int nloop = a.n + ((a.flags & HHSR_MERGE_DO_REF) ? 1 : 0);  // the reference frame is the last "frame"
+    float pr0 = 0.f, pr1 = 0.f, plr = 0.f, plr1 = 0.f;
+    float4 pc = make_float4(0.f, 0.f, 0.f, 0.f);
+    float2 pfl = make_float2(0.f, 0.f);
+    auto prefetch = [&](int n) {  // all windows are inside the image (checked above): no bounds tests
+        const bool isref = n >= a.n;
+        const float* __restrict__ raw = isref ? a.ref_raw : a.f[n].raw;
+        const float4* __restrict__ cov = isref ? a.ref_cov : a.f[n].cov;
+        int ox = lx0 - 1, oy = ly0 - 1;
+        if (!isref) {
+            pfl = a.f[n].flow[tile];
+            ox = x2_comp_org(pfl.x, lx0);
+            oy = x2_comp_org(pfl.y, ly0);
+        }
+        pr0 = raw[(size_t)(oy + e0y) * g.pitch + ox + e0x];
+        if (has1) pr1 = raw[(size_t)(oy + e1y) * g.pitch + ox + e1x];
+        if (!ISO && hasc) pc = cov[(size_t)min((oy >> 1) + cey, g.gh - 1) * g.gw + min((ox >> 1) + cex, g.gw - 1)];
+        if (!isref) {
+            if (LMIN) {
+                plr = a.f[n].r[moff0];
+                if (hasm1) plr1 = a.f[n].r[moff1];
+            } else {
+                plr = a.f[n].r[ridx];
+            }
+        }
+    };
+
+    const float* __restrict__ rbase = s_R + ty * X2_RP + 2 * lj;
+    const int cbase = li * X2_CP + lj;
+
+    if (nloop > 0) prefetch(0);
+    for (int n = 0; n < nloop; ++n) {
+        const bool isref = n >= a.n;  // uniform
+        __syncthreads();  // the previous frame's taps are done with the LDS windows
+        s_rawA[e0y * X2_RP + e0x] = pr0;
+        if (e0x > 0) s_rawB[e0y * X2_RP + e0x - 1] = pr0;
+        if (has1) {
+            s_rawA[e1y * X2_RP + e1x] = pr1;
+            if (e1x > 0) s_rawB[e1y * X2_RP + e1x - 1] = pr1;
+        }
+        if (!ISO && hasc) s_cov[cey * X2_CP + cex] = pc;
+        if (LMIN && !isref) {
+            s_R[m0y * X2_RP + m0x] = plr;
+            if (hasm1) s_R[m1y * X2_RP + m1x] = plr1;
+        }
+        const float2 fl = pfl;
+        float local_r = isref ? 1.f : plr;
+        __syncthreads();
+        if (n + 1 < nloop) prefetch(n + 1);  // in flight while this frame's taps are evaluated
+        if (LMIN && !isref) {  // 5 x 5 minimum over rows ty .. ty + 4, columns tx .. tx + 4 of the R window
+            float m = 3.0e38f;
+#pragma unroll
+            for (int r = 0; r < 5; ++r) {
+                const float2 v01 = lds_pair(rbase + r * X2_RP), v23 = lds_pair(rbase + r * X2_RP + 2);
+                const float2 v45 = lds_pair(rbase + r * X2_RP + 4);
+                const float edge = px ? v45.y : v01.x;
+                m = fminf(m, fminf(fminf(v01.y, v23.x), fminf(v23.y, fminf(v45.x, edge))));
+            }
+            local_r = m;
+        }
+        if (!isref) racc += local_r;
+        if (local_r == 0.f) continue;
+        const X2Axis ax = isref ? x2_ref_axis(lx0, px) : x2_comp_axis(fl.x, lx0, px);
+        const X2Axis ay = isref ? x2_ref_axis(ly0, py) : x2_comp_axis(fl.y, ly0, py);
+#pragma unroll
+        for (int sa = 0; sa < 2; ++sa)
+#pragma unroll
+            for (int sb = 0; sb < 2; ++sb) {
+                float ixx = 2.f * X2_KEXP, ixy = 0.f, iyy = 2.f * X2_KEXP;
+                if (!ISO) {
+                    const int ca = cbase + ay.oc[sa] * X2_CP + ax.oc[sb];
+                    const float4 c00 = lds_quad(s_cov + ca), c01 = lds_quad(s_cov + ca + 1);
+                    const float4 c10 = lds_quad(s_cov + ca + X2_CP), c11 = lds_quad(s_cov + ca + X2_CP + 1);
+                    const float gx = ax.f[sb], gy = ay.f[sa];
+                    const float w11 = gx * gy, w01 = gx - w11, w10 = gy - w11, w00 = (1.f - gx) - w10;
+                    const float cxx = fmaf(w11, c11.x, fmaf(w10, c10.x, fmaf(w01, c01.x, w00 * c00.x)));
+                    const float cxy = fmaf(w11, c11.y, fmaf(w10, c10.y, fmaf(w01, c01.y, w00 * c00.y)));
+                    const float cyy = fmaf(w11, c11.w, fmaf(w10, c10.w, fmaf(w01, c01.w, w00 * c00.w)));
+                    const float det = fmaf(cxx, cyy, -(cxy * cxy));
+                    const float s1 = __builtin_amdgcn_rcpf(det) * X2_KEXP;
+                    ixx = s1 * cyy;
+                    ixy = (-2.f * s1) * cxy;
+                    iyy = s1 * cxx;
+                    if (isref && !(fabsf(det) > 1e-10f)) {  // linalg.py:53-64: identity (also for NaN, D10)
+                        ixx = X2_KEXP;
+                        ixy = 0.f;
+                        iyy = X2_KEXP;
+                    }
+                }
+                // the 3 x 3 taps: rows ty + e .. + 2, columns tx + e .. + 2 of the window, as aligned pairs from the
+                // copy whose shift makes column tx + e even
+                const int mcol = px + ax.e[sb];  // 0, 1, 2
+                const float* __restrict__ rp = ((mcol & 1) ? s_rawB : s_rawA) + (ty + ay.e[sa]) * X2_RP + 2 * lj + (mcol & 2);
+                const float dx0 = ax.d0[sb], dy0 = ay.d0[sa];
+                const float dxs[3] = {dx0 - 1.f, dx0, dx0 + 1.f};
+                float sv[2][2], sd[2][2];  // by parity of the tap offset (di + 1, dj + 1)
+#pragma unroll
+                for (int di = 0; di < 3; ++di) {
+                    const float2 v01 = lds_pair(rp + di * X2_RP), v23 = lds_pair(rp + di * X2_RP + 2);
+                    const float c3[3] = {v01.x, v01.y, v23.x};
+                    const float dy = dy0 + (float)(di - 1);
+                    const float qa = iyy * dy * dy, qb = ixy * dy;
+#pragma unroll
+                    for (int dj = 0; dj < 3; ++dj) {
+                        const float dx = dxs[dj];
+                        const float z = fminf(fmaf(fmaf(ixx, dx, qb), dx, qa), 0.f);  // min: NaN -> 0 -> w = 1 (D10)
+                        const float w = __builtin_amdgcn_exp2f(z);
+                        if (di < 2 && dj < 2) {  // first tap of its parity class (row-major order)
+                            sv[di & 1][dj & 1] = w * c3[dj];
+                            sd[di & 1][dj & 1] = w;
+                        } else {
+                            sv[di & 1][dj & 1] = fmaf(w, c3[dj], sv[di & 1][dj & 1]);
+                            sd[di & 1][dj & 1] += w;
+                        }
+                    }
+                }
+                // tap-offset parity -> absolute raw-coordinate parity (uniform): n4[a][b] += r * sv[a ^ by][b ^ bx]
+                const int by = (ay.org + py + ay.e[sa]) & 1, bx = (ax.org + px + ax.e[sb]) & 1;
+#define HHSR_FOLD(BY, BX)                                                                             \
+    _Pragma("unroll") for (int aa = 0; aa < 2; ++aa) _Pragma("unroll") for (int bb = 0; bb < 2; ++bb) { \
+        n4[sa][sb][aa][bb] = fmaf(local_r, sv[aa ^ BY][bb ^ BX], n4[sa][sb][aa][bb]);                  \
+        d4[sa][sb][aa][bb] = fmaf(local_r, sd[aa ^ BY][bb ^ BX], d4[sa][sb][aa][bb]);                  \
+    }
+                // (the empty asm statements keep the four arms real branches: if-converted, the permutation costs 16
+                // v_cndmask per sub-pixel, twice the FMAs it feeds;
+                // and distinct, so that the FMAs are not sunk below the arms leaving 8 permutation moves in each)
+                if (by) {
+                    if (bx) { asm volatile("; fold 11"); HHSR_FOLD(1, 1) asm volatile("; end 11"); }
+                    else { asm volatile("; fold 10"); HHSR_FOLD(1, 0) asm volatile("; end 10"); }
+                } else {
+                    if (bx) { asm volatile("; fold 01"); HHSR_FOLD(0, 1) asm volatile("; end 01"); }
+                    else { asm volatile("; fold 00"); HHSR_FOLD(0, 0) asm volatile("; end 00"); }
+                }
+#undef HHSR_FOLD
+            }
+    }
+    if (a.acc_r) a.acc_r[ridx] = ((a.flags & HHSR_MERGE_LOAD_ACC) ? a.acc_r[ridx] : 0.f) + racc;
+    // ---- epilogue: CFA classes -> RGB, normalise, store -----------------------------------------------------------------
+    const int ly = ly0 + ty, lx = lx0 + tx;
+    if (a.flags & HHSR_MERGE_LOAD_ACC) {
+        // chained launches (bursts longer than one launch, multi-GPU finish): per-pixel read-modify-write; the border
+        // bands keep their input for k_merge_border
+#pragma unroll
+        for (int sa = 0; sa < 2; ++sa)
+#pragma unroll
+            for (int sb = 0; sb < 2; ++sb) {
+                const int hi = 2 * ly + sa, hj = 2 * lx + sb;
+                if (border_pixel(g, hi, hj)) continue;
+                const size_t o = ((size_t)(hi - g.row0) * g.sW + hj) * 3;
+                float n3[3], d3[3];
+#pragma unroll
+                for (int k = 0; k < 3; ++k) {
+                    n3[k] = num[o + k];
+                    d3[k] = den[o + k];
+                }
+                classes_to_rgb(cfa, n4[sa][sb], d4[sa][sb], n3, d3);
+#pragma unroll
+                for (int k = 0; k < 3; ++k) {
+                    num[o + k] = (a.flags & HHSR_MERGE_DIVIDE) ? n3[k] / d3[k] : n3[k];
+                    if (a.flags & HHSR_MERGE_STORE_DEN) den[o + k] = d3[k];
+                }
+            }
+        return;
+    }
+    // whole tile through LDS: rows of 96 floats leave as float4 (k_merge_border overwrites the border bands afterwards)
+    const int npass = (a.flags & HHSR_MERGE_STORE_DEN) ? 2 : 1;
+    for (int pass = 0; pass < npass; ++pass) {
+        if (pass) __syncthreads();
+#pragma unroll
+        for (int sa = 0; sa < 2; ++sa) {
+            float v[2][3];
+#pragma unroll
+            for (int sb = 0; sb < 2; ++sb) {
+                float n3[3] = {0.f, 0.f, 0.f}, d3[3] = {0.f, 0.f, 0.f};
+                classes_to_rgb(cfa, n4[sa][sb], d4[sa][sb], n3, d3);
+#pragma unroll
+                for (int k = 0; k < 3; ++k)
+                    v[sb][k] = pass ? d3[k] : ((a.flags & HHSR_MERGE_DIVIDE) ? n3[k] / d3[k] : n3[k]);
+            }
+            float* row = s_out + (2 * ty + sa) * X2_OP + 6 * tx;
+            *reinterpret_cast<float2*>(row) = make_float2(v[0][0], v[0][1]);
+            *reinterpret_cast<float2*>(row + 2) = make_float2(v[0][2], v[1][0]);
+            *reinterpret_cast<float2*>(row + 4) = make_float2(v[1][1], v[1][2]);
+        }
+        __syncthreads();
+        float* __restrict__ dst = pass ? den : num;
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+            const int qd = tid + 256 * r;
+            const int orow = qd / 24, oc = (qd - orow * 24) * 4;
+            *reinterpret_cast<float4*>(dst + ((size_t)(2 * ly0 + orow - g.row0) * g.sW + 2 * lx0) * 3 + oc) =
+                *reinterpret_cast<const float4*>(s_out + orow * X2_OP + oc);
+        }
+    }
+}
+
 static bool scale_is_pow2(double s) {  // 1, 2, 4, 8: (h + 0.5)/s is exact in float32
     return s == 1.0 || s == 2.0 || s == 4.0 || s == 8.0;
 }
@@ -820,7 +1227,24 @@ static int fill_geo(Geo& g, int H, int W, int pitch, int ny, int nx, int ts, dou
     g.H = H; g.W = W; g.pitch = pitch; g.gh = H / 2; g.gw = W / 2;
     g.ny = ny; g.nx = nx; g.ts = ts; g.sH = sH; g.sW = sW; g.scale = scale;
     g.row0 = 0; g.row1 = sH;
+    // border bands: output rows / columns whose reference-window centre rint(float(idx / scale)) (merge.py:113-114,
+    // 179-180) is the first or last raw row / column
+    auto bands = [scale](int n_lr, int n_hr, int& lo, int& hi) {
+        lo = 0;
+        while (lo < n_hr && (int)rintf((float)((double)lo / scale)) <= 0) ++lo;
+        hi = 0;
+        while (hi < n_hr - lo && (int)rintf((float)((double)(n_hr - 1 - hi) / scale)) >= n_lr - 1) ++hi;
+    };
+    bands(H, sH, g.bt, g.bb);
+    bands(W, sW, g.bl, g.br);
     return 0;
+}
+
+// the border bands of a float32 launch, with the float64 chain (after the main kernel, same stream)
+template <class Launch>
+static void launch_border(const Geo& g, Launch launch) {
+    const int64_t n = (int64_t)(g.bt + g.bb) * g.sW + (int64_t)(g.bl + g.br) * (g.sH - g.bt - g.bb);
+    if (n > 0) launch(dim3((unsigned)((n + 255) / 256)), dim3(256));
 }
 
 
@@ -912,15 +1336,37 @@ extern "C" int hhsr_merge_burst(const float* const* raws, const float* const* fl
     const dim3 grid(hhsr_cdiv(sW, 64), hhsr_cdiv(nrows, 4)), block(256);
     hipStream_t s = (hipStream_t)stream;
     const bool p2 = scale_is_pow2(scale);
-    // LDS-staged kernel: integer scale, 16-px HR workgroups inside one flow tile, windows fit the LDS arrays
+    // kernel choice.  LDS-staged tile kernel: integer scale, 16-px HR workgroups inside one flow tile, windows fit the
+    // LDS arrays; x2 kernels: one thread per LR pixel (4 HR pixels), 32 x 32 HR workgroups inside one flow tile.
+    // kflags HHSR_MERGE_FORCE_* (validation / A-B measurements) restrict the choice; the environment variables
+    // HHSR_MERGE_NO_LDS / _NO_QUAD / _X2_V1 do the same for a whole process and are read once.
+    static const int env_force = (getenv("HHSR_MERGE_NO_LDS") ? HHSR_MERGE_FORCE_GENERIC : 0) |
+                                 (getenv("HHSR_MERGE_NO_QUAD") ? HHSR_MERGE_FORCE_TILE : 0) |
+                                 (getenv("HHSR_MERGE_X2_V1") ? HHSR_MERGE_FORCE_X2V1 : 0);
+    const int force = kflags | env_force;
     const int iscale = (int)scale;
     const bool tiled = !f64 && (double)iscale == scale && iscale >= 1 && ((int64_t)ts * iscale) % MT == 0 &&
-                       n_frames > 0 && row0 % MT == 0 && !getenv("HHSR_MERGE_NO_LDS");
-    // x2: one thread per LR pixel (4 HR pixels), 32 x 32 HR workgroups inside one flow tile
+                       n_frames > 0 && row0 % MT == 0 && !(force & HHSR_MERGE_FORCE_GENERIC);
     const bool lmin = (flags & HHSR_MERGE_LOCAL_MIN) != 0;
     const bool quad = tiled && p2 && iscale == 2 && ts % QT == 0 && sW == 2 * W && sH == 2 * H && row0 % (2 * QT) == 0 &&
-                      nrows % 2 == 0 && !getenv("HHSR_MERGE_NO_QUAD");
-    if (quad) {
+                      nrows % 2 == 0 && !(force & HHSR_MERGE_FORCE_TILE);
+    const bool x2_v1 = (force & HHSR_MERGE_FORCE_X2V1) != 0;
+    if (lmin && !quad) {
+        hhsr_set_error("hhsr_merge_burst: HHSR_MERGE_LOCAL_MIN needs the x2 kernel (scale 2, ts %% 16 == 0, "
+                       "sH = 2 H, sW = 2 W, row0 %% 32 == 0, float32 weights)");
+        return -3;
+    }
+    const bool aligned16 = ((uintptr_t)num % 16 == 0) && (!(flags & HHSR_MERGE_STORE_DEN) || (uintptr_t)den % 16 == 0);
+    if (quad && !x2_v1 && aligned16) {
+        const dim3 qgrid(hhsr_cdiv(W, QT), hhsr_cdiv(nrows / 2, QT));
+        if (lmin) {
+            if (iso) hipLaunchKernelGGL((k_merge_x2<true, true>), qgrid, block, 0, s, a, g, c, num, den);
+            else hipLaunchKernelGGL((k_merge_x2<false, true>), qgrid, block, 0, s, a, g, c, num, den);
+        } else {
+            if (iso) hipLaunchKernelGGL((k_merge_x2<true, false>), qgrid, block, 0, s, a, g, c, num, den);
+            else hipLaunchKernelGGL((k_merge_x2<false, false>), qgrid, block, 0, s, a, g, c, num, den);
+        }
+    } else if (quad) {
         const dim3 qgrid(hhsr_cdiv(W, QT), hhsr_cdiv(nrows / 2, QT));
         if (lmin) {
             if (iso) hipLaunchKernelGGL((k_merge_burst_quad<true, true>), qgrid, block, 0, s, a, g, c, num, den);
@@ -929,25 +1375,23 @@ extern "C" int hhsr_merge_burst(const float* const* raws, const float* const* fl
             if (iso) hipLaunchKernelGGL((k_merge_burst_quad<true, false>), qgrid, block, 0, s, a, g, c, num, den);
             else hipLaunchKernelGGL((k_merge_burst_quad<false, false>), qgrid, block, 0, s, a, g, c, num, den);
         }
-        HHSR_LAUNCHED();
-    }
-    if (lmin) {
-        hhsr_set_error("hhsr_merge_burst: HHSR_MERGE_LOCAL_MIN needs the x2 kernel (scale 2, ts %% 16 == 0, "
-                       "sH = 2 H, sW = 2 W, row0 %% 32 == 0, float32 weights)");
-        return -3;
-    }
-    if (tiled) {
+    } else if (tiled) {
         const dim3 tgrid(hhsr_cdiv(sW, MT), hhsr_cdiv(nrows, MT));
 #define HHSR_MT(GEOM, ISO) hipLaunchKernelGGL((k_merge_burst_tile<GEOM, ISO>), tgrid, block, 0, s, a, g, c, num, den)
         if (p2) { if (iso) HHSR_MT(GEOM_P2, true); else HHSR_MT(GEOM_P2, false); }
         else { if (iso) HHSR_MT(GEOM_F64, true); else HHSR_MT(GEOM_F64, false); }
 #undef HHSR_MT
-        HHSR_LAUNCHED();
-    }
+    } else {
 #define HHSR_MB(WT, GEOM, ISO) hipLaunchKernelGGL((k_merge_burst<WT, GEOM, ISO>), grid, block, 0, s, a, g, c, num, den)
-    if (f64) { if (iso) HHSR_MB(double, GEOM_F64, true); else HHSR_MB(double, GEOM_F64, false); }
-    else if (p2) { if (iso) HHSR_MB(float, GEOM_P2, true); else HHSR_MB(float, GEOM_P2, false); }
-    else { if (iso) HHSR_MB(float, GEOM_F64, true); else HHSR_MB(float, GEOM_F64, false); }
+        if (f64) { if (iso) HHSR_MB(double, GEOM_F64, true); else HHSR_MB(double, GEOM_F64, false); }
+        else if (p2) { if (iso) HHSR_MB(float, GEOM_P2, true); else HHSR_MB(float, GEOM_P2, false); }
+        else { if (iso) HHSR_MB(float, GEOM_F64, true); else HHSR_MB(float, GEOM_F64, false); }
 #undef HHSR_MB
+    }
+    if (!f64)  // the border bands the float32 kernels skipped, with the reference's float64 weight chain
+        launch_border(g, [&](dim3 bgrid, dim3 bblock) {
+            if (iso) hipLaunchKernelGGL((k_merge_border<true>), bgrid, bblock, 0, s, a, g, c, num, den);
+            else hipLaunchKernelGGL((k_merge_border<false>), bgrid, bblock, 0, s, a, g, c, num, den);
+        });
     HHSR_LAUNCHED();
 }

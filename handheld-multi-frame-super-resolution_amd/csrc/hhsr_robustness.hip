@@ -605,8 +605,9 @@ extern "C" int hhsr_rob_frame(const float* comp_means, int lh, int lw, const flo
     HHSR_ARG(lh > 0 && lw > 0 && ts > 0 && ncurve > 0);
     const int H = 2 * lh, W = 2 * lw;
     HHSR_ARG(ny * ts >= H && nx * ts >= W);
+    static const bool no_row4 = getenv("HHSR_ROB_NO_ROW4") != nullptr;  // read once
     const bool vec4 = W % 4 == 0 && (((uintptr_t)ref_means | (uintptr_t)ref_sigma_sq | (uintptr_t)ref_curve_index |
-                                      (uintptr_t)R) & 15) == 0 && !getenv("HHSR_ROB_NO_ROW4");
+                                      (uintptr_t)R) & 15) == 0 && !no_row4;
     if (ts % RF_T == 0 && ref_curve_index && ncurve <= 1024 && vec4)
         hipLaunchKernelGGL(k_rob_frame_row4, dim3(hhsr_cdiv(W, RF_BX), hhsr_cdiv(H, RF_BY)), dim3(256), 0,
                            (hipStream_t)stream, comp_means, lh, lw, ref_means, ref_sigma_sq, ref_curve_index,

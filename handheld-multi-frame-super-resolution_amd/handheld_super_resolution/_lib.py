@@ -86,8 +86,9 @@ def version():
     return load().hhsr_version().decode()
 
 
-def stream():
-    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+def stream(device=None):
+    """torch's current HIP stream on `device` (default: the current device) as a hipStream_t."""
+    return C.c_void_p(torch.cuda.current_stream(device).cuda_stream)
 
 
 def ptr(t):
@@ -131,8 +132,14 @@ def ptr_array(tensors):
 
 
 def f32c(t, device=None):
-    """float32 contiguous GPU tensor from a tensor / ndarray."""
+    """float32 contiguous GPU tensor from a tensor / ndarray.  Host data is uploaded on torch's CURRENT stream without
+    blocking the host when it is page-locked (pinned tensors / arrays registered by the caller): the frame pipeline
+    calls this on the frame's side stream, so the upload of one frame overlaps the kernels of the others (the
+    reference uploads synchronously, twice per frame: super_resolution.py:141,145).  Pageable host
+    memory goes through the runtime's staging copy — correct, but the host thread waits for it."""
     if not isinstance(t, torch.Tensor):
         t = torch.as_tensor(t)
     dev = device if device is not None else (t.device if t.is_cuda else torch.device("cuda", torch.cuda.current_device()))
-    return t.to(device=dev, dtype=torch.float32).contiguous()
+    if not t.is_cuda and t.dtype not in (torch.float32, torch.float64, torch.float16, torch.bfloat16):
+        t = t.to(torch.float32)
+    return t.to(device=dev, non_blocking=True).to(dtype=torch.float32).contiguous()

@@ -1,17 +1,31 @@
 """Alg. 4 / Alg. 11 accumulation (reference merge.py) plus the fused burst merge."""
+import os
+
 import torch
 
 from . import _lib
 
 
+# kflags of the C ABI (include/hhsr.h)
+KERNEL_ISO, WEIGHT_F64, FORCE_GENERIC, FORCE_TILE, FORCE_X2V1 = 1, 2, 4, 8, 16
+_FORCE = {"auto": 0, "generic": FORCE_GENERIC, "tile": FORCE_TILE, "x2_v1": FORCE_X2V1}
+# process-wide A/B switches, read once like the library reads them
+_ENV_FORCE = ((FORCE_GENERIC if os.environ.get("HHSR_MERGE_NO_LDS") else 0) |
+              (FORCE_TILE if os.environ.get("HHSR_MERGE_NO_QUAD") else 0) |
+              (FORCE_X2V1 if os.environ.get("HHSR_MERGE_X2_V1") else 0))
+
+
 def _common(config):
     """(scale, kflags): bit 0 = iso kernel, bit 1 = float64 weight chain (config.hip.weight_fp64, the
-    reference's Numba typing; default float32 weights with float64 geometry)."""
+    reference's Numba typing; default float32 weights with float64 geometry), bits 2-4 = restriction of
+    hhsr_merge_burst's kernel choice (config.hip.merge_kernel: auto | generic | tile | x2_v1; validation only)."""
     if config.mode != "bayer":
         raise NotImplementedError("grey mode is outside the MI355X hot path (bayer only)")
     hip = config.get("hip", None) if hasattr(config, "get") else None
     f64 = bool(hip.get("weight_fp64", False)) if hip is not None else False
-    return float(config.scale), (1 if config.merging.kernel == "iso" else 0) | (2 if f64 else 0)
+    force = _FORCE[str(hip.get("merge_kernel", "auto"))] if hip is not None else 0
+    return float(config.scale), ((KERNEL_ISO if config.merging.kernel == "iso" else 0) | (WEIGHT_F64 if f64 else 0) |
+                                 force | _ENV_FORCE)
 
 
 def merge(comp_img, alignments, covs, r, num, den, cfa_pattern, config):
@@ -50,15 +64,12 @@ def can_fuse_acc_r(config):
 
 
 def can_fuse_local_min(config, shape):
-    """merge_burst can take the thresholded maps R and apply the 5x5 local minimum itself (the x2 kernel:
+    """merge_burst can take the thresholded maps R and apply the 5x5 local minimum itself (the x2 kernels:
     scale 2, tile size a multiple of 16, float32 weights) — mirrors the test in hhsr_merge_burst."""
-    import os
-
     scale, kflags = _common(config)
     H, W = shape
-    return (scale == 2.0 and not (kflags & 2) and int(config.block_matching.tuning.tile_size) % 16 == 0 and
-            H % 2 == 0 and W % 2 == 0 and not os.environ.get("HHSR_MERGE_NO_QUAD") and
-            not os.environ.get("HHSR_MERGE_NO_LDS"))
+    return (scale == 2.0 and not (kflags & (WEIGHT_F64 | FORCE_GENERIC | FORCE_TILE)) and
+            int(config.block_matching.tuning.tile_size) % 16 == 0 and H % 2 == 0 and W % 2 == 0)
 
 
 def merge_burst(frames, ref_img, ref_kernels, num, den, cfa_pattern, config, load_acc=False, do_ref=True,

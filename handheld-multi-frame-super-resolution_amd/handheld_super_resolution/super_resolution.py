@@ -64,8 +64,15 @@ class BurstPipeline:
         self.grey_method = config.grey_method
         self.ref = None
         self._streams = _stream_pool.setdefault(self.device.index, [])
+        hip = config.get("hip", None) if hasattr(config, "get") else None
+        # validation hook (bench.py's parity attribution, tests): per-frame flow fields that replace align()
+        self._inject_flows = hip.get("inject_flows", None) if hip is not None else None
 
     def init_ref(self, ref_img):
+        with torch.cuda.device(self.device):  # every launch below goes to this device's current stream
+            return self._init_ref(ref_img)
+
+    def _init_ref(self, ref_img):
         cfg = self.config
         main = torch.cuda.current_stream(self.device)
         self._entry = torch.cuda.Event()  # everything the caller enqueued before (e.g. the frames' upload) is done
@@ -88,7 +95,7 @@ class BurstPipeline:
         self._ref_ready.record(main)
         return self
 
-    def process_frame(self, img, accumulate_r=None, wait_ref=None, fuse_local_min=False):
+    def process_frame(self, img, accumulate_r=None, wait_ref=None, fuse_local_min=False, index=None):
         """grey -> kernels -> align -> robustness for one comp frame; returns (raw, flow, covs, r).
         `accumulate_r`: optional float32 [H, W] that receives += r (fused into the local-min pass).
         `wait_ref`: event after which the reference-frame state is complete — the frame's own grey image and
@@ -100,7 +107,10 @@ class BurstPipeline:
         pyramid = build_gaussian_pyramid(grey, cfg.block_matching.tuning.factors)
         if wait_ref is not None:
             torch.cuda.current_stream(self.device).wait_event(wait_ref)
-        flow = align(*self.align_state, grey, cfg, moving_pyramid=pyramid)
+        if self._inject_flows is not None and index is not None:
+            flow = _lib.f32c(self._inject_flows[index], self.device)
+        else:
+            flow = align(*self.align_state, grey, cfg, moving_pyramid=pyramid)
         if cfg.robustness.enabled:  # guide means + kernel covariances from one pass over the raw frame
             means, _, covs = frame_stats(raw, self.cfa, self.wb, cfg)
         else:
@@ -120,25 +130,36 @@ class BurstPipeline:
         bound coarse pyramid levels of one frame overlap the bandwidth-bound kernels of another.  The caller's
         stream waits for all of them before returning.  A per-frame `accumulate_r` (read-modify-write of one
         map) forces a single stream."""
+        with torch.cuda.device(self.device):
+            return self._process_frames(comp_imgs, accumulate_r, n_streams, fuse_local_min)
+
+    def _process_frames(self, comp_imgs, accumulate_r, n_streams, fuse_local_min):
         n = len(comp_imgs)
         if n_streams is None:
             hip = self.config.get("hip", None) if hasattr(self.config, "get") else None
             n_streams = int(hip.get("streams", DEFAULT_STREAMS)) if hip is not None else DEFAULT_STREAMS
         if n_streams <= 1 or accumulate_r is not None or n < 2:
-            return [self.process_frame(img, accumulate_r, fuse_local_min=fuse_local_min) for img in comp_imgs]
+            return [self.process_frame(img, accumulate_r, fuse_local_min=fuse_local_min, index=i)
+                    for i, img in enumerate(comp_imgs)]
         main = torch.cuda.current_stream(self.device)
         if len(self._streams) < n_streams:
             self._streams += [torch.cuda.Stream(self.device) for _ in range(n_streams - len(self._streams))]
         pool = self._streams[:n_streams]
+        # everything the caller enqueued so far (frame uploads / normalisation, a previous call's merge that still
+        # reads buffers the allocator may hand out again) is ordered before the side streams' work
+        entry = torch.cuda.Event()
+        entry.record(main)
+        for s in pool:
+            s.wait_event(entry)
         frames = []
         for i in range(n):
             s = pool[i % n_streams]
-            if i < n_streams:
-                s.wait_event(self._entry)  # the caller's earlier work (frame upload, previous burst) is done
             with torch.cuda.stream(s):
-                f = self.process_frame(comp_imgs[i], wait_ref=self._ref_ready, fuse_local_min=fuse_local_min)
-            for t in f[1:]:
-                t.record_stream(main)  # consumed by the merge on the caller's stream
+                f = self.process_frame(comp_imgs[i], wait_ref=self._ref_ready, fuse_local_min=fuse_local_min, index=i)
+            for t in f:
+                if t is not None:
+                    t.record_stream(main)  # consumed by the merge on the caller's stream (raw too: it is allocated
+                    # on the side stream when the frame was uploaded / converted there)
             frames.append(f)
         for s in pool:
             main.wait_stream(s)
@@ -200,7 +221,7 @@ def main(ref_img, comp_imgs, config):
             torch.cuda.synchronize()
             print("\nProcessing image {} ---------\n".format(im_id + 1))
             im_time = time.perf_counter()
-        raw, flow, covs, r = pipe.process_frame(comp_imgs[im_id], None if fuse_acc else accumulated_r)
+        raw, flow, covs, r = pipe.process_frame(comp_imgs[im_id], None if fuse_acc else accumulated_r, index=im_id)
         if fused:
             frames.append((raw, flow, covs, r))
         else:

@@ -24,17 +24,19 @@ class _GreyPlan:
             pass
 
 
-_grey_plans = {}
+_grey_plans = {}  # (H, W, device, stream) -> plan, least recently used first
+_GREY_PLAN_CACHE = 16  # e.g. 4 streams x 2 image sizes (bench.py: full size, then the parity crop) x 2 devices
 
 
 def _grey_plan(H, W, device):
     key = (H, W, device.index, torch.cuda.current_stream(device).cuda_stream)
-    p = _grey_plans.get(key)
+    p = _grey_plans.pop(key, None)
     if p is None:
-        if len(_grey_plans) >= 8:
-            _grey_plans.clear()
+        while len(_grey_plans) >= _GREY_PLAN_CACHE:  # evict the least recently used plan only
+            _grey_plans.pop(next(iter(_grey_plans)))
         with torch.cuda.device(device):
-            p = _grey_plans[key] = _GreyPlan(H, W)
+            p = _GreyPlan(H, W)
+    _grey_plans[key] = p  # most recently used last
     return p
 
 
@@ -49,7 +51,8 @@ def compute_grey_images(img, method):
     if method == "FFT":
         # planned rocFFT round trip inside libhhsr_hip.so: r2c -> Hermitian mask (+ normalisation) -> c2r
         out = torch.empty_like(img)
-        _lib.call("hhsr_grey_lowpass", _grey_plan(H, W, img.device).handle, _lib.ptr(img), _lib.ptr(out), _lib.stream())
+        _lib.call("hhsr_grey_lowpass", _grey_plan(H, W, img.device).handle, _lib.ptr(img), _lib.ptr(out),
+                  _lib.stream(img.device))
         return out
     if method == "FFT_torch":  # same maths through torch.fft (rocFFT behind torch), kept for cross-checking
         spec = torch.fft.rfft2(img)

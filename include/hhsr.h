@@ -167,6 +167,10 @@ int hhsr_local_min5(const float* R, int H, int W, float* r, float* acc_r, void* 
 #define HHSR_KERNEL_ISO 1   /* merging.kernel == "iso": w = exp(-(dx^2+dy^2)) instead of the steerable kernel */
 #define HHSR_WEIGHT_F64 2   /* evaluate covariance interpolation / weights in float64 like the reference's
                                Numba typing (validation mode; default = float32 weights, float64 geometry) */
+/* hhsr_merge_burst only — restrict its kernel choice (validation, A/B measurements; default: fastest applicable): */
+#define HHSR_MERGE_FORCE_GENERIC 4  /* no LDS staging: one thread per HR pixel, operands from global memory     */
+#define HHSR_MERGE_FORCE_TILE 8     /* no x2 kernel: the 16 x 16 HR tile kernel                                  */
+#define HHSR_MERGE_FORCE_X2V1 16    /* x2: first-generation kernel (per-pixel geometry) instead of k_merge_x2    */
 
 /* ---- merge, Alg. 4 / Alg. 11 (merge.py; utils.py:62-120) --------------------------------------
  * hhsr_accumulate: one comp frame, num/den += (merge.py:291-434).
@@ -196,8 +200,8 @@ int hhsr_add(float* A, const float* B, int64_t n, void* stream);          /* A +
 #define HHSR_MERGE_STORE_DEN 8  /* also store den                                            */
 #define HHSR_MERGE_LOCAL_MIN 16 /* rs[] hold the thresholded maps R of hhsr_rob_frame; their 5x5 clamp-border minimum
                                    (robustness.py:641-686, hhsr_local_min5) is taken inside the merge.  Only with the
-                                   x2 kernel: scale 2, ts % 16 == 0, sH = 2 H, sW = 2 W, row0 % 32 == 0, float32
-                                   weights, HHSR_MERGE_NO_QUAD unset; error -3 otherwise.                        */
+                                   x2 kernels: scale 2, ts % 16 == 0, sH = 2 H, sW = 2 W, row0 % 32 == 0, float32
+                                   weights, no HHSR_MERGE_FORCE_GENERIC / _TILE; error -3 otherwise.             */
 int hhsr_merge_burst(const float* const* raws, const float* const* flows, const float* const* covs,
                      const float* const* rs, int n_frames, int H, int W, int pitch,
                      int ny, int nx, int ts, const float* ref_raw, const float* ref_covs,

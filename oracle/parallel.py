@@ -1,0 +1,109 @@
+"""Oracle on all host cores: the comp frames of a burst are independent until their contributions are summed
+(reference super_resolution.py:133-173; merge.py:432-434), so one worker process per frame computes
+(flow, r, kernels, that frame's num/den contribution) with the single-frame functions of this package and the parent
+adds the contributions in frame order — the same float32 additions, in the same order, as the sequential
+``oracle.main`` (bit-identical output; checked in tests/test_oracle_kat.py).
+
+Test infrastructure (the ``cpu_baseline`` leg of bench.py and the full-size parity tests); never product code."""
+import multiprocessing as mp
+import os
+
+import numpy as np
+
+from .grey import compute_grey_images
+from .align import init_alignment, align
+from .robustness import init_robustness, compute_robustness
+from .kernels import estimate_kernels
+from .merge import merge, merge_ref, divide
+
+F32 = np.float32
+_state = {}
+
+
+def _init(ref, comp_imgs, config):
+    # one NumPy / BLAS thread per worker: the parallelism is over frames
+    for var in ("OMP_NUM_THREADS", "OPENBLAS_NUM_THREADS", "MKL_NUM_THREADS"):
+        os.environ[var] = "1"
+    try:
+        import torch
+
+        torch.set_num_threads(1)
+    except Exception:
+        pass
+    cfa = np.array(config.exif.cfa_pattern)
+    wb = np.array(config.exif.white_balance, dtype=np.float64)
+    grey_ref = compute_grey_images(ref, config.grey_method)
+    _state.update(ref=ref, comp=comp_imgs, config=config, cfa=cfa, wb=wb, align=init_alignment(grey_ref, config),
+                  rob=init_robustness(ref, cfa, wb, config),
+                  curves=(np.array(config.noise_model.std_curve, np.float64),
+                          np.array(config.noise_model.diff_curve, np.float64)))
+
+
+def _frame(n):
+    s = _state
+    cfg, img = s["config"], s["comp"][n]
+    grey = compute_grey_images(img, cfg.grey_method)
+    flow = align(*s["align"], grey, cfg)
+    r = compute_robustness(img, *s["rob"], flow, s["cfa"], s["wb"], s["curves"], cfg)
+    covs = estimate_kernels(img, cfg)
+    H, W = img.shape
+    osz = (round(cfg.scale * H), round(cfg.scale * W))
+    num = np.zeros((*osz, 3), F32)
+    den = np.zeros((*osz, 3), F32)
+    merge(img, flow, covs, r, num, den, s["cfa"], cfg)
+    return n, flow, r, num, den
+
+
+def main_parallel(ref_img, comp_imgs, config, workers=None, capture=None):
+    """Same result as ``oracle.main(ref_img, comp_imgs, config)`` (bit for bit), computed by ``workers`` processes
+    (default: all host cores, at most one per comp frame).  Returns (output, debug_dict, workers_used)."""
+    if config.mode != "bayer":
+        raise NotImplementedError("grey mode is out of scope")
+    ref = np.asarray(ref_img, dtype=F32)
+    comp_imgs = np.asarray(comp_imgs, dtype=F32)
+    n = comp_imgs.shape[0]
+    workers = max(1, min(workers or os.cpu_count() or 1, max(n, 1)))
+    accumulate_r = bool(config.accumulated_robustness_denoiser.enabled or config.robustness.save_mask)
+    H, W = ref.shape
+    osz = (round(config.scale * H), round(config.scale * W))
+    num = np.zeros((*osz, 3), F32)
+    den = np.zeros((*osz, 3), F32)
+    acc_r = np.zeros((H, W), np.float64) if accumulate_r else None
+    debug = {"robustness": [], "flow": []}
+    if capture is not None:
+        capture.update(flow=[None] * n, r=[None] * n)
+    results = {}
+    if n:
+        if workers == 1:
+            _init(ref, comp_imgs, config)
+            it = map(_frame, range(n))
+        else:
+            ctx = mp.get_context("fork")  # workers inherit the burst; nothing is pickled on the way in
+            pool = ctx.Pool(workers, initializer=_init, initargs=(ref, comp_imgs, config))
+            it = pool.imap_unordered(_frame, range(n))
+        for k, flow, r, nk, dk in it:
+            results[k] = (flow, r, nk, dk)
+            while len(results) and min(results) == len(debug["flow"]):  # consume in frame order
+                i = min(results)
+                flow_i, r_i, nk_i, dk_i = results.pop(i)
+                num += nk_i
+                den += dk_i
+                if accumulate_r:
+                    acc_r += r_i
+                debug["flow"].append(flow_i)
+                debug["robustness"].append(r_i)
+                if capture is not None:
+                    capture["flow"][i], capture["r"][i] = flow_i, r_i
+        if workers > 1:
+            pool.close()
+            pool.join()
+        assert not results and len(debug["flow"]) == n
+    cfa = np.array(config.exif.cfa_pattern)
+    covs = estimate_kernels(ref, config)
+    merge_ref(ref, covs, num, den, cfa, config, acc_r if accumulate_r else None)
+    divide(num, den)
+    if not config.debug:
+        debug = {"robustness": [], "flow": []}
+    if accumulate_r:
+        debug["accumulated robustness"] = acc_r
+    return num, debug, workers

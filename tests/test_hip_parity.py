@@ -441,45 +441,101 @@ def _frames(H, W, n, ts, seed, cfg):
 
 
 @pytest.mark.parametrize("kern", ["handheld", "iso"])
-def test_merge_x2_quad_kernel_equals_tile_kernel(monkeypatch, kern):
-    """scale 2: the one-thread-per-LR-pixel kernel (k_merge_burst_quad) == the 16x16 HR tile kernel, bit for bit,
-    including the fused accumulated robustness, partial launches and an image that is not a tile multiple."""
+def test_merge_x2_kernels_equal_tile_kernel(kern):
+    """scale 2: the first-generation one-thread-per-LR-pixel kernel == the 16x16 HR tile kernel bit for bit; the
+    wave-per-parity-class kernel k_merge_x2 (uniform geometry, weighted covariance blend, single v_exp_f32) to 2e-5
+    relative — including the fused accumulated robustness, partial (chained) launches, a frame pushed partly out of
+    the image and an image that is not a tile multiple (general per-pixel body inside k_merge_x2)."""
     H, W, ts = 72, 104, 16
-    cfg = base_config(ts=ts, scale=2)
-    cfg.merging.kernel = kern
-    ref, fr = _frames(H, W, 4, ts, 77, cfg)
+    ref, fr = _frames(H, W, 4, ts, 77, base_config(ts=ts, scale=2))
     fr[1] = (fr[1][0], fr[1][1] + 9.5, fr[1][2], fr[1][3])  # a frame pushed partly out of the image
     cfa = [[2, 1], [1, 0]]
     tf = [tuple(T(a) for a in f) for f in fr]
-    rc = T(oracle.estimate_kernels(ref, cfg))
 
-    def run():
+    def cfg_for(which):
+        c = base_config(ts=ts, scale=2)
+        c.merging.kernel = kern
+        c.hip = {"merge_kernel": which}
+        return c
+
+    rc = T(oracle.estimate_kernels(ref, cfg_for("auto")))
+
+    def run(which, chained=True):
+        cfg = cfg_for(which)
         out, den = torch.empty(2 * H, 2 * W, 3, device=DEV), torch.empty(2 * H, 2 * W, 3, device=DEV)
         acc = torch.zeros(H, W, device=DEV)
-        merge.merge_burst(tf[:2], None, None, out, den, cfa, cfg, do_ref=False, divide=False, store_den=True, acc_r=acc)
-        merge.merge_burst(tf[2:], T(ref), rc, out, den, cfa, cfg, load_acc=True, acc_r=acc)
+        if chained:
+            merge.merge_burst(tf[:2], None, None, out, den, cfa, cfg, do_ref=False, divide=False, store_den=True, acc_r=acc)
+            merge.merge_burst(tf[2:], T(ref), rc, out, den, cfa, cfg, load_acc=True, acc_r=acc)
+        else:
+            merge.merge_burst(tf, T(ref), rc, out, None, cfa, cfg, acc_r=acc)
         return N(out), N(acc)
 
-    out_q, acc_q = run()
-    monkeypatch.setenv("HHSR_MERGE_NO_QUAD", "1")
-    out_t, acc_t = run()
-    assert_close(out_q, out_t, 0, 0, "quad vs tile kernel")
-    assert_close(acc_q, acc_t, 0, 0, "quad vs tile accumulated robustness")
+    out_t, acc_t = run("tile")
+    out_q, acc_q = run("x2_v1")
+    assert_close(out_q, out_t, 0, 0, "x2_v1 vs tile kernel")
+    assert_close(acc_q, acc_t, 0, 0, "x2_v1 vs tile accumulated robustness")
     assert_close(acc_q, sum(f[3] for f in fr), 1e-6, 1e-6, "accumulated robustness")
+    for chained in (True, False):
+        out_x, acc_x = run("auto", chained)
+        assert_close(out_x, out_t, 2e-5, 1e-6, f"k_merge_x2 vs tile kernel (chained={chained})")
+        if chained:  # same association (r0 + r1) + (r2 + r3)
+            assert_close(acc_x, acc_t, 0, 0, "k_merge_x2 vs tile accumulated robustness")
+        else:
+            assert_close(acc_x, acc_t, 1e-6, 1e-6, "k_merge_x2 accumulated robustness, one launch")
+    # num / den partial sums of the vectorised store path (multi-GPU ranks)
+    cfg = cfg_for("auto")
+    pn, pd = torch.empty(2 * H, 2 * W, 3, device=DEV), torch.empty(2 * H, 2 * W, 3, device=DEV)
+    merge.merge_burst(tf, None, None, pn, pd, cfa, cfg, do_ref=False, divide=False, store_den=True)
+    tn, td = torch.empty_like(pn), torch.empty_like(pd)
+    merge.merge_burst(tf, None, None, tn, td, cfa, cfg_for("tile"), do_ref=False, divide=False, store_den=True)
+    assert_close(N(pn), N(tn), 2e-5, 1e-7, "partial num")
+    assert_close(N(pd), N(td), 2e-5, 1e-7, "partial den")
     # 5x5 local minimum of the robustness taken inside the merge == hhsr_local_min5 followed by the merge
-    monkeypatch.delenv("HHSR_MERGE_NO_QUAD")
-    assert merge.can_fuse_local_min(cfg, (H, W))
-    tf_min = [(f[0], f[1], f[2], robustness.local_min(f[3])) for f in tf]
-    want, acc_w = torch.empty(2 * H, 2 * W, 3, device=DEV), torch.zeros(H, W, device=DEV)
-    merge.merge_burst(tf_min, T(ref), rc, want, None, cfa, cfg, acc_r=acc_w)
-    got, acc_g = torch.empty(2 * H, 2 * W, 3, device=DEV), torch.zeros(H, W, device=DEV)
-    merge.merge_burst(tf, T(ref), rc, got, None, cfa, cfg, acc_r=acc_g, local_min=True)
-    assert_close(N(got), N(want), 0, 0, "fused local minimum")
-    assert_close(N(acc_g), N(acc_w), 0, 0, "fused local minimum, accumulated robustness")
+    for which in ("auto", "x2_v1"):
+        cfg = cfg_for(which)
+        assert merge.can_fuse_local_min(cfg, (H, W))
+        tf_min = [(f[0], f[1], f[2], robustness.local_min(f[3])) for f in tf]
+        want, acc_w = torch.empty(2 * H, 2 * W, 3, device=DEV), torch.zeros(H, W, device=DEV)
+        merge.merge_burst(tf_min, T(ref), rc, want, None, cfa, cfg, acc_r=acc_w)
+        got, acc_g = torch.empty(2 * H, 2 * W, 3, device=DEV), torch.zeros(H, W, device=DEV)
+        merge.merge_burst(tf, T(ref), rc, got, None, cfa, cfg, acc_r=acc_g, local_min=True)
+        assert_close(N(got), N(want), 0, 0, f"fused local minimum ({which})")
+        assert_close(N(acc_g), N(acc_w), 0, 0, f"fused local minimum, accumulated robustness ({which})")
+    assert not merge.can_fuse_local_min(cfg_for("tile"), (H, W))
     cfg3 = base_config(ts=ts, scale=3)
     assert not merge.can_fuse_local_min(cfg3, (H, W))
     with pytest.raises(RuntimeError):
         merge.merge_burst(tf, T(ref), rc, torch.empty(3 * H, 3 * W, 3, device=DEV), None, cfa, cfg3, local_min=True)
+
+
+def test_merge_border_bands_float64_chain():
+    """The border bands (reference window centred on the outermost raw row / column) are computed with the reference's
+    float64 weight chain by k_merge_border: identical to the float64 validation mode there, for every float32 kernel,
+    with and without the fused local minimum — a colour whose only samples have denormal weights is num / den of two
+    denormals in the reference (merge.py:419-434), not 0 / 0."""
+    H, W, ts = 64, 80, 16
+    for scale in (2, 3, 1.5):
+        c64 = base_config(ts=ts, scale=scale)
+        c64.hip = {"weight_fp64": True}
+        ref, fr = _frames(H, W, 3, ts, 5, c64)
+        tf = [tuple(T(a) for a in f) for f in fr]
+        rc = T(oracle.estimate_kernels(ref, c64))
+        sH, sW = round(scale * H), round(scale * W)
+        want = torch.empty(sH, sW, 3, device=DEV)
+        merge.merge_burst(tf, T(ref), rc, want, None, [[0, 1], [1, 2]], c64)
+        want = N(want)
+        band = np.zeros((sH, sW), bool)
+        nb = int(np.ceil(scale))  # at least the rows / columns whose window centre is row / column 0 or H-1 / W-1
+        band[:1], band[-nb:], band[:, :1], band[:, -nb:] = True, True, True, True
+        for which in (["auto", "x2_v1", "tile", "generic"] if scale == 2 else ["auto", "generic"]):
+            c = base_config(ts=ts, scale=scale)
+            c.hip = {"merge_kernel": which}
+            got = torch.empty(sH, sW, 3, device=DEV)
+            merge.merge_burst(tf, T(ref), rc, got, None, [[0, 1], [1, 2]], c)
+            got = N(got)
+            assert_close(got[band], want[band], 0, 0, f"border band x{scale} {which}")
+            assert_close(got, want, 2e-5, 1e-6, f"interior x{scale} {which}")
 
 
 def test_merge_burst_more_frames_than_one_launch_holds():
@@ -536,8 +592,11 @@ def test_merge_burst_equals_sequential(scale):
     merge.merge_burst(tf[1::2], None, None, nB, dB, cfa, cfg, do_ref=False, divide=False, store_den=True)
     nS, dS = nA + nB, dA + dB
     merge.merge_burst([], T(ref), rc, nS, dS, cfa, cfg, load_acc=True, do_ref=True, divide=False, store_den=True)
-    assert_close(N(nS), N(num_seq), 1e-6, 1e-7, "sharded num")
-    assert_close(N(dS), N(den_seq), 1e-6, 1e-7, "sharded den")
+    # (x2: k_merge_x2 blends the covariances with bilinear weights and takes one v_exp_f32 per tap — 2e-5 relative
+    # to the per-frame kernel, the merge tolerance; the other scales share the per-frame kernel's arithmetic)
+    tol = (2e-5, 1e-7) if scale == 2 else (1e-6, 1e-7)
+    assert_close(N(nS), N(num_seq), *tol, "sharded num")
+    assert_close(N(dS), N(den_seq), *tol, "sharded den")
     # and against the oracle
     onum, oden = np.zeros((oh, ow, 3), np.float32), np.zeros((oh, ow, 3), np.float32)
     for f in fr:

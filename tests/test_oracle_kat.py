@@ -75,3 +75,23 @@ def test_hr_pixels_missing_a_colour_are_nan():
     out, _ = oracle.main(ref, comp, cfg)
     assert np.isnan(out[:, -1, 0]).any() or np.isnan(out[-1, :, 0]).any()
     assert np.isfinite(out[16:-16, 16:-16]).all()
+
+
+def test_parallel_oracle_is_bit_identical_to_sequential():
+    """oracle.main_parallel (one worker process per frame, contributions added in frame order — the all-cores CPU
+    baseline of bench.py) == oracle.main, bit for bit, including the accumulated robustness."""
+    ref, comp, _ = synth.make_burst(128, 160, 4, seed=11, max_shift=2.0, occluder=True)
+    def cfg0():
+        c = base_config(ts=16, scale=2)
+        c.block_matching.tuning.factors = [1, 2, 2, 2]
+        c.robustness.save_mask = True
+        return c
+    want, wdbg = oracle.main(ref, comp, cfg0())
+    cap = {}
+    got, gdbg, used = oracle.main_parallel(ref, comp, cfg0(), workers=3, capture=cap)
+    assert used == 3
+    assert np.array_equal(got, want, equal_nan=True)
+    assert np.array_equal(gdbg["accumulated robustness"], wdbg["accumulated robustness"])
+    assert len(cap["flow"]) == 3 and all(f is not None for f in cap["flow"])
+    got1, _, used1 = oracle.main_parallel(ref, comp, cfg0(), workers=1)
+    assert used1 == 1 and np.array_equal(got1, want, equal_nan=True)
