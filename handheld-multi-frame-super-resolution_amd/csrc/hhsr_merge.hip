@@ -899,6 +899,12 @@ __global__ void __launch_bounds__(256) k_merge_burst_quad(BurstArgs a, Geo g, Cf
 //     class reads 8-byte aligned pairs (stride-2 dword reads would be 2-way bank conflicts);
 //   * the finished 32 x 32 x 3 tile goes through LDS and leaves as whole 16-byte vectors in 384-byte row segments
 //     (the per-thread dword stores of the first kernel wrote 1.42 x the output bytes).
+#ifndef HHSR_X2_DB
+#define HHSR_X2_DB 0   // 1: double-buffered LDS windows, one barrier per frame (A/B measured: see DESIGN.md)
+#endif
+#ifndef HHSR_X2_OCC
+#define HHSR_X2_OCC 4  // waves per SIMD the register allocation of k_merge_x2 is held to (128 VGPRs)
+#endif
 constexpr int X2_RP = 24;   // raw / R window pitch in floats: rows are read with stride 2 -> 48 dwords = 16 (mod 32) banks
 constexpr int X2_CP = 24;   // covariance window pitch in float4: 96 dwords = 32 (mod 64) banks for ds_read_b128
 constexpr int X2_OP = 100;  // output tile pitch in floats (96 + 4: rows stay 16-byte aligned)
@@ -970,12 +976,14 @@ __device__ __forceinline__ X2Axis x2_ref_axis(int l0, int p) {
 }
 
 template <bool ISO, bool LMIN>
-__global__ void __launch_bounds__(256, 4) k_merge_x2(BurstArgs a, Geo g, Cfa4 cfa, float* __restrict__ num,
+__global__ void __launch_bounds__(256, HHSR_X2_OCC) k_merge_x2(BurstArgs a, Geo g, Cfa4 cfa, float* __restrict__ num,
                                                    float* __restrict__ den) {
-    __shared__ __align__(16) float s_rawA[20 * X2_RP];              // window[y][x]
-    __shared__ __align__(16) float s_rawB[20 * X2_RP];              // window[y][x + 1]
-    __shared__ float4 s_cov[CWIN * X2_CP];
-    __shared__ __align__(16) float s_R[20 * X2_RP];                 // LMIN: un-filtered robustness, tile + 2-pixel border
+    constexpr int NB = HHSR_X2_DB ? 2 : 1;                           // window buffers (2: one barrier per frame)
+    constexpr int RAWSZ = 20 * X2_RP, COVSZ = CWIN * X2_CP;
+    __shared__ __align__(16) float s_rawA[NB * RAWSZ];              // window[y][x]
+    __shared__ __align__(16) float s_rawB[NB * RAWSZ];              // window[y][x + 1]
+    __shared__ float4 s_cov[NB * COVSZ];
+    __shared__ __align__(16) float s_R[NB * RAWSZ];                 // LMIN: un-filtered robustness, tile + 2-pixel border
     __shared__ __align__(16) float s_out[32 * X2_OP];
     const int tid = threadIdx.x;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;  // readfirstlane: known wave-uniform
@@ -1053,38 +1061,39 @@ __global__ void __launch_bounds__(256, 4) k_merge_x2(BurstArgs a, Geo g, Cfa4 cf
     const float* __restrict__ rbase = s_R + ty * X2_RP + 2 * lj;
     const int cbase = li * X2_CP + lj;
 
-    if (nloop > 0) prefetch(0);
-    for (int n = 0; n < nloop; ++n) {
-        const bool isref = n >= a.n;  // uniform
-        __syncthreads();  // the previous frame's taps are done with the LDS windows
-        s_rawA[e0y * X2_RP + e0x] = pr0;
-        if (e0x > 0) s_rawB[e0y * X2_RP + e0x - 1] = pr0;
+    // write the prefetched registers of one frame into window buffer `bo`; returns that frame's flow / robustness
+    float2 sfl = make_float2(0.f, 0.f);
+    float sr = 0.f;
+    auto stage = [&](int n, int bo) {
+        const bool isref = n >= a.n;
+        s_rawA[bo * RAWSZ + e0y * X2_RP + e0x] = pr0;
+        if (e0x > 0) s_rawB[bo * RAWSZ + e0y * X2_RP + e0x - 1] = pr0;
         if (has1) {
-            s_rawA[e1y * X2_RP + e1x] = pr1;
-            if (e1x > 0) s_rawB[e1y * X2_RP + e1x - 1] = pr1;
+            s_rawA[bo * RAWSZ + e1y * X2_RP + e1x] = pr1;
+            if (e1x > 0) s_rawB[bo * RAWSZ + e1y * X2_RP + e1x - 1] = pr1;
         }
-        if (!ISO && hasc) s_cov[cey * X2_CP + cex] = pc;
+        if (!ISO && hasc) s_cov[bo * COVSZ + cey * X2_CP + cex] = pc;
         if (LMIN && !isref) {
-            s_R[m0y * X2_RP + m0x] = plr;
-            if (hasm1) s_R[m1y * X2_RP + m1x] = plr1;
+            s_R[bo * RAWSZ + m0y * X2_RP + m0x] = plr;
+            if (hasm1) s_R[bo * RAWSZ + m1y * X2_RP + m1x] = plr1;
         }
-        const float2 fl = pfl;
-        float local_r = isref ? 1.f : plr;
-        __syncthreads();
-        if (n + 1 < nloop) prefetch(n + 1);  // in flight while this frame's taps are evaluated
+        sfl = pfl;
+        sr = isref ? 1.f : plr;
+    };
+    auto frame = [&](const bool isref, const float2 fl, float local_r, const int bo) {
         if (LMIN && !isref) {  // 5 x 5 minimum over rows ty .. ty + 4, columns tx .. tx + 4 of the R window
             float m = 3.0e38f;
 #pragma unroll
             for (int r = 0; r < 5; ++r) {
-                const float2 v01 = lds_pair(rbase + r * X2_RP), v23 = lds_pair(rbase + r * X2_RP + 2);
-                const float2 v45 = lds_pair(rbase + r * X2_RP + 4);
+                const float2 v01 = lds_pair(rbase + bo * RAWSZ + r * X2_RP), v23 = lds_pair(rbase + bo * RAWSZ + r * X2_RP + 2);
+                const float2 v45 = lds_pair(rbase + bo * RAWSZ + r * X2_RP + 4);
                 const float edge = px ? v45.y : v01.x;
                 m = fminf(m, fminf(fminf(v01.y, v23.x), fminf(v23.y, fminf(v45.x, edge))));
             }
             local_r = m;
         }
         if (!isref) racc += local_r;
-        if (local_r == 0.f) continue;
+        if (local_r == 0.f) return;
         const X2Axis ax = isref ? x2_ref_axis(lx0, px) : x2_comp_axis(fl.x, lx0, px);
         const X2Axis ay = isref ? x2_ref_axis(ly0, py) : x2_comp_axis(fl.y, ly0, py);
 #pragma unroll
@@ -1094,8 +1103,8 @@ __global__ void __launch_bounds__(256, 4) k_merge_x2(BurstArgs a, Geo g, Cfa4 cf
                 float ixx = 2.f * X2_KEXP, ixy = 0.f, iyy = 2.f * X2_KEXP;
                 if (!ISO) {
                     const int ca = cbase + ay.oc[sa] * X2_CP + ax.oc[sb];
-                    const float4 c00 = lds_quad(s_cov + ca), c01 = lds_quad(s_cov + ca + 1);
-                    const float4 c10 = lds_quad(s_cov + ca + X2_CP), c11 = lds_quad(s_cov + ca + X2_CP + 1);
+                    const float4 c00 = lds_quad(s_cov + bo * COVSZ + ca), c01 = lds_quad(s_cov + bo * COVSZ + ca + 1);
+                    const float4 c10 = lds_quad(s_cov + bo * COVSZ + ca + X2_CP), c11 = lds_quad(s_cov + bo * COVSZ + ca + X2_CP + 1);
                     const float gx = ax.f[sb], gy = ay.f[sa];
                     const float w11 = gx * gy, w01 = gx - w11, w10 = gy - w11, w00 = (1.f - gx) - w10;
                     const float cxx = fmaf(w11, c11.x, fmaf(w10, c10.x, fmaf(w01, c01.x, w00 * c00.x)));
@@ -1115,7 +1124,7 @@ __global__ void __launch_bounds__(256, 4) k_merge_x2(BurstArgs a, Geo g, Cfa4 cf
                 // the 3 x 3 taps: rows ty + e .. + 2, columns tx + e .. + 2 of the window, as aligned pairs from the
                 // copy whose shift makes column tx + e even
                 const int mcol = px + ax.e[sb];  // 0, 1, 2
-                const float* __restrict__ rp = ((mcol & 1) ? s_rawB : s_rawA) + (ty + ay.e[sa]) * X2_RP + 2 * lj + (mcol & 2);
+                const float* __restrict__ rp = ((mcol & 1) ? s_rawB : s_rawA) + bo * RAWSZ + (ty + ay.e[sa]) * X2_RP + 2 * lj + (mcol & 2);
                 const float dx0 = ax.d0[sb], dy0 = ay.d0[sa];
                 const float dxs[3] = {dx0 - 1.f, dx0, dx0 + 1.f};
                 float sv[2][2], sd[2][2];  // by parity of the tap offset (di + 1, dj + 1)
@@ -1158,7 +1167,36 @@ __global__ void __launch_bounds__(256, 4) k_merge_x2(BurstArgs a, Geo g, Cfa4 cf
                 }
 #undef HHSR_FOLD
             }
+    };
+#if HHSR_X2_DB
+    // double-buffered windows: frame n is evaluated from buffer n & 1 while frame n + 1 is written into the other one
+    // (its global loads were issued before frame n's taps): ONE workgroup barrier per frame
+    if (nloop > 0) {
+        prefetch(0);
+        stage(0, 0);
+        __syncthreads();
+        if (nloop > 1) prefetch(1);
     }
+    for (int n = 0; n < nloop; ++n) {
+        const float2 fl = sfl;
+        const float lr = sr;
+        frame(n >= a.n, fl, lr, n & 1);
+        if (n + 1 < nloop) stage(n + 1, (n + 1) & 1);
+        __syncthreads();
+        if (n + 2 < nloop) prefetch(n + 2);
+    }
+#else
+    if (nloop > 0) prefetch(0);
+    for (int n = 0; n < nloop; ++n) {
+        __syncthreads();  // the previous frame's taps are done with the LDS windows
+        stage(n, 0);
+        const float2 fl = sfl;
+        const float lr = sr;
+        __syncthreads();
+        if (n + 1 < nloop) prefetch(n + 1);  // in flight while this frame's taps are evaluated
+        frame(n >= a.n, fl, lr, 0);
+    }
+#endif
     if (a.acc_r) a.acc_r[ridx] = ((a.flags & HHSR_MERGE_LOAD_ACC) ? a.acc_r[ridx] : 0.f) + racc;
     // ---- epilogue: CFA classes -> RGB, normalise, store -----------------------------------------------------------------
     const int ly = ly0 + ty, lx = lx0 + tx;

@@ -11,7 +11,7 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libhhsr_hip.so")
+LIB_PATH = os.environ.get("HHSR_LIB") or os.path.join(_HERE, "libhhsr_hip.so")  # HHSR_LIB: A/B builds of the library
 
 P, I, L, D, F = C.c_void_p, C.c_int, C.c_int64, C.c_double, C.c_float
 U8P = C.POINTER(C.c_uint8)

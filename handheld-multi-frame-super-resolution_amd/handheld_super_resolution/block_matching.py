@@ -12,12 +12,24 @@ def align_lvl_block_matching_L2(ref_lvl, ref_fft_lvl, moving_lvl, alignment, l, 
     """L2 tile search (block_matching.py:20-76).  The reference correlates zero-padded reference tiles
     with gathered moving windows by FFT and adds a box-filtered window energy; the HIP kernel stages
     the same clamp-to-edge window in LDS and evaluates the (2r+1)^2 SSDs directly (identical argmin up
-    to float32 near-ties).  `ref_lvl` is the reference pyramid level (the reference passes its tiled
-    copy here); `ref_fft_lvl` is accepted for signature parity and ignored."""
+    to float32 near-ties).  `ref_lvl` is the reference pyramid level [H_l, W_l] (what init_alignment of this
+    package keeps) or the reference's tiled, zero-padded copy [ny, nx, ts + 2r, ts + 2r] (what upstream callers
+    pass: it is un-tiled on the fly); anything else raises TypeError.  `ref_fft_lvl` is accepted for signature
+    parity and ignored."""
     ts = config.block_matching.tuning.tile_sizes[l]
     r = config.block_matching.tuning.search_radii[l]
     if ts not in (8, 16, 32, 64):
         raise NotImplementedError("Box filter for tile size {} not implemented".format(ts))
+    if ref_lvl.dim() == 4:
+        # a reference caller's `tyled_pyr_lvl`: [ny, nx, ts + 2r, ts + 2r], every tile zero-padded by r on each side
+        # (alignment.py:56-60 upstream) -> back to the level the kernel reads, [ny ts, nx ts]
+        ny4, nx4, p4, q4 = ref_lvl.shape
+        if p4 != ts + 2 * r or q4 != ts + 2 * r or (ny4, nx4) != tuple(alignment.shape[:2]):
+            raise TypeError(f"tiled reference level of shape {tuple(ref_lvl.shape)} does not match tile size {ts}, "
+                            f"search radius {r} and a flow field of shape {tuple(alignment.shape)}")
+        ref_lvl = ref_lvl[:, :, r:r + ts, r:r + ts].permute(0, 2, 1, 3).reshape(ny4 * ts, nx4 * ts).contiguous()
+    elif ref_lvl.dim() != 2:
+        raise TypeError(f"reference level must be [H, W] or the tiled [ny, nx, ts + 2r, ts + 2r], got {tuple(ref_lvl.shape)}")
     ny, nx = _check(ref_lvl, moving_lvl, alignment)
     mh, mw = moving_lvl.shape
     _lib.call("hhsr_bm_l2", _lib.ptr(ref_lvl), ref_lvl.shape[1], _lib.ptr(moving_lvl), mh, mw, mw,

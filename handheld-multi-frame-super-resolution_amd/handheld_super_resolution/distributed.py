@@ -1,30 +1,43 @@
-"""Frame-sharded multi-GPU merge.  The reference is single-GPU; this is the one
-parallelism the build adds.
+"""Multi-GPU burst merge.  The reference is single-GPU; this is the one parallelism the build adds.
 
-Every comp frame's contribution to num/den depends only on the reference-frame state and that frame
-(reference super_resolution.py:133-173) and contributions are summed (merge.py:432-434), so:
-  * one process per GPU, rank k takes comp frames k, k+G, k+2G, ... (no data-path collective);
-  * every rank replicates the cheap reference-frame precompute;
-  * ONE exchange of the float32 accumulators: the output is cut into G row slabs; every rank merges its
-    frames slab by slab into a slab-major buffer [G][2][rows][sW][3] (num | den per slab) and a single
-    all-to-all (= a reduce-scatter on the fully connected xGMI fabric: 7 concurrent point-to-point
-    transfers per GPU, 1/8 of the buffer each — RCCL's ring reduce would cross 7 links in sequence) hands
-    slab j of every rank to rank j, which sums the G partials;
-  * each rank adds the reference frame (Alg. 11) and normalises ITS slab — so the finish is parallel too — and
-    sends the finished [rows][sW][3] slab to rank 0 (half the volume of the accumulators);
-  * the [H][W] accumulated robustness, when requested, is a plain sum-reduce to rank 0.
-The accumulated-robustness *denoiser* (merge.py:223-228 overwrite rule) needs the full accumulators on one
-rank and falls back to one reduce + rank-0 finish.  The engine that does the per-rank compute is injected
-so that the sharding / exchange logic can be exercised without a GPU (tests run it on gloo, world_size 2).
+One process per GPU.  The path has two kinds of work and they shard differently:
+
+  A. alignment (FFT grey image, pyramid, block matching, ICA) needs a WHOLE frame -> frame-parallel:
+     rank k aligns comp frames k, k+G, k+2G, ... (reference super_resolution.py:133-151 per frame);
+  B. kernel estimation, robustness and the merge are local in the image plane (a few pixels of halo plus the flow)
+     -> row-parallel: the output is cut into G row slabs and rank j runs steps B for ALL frames on the raw rows its
+     slab needs (slab + |flow| + 8 rows of halo), finishing its slab completely: reference frame, normalisation.
+
+The only data-path exchange is therefore ONE all-gather of the flow fields (ny x nx x 2 floats per frame: 376 kB at
+12 MP, 7 MB per 20-frame burst) between A and B — instead of the 1.15 GB of float32 accumulators a frame-sharded
+merge has to reduce (round 1 did that: modelled 0.6x at 2 GPUs / 1.8x at 8, bound by xGMI).  The output stays sharded
+(`gather=False`: rank j owns rows slab_bounds[j] .. slab_bounds[j+1]) or is gathered to rank 0 (`gather=True`, the
+reference's single-image result; 72 MB per rank at 12 MP x2 over 7 parallel links).
+
+Step B works on SUB-IMAGES: row ranges [S0, S1) of every raw frame, S0 a multiple of the flow tile size (so the
+tile grid, the Bayer phase and — for integer S0 * scale — the output grid of the sub-image coincide with the full
+image's).  The kernels are the single-GPU ones, unchanged; per-pixel results inside the slab are bit-identical to the
+single-GPU run (power-of-two scales; other scales: to the last bit of the float64 position (h + 0.5) / scale) because every pixel the slab's outputs depend on lies at least 8 rows inside the sub-image (the
+first rows of a sub-image see an artificial image border: D6's r = 0 rows, clamped neighbourhoods — they are halo).
+
+The engine that does the per-rank compute is injected so that the sharding / exchange logic can be exercised without
+a GPU (tests run it on gloo with the NumPy oracle as the engine, world_size 2 and 3).
 """
+import math
+
 import torch
 import torch.distributed as dist
 
-SLAB_ALIGN = 32  # slabs start on the 32-row workgroup grid of the x2 merge kernel (16-row grid of the generic one)
+SLAB_ALIGN = 32  # slabs start on the 32-row workgroup grid of the x2 merge kernels (16-row grid of the tile kernel)
+HALO = 12        # rows of context beyond slab + |flow|.  r[y] = min of R over y +- 2 (robustness.py:641-686); R[y'] reads
+                 # the guide statistics at (y' + flow) / 2 with Dodgson taps +- 1.5 guide pixels on 3 x 3 local means
+                 # (robustness.py:207-294, 359-421): raw rows y' +- 7 (+ flow) -> r depends on rows y +- 9; kernel
+                 # estimation and the merge window need less.  + 2 rows for the clamped neighbourhoods at a sub-image's
+                 # artificial border, + 1 spare.
 
 
 def shard_indices(n_frames, rank, world):
-    """Indices of the comp frames rank `rank` of `world` processes (round-robin: balanced to +-1)."""
+    """Indices of the comp frames rank `rank` of `world` processes aligns (round-robin: balanced to +-1)."""
     return list(range(rank, n_frames, world))
 
 
@@ -41,69 +54,107 @@ def slab_bounds(sH, world):
     return [min(j * rows, sH) for j in range(world + 1)]
 
 
+def sub_image_rows(r0, r1, scale, H, ts, max_flow_y):
+    """Raw rows [S0, S1) that output rows [r0, r1) depend on, for flows of at most `max_flow_y` pixels.
+    S0 is a multiple of the tile size with S0 * scale an integer (else 0: the sub-image starts at the top);
+    S1 is even (Bayer quads).  Returns (S0, S1, row0_sub) with row0_sub = r0 - S0 * scale, the slab's first row
+    inside the sub-image's output."""
+    halo = int(math.ceil(max_flow_y)) + HALO
+    lo = int(math.floor(r0 / scale)) - halo
+    hi = int(math.ceil(r1 / scale)) + halo
+    S0 = max(0, (lo // ts) * ts)
+    while S0 > 0 and abs(S0 * scale - round(S0 * scale)) > 1e-9:
+        S0 -= ts
+    S1 = min(H, hi + (hi & 1))
+    return S0, S1, r0 - int(round(S0 * scale))
+
+
 class HipEngine:
     """Per-rank compute on the local MI355X."""
 
     def __init__(self, config):
-        from .super_resolution import BurstPipeline, denoiser_enabled
+        from .super_resolution import denoiser_enabled
 
         self.config = config
         self.denoiser_on = denoiser_enabled(config)
         self.accumulate_r = self.denoiser_on or bool(config.robustness.save_mask)
-        self.pipe = BurstPipeline(config)
+        self.pipe = None
+
+    def single(self, ref_img, comp_imgs):
+        """world = 1: the single-GPU path itself."""
+        from .super_resolution import main
+
+        return main(ref_img, comp_imgs, self.config)
 
     def init_ref(self, ref_img):
-        self.pipe.init_ref(ref_img)
+        """Replicated on every rank: the reference frame's alignment state (step A needs the whole frame)."""
+        from .super_resolution import BurstPipeline
+
+        self.pipe = BurstPipeline(self.config)
+        self.device = self.pipe.device
+        self.pipe.init_ref(ref_img, robustness=False)
         return self
+
+    def shape(self):
+        return tuple(self.pipe.ref.shape)
 
     def output_shape(self):
         return (*self.pipe.output_size(), 3)
 
-    def partial(self, comp_imgs, world=1):
-        """This rank's frames merged into slab-major accumulators: float32 [world][2][rows][sW][3] with
-        rows = slab_rows(sH, world) (num | den per slab; rows past the image stay zero).  world = 1: one slab =
-        the whole output.  Returns (acc, acc_r)."""
-        from .merge import merge_burst, can_fuse_acc_r
+    def tile_size(self):
+        return int(self.config.block_matching.tuning.tile_size)
 
-        pipe = self.pipe
-        sH, sW = pipe.output_size()
-        rows = slab_rows(sH, world) if world > 1 else sH
-        bounds = slab_bounds(sH, world) if world > 1 else [0, sH]
-        padded = world * rows != sH
-        alloc = torch.zeros if (padded or not comp_imgs) else torch.empty
-        acc = alloc((world, 2, rows, sW, 3), dtype=torch.float32, device=pipe.device)
-        acc_r = torch.zeros(tuple(pipe.ref.shape), dtype=torch.float32, device=pipe.device) if self.accumulate_r else None
-        fuse_acc = acc_r is not None and can_fuse_acc_r(self.config) and len(comp_imgs) > 0
-        fuse_min = pipe.fuses_local_min() and (fuse_acc or acc_r is None)  # 5x5 local minimum inside the merge
-        frames = pipe.process_frames(list(comp_imgs), None if fuse_acc else acc_r, fuse_local_min=fuse_min)
-        if not frames:
-            return acc, acc_r
-        for j in range(world):
-            r0, r1 = bounds[j], bounds[j + 1]
-            if r1 > r0:
-                merge_burst(frames, None, None, acc[j, 0, : r1 - r0], acc[j, 1, : r1 - r0], pipe.cfa, self.config,
-                            do_ref=False, divide=False, store_den=True, acc_r=acc_r if fuse_acc else None,
-                            rows=(r0, r1 - r0), out_height=sH, local_min=fuse_min)
-        return acc, acc_r
+    def align_frames(self, comp_imgs):
+        """Step A for this rank's frames: float32 [n, ny, nx, 2] on the device (n may be 0)."""
+        flows = self.pipe.align_frames(list(comp_imgs))
+        ny, nx = self.pipe.flow_grid()
+        if not flows:
+            return torch.empty((0, ny, nx, 2), dtype=torch.float32, device=self.device)
+        return torch.stack(flows)
 
-    def finish_slab(self, acc, row0, acc_r=None):
-        """acc [2][rows][sW][3] (summed over ranks) -> finished output slab: reference frame + normalise."""
-        from .merge import merge_burst, merge_ref
+    def merge_rows(self, comp_imgs, flows, r0, r1, max_flow_y):
+        """Step B: output rows [r0, r1) from ALL frames (flows: [N-1, ny, nx, 2]).  Returns (slab float32
+        [r1 - r0, sW, 3], acc_r rows of the slab [(r1 - r0) / scale, W] or None)."""
+        from .super_resolution import BurstPipeline
+        from .merge import merge, merge_ref, merge_burst, can_fuse_acc_r
         from .utils import divide
 
-        pipe = self.pipe
-        sH, _ = pipe.output_size()
-        self._ref_covs = pipe.ref_covs
-        if acc.shape[1] == 0:
-            return acc[0]
-        if self.denoiser_on:  # whole image only (row0 == 0 and all rows)
-            assert row0 == 0 and acc.shape[1] == sH
-            merge_ref(pipe.ref, self._ref_covs, acc[0], acc[1], pipe.cfa, self.config, acc_r)
-            divide(acc[0], acc[1])
+        cfg = self.config
+        H, W = self.shape()
+        sH, sW, _ = self.output_shape()
+        scale, ts = cfg.scale, self.tile_size()
+        S0, S1, row0 = sub_image_rows(r0, r1, scale, H, ts, max_flow_y)
+        Hs = S1 - S0
+        sHs = int(round(scale * Hs))
+        nrows = r1 - r0
+        t0, t1 = S0 // ts, -(-S1 // ts)
+        sub = BurstPipeline(cfg, self.device)
+        sub.init_ref(self.pipe.ref[S0:S1], alignment=False)  # device-resident rows of the replicated reference frame
+        n = len(comp_imgs)
+        sub_flows = [flows[i, t0:t1].contiguous() for i in range(n)]
+        out = torch.empty((nrows, sW, 3), dtype=torch.float32, device=self.device)
+        acc_r = torch.zeros((Hs, W), dtype=torch.float32, device=self.device) if self.accumulate_r else None
+        L0 = int(math.floor(r0 / scale)) - S0
+        L1 = min(Hs, int(math.ceil(r1 / scale)) - S0)
+        if self.denoiser_on:
+            # the accumulated-robustness denoiser (merge.py:223-228) needs sum_n r_n before the reference frame is
+            # merged: sequential operator path on the sub-image
+            num = torch.zeros((sHs, sW, 3), dtype=torch.float32, device=self.device)
+            den = torch.zeros_like(num)
+            for i in range(n):
+                raw, flow, covs, r = sub.process_frame(comp_imgs[i][S0:S1], acc_r, flow=sub_flows[i])
+                merge(raw, flow, covs, r, num, den, sub.cfa, cfg)
+            merge_ref(sub.ref, sub.ref_covs, num, den, sub.cfa, cfg, acc_r)
+            divide(num, den)
+            out.copy_(num[row0:row0 + nrows])
         else:
-            merge_burst([], pipe.ref, self._ref_covs, acc[0], acc[1], pipe.cfa, self.config, load_acc=True, do_ref=True,
-                        divide=True, rows=(row0, acc.shape[1]), out_height=sH)
-        return acc[0]
+            fuse_acc = acc_r is not None and can_fuse_acc_r(cfg) and n > 0
+            fuse_min = sub.fuses_local_min() and (fuse_acc or acc_r is None) and row0 % SLAB_ALIGN == 0
+            frames = sub.process_frames([img[S0:S1] for img in comp_imgs], None if fuse_acc else acc_r,
+                                        fuse_local_min=fuse_min, flows=sub_flows)
+            merge_burst(frames, sub.ref, sub.ref_covs, out, None, sub.cfa, cfg, do_ref=True, divide=True,
+                        acc_r=acc_r if fuse_acc else None, rows=(row0, nrows), out_height=sHs, local_min=fuse_min)
+        return out, (acc_r[L0:L1] if acc_r is not None else None)
 
 
 def _staged(t, group):
@@ -111,25 +162,12 @@ def _staged(t, group):
     return t.is_cuda and dist.get_backend(group) != "nccl"
 
 
-def _reduce_sum(t, dst, group):
-    """Sum-reduce to `dst`.  RCCL ("nccl") reduces device tensors in place over xGMI."""
-    if _staged(t, group):
-        h = t.cpu()
-        dist.reduce(h, dst=dst, op=dist.ReduceOp.SUM, group=group)
-        t.copy_(h)
-        return t
-    dist.reduce(t, dst=dst, op=dist.ReduceOp.SUM, group=group)
-    return t
-
-
-def _all_to_all(recv, send, group):
-    """Equal-split all-to-all: chunk j of `send` goes to rank j."""
-    if _staged(send, group):
-        hr, hs = torch.empty(recv.shape, dtype=recv.dtype), send.cpu()
-        dist.all_to_all_single(hr, hs, group=group)
-        recv.copy_(hr)
-    else:
-        dist.all_to_all_single(recv, send, group=group)
+def _all_gather(t, world, group):
+    """Equal-size all-gather: [world, *t.shape].  RCCL ("nccl") gathers device tensors in place over xGMI."""
+    src = t.cpu() if _staged(t, group) else t.contiguous()
+    out = torch.empty((world, *src.shape), dtype=src.dtype, device=src.device)
+    dist.all_gather_into_tensor(out, src, group=group) if src.is_cuda else dist.all_gather(list(out.unbind(0)), src, group=group)
+    return out.to(t.device)
 
 
 def _gather(t, dst, world, group):
@@ -144,50 +182,84 @@ def _gather(t, dst, world, group):
     return out.to(t.device) if staged else out
 
 
-def main_sharded(ref_img, comp_imgs, config, group=None, engine=None):
-    """Frame-sharded equivalent of main().  Returns (output, debug_dict) on rank 0 and (None, {}) on
-    the other ranks.  Works un-initialised / with world_size 1 (then it is main() without collectives)."""
+def main_sharded(ref_img, comp_imgs, config, group=None, engine=None, gather=True, max_flow=None):
+    """Multi-GPU equivalent of main() (see the module docstring).
+
+    gather=True : returns (output [sH, sW, 3], debug_dict) on rank 0 and (None, {}) on the other ranks;
+    gather=False: every rank returns (its slab [rows_j, sW, 3], {"rows": (r0, r1), ...}) — the output stays sharded.
+    `max_flow`: bound on |flow_y| in pixels used for the sub-image halo; default: measured from the gathered flow
+    fields (one device-to-host read of a scalar).  Works un-initialised / with world_size 1 (then it IS main())."""
     world = dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
     rank = dist.get_rank(group) if world > 1 else 0
     eng = engine if engine is not None else HipEngine(config)
-    eng.init_ref(ref_img)
-    mine = [comp_imgs[i] for i in shard_indices(len(comp_imgs), rank, world)]
-    sH, sW, _ = eng.output_shape()
-    root = dist.get_global_rank(group, 0) if (world > 1 and group is not None) else 0
-    debug = {"robustness": [], "flow": []}
-
-    if world == 1 or getattr(eng, "denoiser_on", False):
-        # single exchange of the whole accumulators, finish on rank 0
-        acc, acc_r = eng.partial(mine, 1)
-        if world > 1:
-            acc = _reduce_sum(acc, root, group)
-            if acc_r is not None:
-                acc_r = _reduce_sum(acc_r, root, group)
-        if rank != 0:
-            return None, {}
-        out = eng.finish_slab(acc[0], 0, acc_r)
-        if acc_r is not None:
-            debug["accumulated robustness"] = acc_r
+    n = len(comp_imgs)
+    if world == 1:
+        out, debug = eng.single(ref_img, comp_imgs)
+        if not gather:
+            debug = dict(debug, rows=(0, int(out.shape[0])))
         return out, debug
+    root = dist.get_global_rank(group, 0) if group is not None else 0
+    eng.init_ref(ref_img)
+    sH, sW, _ = eng.output_shape()
+    H, W = eng.shape()
 
+    # ---- A: frame-parallel alignment, then ONE all-gather of the flow fields ---------------------------------------
+    mine = shard_indices(n, rank, world)
+    per_rank = -(-n // world) if n else 0
+    flows = None
+    if n:
+        local = eng.align_frames([comp_imgs[i] for i in mine])            # [len(mine), ny, nx, 2]
+        padded = torch.zeros((per_rank, *local.shape[1:]), dtype=local.dtype, device=local.device)
+        padded[: local.shape[0]] = local
+        allf = _all_gather(padded, world, group)                            # [world, per_rank, ny, nx, 2]
+        # frame i was aligned by rank i % world as its (i // world)-th frame
+        flows = allf.transpose(0, 1).reshape(per_rank * world, *local.shape[1:])[:n]
+        if max_flow is None:
+            max_flow = float(flows[..., 1].abs().max())                     # the one host read of the step
+            if not math.isfinite(max_flow):
+                max_flow = float(H)
+    max_flow = 0.0 if max_flow is None else float(max_flow)
+
+    # ---- B: row-parallel kernels + robustness + merge + reference frame + normalisation ----------------------------
     rows = slab_rows(sH, world)
     bounds = slab_bounds(sH, world)
-    acc, acc_r = eng.partial(mine, world)              # [world][2][rows][sW][3]
-    recv = torch.empty_like(acc)
-    _all_to_all(recv, acc, group)                        # recv[k] = rank k's partial of MY slab
-    del acc
-    summed = recv.sum(dim=0)                             # [2][rows][sW][3]
-    del recv
-    valid = bounds[rank + 1] - bounds[rank]
-    out_slab = torch.zeros((rows, sW, 3), dtype=torch.float32, device=summed.device)
-    if valid > 0:
-        out_slab[:valid] = eng.finish_slab(summed[:, :valid].contiguous() if valid != rows else summed, bounds[rank])
-    if acc_r is not None:
-        acc_r = _reduce_sum(acc_r, root, group)
-    gathered = _gather(out_slab, root, world, group)     # [world][rows][sW][3] on rank 0
+    r0, r1 = bounds[rank], bounds[rank + 1]
+    debug = {"robustness": [], "flow": [], "rows": (r0, r1)}
+    slab, acc_r = None, None
+    if r1 > r0:
+        slab, acc_r = eng.merge_rows(comp_imgs, flows, r0, r1, max_flow)
+    if not gather:
+        if acc_r is not None:
+            debug["accumulated robustness"] = acc_r
+        return slab, debug
+
+    # ---- optional: the finished slabs to rank 0 (equal padded chunks) -----------------------------------------------
+    dev = flows.device if flows is not None else (slab.device if slab is not None else torch.device("cpu"))
+    send = torch.zeros((rows, sW, 3), dtype=torch.float32, device=dev)
+    if slab is not None:
+        send[: r1 - r0] = slab
+    gathered = _gather(send, root, world, group)                            # [world, rows, sW, 3] on rank 0
+    want_acc = bool(getattr(eng, "accumulate_r", False))
+    acc_all = None
+    if want_acc:
+        lrows = -(-rows // max(1, int(math.floor(config.scale))))
+        a_send = torch.zeros((lrows, W), dtype=torch.float32, device=dev)
+        if acc_r is not None:
+            a_send[: acc_r.shape[0]] = acc_r
+        acc_all = _gather(a_send, root, world, group)
     if rank != 0:
         return None, {}
     out = gathered.view(world * rows, sW, 3)[:sH]
-    if acc_r is not None:
-        debug["accumulated robustness"] = acc_r
+    debug = {"robustness": [], "flow": []}
+    if want_acc:
+        parts = []
+        for j in range(world):
+            a0 = int(math.floor(bounds[j] / config.scale))
+            a1 = min(H, int(math.ceil(bounds[j + 1] / config.scale)))
+            if bounds[j + 1] > bounds[j]:
+                parts.append((a0, acc_all[j, : a1 - a0]))
+        acc_full = torch.zeros((H, W), dtype=torch.float32, device=dev)
+        for a0, p in parts:
+            acc_full[a0: a0 + p.shape[0]] = p
+        debug["accumulated robustness"] = acc_full
     return out, debug

@@ -68,48 +68,81 @@ class BurstPipeline:
         # validation hook (bench.py's parity attribution, tests): per-frame flow fields that replace align()
         self._inject_flows = hip.get("inject_flows", None) if hip is not None else None
 
-    def init_ref(self, ref_img):
+    def init_ref(self, ref_img, alignment=True, robustness=True):
+        """Reference-frame precompute.  `alignment=False` / `robustness=False` skip the halves the multi-GPU
+        path does not need on a given pipeline (distributed.py: whole-frame alignment state vs the sub-image's
+        robustness / kernel state)."""
         with torch.cuda.device(self.device):  # every launch below goes to this device's current stream
-            return self._init_ref(ref_img)
+            return self._init_ref(ref_img, alignment, robustness)
 
-    def _init_ref(self, ref_img):
+    def _init_ref(self, ref_img, alignment, robustness):
         cfg = self.config
         main = torch.cuda.current_stream(self.device)
         self._entry = torch.cuda.Event()  # everything the caller enqueued before (e.g. the frames' upload) is done
         self._entry.record(main)
         self.ref = _lib.f32c(ref_img, self.device)
-        sanitize_config(cfg, tuple(self.ref.shape))
-        grey = compute_grey_images(self.ref, self.grey_method)
-        self.align_state = init_alignment(grey, cfg)
-        if cfg.robustness.enabled:  # init_robustness + the reference frame's kernels from one raw pass, then the
-            # upsampled means, sigma^2 and curve indices from one pass over the guide statistics
+        self.align_state = self.grey_ref = None
+        if alignment:
+            sanitize_config(cfg, tuple(self.ref.shape))
+            grey = compute_grey_images(self.ref, self.grey_method)
+            self.align_state = init_alignment(grey, cfg)
+            self.grey_ref = grey
+        self.ref_means = self.ref_vars = self.ref_covs = self.ref_sigma_sq = None
+        if robustness and cfg.robustness.enabled:  # init_robustness + the reference frame's kernels from one raw pass,
+            # then the upsampled means, sigma^2 and curve indices from one pass over the guide statistics
             m, v, self.ref_covs = frame_stats(self.ref, self.cfa, self.wb, cfg, want_vars=True)
             self.ref_means, self.ref_sigma_sq = ref_planes(m, v, self.curves[0])
             self.ref_vars = None  # only needed for sigma^2, which is already there
-        else:
+        elif robustness:
             self.ref_means, self.ref_vars = init_robustness(self.ref, self.cfa, self.wb, cfg)
             self.ref_covs = estimate_kernels(self.ref, cfg)
-            self.ref_sigma_sq = None
-        self.grey_ref = grey
         self._ref_ready = torch.cuda.Event()
         self._ref_ready.record(main)
         return self
 
-    def process_frame(self, img, accumulate_r=None, wait_ref=None, fuse_local_min=False, index=None):
-        """grey -> kernels -> align -> robustness for one comp frame; returns (raw, flow, covs, r).
-        `accumulate_r`: optional float32 [H, W] that receives += r (fused into the local-min pass).
-        `wait_ref`: event after which the reference-frame state is complete — the frame's own grey image and
-        pyramid do not need it and are enqueued before the wait, so on a side stream they overlap the
-        (latency-bound) reference precompute."""
+    def flow_grid(self):
+        """(ny, nx) of the flow field: tiles of the (padded) finest reference level."""
+        lvl0 = self.align_state[0][-1]
+        ts = int(self.config.block_matching.tuning.tile_size)
+        return lvl0.shape[0] // ts, lvl0.shape[1] // ts
+
+    def align_frame(self, img, wait_ref=None):
+        """grey -> pyramid -> coarse-to-fine alignment of one comp frame: flow float32 [ny, nx, 2]."""
         cfg = self.config
         raw = _lib.f32c(img, self.device)
         grey = compute_grey_images(raw, self.grey_method)
         pyramid = build_gaussian_pyramid(grey, cfg.block_matching.tuning.factors)
         if wait_ref is not None:
             torch.cuda.current_stream(self.device).wait_event(wait_ref)
-        if self._inject_flows is not None and index is not None:
-            flow = _lib.f32c(self._inject_flows[index], self.device)
+        return align(*self.align_state, grey, cfg, moving_pyramid=pyramid)
+
+    def align_frames(self, comp_imgs, n_streams=None):
+        """align_frame() over a list of frames, round-robin on the side streams (like process_frames)."""
+        with torch.cuda.device(self.device):
+            return [f[0] for f in self._on_streams(len(comp_imgs), n_streams, False,
+                                                   lambda i, wait: (self.align_frame(comp_imgs[i], wait_ref=wait),))]
+
+    def process_frame(self, img, accumulate_r=None, wait_ref=None, fuse_local_min=False, index=None, flow=None):
+        """grey -> kernels -> align -> robustness for one comp frame; returns (raw, flow, covs, r).
+        `accumulate_r`: optional float32 [H, W] that receives += r (fused into the local-min pass).
+        `wait_ref`: event after which the reference-frame state is complete — the frame's own grey image and
+        pyramid do not need it and are enqueued before the wait, so on a side stream they overlap the
+        (latency-bound) reference precompute.
+        `flow`: a flow field that replaces the alignment (multi-GPU step B; validation hook
+        config.hip.inject_flows via `index`)."""
+        cfg = self.config
+        raw = _lib.f32c(img, self.device)
+        if flow is None and self._inject_flows is not None and index is not None:
+            flow = self._inject_flows[index]
+        if flow is not None:
+            flow = _lib.f32c(flow, self.device)
+            if wait_ref is not None:
+                torch.cuda.current_stream(self.device).wait_event(wait_ref)
         else:
+            grey = compute_grey_images(raw, self.grey_method)
+            pyramid = build_gaussian_pyramid(grey, cfg.block_matching.tuning.factors)
+            if wait_ref is not None:
+                torch.cuda.current_stream(self.device).wait_event(wait_ref)
             flow = align(*self.align_state, grey, cfg, moving_pyramid=pyramid)
         if cfg.robustness.enabled:  # guide means + kernel covariances from one pass over the raw frame
             means, _, covs = frame_stats(raw, self.cfa, self.wb, cfg)
@@ -124,23 +157,26 @@ class BurstPipeline:
         """True when the fused merge can take the un-filtered robustness maps (see merge.can_fuse_local_min)."""
         return bool(self.config.robustness.enabled) and can_fuse_local_min(self.config, tuple(self.ref.shape))
 
-    def process_frames(self, comp_imgs, accumulate_r=None, n_streams=None, fuse_local_min=False):
+    def process_frames(self, comp_imgs, accumulate_r=None, n_streams=None, fuse_local_min=False, flows=None):
         """process_frame() over a list of frames.  Frames are independent until the merge, so they are
         issued round-robin on `n_streams` HIP streams (config.hip.streams, default 3): the launch-latency-
         bound coarse pyramid levels of one frame overlap the bandwidth-bound kernels of another.  The caller's
         stream waits for all of them before returning.  A per-frame `accumulate_r` (read-modify-write of one
-        map) forces a single stream."""
+        map) forces a single stream.  `flows`: per-frame flow fields that replace the alignment."""
         with torch.cuda.device(self.device):
-            return self._process_frames(comp_imgs, accumulate_r, n_streams, fuse_local_min)
+            return self._on_streams(
+                len(comp_imgs), n_streams, accumulate_r is not None,
+                lambda i, wait: self.process_frame(comp_imgs[i], accumulate_r if wait is None else None, wait_ref=wait,
+                                                   fuse_local_min=fuse_local_min, index=i,
+                                                   flow=None if flows is None else flows[i]))
 
-    def _process_frames(self, comp_imgs, accumulate_r, n_streams, fuse_local_min):
-        n = len(comp_imgs)
+    def _on_streams(self, n, n_streams, serial, work):
+        """work(i, wait_event) for i < n; on one stream (wait_event None) or round-robin on the side streams."""
         if n_streams is None:
             hip = self.config.get("hip", None) if hasattr(self.config, "get") else None
             n_streams = int(hip.get("streams", DEFAULT_STREAMS)) if hip is not None else DEFAULT_STREAMS
-        if n_streams <= 1 or accumulate_r is not None or n < 2:
-            return [self.process_frame(img, accumulate_r, fuse_local_min=fuse_local_min, index=i)
-                    for i, img in enumerate(comp_imgs)]
+        if n_streams <= 1 or serial or n < 2:
+            return [work(i, None) for i in range(n)]
         main = torch.cuda.current_stream(self.device)
         if len(self._streams) < n_streams:
             self._streams += [torch.cuda.Stream(self.device) for _ in range(n_streams - len(self._streams))]
@@ -151,19 +187,19 @@ class BurstPipeline:
         entry.record(main)
         for s in pool:
             s.wait_event(entry)
-        frames = []
+        results = []
         for i in range(n):
             s = pool[i % n_streams]
             with torch.cuda.stream(s):
-                f = self.process_frame(comp_imgs[i], wait_ref=self._ref_ready, fuse_local_min=fuse_local_min, index=i)
+                f = work(i, self._ref_ready)
             for t in f:
                 if t is not None:
                     t.record_stream(main)  # consumed by the merge on the caller's stream (raw too: it is allocated
                     # on the side stream when the frame was uploaded / converted there)
-            frames.append(f)
+            results.append(f)
         for s in pool:
             main.wait_stream(s)
-        return frames
+        return results
 
     def output_size(self):
         s = self.config.scale
@@ -292,8 +328,11 @@ def process(burst_path, config):
     ``iso``, ``std_curve``, ``diff_curve``; ref / comp are either normalised white-balanced float RAW or integer
     sensor counts with ``black_levels`` and ``white_level`` (normalised on the GPU like utils_dng.py:149-160) —
     or a folder of .dng files, which needs rawpy + exifread like the reference (absent from this image:
-    ImportError).  Noise curves: given, or ``config.noise_model.estimator``: "analytic" (default) /
-    "monte_carlo" (the reference's estimator, seeded by ``config.noise_model.seed``).  The CPU-side
+    ImportError).  Noise curves: given in the burst, or ``config.noise_model.estimator``: "monte_carlo" (default — the
+    reference's estimator run_fast_MC, super_resolution.py:252, whose curves include the clipping of the noisy samples
+    to [0, 1]: near black and near saturation sigma_t and d_t are up to ~1.6x smaller than the un-clipped law; seeded by
+    ``config.noise_model.seed``, default 0, so process() is reproducible where the reference is not, D18) or
+    "analytic" (the un-clipped limit, synthetic.noise_curves — what prepare_config() uses when called directly).  The CPU-side
     ISP after the hot path (colour matrix, gamma, sharpening, orientation; raw2rgb.py) is out of scope:
     the un-post-processed linear RGB image is returned, as with ``postprocessing.enabled: false``."""
     import os
@@ -323,7 +362,7 @@ def process(burst_path, config):
         brightness_src = None
     std_curve, diff_curve = burst.get("std_curve"), burst.get("diff_curve")
     alpha, beta = burst.get("alpha"), burst.get("beta")
-    if (std_curve is None or diff_curve is None) and config.noise_model.get("estimator", "analytic") == "monte_carlo":
+    if (std_curve is None or diff_curve is None) and config.noise_model.get("estimator", "monte_carlo") == "monte_carlo":
         from .fast_monte_carlo import run_fast_MC  # the reference's estimator (super_resolution.py:252), seeded
 
         if config.noise_model.get("alpha", None) is not None:

@@ -144,7 +144,7 @@ def bm_l2(ref_lvl, mov_lvl, flow, ts, r, return_cost=False):
     return flow
 
 
-def bm_l1(ref_lvl, mov_lvl, flow, ts, r, effective=False):
+def bm_l1(ref_lvl, mov_lvl, flow, ts, r, effective=False, return_cost=False):
     """INTENDED semantics of reference block_matching.py:78-345 (the upstream kernels are
     undefined behaviour, SURVEY.md App. A D1 — this function is the build's specification, not a
     captured reference result): SAD over the tile, window origin tile*ts + round(flow) - r,
@@ -169,6 +169,8 @@ def bm_l1(ref_lvl, mov_lvl, flow, ts, r, effective=False):
     out = np.empty_like(flow)
     out[..., 0] = fr[..., 0] + (idx % n - r)
     out[..., 1] = fr[..., 1] + (idx // n - r)
+    if return_cost:
+        return out, cost
     return out
 
 

@@ -1,6 +1,8 @@
-"""Frame-sharded merge over torch.distributed with world_size 2 on gloo (CPU): the sharding, the single
-sum-reduce of the packed accumulators and the rank-0 finish are exercised with the oracle as the
-per-rank engine, and must reproduce the sequential result."""
+"""Multi-GPU path over torch.distributed with world_size 2 and 3 on gloo (CPU): frame-parallel alignment, the single
+all-gather of the flow fields, row-parallel merge on sub-images and the gather of the finished slabs are exercised
+with the NumPy oracle as the per-rank engine, and must reproduce the sequential result — which also checks the
+sub-image halo rule (distributed.sub_image_rows) against the reference algorithm itself."""
+import math
 import os
 import socket
 
@@ -20,6 +22,7 @@ class OracleEngine:
     """Test double for distributed.HipEngine with the same methods (NumPy oracle as the compute)."""
 
     denoiser_on = False
+    accumulate_r = True
 
     def __init__(self, config):
         self.cfg = config
@@ -27,41 +30,59 @@ class OracleEngine:
         self.wb = np.array(config.exif.white_balance, dtype=np.float64)
         self.curves = (np.array(config.noise_model.std_curve), np.array(config.noise_model.diff_curve))
 
+    def single(self, ref, comps):
+        out, dbg = oracle.main(ref, comps, self.cfg)
+        return torch.from_numpy(out), {k: (torch.from_numpy(np.asarray(v, np.float32)) if k == "accumulated robustness" else v)
+                                       for k, v in dbg.items()}
+
     def init_ref(self, ref):
         self.ref = np.asarray(ref, np.float32)
         grey = oracle.compute_grey_images(self.ref, "FFT")
         self.al = oracle.init_alignment(grey, self.cfg)
-        self.stats = oracle.init_robustness(self.ref, self.cfa, self.wb, self.cfg)
         return self
+
+    def shape(self):
+        return self.ref.shape
 
     def output_shape(self):
         H, W = self.ref.shape
         s = self.cfg.scale
         return (round(s * H), round(s * W), 3)
 
-    def partial(self, comps, world=1):
-        H, W = self.ref.shape
-        sH, sW, _ = self.output_shape()
-        rows = hdist.slab_rows(sH, world) if world > 1 else sH
-        acc = np.zeros((2, world * rows, sW, 3), np.float32)
-        acc_r = np.zeros((H, W), np.float32)
-        for img in comps:
-            flow = oracle.align(*self.al, oracle.compute_grey_images(img, "FFT"), self.cfg)
-            r = oracle.compute_robustness(img, *self.stats, flow, self.cfa, self.wb, self.curves, self.cfg)
-            acc_r += r
-            oracle.merge(img, flow, oracle.estimate_kernels(img, self.cfg), r, acc[0, :sH], acc[1, :sH], self.cfa, self.cfg)
-        slabs = np.ascontiguousarray(acc.reshape(2, world, rows, sW, 3).transpose(1, 0, 2, 3, 4))
-        return torch.from_numpy(slabs), torch.from_numpy(acc_r)
+    def tile_size(self):
+        return int(self.cfg.block_matching.tuning.tile_size)
 
-    def finish_slab(self, acc, row0, acc_r=None):
-        sH, sW, _ = self.output_shape()
-        a = acc.numpy()
-        rows = a.shape[1]
-        full = np.zeros((2, sH, sW, 3), np.float32)
-        full[:, row0:row0 + rows] = a
-        oracle.merge_ref(self.ref, oracle.estimate_kernels(self.ref, self.cfg), full[0], full[1], self.cfa, self.cfg)
-        oracle.divide(full[0], full[1])
-        return torch.from_numpy(np.ascontiguousarray(full[0, row0:row0 + rows]))
+    def align_frames(self, comps):
+        ts = self.tile_size()
+        H, W = self.ref.shape
+        fl = [oracle.align(*self.al, oracle.compute_grey_images(img, "FFT"), self.cfg) for img in comps]
+        if not fl:
+            return torch.empty((0, -(-H // ts), -(-W // ts), 2), dtype=torch.float32)
+        return torch.from_numpy(np.stack(fl))
+
+    def merge_rows(self, comps, flows, r0, r1, max_flow_y):
+        cfg, ts = self.cfg, self.tile_size()
+        H, W = self.ref.shape
+        s = cfg.scale
+        S0, S1, row0 = hdist.sub_image_rows(r0, r1, s, H, ts, max_flow_y)
+        Hs = S1 - S0
+        t0, t1 = S0 // ts, -(-S1 // ts)
+        ref_s = self.ref[S0:S1]
+        stats = oracle.init_robustness(ref_s, self.cfa, self.wb, cfg)
+        num = np.zeros((round(s * Hs), round(s * W), 3), np.float32)
+        den = np.zeros_like(num)
+        acc_r = np.zeros((Hs, W), np.float32)
+        for i, img in enumerate(comps):
+            img_s = np.asarray(img, np.float32)[S0:S1]
+            flow_s = flows[i, t0:t1].numpy()
+            r = oracle.compute_robustness(img_s, *stats, flow_s, self.cfa, self.wb, self.curves, cfg)
+            acc_r += r
+            oracle.merge(img_s, flow_s, oracle.estimate_kernels(img_s, cfg), r, num, den, self.cfa, cfg)
+        oracle.merge_ref(ref_s, oracle.estimate_kernels(ref_s, cfg), num, den, self.cfa, cfg)
+        oracle.divide(num, den)
+        L0 = int(math.floor(r0 / s)) - S0
+        L1 = min(Hs, int(math.ceil(r1 / s)) - S0)
+        return torch.from_numpy(np.ascontiguousarray(num[row0:row0 + (r1 - r0)])), torch.from_numpy(acc_r[L0:L1].copy())
 
 
 def _burst():
@@ -118,13 +139,51 @@ def test_sharded_equals_sequential(tmp_path, world):
     with np.errstate(all="ignore"):
         d = np.abs(got["out"] - want)
     assert (np.isnan(got["out"]) == np.isnan(want)).all()
-    assert np.nanmax(d) < 1e-5  # only the float32 summation order differs
-    np.testing.assert_allclose(got["acc_r"], dbg["accumulated robustness"], atol=1e-6)
+    # every pixel a slab depends on lies >= 8 rows inside its sub-image: the row-sharded result is the sequential one,
+    # bit for bit (no partial sums are exchanged, so there is no summation-order difference either)
+    assert np.nanmax(d) == 0.0
+    assert np.array_equal(got["acc_r"], dbg["accumulated robustness"].astype(np.float32))
 
 
 def test_single_process_path_is_main():
     ref, comp, cfg = _burst()
     out, _ = hdist.main_sharded(ref, comp[:2], cfg, engine=OracleEngine(cfg))
     want, _ = oracle.main(ref, comp[:2], cfg)
-    with np.errstate(all="ignore"):
-        assert np.nanmax(np.abs(out.numpy() - want)) < 1e-6
+    assert np.array_equal(out.numpy(), want, equal_nan=True)
+
+
+def test_sub_image_rows():
+    # 12 MP x2, 8 ranks: slab 3 = output rows [2304, 3072) -> raw rows [1152, 1536) +- (4 + HALO), tile aligned, even
+    h = 4 + hdist.HALO
+    S0, S1, row0 = hdist.sub_image_rows(2304, 3072, 2, 3000, 16, 3.2)
+    assert S0 == ((1152 - h) // 16) * 16 and S1 == 1536 + h + ((1536 + h) & 1) and row0 == 2304 - 2 * S0
+    assert S0 % 16 == 0 and S1 % 2 == 0 and row0 % 32 == 0
+    assert hdist.sub_image_rows(0, 768, 2, 3000, 16, 3.2)[:2] == (0, 384 + h)      # clipped at the top
+    assert hdist.sub_image_rows(5376, 6000, 2, 3000, 16, 3.2)[1] == 3000           # ... and at the bottom
+    # non-integer scale: S0 * scale must be an integer output row
+    S0, S1, row0 = hdist.sub_image_rows(300, 450, 1.5, 400, 16, 2.0)
+    assert S0 % 16 == 0 and (S0 * 1.5).is_integer() and row0 == 300 - int(S0 * 1.5)
+
+
+@pytest.mark.timeout(600)
+def test_bench_launches_ranks_itself():
+    """`python bench.py --gpus 2` run by hand re-executes itself under torch.distributed.run: two ranks rendezvous
+    (gloo here; RCCL on the GPU box), go through main_sharded and rank 0 prints ONE JSON line with n_gpus = 2.  The
+    per-rank engine is this file's NumPy test double — launch plumbing only, not a measurement."""
+    import json
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ)
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT"):
+        env.pop(k, None)
+    p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--backend", "gloo", "--engine",
+                        os.path.abspath(__file__) + ":OracleEngine", "--height", "512", "--width", "512", "--frames", "3",
+                        "--steps", "1", "--warmup", "0", "--no-cpu-baseline"], capture_output=True, text=True, env=env,
+                       timeout=550)
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert p.returncode == 0 and len(lines) == 1, p.stderr[-2000:]
+    rec = json.loads(lines[0])
+    assert rec["n_gpus"] == 2 and rec["rccl_ranks"] == 2 and rec["steps"] == 1 and rec["value"] > 0
+    assert rec["scaling"] == "strong" and "sharded by rows" in rec["config"]["parallelism"]

@@ -9,7 +9,7 @@ import pytest
 import torch
 
 import oracle
-from helpers import base_config, acc_pattern, assert_close
+from helpers import flipped_tiles, assert_explained, base_config, acc_pattern, assert_close
 
 pytestmark = pytest.mark.gpu
 
@@ -18,6 +18,14 @@ from handheld_super_resolution import (utils_image, alignment, block_matching, I
                                        utils, synthetic as synth)
 
 DEV = "cuda"
+
+# Allowed numbers of tiles (over all comp frames of the test's burst) whose block-matching decision differs from the
+# oracle's — float32 near-ties, see helpers.flipped_tiles.  Measured on MI355X: NONE in any of these bursts, at any size
+# (PARITY.md; round 1's end-to-end outliers were border pixels with denormal weights, now k_merge_border's) — so the
+# budgets are zero and every image / robustness difference has to be within tolerance everywhere.  Should a future
+# kernel change flip a near-tie, the footprint rule of helpers.assert_explained keeps the image check meaningful.
+FLIP_BUDGET = {"c1": 0, "ts32": 0, "ts64": 0, "ragged2": 0, "ragged1.5": 0, "ragged3": 0, "matrix": 0,
+               "c2_full": 0, "c4_crop": 0}
 
 
 def T(a, dtype=torch.float32):
@@ -141,12 +149,14 @@ def _bm_inputs(rng, ts, r, ny, nx, shift):
     return ref, mov, flow
 
 
-def _check_bm(got, want, cost, what):
-    diff = np.abs(got - want).max(-1) > 0
+def _check_bm(got, want, cost, what, atol=0.0, max_ties=1):
+    """Integer block-matching result: equal to the oracle's, except on tiles whose two best costs are tied within 1e-4
+    relative (the kernel sums float32 FMAs per lane in a fixed order, the oracle float64) — at most `max_ties` of them."""
+    diff = np.abs(got - want).max(-1) > atol
     for ty, tx in zip(*np.nonzero(diff)):
         c = np.sort(cost[ty, tx].ravel())
         assert (c[1] - c[0]) <= 1e-4 * max(1.0, abs(c[0])), (what, ty, tx, c[:3], got[ty, tx], want[ty, tx])
-    assert diff.mean() <= 0.02, (what, diff.mean())
+    assert diff.sum() <= max_ties, (what, int(diff.sum()))
 
 
 @pytest.mark.parametrize("ts,r", [(8, 4), (16, 4), (16, 1), (32, 4), (64, 4), (16, 9)])
@@ -160,6 +170,27 @@ def test_bm_l2(ts, r):
     block_matching.align_lvl_block_matching_L2(T(ref), None, T(mov), f, 0, cfg)
     want, cost = oracle.bm_l2(ref, mov, flow, ts, r, return_cost=True)
     _check_bm(N(f), want, cost, f"bm_l2 ts={ts} r={r}")
+
+
+def test_bm_l2_accepts_the_reference_tiled_tensor():
+    """Upstream callers pass the tiled, zero-padded reference level [ny, nx, ts + 2r, ts + 2r] (block_matching.py:20,
+    alignment.py:56-60, 131): same result as with the level itself; a mismatching tensor raises TypeError."""
+    ts, r = 16, 4
+    rng = np.random.default_rng(3)
+    ref, mov, flow = _bm_inputs(rng, ts, r, 5, 6, (2, -3))
+    cfg = base_config(ts=16)
+    cfg.block_matching.tuning.tile_sizes = [ts] * 4
+    cfg.block_matching.tuning.search_radii = [r] * 4
+    f0, f1 = T(flow), T(flow)
+    block_matching.align_lvl_block_matching_L2(T(ref), None, T(mov), f0, 0, cfg)
+    tiled = torch.nn.functional.pad(T(ref).unfold(0, ts, ts).unfold(1, ts, ts), (r, r, r, r))
+    assert tiled.shape == (5, 6, ts + 2 * r, ts + 2 * r)
+    block_matching.align_lvl_block_matching_L2(tiled, None, T(mov), f1, 0, cfg)
+    assert torch.equal(f0, f1)
+    with pytest.raises(TypeError):
+        block_matching.align_lvl_block_matching_L2(tiled[:, :, 1:], None, T(mov), T(flow), 0, cfg)
+    with pytest.raises(TypeError):
+        block_matching.align_lvl_block_matching_L2(T(ref)[None], None, T(mov), T(flow), 0, cfg)
 
 
 def test_bm_l2_golden(golden):
@@ -184,8 +215,8 @@ def test_bm_l1(ts, r):
     cfg.block_matching.tuning.search_radii = [r] * 4
     f = T(flow)
     block_matching.align_lvl_block_matching_L1(T(ref), T(mov), f, 0, cfg)
-    want = oracle.bm_l1(ref, mov, flow, ts, r)
-    assert (np.abs(N(f) - want).max(-1) > 0).mean() <= 0.05
+    want, cost = oracle.bm_l1(ref, mov, flow, ts, r, return_cost=True)
+    _check_bm(N(f), want, cost, f"bm_l1 ts={ts} r={r}")
     f = T(flow)
     block_matching.align_lvl_block_matching_L1(T(ref), T(mov), f, 0, cfg, effective=True)
     assert_close(N(f), oracle.bm_l1(ref, mov, flow, ts, r, effective=True), 0, 0, "L1 effective")
@@ -253,7 +284,12 @@ def test_fused_align_level(ts, r, metric):
     assert_close(N(f_fused), N(f_sep), 0, 2e-5, f"fused vs separate ts={ts} {metric}")
     ogx, ogy, oH = oracle.init_ica(ref, ts)
     want = oracle.align_lvl(ref, ogx, ogy, oH, mov, flow, 0, cfg)
-    assert_close(N(f_fused), want, 0, 2e-4, f"fused vs oracle ts={ts} {metric}", max_bad_frac=0.07)
+    # a tile may differ from the oracle only when its block-matching step sat on a near-tie of the two best costs
+    if metric == "L1_ref_effective":
+        assert_close(N(f_fused), want, 0, 2e-4, f"fused vs oracle ts={ts} {metric}")
+    else:
+        _, cost = (oracle.bm_l2 if metric == "L2" else oracle.bm_l1)(ref, mov, flow, ts, r, return_cost=True)
+        _check_bm(N(f_fused), want, cost, f"fused vs oracle ts={ts} {metric}", atol=2e-4)
 
 
 @pytest.mark.parametrize("mode", ["nearest", "bilinear", "bicubic"])
@@ -673,21 +709,42 @@ def test_e2e_golden_x1_denoiser(golden):
     assert_close(N(out2), o, 0, 0, "debug path == fast path")
 
 
+def _e2e_vs_oracle(ref, comp, cfg_fn, ts, what, max_flipped, out_atol=1e-4, flow_atol=2e-3, r_atol=2e-3, acc_atol=4e-3,
+                   parallel=False):
+    """HIP main() against the oracle on one burst, every difference accounted for: flows equal to `flow_atol` except on
+    tiles whose block-matching decision flipped (count <= max_flipped, the measured number); robustness, accumulated
+    robustness and the output image equal to their tolerances everywhere OUTSIDE the footprint of those tiles."""
+    H, W = ref.shape
+    cap = {}
+    if parallel:  # one worker process per frame (bit-identical to oracle.main, tests/test_oracle_kat.py)
+        want, wdbg, _ = oracle.main_parallel(ref, comp, cfg_fn(), capture=cap)
+    else:
+        want, wdbg = oracle.main(ref, comp, cfg_fn(), capture=cap)
+    cfg = cfg_fn()
+    cfg.debug = True
+    out, dbg = hsr.main(ref, comp, cfg)
+    scale = cfg.scale
+    gflow, oflow = np.stack(dbg["flow"]), np.stack(cap["flow"])
+    flipped = flipped_tiles(gflow, oflow)
+    assert int(flipped.sum()) <= max_flipped, f"{what}: {int(flipped.sum())} flipped tiles (allowed {max_flipped})"
+    assert_close(gflow[~flipped], oflow[~flipped], 0, flow_atol, what + " flow (un-flipped tiles)")
+    assert_explained(np.stack(dbg["robustness"]), np.stack(cap["r"]), r_atol, flipped, ts, (H, W), 1.0, what + " r",
+                     max_flipped, per_frame=True)
+    o = N(out)
+    assert o.shape == want.shape
+    assert_explained(o, want, out_atol, flipped, ts, (H, W), scale, what + " output", max_flipped)
+    if "accumulated robustness" in wdbg:
+        assert_explained(N(dbg["accumulated robustness"]), wdbg["accumulated robustness"], acc_atol, flipped, ts, (H, W),
+                         1.0, what + " acc r", max_flipped)
+    return o, want, flipped
+
+
 @pytest.mark.parametrize("metric0", ["L1", "L2", "L1_ref_effective"])
 def test_e2e_c1_512(metric0):
     """BASELINE config C1: 512x512, 3 frames, x1 (demosaick only), Ts=16."""
     ref, comp, _ = synth.make_burst(512, 512, 3, seed=1234, max_shift=4.0)
-    cfg = base_config(ts=16, scale=1, metrics=(metric0, "L2", "L2", "L2"))
-    cap = {}
-    want, _ = oracle.main(ref, comp, cfg, capture=cap)
-    cfg.debug = True
-    out, dbg = hsr.main(ref, comp, cfg)
-    assert_close(np.stack(dbg["flow"]), np.stack(cap["flow"]), 0, 2e-3, "flow", max_bad_frac=0.02)
-    o = N(out)
-    assert_close(o, want, 0, 1e-3, "output", max_bad_frac=0.005)
-    with np.errstate(all="ignore"):
-        d = np.abs(o - want)
-        assert np.nanpercentile(d, 99) < 1e-4, np.nanpercentile(d, 99)
+    _e2e_vs_oracle(ref, comp, lambda: base_config(ts=16, scale=1, metrics=(metric0, "L2", "L2", "L2")), 16,
+                   f"C1 {metric0}", max_flipped=FLIP_BUDGET["c1"])
 
 
 @pytest.mark.parametrize("ts,snr", [(32, 18.0), (64, 10.0)])
@@ -696,19 +753,17 @@ def test_e2e_large_tiles(ts, snr):
     H, W = 768, 1024
     a, b = 16 * synth.ALPHA_ISO100, 16 * synth.BETA_ISO100
     ref, comp, _ = synth.make_burst(H, W, 2, seed=7, alpha=a, beta=b, max_shift=3.0)
-    cfg = base_config(ts=ts, scale=2, snr=snr)
-    if ts == 64:
-        cfg.block_matching.tuning.factors = [1, 2, 2, 2]  # keeps >= 1 tile at the coarsest level at this size
-    cfg.noise_model.alpha, cfg.noise_model.beta = a, b
-    std, dif = synth.noise_curves(a, b)
-    cfg.noise_model.update({"std_curve": std.tolist(), "diff_curve": dif.tolist()})
-    cap = {}
-    want, _ = oracle.main(ref, comp, cfg, capture=cap)
-    cfg.debug = True
-    out, dbg = hsr.main(ref, comp, cfg)
-    assert_close(np.stack(dbg["flow"]), np.stack(cap["flow"]), 0, 3e-3, "flow", max_bad_frac=0.03)
-    o = N(out)
-    assert_close(o, want, 0, 1e-3, "output", max_bad_frac=0.01)
+
+    def cfg0():
+        cfg = base_config(ts=ts, scale=2, snr=snr)
+        if ts == 64:
+            cfg.block_matching.tuning.factors = [1, 2, 2, 2]  # keeps >= 1 tile at the coarsest level at this size
+        cfg.noise_model.alpha, cfg.noise_model.beta = a, b
+        std, dif = synth.noise_curves(a, b)
+        cfg.noise_model.update({"std_curve": std.tolist(), "diff_curve": dif.tolist()})
+        return cfg
+
+    _e2e_vs_oracle(ref, comp, cfg0, ts, f"Ts={ts}", max_flipped=FLIP_BUDGET[f"ts{ts}"], flow_atol=3e-3)
 
 
 @pytest.mark.parametrize("shape,scale", [((502, 618), 2), ((486, 520), 1.5), ((512, 640), 3)])
@@ -717,19 +772,10 @@ def test_e2e_ragged_sizes_and_scales(shape, scale):
     D16; partial tiles at the right / bottom) and non-power-of-two scales (float64 geometry path)."""
     H, W = shape
     ref, comp, _ = synth.make_burst(H, W, 3, seed=23, max_shift=3.0, occluder=True)
-    cfg = base_config(ts=16, scale=scale, metrics=("L1", "L2", "L2", "L2"))
-    cap = {}
-    want, wdbg = oracle.main(ref, comp, cfg, capture=cap)
-    cfg.debug = True
-    out, dbg = hsr.main(ref, comp, cfg)
-    assert_close(np.stack(dbg["flow"]), np.stack(cap["flow"]), 0, 3e-3, "flow", max_bad_frac=0.03)
-    assert_close(np.stack(dbg["robustness"]), np.stack(cap["r"]), 0, 2e-3, "r", max_bad_frac=0.02)
-    o = N(out)
-    assert o.shape == want.shape
-    assert_close(o, want, 0, 1e-3, "output", max_bad_frac=0.01)
+    o, want, _ = _e2e_vs_oracle(ref, comp, lambda: base_config(ts=16, scale=scale, metrics=("L1", "L2", "L2", "L2")), 16,
+                                f"ragged x{scale}", max_flipped=FLIP_BUDGET[f"ragged{scale}"], flow_atol=3e-3)
     with np.errstate(all="ignore"):
         assert np.nanpercentile(np.abs(o - want), 99) < 2e-4
-    assert_close(N(dbg["accumulated robustness"]), wdbg["accumulated robustness"], 0, 4e-3, "acc r", max_bad_frac=0.02)
 
 
 def _opt_robustness_off(c):
@@ -779,17 +825,13 @@ def test_e2e_config_matrix(opt, capsys):
         c.verbose = verbose
         return c
 
-    out, dbg = hsr.main(ref, comp, cfg0())
-    want, wdbg = oracle.main(ref, comp, cfg0())
-    o = N(out)
-    assert_close(o, want, 0, 1e-3, "output", max_bad_frac=0.005)
-    with np.errstate(all="ignore"):
-        assert np.nanpercentile(np.abs(o - want), 99) < 1e-4
-    if "accumulated robustness" in wdbg:
-        assert_close(N(dbg["accumulated robustness"]), wdbg["accumulated robustness"], 0, 2e-3, "acc r", max_bad_frac=0.01)
+    o, want, flipped = _e2e_vs_oracle(ref, comp, cfg0, 16, "matrix " + opt.__name__[5:],
+                                      max_flipped=FLIP_BUDGET["matrix"])
+    out_q, _ = hsr.main(ref, comp, cfg0())  # quiet, pipelined, fused (the debug run above is the per-frame path)
+    assert_close(N(out_q), o, 2e-5, 1e-6, "quiet (fused, pipelined) == debug (per-frame)")
     out_v, _ = hsr.main(ref, comp, cfg0(verbose=2))
     assert "Total ellapsed time" in capsys.readouterr().out
-    assert_close(N(out_v), o, 2e-5, 1e-6, "verbose (sequential) == quiet (fused, pipelined)")
+    assert_close(N(out_v), o, 2e-5, 1e-6, "verbose (sequential) == debug")
 
 
 @pytest.mark.parametrize("n_comp", [0, 1, 2])
@@ -860,6 +902,34 @@ def test_monte_carlo_noise_curves_gpu():
     for i in (0, 2, 999):
         dm, sm = oracle.frontend.unitary_mc(a, b, i / 1000, 50000, rng)
         assert abs(s1[i] / sm - 1) < 0.02 and abs(d1[i] / dm - 1) < 0.03
+
+
+def test_process_default_noise_curves_include_clipping():
+    """process() without explicit curves runs the reference's estimator (run_fast_MC: clipped Poisson-Gaussian patches),
+    not the analytic un-clipped law: within ~3 sigma of black / saturation the two differ by tens of percent, which
+    changes the robustness in shadows and highlights."""
+    ref, comp, _ = synth.make_burst(512, 512, 2, seed=3)
+    a, b = synth.ALPHA_ISO100 * 16, synth.BETA_ISO100 * 16
+    cfg = hsr.default_config()
+    cfg.verbose = 0
+    cfg.block_matching.tuning.tile_size = 16
+    hsr.process({"ref": ref, "comp": comp, "cfa_pattern": [[0, 1], [1, 2]], "white_balance": [1.0, 1.0, 1.0],
+                 "alpha": a, "beta": b}, cfg)
+    std, dif = np.array(cfg.noise_model.std_curve), np.array(cfg.noise_model.diff_curve)
+    sa, da = synth.noise_curves(a, b)
+    rng = np.random.default_rng(1)
+    for i in (0, 1, 1000):  # black, near black, saturation: clipped regime
+        dm, sm = oracle.frontend.unitary_mc(a, b, i / 1000, 100000, rng)
+        assert abs(std[i] / sm - 1) < 0.02 and abs(dif[i] / dm - 1) < 0.03, (i, std[i], sm, dif[i], dm)
+        assert std[i] < 0.8 * sa[i], (i, std[i], sa[i])  # the un-clipped law is far off here
+    assert np.abs(std[200:800] / sa[200:800] - 1).max() < 0.01  # ... and right in the mid-tones
+    cfg2 = hsr.default_config()
+    cfg2.verbose = 0
+    cfg2.block_matching.tuning.tile_size = 16
+    cfg2.noise_model.estimator = "analytic"
+    hsr.process({"ref": ref, "comp": comp, "cfa_pattern": [[0, 1], [1, 2]], "white_balance": [1.0, 1.0, 1.0],
+                 "alpha": a, "beta": b}, cfg2)
+    assert np.allclose(cfg2.noise_model.std_curve, sa)
 
 
 def test_process_integer_burst_and_monte_carlo_estimator():
@@ -934,6 +1004,123 @@ def test_full_size_properties():
     o3, _ = hsr.main(const, const[None].repeat(2, 1, 1), cfg3)
     inner = o3[8:-8, 8:-8]
     assert float((inner - 0.4).abs().max()) < 1e-5
+
+
+def test_c2_full_size_against_oracle():
+    """BASELINE config C2 geometry at FULL size — 3000x4000, x2 -> 48 MP — against the oracle (2 comp frames: ~1 min of
+    NumPy on two host cores), every difference attributed to a flipped block-matching tile."""
+    H, W = 3000, 4000
+    ref, comp, _ = synth.make_burst(H, W, 3, seed=1234)
+    _e2e_vs_oracle(ref, comp, lambda: base_config(ts=16, scale=2, metrics=("L1", "L2", "L2", "L2")), 16, "C2 full size",
+                   max_flipped=FLIP_BUDGET["c2_full"], flow_atol=3e-3, parallel=True)
+
+
+def test_c4_substitute_13_frames_sensor_size():
+    """BASELINE config C4 (a real 13-frame DNG burst) cannot run: no DNG burst and no decoder exist offline.  Its stated
+    substitute: 13 frames of 4032x3024, x2, robustness on, white balance != 1, BGGR — size-independent
+    properties at full size, and a 512x512 crop of the same burst against the oracle (all 13 frames)."""
+    H, W, NF = 3024, 4032, 13
+    cfa, wb = ((2, 1), (1, 0)), (2.0, 1.0, 1.5)
+    ref, comp, shifts = synth.make_burst(H, W, NF, seed=77, cfa=cfa, wb=wb, max_shift=3.0)
+
+    def cfg0(**hip):
+        c = base_config(ts=16, scale=2, metrics=("L1", "L2", "L2", "L2"))
+        c.exif = {"cfa_pattern": [list(r) for r in cfa], "iso": 100, "white_balance": list(wb)}
+        c.robustness.save_mask = True
+        if hip:
+            c.hip = hip
+        return c
+
+    tref, tcomp = T(ref), T(comp)
+    out, dbg = hsr.main(tref, tcomp, cfg0())
+    assert out.shape == (2 * H, 2 * W, 3)
+    # run-to-run determinism of the 3-stream pipeline: bitwise
+    out_b, dbg_b = hsr.main(tref, tcomp, cfg0())
+    assert torch.equal(torch.nan_to_num(out, nan=-1.0), torch.nan_to_num(out_b, nan=-1.0))
+    assert torch.equal(dbg["accumulated robustness"], dbg_b["accumulated robustness"])
+    # sequential operator path (per-frame merge, separate local minimum) == fused pipelined path
+    out_s, dbg_s = hsr.main(tref, tcomp, cfg0(fused_merge=False, streams=1))
+    ok = ((out - out_s).abs() <= 2e-5 * out_s.abs() + 1e-6) | (out.isnan() & out_s.isnan())
+    assert int((~ok).sum()) == 0
+    assert_close(N(dbg["accumulated robustness"]), N(dbg_s["accumulated robustness"]), 1e-6, 1e-5, "acc r")
+    # the burst's known translations are recovered and most of the image is merged from (almost) all frames
+    acc = dbg["accumulated robustness"]
+    assert float(acc[8:-8, 8:-8].mean()) > 0.8 * (NF - 1)
+    assert bool(torch.isfinite(out[4:-4, 4:-4]).all())
+    # the white-balanced channels come back with their gains: channel means follow the scene's (0.5 per channel x gain)
+    m = out[64:-64, 64:-64].mean((0, 1)).cpu().numpy()
+    assert abs(m[0] / m[1] - 2.0) < 0.1 and abs(m[2] / m[1] - 1.5) < 0.1, m
+    del out_b, out_s, dbg_b, dbg_s
+    # a crop of the same burst against the oracle
+    c, y0, x0 = 512, 1216, 1792
+    _e2e_vs_oracle(ref[y0:y0 + c, x0:x0 + c], comp[:, y0:y0 + c, x0:x0 + c], cfg0, 16, "C4 substitute crop",
+                   max_flipped=FLIP_BUDGET["c4_crop"], flow_atol=3e-3, parallel=True)
+
+
+def test_c5_geometry_48mp_x3():
+    """BASELINE config C5 geometry: 6000x8000, x3 -> 18000x24000 (432 MP, 5.2 GB of output) on one GPU with 3 frames:
+    size-independent properties (x3 takes the generic-scale merge kernels and their border bands)."""
+    H, W = 6000, 8000
+    ref, comp, shifts = synth.make_burst_torch(H, W, 3, DEV, seed=5)
+    cfg = base_config(ts=16, scale=3, metrics=("L1", "L2", "L2", "L2"))
+    out, _ = hsr.main(ref, comp, cfg)
+    assert out.shape == (3 * H, 3 * W, 3)
+    assert bool(torch.isfinite(out[6:-6, 6:-6]).all())
+    # fused burst merge == per-frame operator path
+    cfg2 = base_config(ts=16, scale=3, metrics=("L1", "L2", "L2", "L2"))
+    cfg2.hip = {"fused_merge": False}
+    out2, _ = hsr.main(ref, comp, cfg2)
+    ok = ((out - out2).abs() <= 2e-5 * out2.abs() + 1e-6) | (out.isnan() & out2.isnan())
+    assert int((~ok).sum()) == 0
+    del out2
+    # known translation recovered
+    pipe = hsr.BurstPipeline(cfg).init_ref(ref)
+    _, flow1, _, r1 = pipe.process_frame(comp[0])
+    med = flow1.reshape(-1, 2).median(0).values.cpu().numpy()
+    assert np.abs(med + shifts[1]).max() < 0.35, (med, shifts[1])
+    # a row slab computed on a sub-image (the multi-GPU step B) == the same rows of the whole-image result, bitwise
+    from handheld_super_resolution import distributed as hdist
+
+    eng = hdist.HipEngine(cfg).init_ref(ref)
+    flows = eng.align_frames([comp[0], comp[1]])
+    r0, r1 = 9024, 9024 + 2240
+    slab, _ = eng.merge_rows([comp[0], comp[1]], flows, r0, r1, float(flows[..., 1].abs().max()))
+    # (x3: positions (h + 0.5) / 3 are rounded float64 values, so sub-image and whole-image coordinates differ in the
+    # last bit of a float64 and a few weights in the last bit of a float32; x2 is exact — test_sharded_hip_engine_*)
+    a, b = slab, out[r0:r1]
+    ok = ((a - b).abs() <= 1e-5 * b.abs() + 1e-7) | (a.isnan() & b.isnan())
+    assert int((~ok).sum()) == 0
+    del out, slab
+    # constant-colour scene (no noise) reproduces the colour: kernel regression is a partition of unity
+    const = torch.full((H, W), 0.4, device=DEV)
+    o3, _ = hsr.main(const, const[None].repeat(2, 1, 1), base_config(ts=16, scale=3, metrics=("L2",) * 4))
+    assert float((o3[12:-12, 12:-12] - 0.4).abs().max()) < 1e-5
+
+
+def test_determinism_streams_and_wave_fences():
+    """Run-to-run determinism: the same burst twice through the 3-stream pipeline, and through 4 streams (k_align_wave
+    replaces workgroup barriers by wave-level fences; the frames of a burst share the reference-frame state across
+    streams) — flow, robustness and output bitwise equal to the single-stream run."""
+    ref, comp, _ = synth.make_burst(768, 1024, 7, seed=3, max_shift=3.0, occluder=True)
+    tref, tcomp = T(ref), T(comp)
+
+    def run(streams):
+        cfg = base_config(ts=16, scale=2, metrics=("L1", "L2", "L2", "L2"))
+        cfg.hip = {"streams": streams}
+        pipe = hsr.BurstPipeline(cfg).init_ref(tref)
+        frames = pipe.process_frames([tcomp[i] for i in range(6)])
+        out, _ = hsr.main(tref, tcomp, cfg)
+        torch.cuda.synchronize()
+        return [f[1].clone() for f in frames], [f[3].clone() for f in frames], out
+
+    base = run(1)
+    for streams in (3, 3, 4, 4):
+        got = run(streams)
+        for a, b in zip(got[0], base[0]):
+            assert torch.equal(a, b), f"flow differs with {streams} streams"
+        for a, b in zip(got[1], base[1]):
+            assert torch.equal(a, b), f"robustness differs with {streams} streams"
+        assert torch.equal(torch.nan_to_num(got[2], nan=-1.0), torch.nan_to_num(base[2], nan=-1.0))
 
 
 # ------------------------------------------------------------------------------------------ frame sharding
