@@ -902,8 +902,14 @@ __global__ void __launch_bounds__(256) k_merge_burst_quad(BurstArgs a, Geo g, Cf
 #ifndef HHSR_X2_DB
 #define HHSR_X2_DB 0   // 1: double-buffered LDS windows, one barrier per frame (A/B measured: see DESIGN.md)
 #endif
+#ifndef HHSR_X2_CLAMP
+#define HHSR_X2_CLAMP 1  // 1: clamp(v_exp_f32) + exact path for non-finite coefficients (A/B: 3.54 ms); 0: min + v_exp_f32 per tap (3.63)
+#endif
+#ifndef HHSR_X2_PEEL
+#define HHSR_X2_PEEL 0   // 1: reference frame as a compile-time variant of the frame code (A/B: 160 VGPRs, 3.97 vs 3.54 ms); 0: run-time selects
+#endif
 #ifndef HHSR_X2_OCC
-#define HHSR_X2_OCC 4  // waves per SIMD the register allocation of k_merge_x2 is held to (128 VGPRs)
+#define HHSR_X2_OCC 4  // waves per SIMD the register allocation of k_merge_x2 is held to (125 VGPRs; A/B: 3 = 4; 5 spills: 6.9 ms)
 #endif
 constexpr int X2_RP = 24;   // raw / R window pitch in floats: rows are read with stride 2 -> 48 dwords = 16 (mod 32) banks
 constexpr int X2_CP = 24;   // covariance window pitch in float4: 96 dwords = 32 (mod 64) banks for ds_read_b128
@@ -1080,15 +1086,28 @@ __global__ void __launch_bounds__(256, HHSR_X2_OCC) k_merge_x2(BurstArgs a, Geo 
         sfl = pfl;
         sr = isref ? 1.f : plr;
     };
-    auto frame = [&](const bool isref, const float2 fl, float local_r, const int bo) {
+    // One frame of taps.  ISREF is a compile-time flag (the reference frame runs the same code with its own uniform
+    // geometry, the identity fallback of the inverse and r = 1): as a run-time select it costs ~40 v_cndmask per frame,
+    // and on gfx950 v_cndmask / v_min / v_cmp / v_floor / v_cvt issue at HALF the v_fma rate, v_exp / v_rcp at a quarter
+    // (tools/ubench/valu_rate.hip) — the kernel is VALU-bound, so instruction classes are what to count.
+    auto frame = [&](auto isref_c, const bool isref_rt, const float2 fl, float local_r, const int bo) {
+        const bool isref = HHSR_X2_PEEL ? decltype(isref_c)::value : isref_rt;
         if (LMIN && !isref) {  // 5 x 5 minimum over rows ty .. ty + 4, columns tx .. tx + 4 of the R window
             float m = 3.0e38f;
+            if (px) {  // (uniform branch instead of a select per row)
 #pragma unroll
-            for (int r = 0; r < 5; ++r) {
-                const float2 v01 = lds_pair(rbase + bo * RAWSZ + r * X2_RP), v23 = lds_pair(rbase + bo * RAWSZ + r * X2_RP + 2);
-                const float2 v45 = lds_pair(rbase + bo * RAWSZ + r * X2_RP + 4);
-                const float edge = px ? v45.y : v01.x;
-                m = fminf(m, fminf(fminf(v01.y, v23.x), fminf(v23.y, fminf(v45.x, edge))));
+                for (int r = 0; r < 5; ++r) {
+                    const float2 v01 = lds_pair(rbase + bo * RAWSZ + r * X2_RP), v23 = lds_pair(rbase + bo * RAWSZ + r * X2_RP + 2);
+                    const float2 v45 = lds_pair(rbase + bo * RAWSZ + r * X2_RP + 4);
+                    m = fminf(m, fminf(fminf(v01.y, v23.x), fminf(v23.y, fminf(v45.x, v45.y))));
+                }
+            } else {
+#pragma unroll
+                for (int r = 0; r < 5; ++r) {
+                    const float2 v01 = lds_pair(rbase + bo * RAWSZ + r * X2_RP), v23 = lds_pair(rbase + bo * RAWSZ + r * X2_RP + 2);
+                    const float2 v45 = lds_pair(rbase + bo * RAWSZ + r * X2_RP + 4);
+                    m = fminf(m, fminf(fminf(v01.y, v23.x), fminf(v23.y, fminf(v45.x, v01.x))));
+                }
             }
             local_r = m;
         }
@@ -1101,6 +1120,7 @@ __global__ void __launch_bounds__(256, HHSR_X2_OCC) k_merge_x2(BurstArgs a, Geo 
 #pragma unroll
             for (int sb = 0; sb < 2; ++sb) {
                 float ixx = 2.f * X2_KEXP, ixy = 0.f, iyy = 2.f * X2_KEXP;
+                bool finite = true;
                 if (!ISO) {
                     const int ca = cbase + ay.oc[sa] * X2_CP + ax.oc[sb];
                     const float4 c00 = lds_quad(s_cov + bo * COVSZ + ca), c01 = lds_quad(s_cov + bo * COVSZ + ca + 1);
@@ -1120,6 +1140,11 @@ __global__ void __launch_bounds__(256, HHSR_X2_OCC) k_merge_x2(BurstArgs a, Geo 
                         ixy = 0.f;
                         iyy = X2_KEXP;
                     }
+                    // 0 * x is 0 for finite x and NaN for NaN / inf: one NaN test for the three coefficients
+                    if (HHSR_X2_CLAMP) {
+                        const float probe = fmaf(0.f, ixx, fmaf(0.f, ixy, 0.f * iyy));
+                        finite = probe == probe;
+                    }
                 }
                 // the 3 x 3 taps: rows ty + e .. + 2, columns tx + e .. + 2 of the window, as aligned pairs from the
                 // copy whose shift makes column tx + e even
@@ -1128,26 +1153,37 @@ __global__ void __launch_bounds__(256, HHSR_X2_OCC) k_merge_x2(BurstArgs a, Geo 
                 const float dx0 = ax.d0[sb], dy0 = ay.d0[sa];
                 const float dxs[3] = {dx0 - 1.f, dx0, dx0 + 1.f};
                 float sv[2][2], sd[2][2];  // by parity of the tap offset (di + 1, dj + 1)
+                // w = exp(-max(0, q) / 2) with Python's max (NaN -> 0, D10).  With finite coefficients q is finite and
+                // w = clamp(exp2(z), 0, 1): the clamp is an output modifier of v_exp_f32 (free) and equals the max for
+                // z > 0 (non-positive-definite blends at the image border, D11).  Non-finite coefficients (NaN
+                // covariances of flat regions, D10; singular hand-made covariances) take the exact per-tap form.
+                auto taps = [&](auto exact_c) {
+                    constexpr bool EXACT = decltype(exact_c)::value;
 #pragma unroll
-                for (int di = 0; di < 3; ++di) {
-                    const float2 v01 = lds_pair(rp + di * X2_RP), v23 = lds_pair(rp + di * X2_RP + 2);
-                    const float c3[3] = {v01.x, v01.y, v23.x};
-                    const float dy = dy0 + (float)(di - 1);
-                    const float qa = iyy * dy * dy, qb = ixy * dy;
+                    for (int di = 0; di < 3; ++di) {
+                        const float2 v01 = lds_pair(rp + di * X2_RP), v23 = lds_pair(rp + di * X2_RP + 2);
+                        const float c3[3] = {v01.x, v01.y, v23.x};
+                        const float dy = dy0 + (float)(di - 1);
+                        const float qa = iyy * dy * dy, qb = ixy * dy;
 #pragma unroll
-                    for (int dj = 0; dj < 3; ++dj) {
-                        const float dx = dxs[dj];
-                        const float z = fminf(fmaf(fmaf(ixx, dx, qb), dx, qa), 0.f);  // min: NaN -> 0 -> w = 1 (D10)
-                        const float w = __builtin_amdgcn_exp2f(z);
-                        if (di < 2 && dj < 2) {  // first tap of its parity class (row-major order)
-                            sv[di & 1][dj & 1] = w * c3[dj];
-                            sd[di & 1][dj & 1] = w;
-                        } else {
-                            sv[di & 1][dj & 1] = fmaf(w, c3[dj], sv[di & 1][dj & 1]);
-                            sd[di & 1][dj & 1] += w;
+                        for (int dj = 0; dj < 3; ++dj) {
+                            const float dx = dxs[dj];
+                            const float z = fmaf(fmaf(ixx, dx, qb), dx, qa);
+                            const float w = EXACT ? __builtin_amdgcn_exp2f(fminf(z, 0.f))
+                                                  : __builtin_amdgcn_fmed3f(__builtin_amdgcn_exp2f(z), 0.f, 1.f);
+                            if (di < 2 && dj < 2) {  // first tap of its parity class (row-major order)
+                                sv[di & 1][dj & 1] = w * c3[dj];
+                                sd[di & 1][dj & 1] = w;
+                            } else {
+                                sv[di & 1][dj & 1] = fmaf(w, c3[dj], sv[di & 1][dj & 1]);
+                                sd[di & 1][dj & 1] += w;
+                            }
                         }
                     }
-                }
+                };
+                if (!HHSR_X2_CLAMP) taps(std::true_type{});
+                else if (ISO || finite) taps(std::false_type{});
+                else taps(std::true_type{});
                 // tap-offset parity -> absolute raw-coordinate parity (uniform): n4[a][b] += r * sv[a ^ by][b ^ bx]
                 const int by = (ay.org + py + ay.e[sa]) & 1, bx = (ax.org + px + ax.e[sb]) & 1;
 #define HHSR_FOLD(BY, BX)                                                                             \
@@ -1168,6 +1204,11 @@ __global__ void __launch_bounds__(256, HHSR_X2_OCC) k_merge_x2(BurstArgs a, Geo 
 #undef HHSR_FOLD
             }
     };
+    auto frame_n = [&](int n, const float2 fl, float lr, int bo) {
+        if (!HHSR_X2_PEEL) frame(std::false_type{}, n >= a.n, fl, lr, bo);
+        else if (n >= a.n) frame(std::true_type{}, true, fl, lr, bo);
+        else frame(std::false_type{}, false, fl, lr, bo);
+    };
 #if HHSR_X2_DB
     // double-buffered windows: frame n is evaluated from buffer n & 1 while frame n + 1 is written into the other one
     // (its global loads were issued before frame n's taps): ONE workgroup barrier per frame
@@ -1180,7 +1221,7 @@ __global__ void __launch_bounds__(256, HHSR_X2_OCC) k_merge_x2(BurstArgs a, Geo 
     for (int n = 0; n < nloop; ++n) {
         const float2 fl = sfl;
         const float lr = sr;
-        frame(n >= a.n, fl, lr, n & 1);
+        frame_n(n, fl, lr, n & 1);
         if (n + 1 < nloop) stage(n + 1, (n + 1) & 1);
         __syncthreads();
         if (n + 2 < nloop) prefetch(n + 2);
@@ -1194,7 +1235,7 @@ __global__ void __launch_bounds__(256, HHSR_X2_OCC) k_merge_x2(BurstArgs a, Geo 
         const float lr = sr;
         __syncthreads();
         if (n + 1 < nloop) prefetch(n + 1);  // in flight while this frame's taps are evaluated
-        frame(n >= a.n, fl, lr, 0);
+        frame_n(n, fl, lr, 0);
     }
 #endif
     if (a.acc_r) a.acc_r[ridx] = ((a.flags & HHSR_MERGE_LOAD_ACC) ? a.acc_r[ridx] : 0.f) + racc;
