@@ -25,6 +25,10 @@ struct Geo {
     int ny, nx, ts;     // flow tile grid
     int sH, sW;         // output
     int row0, row1;     // output rows [row0, row1) handled by this launch (merge_burst slabs); num/den point at row0
+    int off_lr, off_hr; // sub-images (multi-GPU row slabs): raw row 0 of this image is row off_lr of the full frame and
+                        // output row 0 is row off_hr = off_lr * scale: positions are evaluated at FULL-FRAME coordinates
+                        // and shifted back exactly, so that their float64 / float32 roundings (the reference keeps the
+                        // reference frame's position idx / scale in float32, merge.py:113-114) do not depend on the split
     int bt, bb, bl, br; // border bands: output rows < bt / >= sH - bb and columns < bl / >= sW - br are the pixels whose
                         // reference-frame window centre lies on the outermost raw row / column (see border_pixel)
     double scale;
@@ -64,7 +68,7 @@ template <typename WT, bool ISO>
 __device__ __forceinline__ void comp_contrib(const FramePtr f, const Geo& g, const Cfa4 cfa, int hi, int hj,
                                              float val[3], float acc[3], bool lmin = false) {
     const double lr_x = ((double)hj + 0.5) / g.scale;
-    const double lr_y = ((double)hi + 0.5) / g.scale;
+    const double lr_y = ((double)(hi + g.off_hr) + 0.5) / g.scale - (double)g.off_lr;
     const int px = (int)lr_x / g.ts, py = (int)lr_y / g.ts;  // == int(lr // tile_size) for lr >= 0
     const float2 fl = f.flow[(size_t)py * g.nx + px];
     const int i_r = min((int)lr_y, g.H - 1), j_r = min((int)lr_x, g.W - 1);
@@ -150,7 +154,7 @@ struct Pix {
 __device__ __forceinline__ Pix make_pix(const Geo& g, int hi, int hj) {
     Pix p;
     p.lr_x = ((double)hj + 0.5) / g.scale;
-    p.lr_y = ((double)hi + 0.5) / g.scale;
+    p.lr_y = ((double)(hi + g.off_hr) + 0.5) / g.scale - (double)g.off_lr;
     p.lix = (int)p.lr_x;
     p.liy = (int)p.lr_y;
     p.lfx = (float)(p.lr_x - (double)p.lix);
@@ -313,7 +317,7 @@ __device__ __forceinline__ void comp_accum_fast(const FramePtr f, const Geo& g, 
 template <bool ISO>
 __device__ __forceinline__ void ref_accum_fast(const float* __restrict__ raw, const float4* __restrict__ cov,
                                                const Geo& g, int oi, int oj, float n4[2][2], float d4[2][2]) {
-    const float pyf = (float)((double)oi / g.scale), pxf = (float)((double)oj / g.scale);
+    const float pyf = (float)((double)(oi + g.off_hr) / g.scale) - (float)g.off_lr, pxf = (float)((double)oj / g.scale);
     FrameGeo q;
     q.cj = (int)rintf(pxf);
     q.ci = (int)rintf(pyf);
@@ -365,7 +369,7 @@ __device__ __forceinline__ bool ref_contrib(const float* __restrict__ raw, const
                                             const Geo& g, const Cfa4 cfa, int oi, int oj,
                                             const float* __restrict__ acc_rob, int rad_max, double max_mult,
                                             double max_fc, float val[3], float acc[3]) {
-    const float pyf = (float)((double)oi / g.scale);  // coarse_ref_sub_pos is a float32 local array
+    const float pyf = (float)((double)(oi + g.off_hr) / g.scale) - (float)g.off_lr;  // coarse_ref_sub_pos is a float32 local array
     const float pxf = (float)((double)oj / g.scale);
     float i00 = 1.f, i01 = 0.f, i10 = 0.f, i11 = 1.f;
     if (!ISO) {
@@ -1306,6 +1310,7 @@ static int fill_geo(Geo& g, int H, int W, int pitch, int ny, int nx, int ts, dou
     g.H = H; g.W = W; g.pitch = pitch; g.gh = H / 2; g.gw = W / 2;
     g.ny = ny; g.nx = nx; g.ts = ts; g.sH = sH; g.sW = sW; g.scale = scale;
     g.row0 = 0; g.row1 = sH;
+    g.off_lr = g.off_hr = 0;
     // border bands: output rows / columns whose reference-window centre rint(float(idx / scale)) (merge.py:113-114,
     // 179-180) is the first or last raw row / column
     auto bands = [scale](int n_lr, int n_hr, int& lo, int& hi) {
@@ -1381,7 +1386,7 @@ extern "C" int hhsr_merge_burst(const float* const* raws, const float* const* fl
                                 const float* const* rs, int n_frames, int H, int W, int pitch, int ny, int nx,
                                 int ts, const float* ref_raw, const float* ref_covs, const uint8_t cfa[4],
                                 double scale, int kflags, int flags, float* num, float* den, float* acc_r, int sH,
-                                int sW, int row0, int nrows, void* stream) {
+                                int sW, int row0, int nrows, int lr_row_offset, void* stream) {
     const int iso = kflags & HHSR_KERNEL_ISO, f64 = kflags & HHSR_WEIGHT_F64;
     HHSR_ARG(n_frames >= 0 && n_frames <= HHSR_MAX_FRAMES && cfa && num);
     HHSR_ARG(n_frames == 0 || (raws && flows && rs && (iso || covs)));
@@ -1408,6 +1413,10 @@ extern "C" int hhsr_merge_burst(const float* const* raws, const float* const* fl
     Geo g;
     fill_geo(g, H, W, pitch, ny, nx, ts, scale, sH, sW);
     HHSR_ARG(row0 >= 0 && nrows > 0 && row0 + nrows <= sH);
+    HHSR_ARG(lr_row_offset >= 0 && lr_row_offset % ts == 0 && lr_row_offset % 2 == 0 &&
+             (double)(int64_t)(lr_row_offset * scale) == lr_row_offset * scale);  // whole tiles, Bayer quads, output rows
+    g.off_lr = lr_row_offset;
+    g.off_hr = (int)(lr_row_offset * scale);
     g.row0 = row0;
     g.row1 = row0 + nrows;
     Cfa4 c;

@@ -48,7 +48,7 @@ _SIGS = {
     "hhsr_accumulate_ref": [P, I, I, I, P, U8P, D, I, P, I, D, D, P, P, I, I, P],
     "hhsr_divide": [P, P, L, P],
     "hhsr_add": [P, P, L, P],
-    "hhsr_merge_burst": [PP, PP, PP, PP, I, I, I, I, I, I, I, P, P, U8P, D, I, I, P, P, P, I, I, I, I, P],
+    "hhsr_merge_burst": [PP, PP, PP, PP, I, I, I, I, I, I, I, P, P, U8P, D, I, I, P, P, P, I, I, I, I, I, P],
 }
 
 MERGE_LOAD_ACC, MERGE_DO_REF, MERGE_DIVIDE, MERGE_STORE_DEN = 1, 2, 4, 8

@@ -17,7 +17,7 @@ reference's single-image result; 72 MB per rank at 12 MP x2 over 7 parallel link
 Step B works on SUB-IMAGES: row ranges [S0, S1) of every raw frame, S0 a multiple of the flow tile size (so the
 tile grid, the Bayer phase and — for integer S0 * scale — the output grid of the sub-image coincide with the full
 image's).  The kernels are the single-GPU ones, unchanged; per-pixel results inside the slab are bit-identical to the
-single-GPU run (power-of-two scales; other scales: to the last bit of the float64 position (h + 0.5) / scale) because every pixel the slab's outputs depend on lies at least 8 rows inside the sub-image (the
+single-GPU run (every scale: the merge evaluates positions in full-frame coordinates, `lr_row_offset`) because every pixel the slab's outputs depend on lies at least 8 rows inside the sub-image (the
 first rows of a sub-image see an artificial image border: D6's r = 0 rows, clamped neighbourhoods — they are halo).
 
 The engine that does the per-rank compute is injected so that the sharding / exchange logic can be exercised without
@@ -54,7 +54,7 @@ def slab_bounds(sH, world):
     return [min(j * rows, sH) for j in range(world + 1)]
 
 
-def sub_image_rows(r0, r1, scale, H, ts, max_flow_y):
+def sub_image_rows(r0, r1, scale, H, ts, max_flow_y, from_top=False):
     """Raw rows [S0, S1) that output rows [r0, r1) depend on, for flows of at most `max_flow_y` pixels.
     S0 is a multiple of the tile size with S0 * scale an integer (else 0: the sub-image starts at the top);
     S1 is even (Bayer quads).  Returns (S0, S1, row0_sub) with row0_sub = r0 - S0 * scale, the slab's first row
@@ -62,7 +62,7 @@ def sub_image_rows(r0, r1, scale, H, ts, max_flow_y):
     halo = int(math.ceil(max_flow_y)) + HALO
     lo = int(math.floor(r0 / scale)) - halo
     hi = int(math.ceil(r1 / scale)) + halo
-    S0 = max(0, (lo // ts) * ts)
+    S0 = 0 if from_top else max(0, (lo // ts) * ts)
     while S0 > 0 and abs(S0 * scale - round(S0 * scale)) > 1e-9:
         S0 -= ts
     S1 = min(H, hi + (hi & 1))
@@ -123,7 +123,10 @@ class HipEngine:
         H, W = self.shape()
         sH, sW, _ = self.output_shape()
         scale, ts = cfg.scale, self.tile_size()
-        S0, S1, row0 = sub_image_rows(r0, r1, scale, H, ts, max_flow_y)
+        pow2 = float(scale) in (1.0, 2.0, 4.0, 8.0)
+        # (the per-frame operator path of the denoiser has no row offset: for scales whose positions idx / scale are
+        # not exact in float32 its sub-image starts at the top of the frame, where sub-image = full-frame coordinates)
+        S0, S1, row0 = sub_image_rows(r0, r1, scale, H, ts, max_flow_y, from_top=self.denoiser_on and not pow2)
         Hs = S1 - S0
         sHs = int(round(scale * Hs))
         nrows = r1 - r0
@@ -153,7 +156,8 @@ class HipEngine:
             frames = sub.process_frames([img[S0:S1] for img in comp_imgs], None if fuse_acc else acc_r,
                                         fuse_local_min=fuse_min, flows=sub_flows)
             merge_burst(frames, sub.ref, sub.ref_covs, out, None, sub.cfa, cfg, do_ref=True, divide=True,
-                        acc_r=acc_r if fuse_acc else None, rows=(row0, nrows), out_height=sHs, local_min=fuse_min)
+                        acc_r=acc_r if fuse_acc else None, rows=(row0, nrows), out_height=sHs, local_min=fuse_min,
+                        lr_row_offset=S0)
         return out, (acc_r[L0:L1] if acc_r is not None else None)
 
 

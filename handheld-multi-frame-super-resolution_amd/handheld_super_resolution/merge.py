@@ -73,7 +73,7 @@ def can_fuse_local_min(config, shape):
 
 
 def merge_burst(frames, ref_img, ref_kernels, num, den, cfa_pattern, config, load_acc=False, do_ref=True,
-                divide=True, store_den=False, acc_r=None, rows=None, out_height=None, local_min=False):
+                divide=True, store_den=False, acc_r=None, rows=None, out_height=None, local_min=False, lr_row_offset=0):
     """Fused merge of a whole (shard of a) burst: `frames` is a list of (raw, flow, covs, r).  Per output
     pixel the frames are summed in list order with the accumulators in registers — the same float32
     order as successive merge() calls — then the reference frame is added and the result normalised,
@@ -82,7 +82,9 @@ def merge_burst(frames, ref_img, ref_kernels, num, den, cfa_pattern, config, loa
     of the frames' robustness maps in the same pass.  `rows = (row0, nrows)` restricts the launch to a slab of
     output rows; `num` / `den` are then [nrows, sW, 3] slabs and `out_height` the full output height.
     `local_min`: the frames carry the thresholded maps R (compute_robustness(..., fuse_local_min=True)) and the
-    5x5 minimum of Alg. 9 is taken inside the merge (see can_fuse_local_min)."""
+    5x5 minimum of Alg. 9 is taken inside the merge (see can_fuse_local_min).
+    `lr_row_offset`: the frames are sub-images starting at this raw row of the full frame (multi-GPU row slabs):
+    positions are evaluated in full-frame coordinates (see include/hhsr.h)."""
     scale, kflags = _common(config)
     if do_ref and config.accumulated_robustness_denoiser.enabled:
         raise ValueError("merge_burst cannot apply the accumulated robustness denoiser; use merge_ref")
@@ -116,4 +118,4 @@ def merge_burst(frames, ref_img, ref_kernels, num, den, cfa_pattern, config, loa
                   _lib.ptr_array([c[2] for c in chunk]), _lib.ptr_array([c[3] for c in chunk]), len(chunk),
                   H, W, W, ny, nx, int(ts), _lib.ptr(ref_img if (f & 2) else None),
                   _lib.ptr(ref_kernels if (f & 2) else None), cfa, scale, kflags, f, _lib.ptr(num), _lib.ptr(den),
-                  _lib.ptr(acc_r if chunk else None), sH, sW, int(row0), int(nrows), _lib.stream())
+                  _lib.ptr(acc_r if chunk else None), sH, sW, int(row0), int(nrows), int(lr_row_offset), _lib.stream())

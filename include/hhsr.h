@@ -191,6 +191,10 @@ int hhsr_add(float* A, const float* B, int64_t n, void* stream);          /* A +
  * then optionally add the reference frame and normalise.  HOST arrays of device pointers.
  * Output rows [row0, row0 + nrows) are processed and num / den point at row0 (slabs for the multi-GPU
  * reduce-scatter; row0 = 0, nrows = sH for the whole image).
+ * lr_row_offset: 0 for whole frames.  For a SUB-IMAGE (rows [offset, offset + H) of a larger frame: the row slabs of
+ * the multi-GPU path) the raw row this image starts at — a multiple of ts and of 2 with an integer offset * scale:
+ * sampling positions are then evaluated in full-frame coordinates, so their float64 / float32 roundings (merge.py:113-114
+ * keeps idx / scale in float32) and therefore the results do not depend on how the frame was split.
  * acc_r (optional, float32 [H][W], integer scales only) receives sum_n r_n — the accumulated robustness of
  * super_resolution.py:158-159 — at no extra HBM traffic (+= with HHSR_MERGE_LOAD_ACC).
  * flags: */
@@ -206,7 +210,8 @@ int hhsr_merge_burst(const float* const* raws, const float* const* flows, const 
                      const float* const* rs, int n_frames, int H, int W, int pitch,
                      int ny, int nx, int ts, const float* ref_raw, const float* ref_covs,
                      const uint8_t cfa[4], double scale, int kflags, int flags,
-                     float* num, float* den, float* acc_r, int sH, int sW, int row0, int nrows, void* stream);
+                     float* num, float* den, float* acc_r, int sH, int sW, int row0, int nrows,
+                     int lr_row_offset, void* stream);
 
 /* ---- burst front end (utils_dng.py:149-160) ------------------------------------------------
  * Sensor counts uint16 [n_frames][H][pitch] -> normalised, white-balanced float32 [n_frames][H][W]:
