@@ -139,6 +139,12 @@ __device__ __forceinline__ void comp_contrib(const FramePtr f, const Geo& g, con
 //             in float32, and floor(lr + flow) is decided by ONE exact float comparison
 //             flow >= floor(flow) + (1 - frac(lr)) — no float64 instruction in the frame loop;
 //   GEOM_F64  any scale: positions in float64 exactly like the reference (merge.py:319-345, 396-399).
+//             (An exact integer + float32 form for odd integer scales — h = s q + rem, carry when frac(flow) >=
+//             (2 s - 2 rem - 1)/(2 s) — was built and measured in round 2: x3 at 48 MP 45.2 ms vs 44.4 ms with this
+//             float64 geometry, i.e. no gain: the tile kernel is bound by the ~250 VALU instructions of per-pixel
+//             covariance blend + 9 taps, not by its ~25 float64 operations.  Note for a retry: frac(flow) =
+//             flow - floor(flow) is NOT exact in float32 for small negative flows (-0.1 + 1 rounds), so the carry
+//             must be decided as flow >= floor(flow) + t like GEOM_P2 does, or in float64.)
 // Differences to the float64 weight chain are O(1e-6) relative on num/den (tests: rel 2e-5).
 enum { GEOM_F64 = 0, GEOM_P2 = 1 };
 

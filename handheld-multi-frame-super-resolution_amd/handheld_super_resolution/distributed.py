@@ -114,7 +114,8 @@ class HipEngine:
 
     def merge_rows(self, comp_imgs, flows, r0, r1, max_flow_y):
         """Step B: output rows [r0, r1) from ALL frames (flows: [N-1, ny, nx, 2]).  Returns (slab float32
-        [r1 - r0, sW, 3], acc_r rows of the slab [(r1 - r0) / scale, W] or None)."""
+        [r1 - r0, sW, 3], accumulated robustness of the raw rows [ceil(r0 / scale), ceil(r1 / scale)) — the rows whose
+        first output row lies in the slab: a disjoint cover over the slabs — or None)."""
         from .super_resolution import BurstPipeline
         from .merge import merge, merge_ref, merge_burst, can_fuse_acc_r
         from .utils import divide
@@ -137,7 +138,7 @@ class HipEngine:
         sub_flows = [flows[i, t0:t1].contiguous() for i in range(n)]
         out = torch.empty((nrows, sW, 3), dtype=torch.float32, device=self.device)
         acc_r = torch.zeros((Hs, W), dtype=torch.float32, device=self.device) if self.accumulate_r else None
-        L0 = int(math.floor(r0 / scale)) - S0
+        L0 = int(math.ceil(r0 / scale)) - S0
         L1 = min(Hs, int(math.ceil(r1 / scale)) - S0)
         if self.denoiser_on:
             # the accumulated-robustness denoiser (merge.py:223-228) needs sum_n r_n before the reference frame is
@@ -246,7 +247,7 @@ def main_sharded(ref_img, comp_imgs, config, group=None, engine=None, gather=Tru
     want_acc = bool(getattr(eng, "accumulate_r", False))
     acc_all = None
     if want_acc:
-        lrows = -(-rows // max(1, int(math.floor(config.scale))))
+        lrows = int(math.ceil(rows / config.scale)) + 2  # raw rows [floor(r0 / s), ceil(r1 / s)) of any slab
         a_send = torch.zeros((lrows, W), dtype=torch.float32, device=dev)
         if acc_r is not None:
             a_send[: acc_r.shape[0]] = acc_r
@@ -258,7 +259,7 @@ def main_sharded(ref_img, comp_imgs, config, group=None, engine=None, gather=Tru
     if want_acc:
         parts = []
         for j in range(world):
-            a0 = int(math.floor(bounds[j] / config.scale))
+            a0 = int(math.ceil(bounds[j] / config.scale))
             a1 = min(H, int(math.ceil(bounds[j + 1] / config.scale)))
             if bounds[j + 1] > bounds[j]:
                 parts.append((a0, acc_all[j, : a1 - a0]))

@@ -80,7 +80,7 @@ class OracleEngine:
             oracle.merge(img_s, flow_s, oracle.estimate_kernels(img_s, cfg), r, num, den, self.cfa, cfg)
         oracle.merge_ref(ref_s, oracle.estimate_kernels(ref_s, cfg), num, den, self.cfa, cfg)
         oracle.divide(num, den)
-        L0 = int(math.floor(r0 / s)) - S0
+        L0 = int(math.ceil(r0 / s)) - S0
         L1 = min(Hs, int(math.ceil(r1 / s)) - S0)
         return torch.from_numpy(np.ascontiguousarray(num[row0:row0 + (r1 - r0)])), torch.from_numpy(acc_r[L0:L1].copy())
 

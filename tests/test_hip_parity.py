@@ -574,6 +574,54 @@ def test_merge_border_bands_float64_chain():
             assert_close(got, want, 2e-5, 1e-6, f"interior x{scale} {which}")
 
 
+@pytest.mark.parametrize("scale", [3, 5, 6])
+def test_merge_integer_scale_geometry_decisions(scale):
+    """Odd / composite integer scales: the float32 weight kernels take exactly the window-centre decisions of the
+    reference's float64 evaluation (merge.py:319-345), also for flows whose fractional part is a float32 neighbour of a
+    carry threshold (2s - 2rem - 1)/(2s) and for small negative flows (where flow - floor(flow) is inexact in float32) —
+    a flipped centre pixel would move a window by one raw pixel and show as an O(0.1) difference."""
+    H, W, ts = 48, 64, 16
+    c64 = base_config(ts=ts, scale=scale)
+    c64.hip = {"weight_fp64": True}
+    ref, fr = _frames(H, W, 2, ts, 9, c64)
+    # adversarial flows: k + threshold +- 1 ulp for every remainder class, both signs
+    thr = sorted({(2 * scale - 2 * rem - 1) / (2 * scale) for rem in range(scale)} | {0.0, 0.5})
+    vals = []
+    for k in (-3.0, -1.0, 0.0, 2.0):
+        for t in thr:
+            f = np.float32(k + t)
+            vals += [f, np.nextafter(f, np.float32(-10)), np.nextafter(f, np.float32(10))]
+    vals = np.array(vals, np.float32)
+    ny, nx = fr[0][1].shape[:2]
+    rng = np.random.default_rng(1)
+    for k in range(2):
+        flow = vals[rng.integers(0, len(vals), (ny, nx, 2))]
+        fr[k] = (fr[k][0], flow.astype(np.float32), fr[k][2], fr[k][3])
+    tf = [tuple(T(a) for a in f) for f in fr]
+    rc = T(oracle.estimate_kernels(ref, c64))
+    sH, sW = scale * H, scale * W
+    want = torch.empty(sH, sW, 3, device=DEV)
+    merge.merge_burst(tf, T(ref), rc, want, None, [[0, 1], [1, 2]], c64)
+    for which in ("auto", "generic"):
+        c = base_config(ts=ts, scale=scale)
+        c.hip = {"merge_kernel": which}
+        got = torch.empty(sH, sW, 3, device=DEV)
+        merge.merge_burst(tf, T(ref), rc, got, None, [[0, 1], [1, 2]], c)
+        assert_close(N(got), N(want), 2e-5, 1e-6, f"x{scale} {which} vs float64 geometry")
+    num, den = torch.zeros(sH, sW, 3, device=DEV), torch.zeros(sH, sW, 3, device=DEV)
+    n64, d64 = torch.zeros_like(num), torch.zeros_like(den)
+    for f in tf:
+        merge.merge(*f, num, den, [[0, 1], [1, 2]], base_config(ts=ts, scale=scale))
+        merge.merge(*f, n64, d64, [[0, 1], [1, 2]], c64)
+    # (un-normalised sums.  A flipped decision moves a 3x3 window by a raw pixel: O(1e-2 .. 1e-1).  The tolerance of 1e-3
+    # leaves room for ONE kind of pixel: flow ~ -1 at the first raw row extrapolates the covariance (D11) to a nearly
+    # singular matrix that amplifies the float32 rounding of the blend — measured 3e-5 (x3) and 2.3e-4 (x6) on one pixel;
+    # everywhere else the sums agree to 2e-5)
+    for a_, b_, w_ in ((num, n64, "num"), (den, d64, "den")):
+        assert_close(N(a_), N(b_), 1e-3, 1e-6, f"x{scale} per-frame kernel {w_}")
+        assert_close(N(a_)[2 * scale:], N(b_)[2 * scale:], 2e-5, 1e-6, f"x{scale} per-frame kernel {w_}, rows off the top border")
+
+
 def test_merge_burst_more_frames_than_one_launch_holds():
     """70 frames > HHSR_MAX_FRAMES (64): merge_burst chains two launches through the accumulators (with the fused
     local minimum and accumulated robustness) == per-frame merges."""
