@@ -25,6 +25,7 @@ SOURCES = {
     "hhsr_grey.hip": ["-ffp-contract=off"],
     "hhsr_fft.hip": [],
     "hhsr_io.hip": ["-ffp-contract=off"],
+    "hhsr_post.hip": ["-ffp-contract=off"],
 }
 
 

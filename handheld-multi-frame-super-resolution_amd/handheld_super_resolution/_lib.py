@@ -48,6 +48,9 @@ _SIGS = {
     "hhsr_accumulate_ref": [P, I, I, I, P, U8P, D, I, P, I, D, D, P, P, I, I, P],
     "hhsr_divide": [P, P, L, P],
     "hhsr_add": [P, P, L, P],
+    "hhsr_frame_count_denoise": [P, P, I, I, P, I, I, D, I, D, D, I, P],
+    "hhsr_postprocess": [P, P, P, I, I, FP, I, D, P, I, I, I, I, P],
+    "hhsr_orient_plane": [P, P, I, I, I, P],
     "hhsr_merge_burst": [PP, PP, PP, PP, I, I, I, I, I, I, I, P, P, U8P, D, I, I, P, P, P, I, I, I, I, I, P],
 }
 

@@ -325,16 +325,19 @@ def process(burst_path, config):
 
     `burst_path` is either a burst held in memory / in an .npz file — a mapping with keys ``ref`` [H,W],
     ``comp`` [N-1,H,W], ``cfa_pattern`` [2,2], ``white_balance`` [>=3], ``alpha``, ``beta`` and optionally
-    ``iso``, ``std_curve``, ``diff_curve``; ref / comp are either normalised white-balanced float RAW or integer
+    ``iso``, ``std_curve``, ``diff_curve``, ``orientation`` (EXIF 1..8), ``xyz2cam`` (3x3, DNG ColorMatrix1, for
+    ``postprocessing.do_color_correction``); ref / comp are either normalised white-balanced float RAW or integer
     sensor counts with ``black_levels`` and ``white_level`` (normalised on the GPU like utils_dng.py:149-160) —
     or a folder of .dng files, which needs rawpy + exifread like the reference (absent from this image:
     ImportError).  Noise curves: given in the burst, or ``config.noise_model.estimator``: "monte_carlo" (default — the
     reference's estimator run_fast_MC, super_resolution.py:252, whose curves include the clipping of the noisy samples
     to [0, 1]: near black and near saturation sigma_t and d_t are up to ~1.6x smaller than the un-clipped law; seeded by
     ``config.noise_model.seed``, default 0, so process() is reproducible where the reference is not, D18) or
-    "analytic" (the un-clipped limit, synthetic.noise_curves — what prepare_config() uses when called directly).  The CPU-side
-    ISP after the hot path (colour matrix, gamma, sharpening, orientation; raw2rgb.py) is out of scope:
-    the un-post-processed linear RGB image is returned, as with ``postprocessing.enabled: false``."""
+    "analytic" (the un-clipped limit, synthetic.noise_curves — what prepare_config() uses when called directly).
+    After main(): the frame-count denoisers (``accumulated_robustness_denoiser.median / .gauss``), then
+    ``postprocessing`` (colour matrix, unsharp mask, devignetting, gamma — ON by default like the reference's YAML; tone
+    mapping raises NotImplementedError) and the EXIF orientation, all on the GPU (utils_image.py, raw2rgb.py); only the
+    finished image is copied to the host."""
     import os
 
     from .utils_dng import load_dng_burst, normalize_burst
@@ -346,6 +349,10 @@ def process(burst_path, config):
         nm = tags["Image Tag 0xC761"].values  # DNG NoiseProfile, already scaled for the ISO (reference :232-238)
         burst = {"ref": ref_raw, "comp": raw_comp, "iso": iso, "cfa_pattern": cfa, "white_balance": white_balance,
                  "alpha": sum(x[0] for x in nm[::2]) / 3, "beta": sum(x[0] for x in nm[1::2]) / 3}
+        if "Image Orientation" in tags:
+            burst["orientation"] = tags["Image Orientation"].values[0]
+        if "Image Tag 0xC621" in tags:  # DNG ColorMatrix1 (raw2rgb.py:12-27)
+            burst["xyz2cam"] = np.array([x.decimal() for x in tags["Image Tag 0xC621"].values], np.float32).reshape(3, 3)
     else:
         burst = burst_path
     ref_raw, raw_comp = burst["ref"], burst["comp"]
@@ -372,11 +379,30 @@ def process(burst_path, config):
     prepare_config(config, ref_for_stats, alpha, beta, burst["cfa_pattern"], burst["white_balance"],
                    int(burst.get("iso", 100)), std_curve, diff_curve,
                    shape=tuple(ref_raw.shape))
-    den = config.accumulated_robustness_denoiser
-    if den.median.enabled or den.gauss.enabled:
-        raise NotImplementedError("post-hoc median / gauss frame-count denoisers are out of scope (SURVEY.md §2a)")
     out, debug_dict = main(ref_raw, raw_comp, config)
+
+    # ---- after the path (reference super_resolution.py:303-356), on the device --------------------------------------
+    from . import raw2rgb
+    from .utils_image import apply_orientation, frame_count_denoising_gauss, frame_count_denoising_median
+
+    den = config.accumulated_robustness_denoiser
+    compat = config.get("compat", None) or {}
+    half_index = bool(compat.get("post_denoiser_half_index", True))
+    if den.median.enabled:
+        out = frame_count_denoising_median(out, debug_dict["accumulated robustness"], den.median, scale=config.scale,
+                                           half_index=half_index)
+    if den.gauss.enabled:
+        out = frame_count_denoising_gauss(out, debug_dict["accumulated robustness"], den.gauss, scale=config.scale,
+                                          half_index=half_index)
+    ori = int(burst.get("orientation", 1))  # EXIF 'Image Orientation' (reference :346-352); 1 when the burst has none
+    pp = config.postprocessing
+    if pp.enabled:
+        out = raw2rgb.postprocess(burst.get("rawpy_image", None), out, pp.do_color_correction, pp.do_tonemapping,
+                                  pp.do_gamma_correction, pp.sharpening, pp.do_devignetting, burst.get("xyz2cam", None),
+                                  orientation=ori)
+    else:
+        out = apply_orientation(out, ori)
     output_image = out.cpu().numpy()
     if "accumulated robustness" in debug_dict:
-        debug_dict["accumulated robustness"] = debug_dict["accumulated robustness"].cpu().numpy()
+        debug_dict["accumulated robustness"] = apply_orientation(debug_dict["accumulated robustness"], ori).cpu().numpy()
     return output_image, debug_dict

@@ -99,3 +99,69 @@ def cuda_downsample(th_img, kernel="gaussian", factor=2):
     _lib.call("hhsr_gauss_decimate", _lib.ptr(img), H, W, W, _lib.ptr(out), w2, factor, _lib.floats(taps),
               len(taps), _lib.stream())
     return out.reshape(*lead, h2, w2)
+
+
+# ---- after the path ------------------------------------------------------------------------------------
+def apply_orientation(img, ori):
+    """EXIF orientation 1..8 (utils_image.py:12-55).  NumPy arrays are handled like upstream; GPU tensors stay on the
+    device ([H, W] planes through hhsr_orient_plane, images through flips / transposes of the same memory)."""
+    ori = int(ori)
+    if not torch.is_tensor(img):
+        if ori == 2:
+            img = np.flip(img, axis=1)
+        elif ori == 3:
+            img = np.rot90(img, k=2, axes=(0, 1))
+        elif ori == 4:
+            img = np.flip(img, axis=0)
+        elif ori == 5:
+            img = np.rot90(np.flip(img, axis=1), k=-3, axes=(0, 1))
+        elif ori == 6:
+            img = np.rot90(img, k=-1, axes=(0, 1))
+        elif ori == 7:
+            img = np.rot90(np.flip(img, axis=1), k=-1, axes=(0, 1))
+        elif ori == 8:
+            img = np.rot90(img, k=-3, axes=(0, 1))
+        return img
+    if ori == 1:
+        return img
+    if img.dim() == 2 and img.is_cuda:
+        src = _lib.f32c(img)
+        H, W = src.shape
+        out = torch.empty((W, H) if ori >= 5 else (H, W), dtype=torch.float32, device=src.device)
+        _lib.call("hhsr_orient_plane", _lib.ptr(src), _lib.ptr(out), H, W, ori, _lib.stream(src.device))
+        return out
+    t = {2: lambda a: a.flip(1), 3: lambda a: a.flip(0).flip(1), 4: lambda a: a.flip(0),
+         5: lambda a: a.transpose(0, 1), 6: lambda a: a.transpose(0, 1).flip(1),
+         7: lambda a: a.flip(0).flip(1).transpose(0, 1), 8: lambda a: a.transpose(0, 1).flip(0)}[ori]
+    return t(img).contiguous()
+
+
+def _frame_count_denoise(image, r_acc, config, kind, strength, scale, half_index):
+    if str(config.get("mode", "bayer")) == "grey":
+        raise NotImplementedError("grey mode is outside the MI355X hot path (bayer only)")
+    scale = config.get("scale", scale)
+    if scale is None:
+        raise ValueError("the frame-count denoisers need the scale (config.scale or the scale argument)")
+    img = _lib.f32c(image)
+    acc = _lib.f32c(r_acc, img.device)
+    H, W, C = img.shape
+    assert C == 3
+    out = torch.empty_like(img)
+    _lib.call("hhsr_frame_count_denoise", _lib.ptr(img), _lib.ptr(out), H, W, _lib.ptr(acc), acc.shape[0], acc.shape[1],
+              float(scale), kind, float(strength), float(config.max_frame_count), 1 if half_index else 0,
+              _lib.stream(img.device))
+    return out
+
+
+def frame_count_denoising_median(image, r_acc, config, scale=None, half_index=True):
+    """Median filter whose radius grows where few frames were merged (utils_image.py:236-286).  `config`: the
+    accumulated_robustness_denoiser.median block (radius_max <= 7, max_frame_count); the reference reads `scale` and
+    `mode` from the same block although process() never puts them there — pass `scale`.  `half_index`: keep the
+    reference's index into the accumulated robustness (it addresses the [H, W] map at half resolution)."""
+    return _frame_count_denoise(image, r_acc, config, 0, config.radius_max, scale, half_index)
+
+
+def frame_count_denoising_gauss(image, r_acc, config, scale=None, half_index=True):
+    """Gaussian blur whose sigma grows where few frames were merged (utils_image.py:174-234).  Upstream this kernel does
+    not compile (range() of the float 3 sigma); the build's window is |i|, |j| <= ceil(3 sigma)."""
+    return _frame_count_denoise(image, r_acc, config, 1, config.sigma_max, scale, half_index)

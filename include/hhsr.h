@@ -222,6 +222,26 @@ int hhsr_normalize_raw_u16(const uint16_t* raw, int n_frames, int H, int W, int 
                            const double* black_levels, double white_level, const double* white_balance,
                            float* out, void* stream);
 
+/* ---- after the path: frame-count denoisers, postprocess, orientation — on the device -------------
+ * hhsr_frame_count_denoise: utils_image.py:174-309.  image / out float32 [H][W][3] (the merged image), acc_r float32
+ * [ah][aw] (accumulated robustness).  kind 0 = median (strength_max = radius_max <= 7: the reference's 16 x 16 sample
+ * buffer overflows beyond that, error -2), kind 1 = gauss (strength_max = sigma_max; window |i|, |j| <= ceil(3 sigma) —
+ * the reference's range() of a float does not type under Numba, so the build defines it).  half_index 1 = the
+ * reference's index int(round((y - 0.5) / (2 scale))) into acc_r, 0 = the nearest raw pixel. */
+int hhsr_frame_count_denoise(const float* image, float* out, int H, int W, const float* acc_r, int ah, int aw,
+                             double scale, int kind, double strength_max, double max_frame_count, int half_index,
+                             void* stream);
+/* hhsr_postprocess: raw2rgb.py:206-250 — optional colour matrix cam2rgb (HOST float[9], row major; NULL = off) + clip,
+ * optional unsharp mask (skimage.filters.unsharp_mask = scipy.ndimage.gaussian_filter, mode "reflect": DEVICE double
+ * taps[2 radius + 1], rows first, float64 accumulation, float32 intermediate in tmp [H][W][3]; result = c + (c - blur)
+ * amount), optional devignetting (raw2rgb.py:198-204), clip, optional gamma 1/2.2, clip; the result is stored at its
+ * EXIF-oriented position (utils_image.py:12-55; orientation 5..8: out is [W][H][3]).  Tone mapping is out of scope. */
+int hhsr_postprocess(const float* image, float* tmp, float* out, int H, int W, const float* cam2rgb, int do_sharpen,
+                     double amount, const double* taps, int radius, int do_devignette, int do_gamma, int orientation,
+                     void* stream);
+/* float32 [H][W] plane (accumulated robustness) to its EXIF-oriented position (utils_image.py:12-55). */
+int hhsr_orient_plane(const float* in, float* out, int H, int W, int orientation, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

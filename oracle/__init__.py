@@ -39,3 +39,4 @@ from .merge import merge, merge_ref, divide  # noqa: F401
 from .pipeline import main  # noqa: F401
 from .parallel import main_parallel  # noqa: F401
 from . import frontend  # noqa: F401
+from . import post  # noqa: F401

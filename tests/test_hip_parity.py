@@ -903,20 +903,112 @@ def test_e2e_few_frames_and_foreign_inputs(n_comp):
 
 
 def test_process_facade():
+    from oracle import post
+
     ref, comp, _ = synth.make_burst(512, 512, 3, seed=3)
     cfg = hsr.default_config()
     cfg.verbose = 0
     cfg.block_matching.tuning.tile_size = 16
     cfg.block_matching.tuning.metrics = ["L2"] * 4
     burst = {"ref": ref, "comp": comp, "cfa_pattern": [[0, 1], [1, 2]], "white_balance": [1.0, 1.0, 1.0],
-             "alpha": synth.ALPHA_ISO100, "beta": synth.BETA_ISO100}
+             "alpha": synth.ALPHA_ISO100, "beta": synth.BETA_ISO100, "orientation": 6}
     img, dbg = hsr.process(burst, cfg)
     assert img.shape == (512, 512, 3) and img.dtype == np.float32
     assert cfg.block_matching.tuning.tile_sizes == [16, 16, 16, 8]  # derived in place like the reference
     assert isinstance(dbg["accumulated robustness"], np.ndarray)
-    # same as calling main() on the prepared config
-    out, _ = hsr.main(ref, comp, cfg)
-    assert_close(img, N(out), 0, 0, "process == main")
+    # = main() on the prepared config, then the reference's default post-processing (unsharp mask radius 3 amount 1.5,
+    # gamma 1/2.2; configs/default.yaml:44-53) and the EXIF orientation (super_resolution.py:303-356)
+    out, mdbg = hsr.main(ref, comp, cfg)
+    want = post.apply_orientation(post.postprocess(N(out), False, False, True, {"enabled": True, "amount": 1.5, "radius": 3}),
+                                  6)
+    assert_close(img, want, 0, 2e-6, "process == postprocess(main)")
+    assert_close(dbg["accumulated robustness"], post.apply_orientation(N(mdbg["accumulated robustness"]), 6), 0, 0, "acc r")
+    cfg2 = hsr.default_config()
+    cfg2.verbose = 0
+    cfg2.block_matching.tuning.tile_size = 16
+    cfg2.block_matching.tuning.metrics = ["L2"] * 4
+    cfg2.postprocessing.enabled = False
+    img2, _ = hsr.process(dict(burst, orientation=1), cfg2)
+    assert_close(img2, N(out), 0, 0, "postprocessing off: process == main")
+
+
+def test_post_path(golden):
+    """The step after the path on the device against the reference's own outputs (golden "post":
+    orientation, median frame-count denoiser, postprocess without sharpening) and against the oracle (gauss denoiser,
+    unsharp mask, NaN pixels, orientation folded into the postprocess store)."""
+    from oracle import post
+    from handheld_super_resolution import raw2rgb, config as hcfg
+
+    g = golden("post")
+    for ori in range(1, 9):
+        assert_close(N(utils_image.apply_orientation(T(g["ori_in"]), ori)), g[f"ori{ori}"], 0, 0, f"orientation {ori}")
+        assert_close(N(utils_image.apply_orientation(T(g["ori_in"][..., 0]), ori)), g[f"ori{ori}"][..., 0], 0, 0,
+                     f"plane orientation {ori}")
+        assert np.array_equal(utils_image.apply_orientation(g["ori_in"], ori), g[f"ori{ori}"])  # NumPy in, NumPy out
+    mcfg = hcfg.Config({"enabled": True, "radius_max": 3, "max_frame_count": 8})
+    med = utils_image.frame_count_denoising_median(T(g["med_in"]), T(g["med_racc"]), mcfg, scale=int(g["med_scale"]))
+    assert_close(N(med), g["med_out"], 0, 0, "median denoiser vs the reference's kernel")
+    with pytest.raises(RuntimeError, match="overflows"):
+        utils_image.frame_count_denoising_median(T(g["med_in"]), T(g["med_racc"]),
+                                                 hcfg.Config({"radius_max": 9, "max_frame_count": 8}), scale=2)
+    rng = np.random.default_rng(5)
+    img = rng.random((37, 53, 3)).astype(np.float32)
+    racc = rng.uniform(0, 10, (19, 27))
+    gcfg = hcfg.Config({"enabled": True, "sigma_max": 1.5, "max_frame_count": 8})
+    for half in (True, False):
+        got = utils_image.frame_count_denoising_gauss(T(img), T(racc), gcfg, scale=2, half_index=half)
+        assert_close(N(got), post.frame_count_denoising_gauss(img, racc, gcfg, 2, half), 0, 1e-6, f"gauss denoiser {half}")
+        got = utils_image.frame_count_denoising_median(T(img), T(racc), mcfg, scale=2, half_index=half)
+        assert_close(N(got), post.frame_count_denoising_median(img, racc, mcfg, 2, half), 0, 0, f"median denoiser {half}")
+    # postprocess without sharpening: the reference's outputs
+    off = hcfg.Config({"enabled": False})
+    x2c = g["pp_xyz2cam"]
+    pin = T(g["pp_in"])
+    assert_close(N(raw2rgb.postprocess(None, pin, False, False, True, off, False, x2c)), g["pp_gamma_only"], 0, 1e-6, "gamma")
+    assert_close(N(raw2rgb.postprocess(None, pin, True, False, True, off, False, x2c)), g["pp_ccm_gamma"], 0, 1e-6, "ccm + gamma")
+    assert_close(N(raw2rgb.postprocess(None, pin, True, False, False, off, True, x2c)), g["pp_ccm_devig"], 0, 1e-6, "ccm + devignette")
+    assert_close(N(raw2rgb.postprocess(None, pin, True, False, True, None, False, np.zeros((3, 3)))), g["pp_zero_ccm"], 0, 1e-6,
+                 "zero colour matrix")
+    assert_close(raw2rgb.get_color_matrix(None, x2c), g["pp_ccm"], 0, 1e-7, "colour matrix")
+    with pytest.raises(NotImplementedError):
+        raw2rgb.postprocess(None, pin, False, True, True, off)
+    # sharpening (+ everything else, NaN pixels, every orientation) against the oracle
+    big = (rng.random((45, 70, 3)) * 1.1 - 0.05).astype(np.float32)
+    big[0, 3, 1] = np.nan
+    sharp = hcfg.Config({"enabled": True, "amount": 1.5, "radius": 3})
+    for ori in (1, 3, 6, 7):
+        for ccm in (False, True):
+            got = raw2rgb.postprocess(None, T(big), ccm, False, True, sharp, False, x2c, orientation=ori)
+            want = post.apply_orientation(post.postprocess(big, ccm, False, True, sharp, False, x2c), ori)
+            assert_close(N(got), want, 0, 2e-6, f"unsharp + gamma, orientation {ori}, ccm {ccm}")
+    got = raw2rgb.postprocess(None, T(big), True, False, True, hcfg.Config({"enabled": True}), True, x2c)
+    want = post.postprocess(big, True, False, True, {"enabled": True}, True, x2c)  # fall-back radius 3, amount 0.5
+    assert_close(N(got), want, 0, 2e-6, "sharpening defaults + devignetting")
+
+
+def test_process_frame_count_denoisers():
+    """process() with the median / gauss frame-count denoisers: = main() (merge-stage denoiser active too, as upstream:
+    any of the three switches sets accumulated_robustness_denoiser.enabled) followed by the denoisers of the oracle."""
+    from oracle import post
+
+    ref, comp, _ = synth.make_burst(512, 512, 3, seed=4, occluder=True)
+    for which in ("median", "gauss"):
+        cfg = hsr.default_config()
+        cfg.verbose = 0
+        cfg.scale = 2
+        cfg.block_matching.tuning.tile_size = 16
+        cfg.block_matching.tuning.metrics = ["L2"] * 4
+        cfg.postprocessing.enabled = False
+        cfg.accumulated_robustness_denoiser[which].enabled = True
+        burst = {"ref": ref, "comp": comp, "cfa_pattern": [[0, 1], [1, 2]], "white_balance": [1.0, 1.0, 1.0],
+                 "alpha": synth.ALPHA_ISO100, "beta": synth.BETA_ISO100}
+        img, dbg = hsr.process(burst, cfg)
+        assert cfg.accumulated_robustness_denoiser.enabled is True
+        out, mdbg = hsr.main(ref, comp, cfg)
+        sub = cfg.accumulated_robustness_denoiser[which]
+        fn = post.frame_count_denoising_median if which == "median" else post.frame_count_denoising_gauss
+        want = fn(N(out), N(mdbg["accumulated robustness"]), sub, 2)
+        assert_close(img, want, 0, 1e-6 if which == "gauss" else 0, f"process with the {which} denoiser")
 
 
 # ------------------------------------------------------------------------------------------ burst front end
@@ -1009,8 +1101,10 @@ def test_process_integer_burst_and_monte_carlo_estimator():
     c.noise_model.estimator = "monte_carlo"
     c.noise_model.seed = 7
     img_m, _ = hsr.process({"ref": stack[0], "comp": stack[1:], **meta}, c)
-    assert len(c.noise_model.std_curve) == 1001 and np.isfinite(img_m[8:-8, 8:-8]).all()
-    assert np.abs(img_m[8:-8, 8:-8] - img_f[8:-8, 8:-8]).max() < 0.05  # clipped-regime curves only move r slightly
+    # (default post-processing: the unsharp mask's 25-tap blur spreads the NaN border pixels — D6 — 12 pixels inwards,
+    # exactly as scipy.ndimage.gaussian_filter does upstream)
+    assert len(c.noise_model.std_curve) == 1001 and np.isfinite(img_m[16:-16, 16:-16]).all()
+    assert np.abs(img_m[16:-16, 16:-16] - img_f[16:-16, 16:-16]).max() < 0.05  # clipped-regime curves only move r slightly
 
 
 def test_full_size_properties():

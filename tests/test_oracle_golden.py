@@ -201,3 +201,55 @@ def test_e2e_x1_denoiser(golden):
     assert_close(np.stack(cap["r"]), g["r"], 0, 5e-5, "r")
     assert_close(dbg["accumulated robustness"], g["acc_r"], 0, 5e-5, "acc r")
     assert_close(out, g["out"], 0, 5e-5, "output")
+
+
+def test_post_path_golden(golden):
+    """The step after the path: orientation, median frame-count denoiser and raw2rgb.postprocess
+    without sharpening against outputs of the reference's own functions (tools/refsim stage "post")."""
+    from oracle import post
+
+    g = golden("post")
+    for ori in range(1, 9):
+        assert np.array_equal(post.apply_orientation(g["ori_in"], ori), g[f"ori{ori}"]), ori
+    med = post.frame_count_denoising_median(g["med_in"], g["med_racc"], {"radius_max": 3, "max_frame_count": 8},
+                                            int(g["med_scale"]))
+    assert np.array_equal(med, g["med_out"])
+    assert int(g["gauss_runs_upstream"]) == 0  # range() of a float: the gauss denoiser does not type under Numba
+    assert np.allclose(post.get_color_matrix(g["pp_xyz2cam"]), g["pp_ccm"], rtol=0, atol=1e-7)
+    off = {"enabled": False}
+    kw = dict(do_tonemapping=False, sharpening=off, xyz2cam=g["pp_xyz2cam"])
+    assert np.allclose(post.postprocess(g["pp_in"], do_color_correction=False, do_gamma=True, **kw), g["pp_gamma_only"],
+                       rtol=0, atol=1e-7)
+    assert np.allclose(post.postprocess(g["pp_in"], do_color_correction=True, do_gamma=True, **kw), g["pp_ccm_gamma"],
+                       rtol=0, atol=5e-7)
+    assert np.allclose(post.postprocess(g["pp_in"], do_color_correction=True, do_gamma=False, do_devignette=True, **kw),
+                       g["pp_ccm_devig"], rtol=0, atol=5e-7)
+    assert np.allclose(post.postprocess(g["pp_in"], do_color_correction=True, do_tonemapping=False, do_gamma=True,
+                                        sharpening=None, xyz2cam=np.zeros((3, 3))), g["pp_zero_ccm"], rtol=0, atol=5e-7)
+
+
+def test_post_gauss_and_unsharp_known_answers():
+    """Oracle-only parts of the post path: the gauss denoiser (upstream cannot run it) and the unsharp mask (restated
+    through scipy.ndimage.gaussian_filter, the routine skimage.filters.unsharp_mask calls)."""
+    from oracle import post
+
+    rng = np.random.default_rng(0)
+    img = rng.random((12, 15, 3)).astype(np.float32)
+    # accumulated robustness >= max_frame_count everywhere: sigma = 0 / radius = 0 -> identity
+    full = np.full((6, 8), 9.0)
+    assert np.array_equal(post.frame_count_denoising_gauss(img, full, {"sigma_max": 1.5, "max_frame_count": 8}, 2), img)
+    assert np.array_equal(post.frame_count_denoising_median(img, full, {"radius_max": 3, "max_frame_count": 8}, 2), img)
+    # constant image: any normalised blur is the identity (also at the borders)
+    const = np.full((9, 11, 3), 0.3, np.float32)
+    zero = np.zeros((5, 6))
+    assert np.allclose(post.frame_count_denoising_gauss(const, zero, {"sigma_max": 1.5, "max_frame_count": 8}, 2), 0.3, atol=1e-7)
+    assert np.allclose(post.unsharp_mask(const, 3, 1.5), 0.3, atol=1e-6)
+    # an impulse is sharpened: centre grows by amount * (1 - g0^2), g0 = central tap of the normalised Gaussian
+    imp = np.zeros((41, 41, 3), np.float32)
+    imp[20, 20] = 1.0
+    from handheld_super_resolution.raw2rgb import gaussian_taps
+
+    taps, radius = gaussian_taps(3)
+    assert radius == 12 and abs(taps.sum() - 1) < 1e-15
+    got = post.unsharp_mask(imp, 3, 1.5)[20, 20, 0]
+    assert abs(got - (1 + 1.5 * (1 - taps[radius] ** 2))) < 1e-6

@@ -153,6 +153,9 @@ class _KMath:
 
 
 def _k_range(*a):
+    for t in a:  # Numba has no range(float): "No implementation of function Function(<class 'range'>) ... (float64, ...)"
+        if isinstance(t, (float, np.floating)):
+            raise TypeError(f"range() of a float ({type(t).__name__}) does not type under Numba")
     for v in range(*(int(t) for t in a)):
         yield np.int64(v)
 

@@ -418,7 +418,49 @@ def stage_e2e_x1():
          out=npy(out), acc_r=np.asarray(dbg["accumulated robustness"], dtype=np.float32))
 
 
+def stage_post():
+    """The step after the hot path: apply_orientation, the median frame-count denoiser, and
+    raw2rgb.postprocess without sharpening (colour matrix, devignetting, gamma) — all executed upstream code.
+    The gauss denoiser is recorded as NOT runnable (range() of a float, utils_image.py:214-216)."""
+    from handheld_super_resolution import utils_image as ui
+    from handheld_super_resolution import raw2rgb
+
+    rng = np.random.default_rng(77)
+    out = {}
+    img = rng.random((6, 9, 3)).astype(np.float32)
+    for ori in range(1, 9):
+        out[f"ori{ori}"] = np.ascontiguousarray(ui.apply_orientation(img, ori))
+    out["ori_in"] = img
+    # median denoiser: 20 x 28 x 3 image, accumulated robustness spanning radius 0 .. 3
+    H, W, scale = 20, 28, 2
+    noisy = (smooth_field(rng, H, W)[:H, :W, None] + 0.1 * rng.standard_normal((H, W, 3))).astype(np.float32)
+    r_acc = np.linspace(0.0, 10.0, (H // scale) * (W // scale)).reshape(H // scale, W // scale)
+    r_acc = r_acc[::-1].copy()
+    mcfg = cfgmod.Config({"enabled": True, "radius_max": 3, "max_frame_count": 8, "mode": "bayer", "scale": scale})
+    med = ui.frame_count_denoising_median(cuda.to_device(noisy), cuda.to_device(r_acc), mcfg)
+    out.update(med_in=noisy, med_racc=r_acc, med_out=npy(med.copy_to_host()), med_scale=scale)
+    gcfg = cfgmod.Config({"enabled": True, "sigma_max": 1.5, "max_frame_count": 8, "mode": "bayer", "scale": scale})
+    try:
+        ui.frame_count_denoising_gauss(cuda.to_device(noisy), cuda.to_device(r_acc), gcfg)
+        out["gauss_runs_upstream"] = np.array(1)
+    except TypeError as e:  # 'float' object cannot be interpreted as an integer
+        out["gauss_runs_upstream"] = np.array(0)
+        print("  gauss denoiser does not run upstream:", e)
+    # postprocess without sharpening
+    pimg = (rng.random((10, 14, 3)) * 1.2 - 0.1).astype(np.float32)
+    xyz2cam = np.array([[1.0234, -0.2969, -0.2266], [-0.5625, 1.6328, -0.0469], [-0.0703, 0.2188, 0.6406]], np.float32)
+    sharp_off = cfgmod.Config({"enabled": False})
+    out["pp_in"], out["pp_xyz2cam"] = pimg, xyz2cam
+    out["pp_ccm"] = raw2rgb.get_color_matrix(None, xyz2cam)
+    out["pp_gamma_only"] = raw2rgb.postprocess(None, pimg.copy(), False, False, True, sharp_off, False, xyz2cam)
+    out["pp_ccm_gamma"] = raw2rgb.postprocess(None, pimg.copy(), True, False, True, sharp_off, False, xyz2cam)
+    out["pp_ccm_devig"] = raw2rgb.postprocess(None, pimg.copy(), True, False, False, sharp_off, True, xyz2cam)
+    out["pp_zero_ccm"] = raw2rgb.postprocess(None, pimg.copy(), True, False, True, None, False, np.zeros((3, 3), np.float32))
+    save("post", **out)
+
+
 STAGES = {
+    "post": stage_post,
     "grey": stage_grey, "downsample": stage_downsample, "hessian": stage_hessian, "bm_l2": stage_bm_l2,
     "ica": stage_ica, "upscale": stage_upscale, "kernels": stage_kernels, "robustness": stage_robustness,
     "merge": stage_merge, "params": stage_params, "e2e": stage_e2e, "e2e_x1": stage_e2e_x1,
