@@ -597,6 +597,145 @@ __global__ void __launch_bounds__(256) k_rob_frame_row4(const float* __restrict_
     *reinterpret_cast<float4*>(R + o) = make_float4(out[0], out[1], out[2], out[3]);
 }
 
+// ---- several frames per launch ------------------------------------------------------------------------------------
+// The reference-frame operands — three upsampled mean planes, sigma^2, the packed curve indices: 20 of the 27 bytes a
+// frame moves per pixel — do not depend on the compared frame, and k_rob_frame_row4 streams them again for every frame of
+// the burst (326 MB per launch at 12 MP, 4.3 TB/s: HBM-bound).  This variant keeps them (and the three d_t lookups
+// per pixel) in registers and loops over up to ROB_GROUP frames of the same burst: per frame only the guide-means
+// window (3 B / pixel) comes in and R (4 B / pixel) goes out.  Same arithmetic per frame: bit-identical to one launch
+// of k_rob_frame_row4 per frame.
+constexpr int ROB_GROUP = 4;
+struct RobGroup {
+    const float* cm[ROB_GROUP];
+    const float2* flow[ROB_GROUP];
+    const float* S[ROB_GROUP];
+    float* R[ROB_GROUP];
+    int n;
+};
+
+__global__ void __launch_bounds__(256) k_rob_frames_row4(RobGroup gq, int lh, int lw, const float* __restrict__ rmean,
+                                                          const float* __restrict__ ssq,
+                                                          const uint32_t* __restrict__ cidx, int nx, int ts,
+                                                          const double* __restrict__ difc, double t, int H, int W) {
+    __shared__ float s_g[2][2][3][RF_WN][RF_WN + 2];
+    const int lx4 = threadIdx.x & 7, ly_ = threadIdx.x >> 3;  // 8 threads x 4 pixels per row, 32 rows
+    const int grp = lx4 >> 2, v = ly_ >> 4;                   // the thread's 16 x 16 sub-tile
+    const int bid = xcd_remap(blockIdx.y * gridDim.x + blockIdx.x, gridDim.x * gridDim.y);  // bands of tile rows per XCD
+    const int bxi = bid % gridDim.x, byi = bid / gridDim.x;
+    const int sx0 = bxi * RF_BX + grp * RF_T, sy0 = byi * RF_BY + v * RF_T;
+    const int x0 = bxi * RF_BX + 4 * lx4, y = byi * RF_BY + ly_;
+    const int tix = min(sx0, W - 1) / ts, tiy = min(sy0, H - 1) / ts;
+    const size_t gplane = (size_t)lh * lw, plane = (size_t)H * W;
+    const int tg = (ly_ & (RF_T - 1)) * 4 + (lx4 & 3);  // 0..63 within the sub-tile
+    constexpr int WSZ = 3 * RF_WN * RF_WN, NST = (WSZ + 63) / 64;
+    const bool live = x0 < W && y < H;
+    const size_t o = live ? (size_t)y * W + x0 : 0;
+    // per-burst operands of the thread's 4 pixels, once
+    float4 rb4[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) rb4[c] = *reinterpret_cast<const float4*>(rmean + c * plane + o);
+    const float4 ss4 = *reinterpret_cast<const float4*>(ssq + o);
+    const uint4 ci4 = *reinterpret_cast<const uint4*>(cidx + o);
+    const float rbk[4][3] = {{rb4[0].x, rb4[1].x, rb4[2].x}, {rb4[0].y, rb4[1].y, rb4[2].y},
+                             {rb4[0].z, rb4[1].z, rb4[2].z}, {rb4[0].w, rb4[1].w, rb4[2].w}};
+    const float ssk[4] = {ss4.x, ss4.y, ss4.z, ss4.w};
+    const uint32_t cik[4] = {ci4.x, ci4.y, ci4.z, ci4.w};
+    float d_t2[4][3], iss[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const float d = (float)difc[(cik[k] >> (10 * c)) & 1023u];
+            d_t2[k][c] = d * d;
+        }
+        iss[k] = __builtin_amdgcn_rcpf(ssk[k]);
+    }
+    for (int fr = 0; fr < gq.n; ++fr) {
+        const float* __restrict__ cm = gq.cm[fr];
+        const float2 f = gq.flow[fr][(size_t)tiy * nx + tix];
+        const float Sv = gq.S[fr][(size_t)tiy * nx + tix];
+        const RobAxis ay = rob_axis(f.y), ax = rob_axis(f.x);
+        int wy0, wx0;
+        {
+            float r_;
+            rob_centre(ay, sy0, lh, wy0, r_);
+            rob_centre(ax, sx0, lw, wx0, r_);
+            wy0 = clampi(wy0, -4, lh + 4) - 1;
+            wx0 = clampi(wx0, -4, lw + 4) - 1;
+        }
+        float st[NST];
+#pragma unroll
+        for (int u = 0; u < NST; ++u) {
+            const int p = tg + 64 * u;
+            if (p < WSZ) {
+                const int c = p / (RF_WN * RF_WN), q = p - c * (RF_WN * RF_WN);
+                const int i = q / RF_WN, j = q - i * RF_WN;
+                const int gy = clampi(wy0 + i, 0, lh - 1), gx = clampi(wx0 + j, 0, lw - 1);
+                st[u] = cm[c * gplane + (size_t)gy * lw + gx];
+            }
+        }
+        if (fr) __syncthreads();  // the previous frame's taps are done with the window
+#pragma unroll
+        for (int u = 0; u < NST; ++u) {
+            const int p = tg + 64 * u;
+            if (p < WSZ) {
+                const int c = p / (RF_WN * RF_WN), q = p - c * (RF_WN * RF_WN);
+                const int i = q / RF_WN, j = q - i * RF_WN;
+                s_g[grp][v][c][i][j] = st[u];
+            }
+        }
+        __syncthreads();
+        if (!live) continue;
+        int cy;
+        float ry, wyv[3];
+        const bool iny = rob_centre(ay, y, lh, cy, ry);
+        dodgson3(ry, cy, lh, wyv);
+        const int wi0 = cy - 1 - wy0;
+        float out[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            int cx;
+            float rx;
+            const bool inx = rob_centre(ax, x0 + k, lw, cx, rx);
+            float cmu[3] = {INFINITY, INFINITY, INFINITY};
+            if (iny && inx) {
+                float wxv[3], b0 = 0.f, b1 = 0.f, b2 = 0.f, wacc = 0.f;
+                dodgson3(rx, cx, lw, wxv);
+                const int wj0 = cx - 1 - wx0;
+#pragma unroll
+                for (int i = 0; i < 3; ++i) {
+#pragma unroll
+                    for (int j = 0; j < 3; ++j) {
+                        const float w = wyv[i] * wxv[j];
+                        b0 = fmaf(s_g[grp][v][0][wi0 + i][wj0 + j], w, b0);
+                        b1 = fmaf(s_g[grp][v][1][wi0 + i][wj0 + j], w, b1);
+                        b2 = fmaf(s_g[grp][v][2][wi0 + i][wj0 + j], w, b2);
+                        wacc += w;
+                    }
+                }
+                const float iw = __builtin_amdgcn_rcpf(wacc);
+                cmu[0] = b0 * iw;
+                cmu[1] = b1 * iw;
+                cmu[2] = b2 * iw;
+            }
+            float d_sq = 0.f;
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                const float dp = fabsf(rbk[k][c] - cmu[c]);
+                const float dp2 = dp * dp;
+                const float shrink = dp2 * __builtin_amdgcn_rcpf(dp2 + d_t2[k][c]);
+                d_sq += dp2 * shrink * shrink;
+            }
+            const float e = __builtin_amdgcn_exp2f((-d_sq * iss[k]) * 1.44269504088896341f);
+            double r = (double)(Sv * e) - t;
+            r = r > 0.0 ? r : 0.0;
+            r = r < 1.0 ? r : 1.0;
+            out[k] = (float)r;
+        }
+        *reinterpret_cast<float4*>(gq.R[fr] + o) = make_float4(out[0], out[1], out[2], out[3]);
+    }
+}
+
 extern "C" int hhsr_rob_frame(const float* comp_means, int lh, int lw, const float* ref_means,
                               const float* ref_sigma_sq, const uint32_t* ref_curve_index, const float* flow, int ny,
                               int nx, int ts, const float* S, const double* diff_curve, int ncurve, double t, float* R,
@@ -620,6 +759,42 @@ extern "C" int hhsr_rob_frame(const float* comp_means, int lh, int lw, const flo
         hipLaunchKernelGGL(k_rob_frame, dim3(hhsr_cdiv(W, 64), hhsr_cdiv(H, 4)), dim3(256), 0, (hipStream_t)stream,
                            comp_means, lh, lw, ref_means, ref_sigma_sq, reinterpret_cast<const float2*>(flow), nx, ts,
                            S, diff_curve, ncurve, t, R, H, W);
+    HHSR_LAUNCHED();
+}
+
+extern "C" int hhsr_rob_frames(const float* const* comp_means, int n_frames, int lh, int lw, const float* ref_means,
+                               const float* ref_sigma_sq, const uint32_t* ref_curve_index, const float* const* flows,
+                               int ny, int nx, int ts, const float* const* S, const double* diff_curve, int ncurve,
+                               double t, float* const* R, void* stream) {
+    HHSR_ARG(comp_means && flows && S && R && n_frames >= 0);
+    for (int n = 0; n < n_frames; ++n) HHSR_ARG(comp_means[n] && flows[n] && S[n] && R[n]);
+    HHSR_ARG(ref_means && ref_sigma_sq && diff_curve && lh > 0 && lw > 0 && ts > 0 && ncurve > 0);
+    const int H = 2 * lh, W = 2 * lw;
+    HHSR_ARG(ny * ts >= H && nx * ts >= W);
+    static const bool no_group = getenv("HHSR_ROB_NO_GROUP") != nullptr;  // A/B switch, read once
+    bool vec4 = W % 4 == 0 && (((uintptr_t)ref_means | (uintptr_t)ref_sigma_sq | (uintptr_t)ref_curve_index) & 15) == 0;
+    for (int n = 0; n < n_frames; ++n) vec4 = vec4 && ((uintptr_t)R[n] & 15) == 0;
+    if (no_group || !(ts % RF_T == 0 && ref_curve_index && ncurve <= 1024 && vec4)) {
+        for (int n = 0; n < n_frames; ++n) {
+            const int rc = hhsr_rob_frame(comp_means[n], lh, lw, ref_means, ref_sigma_sq, ref_curve_index, flows[n], ny, nx,
+                                          ts, S[n], diff_curve, ncurve, t, R[n], stream);
+            if (rc) return rc;
+        }
+        return 0;
+    }
+    for (int n0 = 0; n0 < n_frames; n0 += ROB_GROUP) {
+        RobGroup g;
+        g.n = n_frames - n0 < ROB_GROUP ? n_frames - n0 : ROB_GROUP;
+        for (int k = 0; k < ROB_GROUP; ++k) {
+            const int n = n0 + (k < g.n ? k : 0);
+            g.cm[k] = comp_means[n];
+            g.flow[k] = reinterpret_cast<const float2*>(flows[n]);
+            g.S[k] = S[n];
+            g.R[k] = R[n];
+        }
+        hipLaunchKernelGGL(k_rob_frames_row4, dim3(hhsr_cdiv(W, RF_BX), hhsr_cdiv(H, RF_BY)), dim3(256), 0,
+                           (hipStream_t)stream, g, lh, lw, ref_means, ref_sigma_sq, ref_curve_index, nx, ts, diff_curve, t, H, W);
+    }
     HHSR_LAUNCHED();
 }
 

@@ -141,3 +141,27 @@ def compute_robustness(comp_img, ref_local_means, ref_local_stds, flows, cfa_pat
         return R
     r = local_min(R, accumulate_into)
     return (r, R) if return_R else r
+
+
+def compute_robustness_group(comp_imgs, ref_local_means, flows, noise_model, config, ref_sigma_sq, comp_means,
+                             accumulate_into=None, fuse_local_min=False):
+    """compute_robustness() for several frames of one burst: the fused kernel runs once per 4 frames and reads the
+    reference-frame planes (20 of the 27 bytes per pixel and frame) once per group (hhsr_rob_frames); per frame the
+    result is bit-identical to compute_robustness().  Needs the per-burst (sigma_sq, curve_index) and the frames' guide
+    means (kernels.frame_stats).  Returns the list of r (or of the thresholded maps R with fuse_local_min)."""
+    assert config.robustness.enabled and config.mode == "bayer"
+    ts = config.block_matching.tuning.tile_size
+    t = config.robustness.tuning
+    _, diff_curve = noise_model
+    H, W = comp_imgs[0].shape
+    ny, nx, _ = flows[0].shape
+    sigma_sq, curve_index = ref_sigma_sq
+    S = [compute_s(f, t.Mt, t.s1, t.s2) for f in flows]
+    R = [torch.empty((H, W), dtype=torch.float32, device=comp_imgs[0].device) for _ in flows]
+    _lib.call("hhsr_rob_frames", _lib.ptr_array(comp_means), len(flows), H // 2, W // 2, _lib.ptr(ref_local_means),
+              _lib.ptr(sigma_sq), _lib.ptr(curve_index), _lib.ptr_array(flows), ny, nx, int(ts), _lib.ptr_array(S),
+              _lib.ptr(diff_curve), int(diff_curve.numel()), float(t.t), _lib.ptr_array(R), _lib.stream())
+    if fuse_local_min:
+        assert accumulate_into is None
+        return R
+    return [local_min(r_, accumulate_into) for r_ in R]

@@ -20,7 +20,8 @@ from .utils_image import compute_grey_images
 from .utils import divide, add, getTime
 from .alignment import align, init_alignment, build_gaussian_pyramid
 from .params import sanitize_config, update_snr_config
-from .robustness import init_robustness, compute_robustness, noise_curves_to_device, ref_planes
+from .robustness import (init_robustness, compute_robustness, compute_robustness_group, noise_curves_to_device,
+                         ref_planes)
 from .kernels import estimate_kernels, frame_stats
 from .merge import merge, merge_ref, merge_burst, can_fuse_acc_r, can_fuse_local_min
 
@@ -44,6 +45,18 @@ def _device():
         raise RuntimeError("handheld_super_resolution (MI355X build): no HIP device is visible; this package has no "
                            "CPU path (the NumPy oracle under oracle/ is test infrastructure only)")
     return torch.device("cuda", torch.cuda.current_device())
+
+
+ROB_GROUP = 4  # frames per robustness launch (hhsr_rob_frames)
+
+
+def _tensors(x):
+    """All tensors in a nested tuple / list."""
+    if torch.is_tensor(x):
+        yield x
+    elif isinstance(x, (tuple, list)):
+        for y in x:
+            yield from _tensors(y)
 
 
 DEFAULT_STREAMS = 3  # measured at 12 MP x 20: 1 stream 15.3 ms, 2: 14.3, 3: 13.9, 4: 14.3
@@ -122,14 +135,9 @@ class BurstPipeline:
             return [f[0] for f in self._on_streams(len(comp_imgs), n_streams, False,
                                                    lambda i, wait: (self.align_frame(comp_imgs[i], wait_ref=wait),))]
 
-    def process_frame(self, img, accumulate_r=None, wait_ref=None, fuse_local_min=False, index=None, flow=None):
-        """grey -> kernels -> align -> robustness for one comp frame; returns (raw, flow, covs, r).
-        `accumulate_r`: optional float32 [H, W] that receives += r (fused into the local-min pass).
-        `wait_ref`: event after which the reference-frame state is complete — the frame's own grey image and
-        pyramid do not need it and are enqueued before the wait, so on a side stream they overlap the
-        (latency-bound) reference precompute.
-        `flow`: a flow field that replaces the alignment (multi-GPU step B; validation hook
-        config.hip.inject_flows via `index`)."""
+    def _front(self, img, wait_ref=None, index=None, flow=None):
+        """grey -> pyramid -> alignment -> guide means + kernel covariances of one comp frame:
+        (raw, flow, covs, guide means or None)."""
         cfg = self.config
         raw = _lib.f32c(img, self.device)
         if flow is None and self._inject_flows is not None and index is not None:
@@ -148,10 +156,32 @@ class BurstPipeline:
             means, _, covs = frame_stats(raw, self.cfa, self.wb, cfg)
         else:
             means, covs = None, estimate_kernels(raw, cfg)
-        r = compute_robustness(raw, self.ref_means, self.ref_vars, flow, self.cfa, self.wb, self.curves, cfg,
-                               accumulate_into=accumulate_r, ref_sigma_sq=self.ref_sigma_sq, comp_means=means,
-                               fuse_local_min=fuse_local_min and cfg.robustness.enabled)
-        return raw, flow, covs, r
+        return raw, flow, covs, means
+
+    def _robustness(self, fronts, accumulate_r=None, fuse_local_min=False):
+        """Robustness of a group of frames of the burst (one launch per 4 frames shares the pass over the
+        reference-frame planes): list of (raw, flow, covs, r)."""
+        cfg = self.config
+        if not cfg.robustness.enabled or len(fronts) == 1:
+            return [(raw, flow, covs,
+                     compute_robustness(raw, self.ref_means, self.ref_vars, flow, self.cfa, self.wb, self.curves, cfg,
+                                        accumulate_into=accumulate_r, ref_sigma_sq=self.ref_sigma_sq, comp_means=means,
+                                        fuse_local_min=fuse_local_min and cfg.robustness.enabled))
+                    for raw, flow, covs, means in fronts]
+        rs = compute_robustness_group([f[0] for f in fronts], self.ref_means, [f[1] for f in fronts], self.curves, cfg,
+                                      self.ref_sigma_sq, [f[3] for f in fronts], accumulate_into=accumulate_r,
+                                      fuse_local_min=fuse_local_min)
+        return [(f[0], f[1], f[2], r) for f, r in zip(fronts, rs)]
+
+    def process_frame(self, img, accumulate_r=None, wait_ref=None, fuse_local_min=False, index=None, flow=None):
+        """grey -> kernels -> align -> robustness for one comp frame; returns (raw, flow, covs, r).
+        `accumulate_r`: optional float32 [H, W] that receives += r (fused into the local-min pass).
+        `wait_ref`: event after which the reference-frame state is complete — the frame's own grey image and
+        pyramid do not need it and are enqueued before the wait, so on a side stream they overlap the
+        (latency-bound) reference precompute.
+        `flow`: a flow field that replaces the alignment (multi-GPU step B; validation hook
+        config.hip.inject_flows via `index`)."""
+        return self._robustness([self._front(img, wait_ref, index, flow)], accumulate_r, fuse_local_min)[0]
 
     def fuses_local_min(self):
         """True when the fused merge can take the un-filtered robustness maps (see merge.can_fuse_local_min)."""
@@ -164,17 +194,33 @@ class BurstPipeline:
         stream waits for all of them before returning.  A per-frame `accumulate_r` (read-modify-write of one
         map) forces a single stream.  `flows`: per-frame flow fields that replace the alignment."""
         with torch.cuda.device(self.device):
-            return self._on_streams(
-                len(comp_imgs), n_streams, accumulate_r is not None,
-                lambda i, wait: self.process_frame(comp_imgs[i], accumulate_r if wait is None else None, wait_ref=wait,
-                                                   fuse_local_min=fuse_local_min, index=i,
-                                                   flow=None if flows is None else flows[i]))
+            n = len(comp_imgs)
+            streams = self._n_streams(n_streams)
+            # chunks of up to ROB_GROUP frames stay together on a stream: their robustness is one launch that reads the
+            # reference-frame planes once (hhsr_rob_frames); chunk sizes are balanced over the streams
+            n_chunks = min(n, streams * -(-n // (streams * ROB_GROUP))) if n else 0
+            chunks, i = [], 0
+            for c in range(n_chunks):
+                size = n // n_chunks + (1 if c < n % n_chunks else 0)
+                chunks.append(list(range(i, i + size)))
+                i += size
 
-    def _on_streams(self, n, n_streams, serial, work):
-        """work(i, wait_event) for i < n; on one stream (wait_event None) or round-robin on the side streams."""
+            def work(ci, wait):
+                fronts = [self._front(comp_imgs[i], wait, i, None if flows is None else flows[i]) for i in chunks[ci]]
+                return self._robustness(fronts, accumulate_r if wait is None else None, fuse_local_min)
+
+            out = self._on_streams(len(chunks), n_streams, accumulate_r is not None, work)
+            return [f for chunk in out for f in chunk]
+
+    def _n_streams(self, n_streams):
         if n_streams is None:
             hip = self.config.get("hip", None) if hasattr(self.config, "get") else None
             n_streams = int(hip.get("streams", DEFAULT_STREAMS)) if hip is not None else DEFAULT_STREAMS
+        return max(1, int(n_streams))
+
+    def _on_streams(self, n, n_streams, serial, work):
+        """work(i, wait_event) for i < n; on one stream (wait_event None) or round-robin on the side streams."""
+        n_streams = self._n_streams(n_streams)
         if n_streams <= 1 or serial or n < 2:
             return [work(i, None) for i in range(n)]
         main = torch.cuda.current_stream(self.device)
@@ -192,10 +238,9 @@ class BurstPipeline:
             s = pool[i % n_streams]
             with torch.cuda.stream(s):
                 f = work(i, self._ref_ready)
-            for t in f:
-                if t is not None:
-                    t.record_stream(main)  # consumed by the merge on the caller's stream (raw too: it is allocated
-                    # on the side stream when the frame was uploaded / converted there)
+            for t in _tensors(f):
+                t.record_stream(main)  # consumed by the merge on the caller's stream (raw too: it is allocated on
+                # the side stream when the frame was uploaded / converted there)
             results.append(f)
         for s in pool:
             main.wait_stream(s)
