@@ -28,7 +28,7 @@ import math
 import torch
 import torch.distributed as dist
 
-SLAB_ALIGN = 32  # slabs start on the 32-row workgroup grid of the x2 merge kernels (16-row grid of the tile kernel)
+SLAB_ALIGN = 96  # slabs start on the workgroup grids of all merge kernels: 32 output rows (x2), 48 (x3), 16 (tile kernel)
 HALO = 12        # rows of context beyond slab + |flow|.  r[y] = min of R over y +- 2 (robustness.py:641-686); R[y'] reads
                  # the guide statistics at (y' + flow) / 2 with Dodgson taps +- 1.5 guide pixels on 3 x 3 local means
                  # (robustness.py:207-294, 359-421): raw rows y' +- 7 (+ flow) -> r depends on rows y +- 9; kernel

@@ -64,12 +64,13 @@ def can_fuse_acc_r(config):
 
 
 def can_fuse_local_min(config, shape):
-    """merge_burst can take the thresholded maps R and apply the 5x5 local minimum itself (the x2 kernels:
-    scale 2, tile size a multiple of 16, float32 weights) — mirrors the test in hhsr_merge_burst."""
+    """merge_burst can take the thresholded maps R and apply the 5x5 local minimum itself (the wave-per-parity-class
+    kernels: scale 2, or scale 3 with W % 4 == 0; tile size a multiple of 16; float32 weights) — mirrors the test in
+    hhsr_merge_burst."""
     scale, kflags = _common(config)
     H, W = shape
-    return (scale == 2.0 and not (kflags & (WEIGHT_F64 | FORCE_GENERIC | FORCE_TILE)) and
-            int(config.block_matching.tuning.tile_size) % 16 == 0 and H % 2 == 0 and W % 2 == 0)
+    ok = not (kflags & (WEIGHT_F64 | FORCE_GENERIC | FORCE_TILE)) and int(config.block_matching.tuning.tile_size) % 16 == 0
+    return ok and ((scale == 2.0 and H % 2 == 0 and W % 2 == 0) or (scale == 3.0 and W % 4 == 0))
 
 
 def merge_burst(frames, ref_img, ref_kernels, num, den, cfa_pattern, config, load_acc=False, do_ref=True,

@@ -115,9 +115,9 @@ def _free_port():
 
 def test_slab_bounds():
     b = hdist.slab_bounds(6000, 8)
-    assert b[0] == 0 and b[-1] == 6000 and all(x % 32 == 0 for x in b[:-1]) and b == sorted(b)
+    assert b[0] == 0 and b[-1] == 6000 and all(x % 96 == 0 for x in b[:-1]) and b == sorted(b)
     assert hdist.slab_rows(6000, 8) == 768 and hdist.slab_rows(256, 3) == 96
-    assert hdist.slab_bounds(100, 8) == [0, 32, 64, 96, 100, 100, 100, 100, 100]  # trailing slabs may be empty
+    assert hdist.slab_bounds(100, 8) == [0, 96, 100, 100, 100, 100, 100, 100, 100]  # trailing slabs may be empty
 
 
 def test_shard_indices():

@@ -539,10 +539,66 @@ def test_merge_x2_kernels_equal_tile_kernel(kern):
         assert_close(N(got), N(want), 0, 0, f"fused local minimum ({which})")
         assert_close(N(acc_g), N(acc_w), 0, 0, f"fused local minimum, accumulated robustness ({which})")
     assert not merge.can_fuse_local_min(cfg_for("tile"), (H, W))
-    cfg3 = base_config(ts=ts, scale=3)
-    assert not merge.can_fuse_local_min(cfg3, (H, W))
+    cfg5 = base_config(ts=ts, scale=5)  # x2 and x3 have kernels that take the minimum themselves; other scales do not
+    assert not merge.can_fuse_local_min(cfg5, (H, W))
     with pytest.raises(RuntimeError):
-        merge.merge_burst(tf, T(ref), rc, torch.empty(3 * H, 3 * W, 3, device=DEV), None, cfa, cfg3, local_min=True)
+        merge.merge_burst(tf, T(ref), rc, torch.empty(5 * H, 5 * W, 3, device=DEV), None, cfa, cfg5, local_min=True)
+
+
+@pytest.mark.parametrize("kern", ["handheld", "iso"])
+def test_merge_x3_kernel_equals_tile_kernel(kern):
+    """scale 3: the wave-per-parity-class kernel generalised to 3 x 3 sub-pixels (k_merge_xs<3>: uniform float64 geometry
+    per frame, per-thread float32 reference-frame positions) against the 16 x 16 HR tile kernel (float64 geometry per
+    pixel), 2e-5 relative — fused accumulated robustness, chained launches, a frame pushed partly out of the image, an
+    image that is not a tile multiple (generic per-pixel path inside k_merge_xs), fused local minimum, row slabs."""
+    H, W, ts = 80, 112, 16
+    ref, fr = _frames(H, W, 4, ts, 78, base_config(ts=ts, scale=3))
+    fr[1] = (fr[1][0], fr[1][1] + 9.5, fr[1][2], fr[1][3])
+    fr[2] = (fr[2][0], (fr[2][1] - 0.1).astype(np.float32), fr[2][2], fr[2][3])  # small negative flows too
+    cfa = [[2, 1], [1, 0]]
+    tf = [tuple(T(a) for a in f) for f in fr]
+
+    def cfg_for(which):
+        c = base_config(ts=ts, scale=3)
+        c.merging.kernel = kern
+        c.hip = {"merge_kernel": which}
+        return c
+
+    rc = T(oracle.estimate_kernels(ref, cfg_for("auto")))
+
+    def run(which, chained, lmin=False):
+        cfg = cfg_for(which)
+        frames = tf if not lmin or which == "auto" else [(f[0], f[1], f[2], robustness.local_min(f[3])) for f in tf]
+        out, den = torch.empty(3 * H, 3 * W, 3, device=DEV), torch.empty(3 * H, 3 * W, 3, device=DEV)
+        acc = torch.zeros(H, W, device=DEV)
+        kw = dict(local_min=lmin and which == "auto")
+        if chained:
+            merge.merge_burst(frames[:2], None, None, out, den, cfa, cfg, do_ref=False, divide=False, store_den=True, acc_r=acc, **kw)
+            merge.merge_burst(frames[2:], T(ref), rc, out, den, cfa, cfg, load_acc=True, acc_r=acc, **kw)
+        else:
+            merge.merge_burst(frames, T(ref), rc, out, None, cfa, cfg, acc_r=acc, **kw)
+        return N(out), N(acc)
+
+    for chained in (False, True):
+        for lmin in (False, True):
+            out_t, acc_t = run("tile", chained, lmin)
+            out_x, acc_x = run("auto", chained, lmin)
+            assert_close(out_x, out_t, 2e-5, 1e-6, f"k_merge_xs<3> vs tile kernel (chained={chained}, lmin={lmin})")
+            assert_close(acc_x, acc_t, 1e-6, 1e-6, f"accumulated robustness (chained={chained}, lmin={lmin})")
+    # partial sums (num, den) and a row slab
+    cfg = cfg_for("auto")
+    pn, pd = torch.empty(3 * H, 3 * W, 3, device=DEV), torch.empty(3 * H, 3 * W, 3, device=DEV)
+    merge.merge_burst(tf, None, None, pn, pd, cfa, cfg, do_ref=False, divide=False, store_den=True)
+    tn, td = torch.empty_like(pn), torch.empty_like(pd)
+    merge.merge_burst(tf, None, None, tn, td, cfa, cfg_for("tile"), do_ref=False, divide=False, store_den=True)
+    assert_close(N(pn), N(tn), 2e-5, 1e-7, "partial num")
+    assert_close(N(pd), N(td), 2e-5, 1e-7, "partial den")
+    whole = torch.empty(3 * H, 3 * W, 3, device=DEV)
+    merge.merge_burst(tf, T(ref), rc, whole, None, cfa, cfg)
+    slab = torch.empty(96, 3 * W, 3, device=DEV)
+    merge.merge_burst(tf, T(ref), rc, slab, None, cfa, cfg, rows=(48, 96), out_height=3 * H)
+    assert torch.equal(torch.nan_to_num(slab, nan=-1.0), torch.nan_to_num(whole[48:144], nan=-1.0))
+    assert merge.can_fuse_local_min(cfg_for("auto"), (H, W)) and not merge.can_fuse_local_min(cfg_for("tile"), (H, W))
 
 
 def test_merge_border_bands_float64_chain():
@@ -678,7 +734,7 @@ def test_merge_burst_equals_sequential(scale):
     merge.merge_burst([], T(ref), rc, nS, dS, cfa, cfg, load_acc=True, do_ref=True, divide=False, store_den=True)
     # (x2: k_merge_x2 blends the covariances with bilinear weights and takes one v_exp_f32 per tap — 2e-5 relative
     # to the per-frame kernel, the merge tolerance; the other scales share the per-frame kernel's arithmetic)
-    tol = (2e-5, 1e-7) if scale == 2 else (1e-6, 1e-7)
+    tol = (2e-5, 1e-7) if scale in (2, 3) else (1e-6, 1e-7)  # x2 / x3: the wave-per-parity-class kernels
     assert_close(N(nS), N(num_seq), *tol, "sharded num")
     assert_close(N(dS), N(den_seq), *tol, "sharded den")
     # and against the oracle
@@ -1225,7 +1281,7 @@ def test_c5_geometry_48mp_x3():
 
     eng = hdist.HipEngine(cfg).init_ref(ref)
     flows = eng.align_frames([comp[0], comp[1]])
-    r0, r1 = 9024, 9024 + 2240
+    r0, r1 = 9024, 9024 + 2304  # multiples of the x3 kernel's 48-row workgroup grid (distributed.SLAB_ALIGN)
     slab, _ = eng.merge_rows([comp[0], comp[1]], flows, r0, r1, float(flows[..., 1].abs().max()))
     # (bitwise also at x3: positions are evaluated in full-frame coordinates — hhsr_merge_burst's lr_row_offset)
     assert torch.equal(torch.nan_to_num(slab, nan=-1.0), torch.nan_to_num(out[r0:r1], nan=-1.0))

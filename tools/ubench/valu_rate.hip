@@ -63,6 +63,50 @@ KERNEL(k_cnd, A_CND)
 KERNEL(k_iadd, A_IADD)
 KERNEL(k_tap, A_TAP)
 
+
+#define KERNEL64(NAME, ASM)                                                                \
+    __global__ void __launch_bounds__(256) NAME(float* out) {                             \
+        double v0 = threadIdx.x * 1e-3 + 1.0, v1 = v0 + 1., v2 = v0 + 2., v3 = v0 + 3.;     \
+        double v4 = v0 + 4., v5 = v0 + 5., v6 = v0 + 6., v7 = v0 + 7.;                      \
+        double c = 0.999, d = 1e-3;                                                        \
+        for (int i = 0; i < ITERS; ++i) {                                                  \
+            asm volatile(ASM ASM ASM ASM                                                   \
+                         : "+v"(v0), "+v"(v1), "+v"(v2), "+v"(v3), "+v"(v4), "+v"(v5), "+v"(v6), "+v"(v7) \
+                         : "v"(c), "v"(d));                                                \
+        }                                                                                  \
+        double s = v0 + v1 + v2 + v3 + v4 + v5 + v6 + v7;                                  \
+        if (s == 1234.5) *out = (float)s;                                                  \
+    }
+#define R8(OP, ARGS) OP " %0, %0" ARGS "\n " OP " %1, %1" ARGS "\n " OP " %2, %2" ARGS "\n " OP " %3, %3" ARGS "\n " OP " %4, %4" ARGS "\n " OP " %5, %5" ARGS "\n " OP " %6, %6" ARGS "\n " OP " %7, %7" ARGS "\n "
+KERNEL64(k_mul64, R8("v_mul_f64", ", %8"))
+KERNEL64(k_add64, R8("v_add_f64", ", %9"))
+KERNEL64(k_fma64, R8("v_fma_f64", ", %8, %9"))
+KERNEL64(k_rcp64, R8("v_rcp_f64", ""))
+KERNEL64(k_rsq64, R8("v_rsq_f64", ""))
+KERNEL64(k_sqrt64, R8("v_sqrt_f64", ""))
+KERNEL64(k_max64, R8("v_max_f64", ", %8"))
+KERNEL(k_sqrt32, R8("v_sqrt_f32", ""))
+// conversions: f32 <-> f64 round trip (2 instructions per chain element)
+__global__ void __launch_bounds__(256) k_cvt64(float* out) {
+    float v0 = threadIdx.x * 1e-3f, v1 = v0 + 1.f, v2 = v0 + 2.f, v3 = v0 + 3.f;
+    double d0, d1, d2, d3;
+    for (int i = 0; i < ITERS; ++i) {
+#define CV "v_cvt_f64_f32 %4, %0\n v_cvt_f64_f32 %5, %1\n v_cvt_f64_f32 %6, %2\n v_cvt_f64_f32 %7, %3\n v_cvt_f32_f64 %0, %4\n v_cvt_f32_f64 %1, %5\n v_cvt_f32_f64 %2, %6\n v_cvt_f32_f64 %3, %7\n"
+        asm volatile(CV CV CV CV : "+v"(v0), "+v"(v1), "+v"(v2), "+v"(v3), "=&v"(d0), "=&v"(d1), "=&v"(d2), "=&v"(d3));
+    }
+    if (v0 + v1 + v2 + v3 == 1234.5f) *out = v0;
+}
+
+
+// compare + select pairs as compilers emit them: through VCC (VOP2 v_cndmask) and through an SGPR pair (VOP3)
+#define A_CMPSEL_VCC "v_cmp_gt_f32 vcc, %0, %8\n v_cndmask_b32 %0, %0, %9, vcc\n v_cmp_gt_f32 vcc, %1, %8\n v_cndmask_b32 %1, %1, %9, vcc\n v_cmp_gt_f32 vcc, %2, %8\n v_cndmask_b32 %2, %2, %9, vcc\n v_cmp_gt_f32 vcc, %3, %8\n v_cndmask_b32 %3, %3, %9, vcc\n"
+#define A_CMPSEL_SGPR "v_cmp_gt_f32 s[6:7], %0, %8\n v_cndmask_b32 %0, %0, %9, s[6:7]\n v_cmp_gt_f32 s[8:9], %1, %8\n v_cndmask_b32 %1, %1, %9, s[8:9]\n v_cmp_gt_f32 s[6:7], %2, %8\n v_cndmask_b32 %2, %2, %9, s[6:7]\n v_cmp_gt_f32 s[8:9], %3, %8\n v_cndmask_b32 %3, %3, %9, s[8:9]\n"
+// independent compares first, selects later (scheduled apart)
+#define A_CMPSEL_APART "v_cmp_gt_f32 s[6:7], %0, %8\n v_cmp_gt_f32 s[8:9], %1, %8\n v_cmp_gt_f32 s[10:11], %2, %8\n v_cmp_gt_f32 s[12:13], %3, %8\n v_cndmask_b32 %0, %0, %9, s[6:7]\n v_cndmask_b32 %1, %1, %9, s[8:9]\n v_cndmask_b32 %2, %2, %9, s[10:11]\n v_cndmask_b32 %3, %3, %9, s[12:13]\n"
+KERNEL(k_cmpsel_vcc, A_CMPSEL_VCC)
+KERNEL(k_cmpsel_sgpr, A_CMPSEL_SGPR)
+KERNEL(k_cmpsel_apart, A_CMPSEL_APART)
+
 // packed: two floats per register pair
 __global__ void __launch_bounds__(256) k_pkfma(float* out) {
     typedef float v2 __attribute__((ext_vector_type(2)));
@@ -118,5 +162,17 @@ int main() {
     run("exp clamp", k_clampexp, 32, out);
     run("fma clamp", k_fmaclamp, 32, out);
     run("mul_lo", k_mullo, 32, out);
+    run("cmp+sel vcc", k_cmpsel_vcc, 32, out);
+    run("cmp+sel sgpr", k_cmpsel_sgpr, 32, out);
+    run("cmp,sel apart", k_cmpsel_apart, 32, out);
+    run("sqrt f32", k_sqrt32, 32, out);
+    run("mul f64", k_mul64, 32, out);
+    run("add f64", k_add64, 32, out);
+    run("fma f64", k_fma64, 32, out);
+    run("max f64", k_max64, 32, out);
+    run("rcp f64", k_rcp64, 32, out);
+    run("rsq f64", k_rsq64, 32, out);
+    run("sqrt f64", k_sqrt64, 32, out);
+    run("cvt f64", k_cvt64, 32, out);
     return 0;
 }
