@@ -1106,23 +1106,28 @@ __global__ void __launch_bounds__(256, HHSR_X2_OCC) k_merge_x2(BurstArgs a, Geo 
     auto frame = [&](auto isref_c, const bool isref_rt, const float2 fl, float local_r, const int bo) {
         const bool isref = HHSR_X2_PEEL ? decltype(isref_c)::value : isref_rt;
         if (LMIN && !isref) {  // 5 x 5 minimum over rows ty .. ty + 4, columns tx .. tx + 4 of the R window
-            float m = 3.0e38f;
+            // R is clamped to [0, 1] (never negative, never NaN): the order of its float32 bit patterns is the order of
+            // the values, and v_min3_u32 needs no canonicalisation of its inputs (fminf costs a v_max per operand: 28
+            // half-rate instructions per thread and frame here)
+            unsigned m = 0x7f7fffffu;
             if (px) {  // (uniform branch instead of a select per row)
 #pragma unroll
                 for (int r = 0; r < 5; ++r) {
                     const float2 v01 = lds_pair(rbase + bo * RAWSZ + r * X2_RP), v23 = lds_pair(rbase + bo * RAWSZ + r * X2_RP + 2);
                     const float2 v45 = lds_pair(rbase + bo * RAWSZ + r * X2_RP + 4);
-                    m = fminf(m, fminf(fminf(v01.y, v23.x), fminf(v23.y, fminf(v45.x, v45.y))));
+                    m = min(m, min(min(__float_as_uint(v01.y), __float_as_uint(v23.x)),
+                                   min(__float_as_uint(v23.y), min(__float_as_uint(v45.x), __float_as_uint(v45.y)))));
                 }
             } else {
 #pragma unroll
                 for (int r = 0; r < 5; ++r) {
                     const float2 v01 = lds_pair(rbase + bo * RAWSZ + r * X2_RP), v23 = lds_pair(rbase + bo * RAWSZ + r * X2_RP + 2);
                     const float2 v45 = lds_pair(rbase + bo * RAWSZ + r * X2_RP + 4);
-                    m = fminf(m, fminf(fminf(v01.y, v23.x), fminf(v23.y, fminf(v45.x, v01.x))));
+                    m = min(m, min(min(__float_as_uint(v01.y), __float_as_uint(v23.x)),
+                                   min(__float_as_uint(v23.y), min(__float_as_uint(v45.x), __float_as_uint(v01.x)))));
                 }
             }
-            local_r = m;
+            local_r = __uint_as_float(m);
         }
         if (!isref) racc += local_r;
         if (local_r == 0.f) return;

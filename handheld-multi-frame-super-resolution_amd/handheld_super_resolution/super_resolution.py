@@ -17,7 +17,7 @@ import torch
 
 from . import _lib
 from .utils_image import compute_grey_images
-from .utils import divide, add, getTime
+from .utils import divide, add, getTime, timer
 from .alignment import align, init_alignment, build_gaussian_pyramid
 from .params import sanitize_config, update_snr_config
 from .robustness import (init_robustness, compute_robustness, compute_robustness_group, noise_curves_to_device,
@@ -81,6 +81,11 @@ class BurstPipeline:
         # validation hook (bench.py's parity attribution, tests): per-frame flow fields that replace align()
         self._inject_flows = hip.get("inject_flows", None) if hip is not None else None
 
+    def _timed(self, func, level, start_s=None, end_s=None):
+        """The reference's per-stage timers (super_resolution.py:72-81): synchronising wall-clock wrappers, active from
+        config.verbose >= level (2: stages, 3: grey images), plain function otherwise."""
+        return timer(func, self.config.verbose >= level, start_s, end_s)
+
     def init_ref(self, ref_img, alignment=True, robustness=True):
         """Reference-frame precompute.  `alignment=False` / `robustness=False` skip the halves the multi-GPU
         path does not need on a given pipeline (distributed.py: whole-frame alignment state vs the sub-image's
@@ -97,13 +102,17 @@ class BurstPipeline:
         self.align_state = self.grey_ref = None
         if alignment:
             sanitize_config(cfg, tuple(self.ref.shape))
-            grey = compute_grey_images(self.ref, self.grey_method)
-            self.align_state = init_alignment(grey, cfg)
+            grey = self._timed(compute_grey_images, 3, end_s="- Ref grey image estimated by {}".format(self.grey_method))(
+                self.ref, self.grey_method)
+            self.align_state = self._timed(init_alignment, 2, "\nInitializing alignment", "Alignment initialized (Total)")(
+                grey, cfg)
             self.grey_ref = grey
         self.ref_means = self.ref_vars = self.ref_covs = self.ref_sigma_sq = None
         if robustness and cfg.robustness.enabled:  # init_robustness + the reference frame's kernels from one raw pass,
             # then the upsampled means, sigma^2 and curve indices from one pass over the guide statistics
-            m, v, self.ref_covs = frame_stats(self.ref, self.cfa, self.wb, cfg, want_vars=True)
+            m, v, self.ref_covs = self._timed(frame_stats, 2, "\nEstimating ref image local stats + kernels",
+                                              "Local stats + kernels estimated (Total)")(
+                self.ref, self.cfa, self.wb, cfg, want_vars=True)
             self.ref_means, self.ref_sigma_sq = ref_planes(m, v, self.curves[0])
             self.ref_vars = None  # only needed for sigma^2, which is already there
         elif robustness:
@@ -147,15 +156,18 @@ class BurstPipeline:
             if wait_ref is not None:
                 torch.cuda.current_stream(self.device).wait_event(wait_ref)
         else:
-            grey = compute_grey_images(raw, self.grey_method)
+            grey = self._timed(compute_grey_images, 3, end_s="- grey images estimated by {}".format(self.grey_method))(
+                raw, self.grey_method)
             pyramid = build_gaussian_pyramid(grey, cfg.block_matching.tuning.factors)
             if wait_ref is not None:
                 torch.cuda.current_stream(self.device).wait_event(wait_ref)
-            flow = align(*self.align_state, grey, cfg, moving_pyramid=pyramid)
+            flow = self._timed(align, 2, "\nBeginning alignment", "Image aligned (Total)")(
+                *self.align_state, grey, cfg, moving_pyramid=pyramid)
         if cfg.robustness.enabled:  # guide means + kernel covariances from one pass over the raw frame
-            means, _, covs = frame_stats(raw, self.cfa, self.wb, cfg)
+            means, _, covs = self._timed(frame_stats, 2, "\nEstimating kernels + guide statistics",
+                                         "Kernels + guide statistics estimated (Total)")(raw, self.cfa, self.wb, cfg)
         else:
-            means, covs = None, estimate_kernels(raw, cfg)
+            means, covs = None, self._timed(estimate_kernels, 2, "\nEstimating kernels", "Kernels estimated (Total)")(raw, cfg)
         return raw, flow, covs, means
 
     def _robustness(self, fronts, accumulate_r=None, fuse_local_min=False):
@@ -163,8 +175,9 @@ class BurstPipeline:
         reference-frame planes): list of (raw, flow, covs, r)."""
         cfg = self.config
         if not cfg.robustness.enabled or len(fronts) == 1:
+            rob = self._timed(compute_robustness, 2, "\nEstimating robustness", "Robustness estimated (Total)")
             return [(raw, flow, covs,
-                     compute_robustness(raw, self.ref_means, self.ref_vars, flow, self.cfa, self.wb, self.curves, cfg,
+                     rob(raw, self.ref_means, self.ref_vars, flow, self.cfa, self.wb, self.curves, cfg,
                                         accumulate_into=accumulate_r, ref_sigma_sq=self.ref_sigma_sq, comp_means=means,
                                         fuse_local_min=fuse_local_min and cfg.robustness.enabled))
                     for raw, flow, covs, means in fronts]
@@ -306,7 +319,8 @@ def main(ref_img, comp_imgs, config):
         if fused:
             frames.append((raw, flow, covs, r))
         else:
-            merge(raw, flow, covs, r, num, den, pipe.cfa, config)
+            pipe._timed(merge, 2, "\nAccumulating Image", "Image accumulated (Total)")(raw, flow, covs, r, num, den, pipe.cfa,
+                                                                                          config)
         if debug_mode:  # the reference crashes here at HEAD (Tensor.copy_to_host)
             debug_dict["flow"].append(flow.cpu().numpy())
             debug_dict["robustness"].append(r.cpu().numpy())
@@ -316,11 +330,13 @@ def main(ref_img, comp_imgs, config):
 
     ref_covs = pipe.ref_covs
     if fused:
-        merge_burst(frames, pipe.ref, ref_covs, num, None, pipe.cfa, config, do_ref=True, divide=True,
-                    acc_r=accumulated_r if fuse_acc else None, local_min=fuse_min)
+        pipe._timed(merge_burst, 2, "\nAccumulating all frames + ref Img + normalising", "Burst merged (Total)")(
+            frames, pipe.ref, ref_covs, num, None, pipe.cfa, config, do_ref=True, divide=True,
+            acc_r=accumulated_r if fuse_acc else None, local_min=fuse_min)
     else:
-        merge_ref(pipe.ref, ref_covs, num, den, pipe.cfa, config, accumulated_r if denoiser_on else None)
-        divide(num, den)
+        pipe._timed(merge_ref, 2, "\nAccumulating ref Img", "Ref Img accumulated (Total)")(
+            pipe.ref, ref_covs, num, den, pipe.cfa, config, accumulated_r if denoiser_on else None)
+        pipe._timed(divide, 2, end_s="\n------------------------\nImage normalized (Total)")(num, den)
     if verbose:
         torch.cuda.synchronize()
         s = "\nTotal ellapsed time : "

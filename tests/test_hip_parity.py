@@ -813,9 +813,10 @@ def test_e2e_golden_x1_denoiser(golden):
     assert_close(N(out2), o, 0, 0, "debug path == fast path")
 
 
-def _e2e_vs_oracle(ref, comp, cfg_fn, ts, what, max_flipped, out_atol=1e-4, flow_atol=2e-3, r_atol=2e-3, acc_atol=4e-3,
+def _e2e_vs_oracle(ref, comp, cfg_fn, ts, what, max_flipped, out_atol=1e-4, flow_atol=1e-4, r_atol=1e-4, acc_atol=3e-4,
                    parallel=False):
-    """HIP main() against the oracle on one burst, every difference accounted for: flows equal to `flow_atol` except on
+    """HIP main() against the oracle on one burst, every difference accounted for (tolerances ~10x the measured
+    differences of PARITY.md: flow 8e-6 px, r 7e-6, accumulated r 1.4e-5, image 6.4e-5): flows equal to `flow_atol` except on
     tiles whose block-matching decision flipped (count <= max_flipped, the measured number); robustness, accumulated
     robustness and the output image equal to their tolerances everywhere OUTSIDE the footprint of those tiles."""
     H, W = ref.shape
@@ -867,7 +868,7 @@ def test_e2e_large_tiles(ts, snr):
         cfg.noise_model.update({"std_curve": std.tolist(), "diff_curve": dif.tolist()})
         return cfg
 
-    _e2e_vs_oracle(ref, comp, cfg0, ts, f"Ts={ts}", max_flipped=FLIP_BUDGET[f"ts{ts}"], flow_atol=3e-3)
+    _e2e_vs_oracle(ref, comp, cfg0, ts, f"Ts={ts}", max_flipped=FLIP_BUDGET[f"ts{ts}"])
 
 
 @pytest.mark.parametrize("shape,scale", [((502, 618), 2), ((486, 520), 1.5), ((512, 640), 3)])
@@ -877,7 +878,7 @@ def test_e2e_ragged_sizes_and_scales(shape, scale):
     H, W = shape
     ref, comp, _ = synth.make_burst(H, W, 3, seed=23, max_shift=3.0, occluder=True)
     o, want, _ = _e2e_vs_oracle(ref, comp, lambda: base_config(ts=16, scale=scale, metrics=("L1", "L2", "L2", "L2")), 16,
-                                f"ragged x{scale}", max_flipped=FLIP_BUDGET[f"ragged{scale}"], flow_atol=3e-3)
+                                f"ragged x{scale}", max_flipped=FLIP_BUDGET[f"ragged{scale}"])
     with np.errstate(all="ignore"):
         assert np.nanpercentile(np.abs(o - want), 99) < 2e-4
 
@@ -933,8 +934,12 @@ def test_e2e_config_matrix(opt, capsys):
                                       max_flipped=FLIP_BUDGET["matrix"])
     out_q, _ = hsr.main(ref, comp, cfg0())  # quiet, pipelined, fused (the debug run above is the per-frame path)
     assert_close(N(out_q), o, 2e-5, 1e-6, "quiet (fused, pipelined) == debug (per-frame)")
-    out_v, _ = hsr.main(ref, comp, cfg0(verbose=2))
-    assert "Total ellapsed time" in capsys.readouterr().out
+    out_v, _ = hsr.main(ref, comp, cfg0(verbose=3))
+    printed = capsys.readouterr().out
+    assert "Total ellapsed time" in printed
+    for msg in ("Alignment initialized (Total)", "Image aligned (Total)", "Robustness estimated (Total)",
+                "Burst merged (Total)", "- grey images estimated by FFT"):
+        assert msg in printed, msg  # the reference's per-stage timers (super_resolution.py:72-81), verbose >= 2 / 3
     assert_close(N(out_v), o, 2e-5, 1e-6, "verbose (sequential) == debug")
 
 
@@ -1210,7 +1215,7 @@ def test_c2_full_size_against_oracle():
     H, W = 3000, 4000
     ref, comp, _ = synth.make_burst(H, W, 3, seed=1234)
     _e2e_vs_oracle(ref, comp, lambda: base_config(ts=16, scale=2, metrics=("L1", "L2", "L2", "L2")), 16, "C2 full size",
-                   max_flipped=FLIP_BUDGET["c2_full"], flow_atol=3e-3, parallel=True)
+                   max_flipped=FLIP_BUDGET["c2_full"], parallel=True)
 
 
 def test_c4_substitute_13_frames_sensor_size():
@@ -1252,7 +1257,7 @@ def test_c4_substitute_13_frames_sensor_size():
     # a crop of the same burst against the oracle
     c, y0, x0 = 512, 1216, 1792
     _e2e_vs_oracle(ref[y0:y0 + c, x0:x0 + c], comp[:, y0:y0 + c, x0:x0 + c], cfg0, 16, "C4 substitute crop",
-                   max_flipped=FLIP_BUDGET["c4_crop"], flow_atol=3e-3, parallel=True)
+                   max_flipped=FLIP_BUDGET["c4_crop"], parallel=True)
 
 
 def test_c5_geometry_48mp_x3():

@@ -47,7 +47,7 @@ def main(root, steps):
         ipw = per.get("SQ_INSTS_VALU", 0) / per["SQ_WAVES"] if per.get("SQ_WAVES") else 0
         mb = (2 * per.get("FETCH_SIZE", 0) + per.get("WRITE_SIZE", 0)) * 1024 / 1e6
         conf = per.get("SQ_LDS_BANK_CONFLICT", 0) / per["SQ_LDS_IDX_ACTIVE"] if per.get("SQ_LDS_IDX_ACTIVE") else 0
-        rows.append((tot / steps, k, c / steps, us, valu, lds, parked, stall, ipw, mb, mb / us / 1e3 if us else 0, conf))
+        rows.append((tot / steps, k, c / steps, us, valu, lds, parked, stall, ipw, mb, mb / us * 1e3 if us else 0, conf))
     for r in sorted(rows, reverse=True):
         print(f"| `{r[1]}` | {r[2]:.0f} | {r[3]:.1f} | {r[0] / 1e3:.2f} | {100 * r[4]:.0f} % | {100 * r[5]:.0f} % | "
               f"{100 * r[6]:.0f} % | {100 * r[7]:.0f} % | {r[8]:.0f} | {r[9]:.1f} | {r[10]:.0f} | {100 * r[11]:.0f} % |")
