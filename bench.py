@@ -109,7 +109,9 @@ def main():
     if on_gpu:
         if not torch.cuda.is_available():
             raise SystemExit("bench.py: no HIP device visible (the hot path has no CPU fallback)")
-        torch.cuda.set_device(local_rank if world > 1 else 0)
+        # (HHSR_BENCH_SHARE_GPU=1: every rank on device 0 — lets a 1-GPU box exercise the multi-rank path)
+        share = os.environ.get("HHSR_BENCH_SHARE_GPU") == "1"
+        torch.cuda.set_device(local_rank if (world > 1 and not share) else 0)
         dev = torch.device("cuda", torch.cuda.current_device())
     else:
         dev = torch.device("cpu")
