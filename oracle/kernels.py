@@ -91,14 +91,13 @@ def compute_k(l1, l2, t, law):
 
 
 def estimate_kernels(img, config):
-    """reference kernels.py:29-137 (bayer mode): returns covs float32[H/2, W/2, 2, 2]."""
-    if config.mode != "bayer":
-        raise NotImplementedError("grey mode is out of scope")
+    """reference kernels.py:29-137: returns covs float32[H/2, W/2, 2, 2] (bayer mode: one per quad, from the 2x2-mean
+    decimation of the stabilised image) or float32[H, W, 2, 2] (grey mode: one per pixel, kernels.py:83-87)."""
     law = config.merging.selection_law
     if law not in ("hard_threshold", "linear"):
         raise ValueError(f"Unknown selection law: {law}")
     vst = gat(img, config.noise_model.alpha, config.noise_model.beta)
-    grey = decimate_to_grey(vst)
+    grey = decimate_to_grey(vst) if config.mode == "bayer" else vst
     gh, gw = grey.shape
     gx, gy = _gradients(grey)
     # 2x2 window of gradient samples (y-1..y, x-1..x), zero where out of the [gh-1, gw-1] gradient grid;

@@ -15,9 +15,9 @@ def _pymax0(z):
 
 
 def merge(comp, flow, covs, r, num, den, cfa, config):
-    """Alg. 4 (merge.py:236-434), bayer mode.  ``num``/``den`` float32[sH, sW, 3] are updated in place."""
-    if config.mode != "bayer":
-        raise NotImplementedError("grey mode is out of scope")
+    """Alg. 4 (merge.py:236-434).  ``num``/``den`` float32[sH, sW, 3] are updated in place.  Grey mode: every tap goes
+    to channel 0 (channels 1, 2 stay untouched) and the covariance grid is the pixel grid (merge.py:349-354, 410)."""
+    bayer = config.mode == "bayer"
     comp = np.asarray(comp, dtype=F32)
     flow = np.asarray(flow, dtype=F32)
     covs = np.asarray(covs, dtype=F32)
@@ -46,8 +46,8 @@ def merge(comp, flow, covs, r, num, den, cfa, config):
     mys = np.where(inb, my, 0.0)
     with np.errstate(all="ignore"):
         if not iso:
-            kj = mxs / 2 - 0.5
-            ki = mys / 2 - 0.5
+            kj = mxs / 2 - 0.5 if bayer else mxs - 0.5
+            ki = mys / 2 - 0.5 if bayer else mys - 0.5
             fx = kj - np.trunc(kj)
             fy = ki - np.trunc(ki)
             x0 = np.maximum(np.trunc(kj).astype(np.int64), 0)
@@ -79,7 +79,7 @@ def merge(comp, flow, covs, r, num, den, cfa, config):
                 ok = inb & (j >= 0) & (j < lr_w) & (i >= 0) & (i < lr_h)
                 jc = np.clip(j, 0, lr_w - 1)
                 ic = np.clip(i, 0, lr_h - 1)
-                ch = cfa[ic % 2, jc % 2]
+                ch = cfa[ic % 2, jc % 2] if bayer else np.zeros_like(ic)
                 c = comp[ic, jc].astype(F64)
                 dx = j - mj
                 dy = i - mi
@@ -94,17 +94,17 @@ def merge(comp, flow, covs, r, num, den, cfa, config):
                     m = ok & (ch == k)
                     val[k] = np.where(m, (val[k].astype(F64) + wr * c).astype(F32), val[k])
                     acc[k] = np.where(m, (acc[k].astype(F64) + wr).astype(F32), acc[k])
-    for k in range(3):
+    for k in range(3 if bayer else 1):
         num[..., k] = np.where(inb, num[..., k] + val[k], num[..., k])
         den[..., k] = np.where(inb, den[..., k] + acc[k], den[..., k])
 
 
 def merge_ref(ref, covs, num, den, cfa, config, acc_rob=None):
-    """Alg. 11 (merge.py:22-233), bayer mode.  Position = idx/scale without the half-pixel offset
+    """Alg. 11 (merge.py:22-233).  Position = idx/scale without the half-pixel offset
     (D7), stored in float32; centre tap = round-half-even; covariance via interpolate_cov +
-    invert_2x2 (identity when |det| <= 1e-10 or NaN)."""
-    if config.mode != "bayer":
-        raise NotImplementedError("grey mode is out of scope")
+    invert_2x2 (identity when |det| <= 1e-10 or NaN).  Grey mode: channel 0 only, covariance read at the position
+    itself (merge.py:131-137, 191-194)."""
+    bayer = config.mode == "bayer"
     ref = np.asarray(ref, dtype=F32)
     covs = np.asarray(covs, dtype=F32)
     cfa = np.asarray(cfa).astype(np.int64)
@@ -119,8 +119,8 @@ def merge_ref(ref, covs, num, den, cfa, config, acc_rob=None):
     px = (oj / scale).astype(F32)
     with np.errstate(all="ignore"):
         if not iso:
-            gy = ((py.astype(F64) - 0.5) / 2).astype(F32)
-            gx = ((px.astype(F64) - 0.5) / 2).astype(F32)
+            gy = ((py.astype(F64) - 0.5) / 2).astype(F32) if bayer else py
+            gx = ((px.astype(F64) - 0.5) / 2).astype(F32) if bayer else px
             x0 = np.maximum(np.floor(gx), 0).astype(np.int64)
             y0 = np.maximum(np.floor(gy), 0).astype(np.int64)
             x1 = np.minimum(x0 + 1, covs.shape[1] - 1)
@@ -166,7 +166,7 @@ def merge_ref(ref, covs, num, den, cfa, config, acc_rob=None):
                 ok = (np.abs(i) <= rad_map) & (np.abs(j) <= rad_map) & (pj >= 0) & (pj < W) & (pi >= 0) & (pi < H)
                 jc = np.clip(pj, 0, W - 1)
                 ic = np.clip(pi, 0, H - 1)
-                ch = cfa[ic % 2, jc % 2]
+                ch = cfa[ic % 2, jc % 2] if bayer else np.zeros_like(ic)
                 c = ref[ic, jc].astype(F64)
                 dx = pj - px.astype(F64)
                 dy = pi - py.astype(F64)
@@ -185,7 +185,7 @@ def merge_ref(ref, covs, num, den, cfa, config, acc_rob=None):
         over = lacc < d.max_frame_count
     else:
         over = np.zeros((oh, ow), bool)
-    for k in range(3):
+    for k in range(3 if bayer else 1):
         num[..., k] = np.where(over, val[k], num[..., k] + val[k])
         den[..., k] = np.where(over, acc[k], den[..., k] + acc[k])
 

@@ -32,7 +32,7 @@ def _init(ref, comp_imgs, config):
         pass
     cfa = np.array(config.exif.cfa_pattern)
     wb = np.array(config.exif.white_balance, dtype=np.float64)
-    grey_ref = compute_grey_images(ref, config.grey_method)
+    grey_ref = compute_grey_images(ref, config.grey_method) if config.mode == "bayer" else ref
     _state.update(ref=ref, comp=comp_imgs, config=config, cfa=cfa, wb=wb, align=init_alignment(grey_ref, config),
                   rob=init_robustness(ref, cfa, wb, config),
                   curves=(np.array(config.noise_model.std_curve, np.float64),
@@ -42,7 +42,7 @@ def _init(ref, comp_imgs, config):
 def _frame(n):
     s = _state
     cfg, img = s["config"], s["comp"][n]
-    grey = compute_grey_images(img, cfg.grey_method)
+    grey = compute_grey_images(img, cfg.grey_method) if cfg.mode == "bayer" else img
     flow = align(*s["align"], grey, cfg)
     r = compute_robustness(img, *s["rob"], flow, s["cfa"], s["wb"], s["curves"], cfg)
     covs = estimate_kernels(img, cfg)
@@ -57,8 +57,6 @@ def _frame(n):
 def main_parallel(ref_img, comp_imgs, config, workers=None, capture=None):
     """Same result as ``oracle.main(ref_img, comp_imgs, config)`` (bit for bit), computed by ``workers`` processes
     (default: all host cores, at most one per comp frame).  Returns (output, debug_dict, workers_used)."""
-    if config.mode != "bayer":
-        raise NotImplementedError("grey mode is out of scope")
     ref = np.asarray(ref_img, dtype=F32)
     comp_imgs = np.asarray(comp_imgs, dtype=F32)
     n = comp_imgs.shape[0]

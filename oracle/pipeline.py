@@ -14,8 +14,7 @@ def main(ref_img, comp_imgs, config, capture=None):
     """Returns (output float32[sH, sW, 3] = num/den, debug_dict) like the reference.
 
     ``capture``: optional dict that receives per-frame intermediates (grey, flow, r, covs)."""
-    if config.mode != "bayer":
-        raise NotImplementedError("grey mode is out of scope")
+    bayer = config.mode == "bayer"  # grey mode: the frames are their own grey images (super_resolution.py:106-109, 144-147)
     ref = np.asarray(ref_img, dtype=F32)
     comp_imgs = np.asarray(comp_imgs, dtype=F32)
     cfa = np.array(config.exif.cfa_pattern)
@@ -24,7 +23,7 @@ def main(ref_img, comp_imgs, config, capture=None):
     accumulate_r = bool(config.accumulated_robustness_denoiser.enabled or config.robustness.save_mask)
     debug = {"robustness": [], "flow": []}
 
-    grey_ref = compute_grey_images(ref, config.grey_method)
+    grey_ref = compute_grey_images(ref, config.grey_method) if bayer else ref
     pyr, gxs, gys, hs = init_alignment(grey_ref, config)
     ref_means, ref_vars = init_robustness(ref, cfa, wb, config)
     H, W = ref.shape
@@ -37,7 +36,7 @@ def main(ref_img, comp_imgs, config, capture=None):
         capture.update(grey_ref=grey_ref, flow=[], r=[], covs=[])
     for n in range(comp_imgs.shape[0]):
         img = comp_imgs[n]
-        grey = compute_grey_images(img, config.grey_method)
+        grey = compute_grey_images(img, config.grey_method) if bayer else img
         flow = align(pyr, gxs, gys, hs, grey, config)
         r = compute_robustness(img, ref_means, ref_vars, flow, cfa, wb, curves, config)
         if accumulate_r:

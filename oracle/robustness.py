@@ -52,12 +52,16 @@ def _dodgson(x):
 
 
 def upscale_warp_stats(stats, tile_size=None, flow=None):
-    """robustness.py:359-421: guide-res map -> raw res (s = 2 hard-coded, D5), optionally warped by the
+    """robustness.py:296-421: guide-res map -> raw res (s = 2 hard-coded, D5), optionally warped by the
     per-tile flow; 3x3 Dodgson taps around round-half-even(LR) with clamped indices, normalised;
-    +inf where the guide position is outside [0, n) (D6: row 0 / column 0 of the un-warped ref map)."""
+    +inf where the guide position is outside [0, n) (D6: row 0 / column 0 of the un-warped ref map).
+
+    A 1-channel map (grey mode) keeps its size (robustness.py:337-343) while the kernel still divides the position by
+    its hard-coded s = 2 (robustness.py:358): the output is the top-left quadrant of the map stretched over the whole
+    frame, for the reference frame and the warped frames alike.  Deterministic, so reproduced (D5)."""
     stats = np.asarray(stats, dtype=F32)
     nc, lh, lw = stats.shape
-    H, W = 2 * lh, 2 * lw
+    H, W = (2 * lh, 2 * lw) if nc == 3 else (lh, lw)
     y = np.arange(H)[:, None]
     x = np.arange(W)[None, :]
     if flow is None:
@@ -160,13 +164,18 @@ def local_min(R):
     return out
 
 
+def _guide(raw, cfa, wb, config):
+    """Bayer: Alg. 7; grey: the frame itself as one channel, white balance not involved (robustness.py:62-66, 145-148)."""
+    if config.mode == "bayer":
+        return guide_image(raw, cfa, wb)
+    return np.asarray(raw, dtype=F32)[None]
+
+
 def init_robustness(ref, cfa, wb, config):
     """robustness.py:23-76: reference-frame local means / variances at raw resolution."""
     if not config.robustness.enabled:
         return None, None
-    if config.mode != "bayer":
-        raise NotImplementedError("grey mode is out of scope")
-    m, v = local_stats(guide_image(ref, cfa, wb))
+    m, v = local_stats(_guide(ref, cfa, wb, config))
     return upscale_warp_stats(m), upscale_warp_stats(v)
 
 
@@ -177,7 +186,7 @@ def compute_robustness(comp, ref_means, ref_vars, flow, cfa, wb, noise_model, co
         return np.ones_like(comp, F32)
     ts = config.block_matching.tuning.tile_size
     t = config.robustness.tuning
-    cm, _ = local_stats(guide_image(comp, cfa, wb))
+    cm, _ = local_stats(_guide(comp, cfa, wb, config))
     cmu = upscale_warp_stats(cm, ts, flow)
     with np.errstate(all="ignore"):
         d_p = np.abs(ref_means - cmu).astype(F32)

@@ -253,3 +253,72 @@ def test_post_gauss_and_unsharp_known_answers():
     assert radius == 12 and abs(taps.sum() - 1) < 1e-15
     got = post.unsharp_mask(imp, 3, 1.5)[20, 20, 0]
     assert abs(got - (1 + 1.5 * (1 - taps[radius] ** 2))) < 1e-6
+
+
+MONO = ((1, 1), (1, 1))  # synthetic "CFA" that samples the scene's green plane at every pixel: a monochrome sensor
+
+
+def test_grey_mode_stages(golden):
+    """`mode: grey` (monochrome sensors): per-pixel covariances, one-channel robustness (including the
+    reference's hard-coded s = 2 in the statistics upscale, which stretches the top-left quadrant over the frame) and
+    the one-channel merge / merge_ref, against outputs of the reference's own functions (tools/refsim "grey_mode")."""
+    g = golden("grey_mode")
+    cfa, wb = np.array([[0, 1], [1, 2]]), np.ones(3)
+    cfg = base_config(mode="grey")
+    covs = oracle.estimate_kernels(g["k_raw"], cfg)
+    assert covs.shape == g["k_raw"].shape + (2, 2)
+    assert_close(covs, g["k_cov"], 2e-5, 1e-7, "grey covs")
+    rm, rv = oracle.init_robustness(g["r_ref"], cfa, wb, cfg)
+    assert rm.shape == (1,) + g["r_ref"].shape
+    assert_close(rm, g["r_means"], 1e-6, 1e-8, "grey ref means")
+    assert_close(rv, g["r_vars"], 1e-5, 1e-9, "grey ref vars")
+    std, diff = np.array(cfg.noise_model.std_curve), np.array(cfg.noise_model.diff_curve)
+    r = oracle.compute_robustness(g["r_comp"], g["r_means"], g["r_vars"], g["r_flow"], cfa, wb, (std, diff), cfg)
+    assert_close(r, g["r_out"], 1e-4, 1e-5, "grey r")
+    H, W = g["m_comp"].shape
+    for tag, scale, kern in (("s2", 2, "steerable"), ("s15", 1.5, "steerable"), ("s3", 3, "steerable"), ("s2iso", 2, "iso")):
+        cfg = base_config(ts=16, scale=scale, mode="grey")
+        cfg.merging.kernel = kern
+        oh, ow = round(scale * H), round(scale * W)
+        num, den = acc_pattern(oh, ow, 0), acc_pattern(oh, ow, 5)
+        oracle.merge(g["m_comp"], g["m_flow"], g["m_covs"], g["m_r"], num, den, cfa, cfg)
+        assert np.array_equal(num[..., 1:], acc_pattern(oh, ow, 0)[..., 1:])  # channels 1, 2 untouched
+        assert_close(num, g[f"m_{tag}_num"], 2e-6, 1e-7, tag + " num")
+        assert_close(den, g[f"m_{tag}_den"], 2e-6, 1e-7, tag + " den")
+        num, den = acc_pattern(oh, ow, 0), acc_pattern(oh, ow, 5)
+        oracle.merge_ref(g["m_ref"], g["m_covs_ref"], num, den, cfa, cfg)
+        assert_close(num, g[f"m_{tag}_numref"], 1e-5, 1e-7, tag + " numref")
+        assert_close(den, g[f"m_{tag}_denref"], 1e-5, 1e-7, tag + " denref")
+    cfg = base_config(ts=16, scale=2, mode="grey")
+    cfg.accumulated_robustness_denoiser.enabled = True
+    cfg.accumulated_robustness_denoiser.merge.enabled = True
+    num, den = acc_pattern(2 * H, 2 * W, 0), acc_pattern(2 * H, 2 * W, 5)
+    oracle.merge_ref(g["m_ref"], g["m_covs_ref"], num, den, cfa, cfg, g["m_acc_rob"].astype(np.float64))
+    assert_close(num, g["m_den_numref"], 1e-5, 1e-7, "grey denoiser numref")
+    assert_close(den, g["m_den_denref"], 1e-5, 1e-7, "grey denoiser denref")
+
+
+def grey_e2e_inputs(g):
+    from handheld_super_resolution import synthetic as synth
+
+    ref, comp, shifts = synth.make_burst(128, 128, 3, seed=int(g["e_seed"]), cfa=MONO, max_shift=2.0, occluder=True)
+    np.testing.assert_array_equal(shifts, g["e_shifts"])
+    cfg = base_config(ts=16, scale=2, mode="grey")
+    cfg.block_matching.tuning.factors = [1, 2, 2, 2]
+    cfg.robustness.save_mask = True
+    return ref, comp, cfg
+
+
+def test_e2e_grey_mode(golden):
+    """main() with `mode: grey` on the 128x128 x3 monochrome burst the reference itself processed (x2, Ts=16, all-L2):
+    channel 0 carries the image, channels 1 and 2 are 0/0 = NaN (the accumulators always have three channels,
+    super_resolution.py:123-124)."""
+    g = golden("grey_mode")
+    ref, comp, cfg = grey_e2e_inputs(g)
+    cap = {}
+    out, dbg = oracle.main(ref, comp, cfg, capture=cap)
+    assert np.isnan(g["e_out"][..., 1:]).all() and np.isfinite(g["e_out"][..., 0]).mean() > 0.99
+    assert_close(np.stack(cap["flow"]), g["e_flow"], 0, 5e-5, "flow")
+    assert_close(np.stack(cap["r"]), g["e_r"], 0, 5e-5, "r")
+    assert_close(dbg["accumulated robustness"], g["e_acc_r"], 0, 5e-5, "acc r")
+    assert_close(out, g["e_out"], 0, 5e-5, "output")

@@ -459,7 +459,104 @@ def stage_post():
     save("post", **out)
 
 
+def stage_grey_mode():
+    """`mode: grey` (monochrome sensors): the reference's own estimate_kernels / init_robustness / compute_robustness /
+    merge / merge_ref on one-channel frames, and main() end to end (128x128, 3 frames, x2, Ts=16, all-L2)."""
+    k, rb, mg = loader.ref("kernels"), loader.ref("robustness"), loader.ref("merge")
+    sr = loader.ref("super_resolution")
+    mono = ((1, 1), (1, 1))  # the synthetic scene's green plane at every pixel
+    rng = np.random.default_rng(21)
+    out = {}
+    # --- kernels
+    raw = smooth_field(rng, 40, 48, sigma=1.2)[:40, :48]
+    raw = np.clip(raw + 0.02 * rng.standard_normal(raw.shape), 0, 1).astype(np.float32)
+    raw[:6, :6] = 0.25
+    cfg = base_config(mode="grey")
+    out.update(k_raw=raw, k_cov=npy(k.estimate_kernels(cuda.to_device(raw), cfg)))
+    # --- robustness
+    H, W, ts = 64, 80, 16
+    ref, comp, _ = synth.make_burst(H, W, 2, seed=78, cfa=mono, occluder=True, max_shift=1.0)
+    comp = comp[0]
+    cfa = np.array([[0, 1], [1, 2]])
+    d_cfa, d_wb = cuda.to_device(cfa), cuda.to_device(np.array([1.0, 1.0, 1.0]))
+    cfg = base_config(ts=ts, mode="grey")
+    means, stds = rb.init_robustness(cuda.to_device(ref), d_cfa, d_wb, cfg)
+    flow = rng.uniform(-0.4, 0.4, (H // ts, W // ts, 2)).astype(np.float32)
+    flow[1, 2] = (1.7, -1.2)
+    flow[-1, -1] = (3.5, 2.5)
+    flow[0, 0] = (-2.5, -1.5)
+    std, diff = synth.noise_curves(ALPHA, BETA)
+    r = rb.compute_robustness(cuda.to_device(comp), means, stds, cuda.to_device(flow), d_cfa, d_wb,
+                              (cuda.to_device(std), cuda.to_device(diff)), cfg)
+    out.update(r_ref=ref, r_comp=comp, r_flow=flow, r_means=npy(means), r_vars=npy(stds), r_out=npy(r))
+    # --- merge / merge_ref
+    H, W = 32, 48
+    ref, comp, _ = synth.make_burst(H, W, 2, seed=98, cfa=mono, max_shift=1.0)
+    comp = comp[0]
+    cfg = base_config(ts=ts, mode="grey")
+    covs = npy(k.estimate_kernels(cuda.to_device(comp), cfg))
+    covs_ref = npy(k.estimate_kernels(cuda.to_device(ref), cfg))
+    covs[3, 5] = np.nan
+    mflow = _flows(rng, H // ts, W // ts, amp=1.5)
+    mr = rng.random((H, W), dtype=np.float32)
+    out.update(m_ref=ref, m_comp=comp, m_covs=covs, m_covs_ref=covs_ref, m_flow=mflow, m_r=mr)
+    for tag, scale, kern in (("s2", 2, "steerable"), ("s15", 1.5, "steerable"), ("s3", 3, "steerable"), ("s2iso", 2, "iso")):
+        cfg = base_config(ts=ts, scale=scale, mode="grey")
+        cfg.merging.kernel = kern
+        oh, ow = round(scale * H), round(scale * W)
+        num0, den0 = acc_pattern(oh, ow, 0), acc_pattern(oh, ow, 5)
+        num, den = cuda.to_device(num0), cuda.to_device(den0)
+        mg.merge(cuda.to_device(comp), cuda.to_device(mflow), cuda.to_device(covs), cuda.to_device(mr),
+                 num, den, cuda.to_device(cfa), cfg)
+        numr, denr = cuda.to_device(num0), cuda.to_device(den0)
+        mg.merge_ref(cuda.to_device(ref), cuda.to_device(covs_ref), numr, denr, cuda.to_device(cfa), cfg)
+        out.update({f"m_{tag}_num": npy(num), f"m_{tag}_den": npy(den), f"m_{tag}_numref": npy(numr),
+                    f"m_{tag}_denref": npy(denr)})
+    cfg = base_config(ts=ts, scale=2, mode="grey")
+    cfg.accumulated_robustness_denoiser.enabled = True
+    cfg.accumulated_robustness_denoiser.merge.enabled = True
+    acc_rob = (rng.random((H, W)) * 4).astype(np.float32).astype(np.float64)
+    num0, den0 = acc_pattern(2 * H, 2 * W, 0), acc_pattern(2 * H, 2 * W, 5)
+    numr, denr = cuda.to_device(num0), cuda.to_device(den0)
+    mg.merge_ref(cuda.to_device(ref), cuda.to_device(covs_ref), numr, denr, cuda.to_device(cfa), cfg,
+                 cuda.to_device(acc_rob))
+    out.update(m_acc_rob=acc_rob.astype(np.float32), m_den_numref=npy(numr), m_den_denref=npy(denr))
+    # --- main()
+    H = W = 128
+    ref, comp, shifts = synth.make_burst(H, W, 3, seed=4321, cfa=mono, max_shift=2.0, occluder=True)
+    cfg = base_config(ts=16, scale=2, mode="grey")
+    cfg.block_matching.tuning.factors = [1, 2, 2, 2]
+    cfg.robustness.save_mask = True
+    cap = {"flow": [], "r": []}
+    saved = {}
+
+    def wrap(name, key):
+        f = saved[name] = getattr(sr, name)
+
+        def g(*a, **kw):
+            o = f(*a, **kw)
+            cap[key].append(npy(o))
+            return o
+
+        setattr(sr, name, g)
+
+    wrap("align", "flow")
+    wrap("compute_robustness", "r")
+    t0 = time.time()
+    try:
+        with np.errstate(all="ignore"):
+            res, dbg = sr.main(ref, comp, cfg)
+    finally:
+        for name, f in saved.items():
+            setattr(sr, name, f)
+    print(f"    main(): {time.time() - t0:.1f}s")
+    out.update(e_shifts=shifts, e_seed=np.array(4321), e_flow=np.stack(cap["flow"]), e_r=np.stack(cap["r"]),
+               e_out=npy(res), e_acc_r=np.asarray(dbg["accumulated robustness"], dtype=np.float32))
+    save("grey_mode", **out)
+
+
 STAGES = {
+    "grey_mode": stage_grey_mode,
     "post": stage_post,
     "grey": stage_grey, "downsample": stage_downsample, "hessian": stage_hessian, "bm_l2": stage_bm_l2,
     "ica": stage_ica, "upscale": stage_upscale, "kernels": stage_kernels, "robustness": stage_robustness,
