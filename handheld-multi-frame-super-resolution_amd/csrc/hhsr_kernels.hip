@@ -281,3 +281,92 @@ extern "C" int hhsr_frame_stats(const float* raw, int H, int W, int pitch, const
     CovParams P{alpha, beta, k_detail, k_denoise, D_th, D_tr, k_stretch, k_shrink, law};
     return frame_stats_launch(raw, H, W, pitch, cfa, wb, means, vars, covs, P, stream);
 }
+
+// ---- monochrome sensors (`mode: grey`) ---------------------------------------------------------------------------
+// The frame is its own guide image (one channel, white balance not involved: robustness.py:62-66) and the kernel
+// covariances are estimated per PIXEL from the stabilised frame itself (kernels.py:83-87): the same tile kernel with
+// pixels in the place of Bayer quads — 32 x 16 pixels per workgroup with a one-pixel halo, two pixels per thread.
+struct MonoStatsArgs {
+    const float* raw;
+    int pitch, H, W;
+    float* means;  // [H][W] or NULL
+    float* vars;   // [H][W] or NULL
+    float4* covs;  // [H][W] or NULL
+    CovParams P;
+};
+
+template <bool STATS, bool COV>
+__global__ void __launch_bounds__(256) k_mono_stats(MonoStatsArgs A) {
+    __shared__ float s_v[STATS ? FS_TY + 2 : 1][FS_P];
+    __shared__ float s_g[COV ? (FS_TY + 2) * FS_P : 1];
+    const int bid = xcd_remap(blockIdx.y * gridDim.x + blockIdx.x, gridDim.x * gridDim.y);
+    const int x0 = (bid % gridDim.x) * FS_TX, y0 = (bid / gridDim.x) * FS_TY;
+    const int H = A.H, W = A.W;
+    const double c0 = 3.0 / 8.0 * A.P.alpha * A.P.alpha + A.P.beta;
+    const double toa = 2.0 / A.P.alpha;
+    float v[FS_IT];
+#pragma unroll
+    for (int u = 0; u < FS_IT; ++u) {  // clamped pixel = the statistics' border rule (robustness.py:281-282)
+        const int p = min(threadIdx.x + 256 * u, FS_N - 1);
+        const int i = p / (FS_TX + 2), j = p - i * (FS_TX + 2);
+        v[u] = A.raw[(size_t)clampi(y0 + i - 1, 0, H - 1) * A.pitch + clampi(x0 + j - 1, 0, W - 1)];
+    }
+#pragma unroll
+    for (int u = 0; u < FS_IT; ++u) {
+        const int p = threadIdx.x + 256 * u;
+        if (p < FS_N) {
+            const int i = p / (FS_TX + 2), j = p - i * (FS_TX + 2);
+            if (STATS) s_v[i][j] = v[u];
+            if (COV) {  // zero outside the frame: quad_cov only reads gradient samples that exist
+                const int y = y0 + i - 1, x = x0 + j - 1;
+                s_g[i * FS_P + j] = (y >= 0 && y < H && x >= 0 && x < W) ? gat1(v[u], A.P.alpha, c0, toa) : 0.f;
+            }
+        }
+    }
+    __syncthreads();
+    const int lx = threadIdx.x % FS_TX, ly0 = threadIdx.x / FS_TX;
+    const int gx = x0 + lx;
+    if (gx >= W) return;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        const int ly = ly0 + 8 * h, gy = y0 + ly;
+        if (gy >= H) break;
+        const size_t o = (size_t)gy * W + gx;
+        if (STATS) {
+            float s0 = 0.f, s1 = 0.f;  // float32 running sums in (i, j) order (robustness.py:280-288)
+#pragma unroll
+            for (int i = 0; i < 3; ++i)
+#pragma unroll
+                for (int j = 0; j < 3; ++j) {
+                    const float t = s_v[ly + i][lx + j];
+                    s0 += t;
+                    s1 += t * t;
+                }
+            const double m = div_by((double)s0, 9.0, 1.0 / 9.0);
+            A.means[o] = (float)m;
+            if (A.vars) A.vars[o] = (float)(div_by((double)s1, 9.0, 1.0 / 9.0) - m * m);
+        }
+        if (COV) A.covs[o] = quad_cov<FS_P>(s_g, ly, lx, gy, gx, H, W, A.P);
+    }
+}
+
+extern "C" int hhsr_mono_frame_stats(const float* raw, int H, int W, int pitch, float* means, float* vars, float* covs,
+                                     double alpha, double beta, double k_detail, double k_denoise, double D_th,
+                                     double D_tr, double k_stretch, double k_shrink, int law, void* stream) {
+    HHSR_ARG(raw && (means || covs) && H >= 2 && W >= 2 && pitch >= W);
+    HHSR_ARG(!vars || means);
+    HHSR_ARG(!covs || (((uintptr_t)covs & 15) == 0 && alpha > 0.0 && (law == 0 || law == 1)));
+    MonoStatsArgs A;
+    A.raw = raw; A.pitch = pitch; A.H = H; A.W = W;
+    A.means = means; A.vars = vars; A.covs = reinterpret_cast<float4*>(covs);
+    A.P = covs ? CovParams{alpha, beta, k_detail, k_denoise, D_th, D_tr, k_stretch, k_shrink, law}
+               : CovParams{1.0, 0.0, 0, 0, 0, 1.0, 0, 1.0, 0};
+    A.P.r_D_tr = 1.0 / A.P.D_tr;
+    A.P.inv_k_shrink = 1.0 / A.P.k_shrink;
+    const dim3 grid(hhsr_cdiv(W, FS_TX), hhsr_cdiv(H, FS_TY)), block(256);
+    hipStream_t s = (hipStream_t)stream;
+    if (means && covs) hipLaunchKernelGGL((k_mono_stats<true, true>), grid, block, 0, s, A);
+    else if (means) hipLaunchKernelGGL((k_mono_stats<true, false>), grid, block, 0, s, A);
+    else hipLaunchKernelGGL((k_mono_stats<false, true>), grid, block, 0, s, A);
+    return hhsr_launch_status("hhsr_mono_frame_stats");
+}

@@ -21,7 +21,8 @@ struct Cfa4 {
 
 struct Geo {
     int H, W, pitch;    // raw frame
-    int gh, gw;         // covariance grid (H/2, W/2)
+    int gh, gw;         // covariance grid (H/2, W/2; monochrome sensors: H, W)
+    int mono;           // `mode: grey`: one channel, covariances per pixel (merge.py:131-137, 349-354, 410)
     int ny, nx, ts;     // flow tile grid
     int sH, sW;         // output
     int row0, row1;     // output rows [row0, row1) handled by this launch (merge_burst slabs); num/den point at row0
@@ -77,7 +78,7 @@ __device__ __forceinline__ void comp_contrib(const FramePtr f, const Geo& g, con
     const WT local_r = (WT)robustness_at(f.r, g, i_r, j_r, lmin);
     WT ixx = 0, ixy = 0, iyy = 0;
     if (!ISO) {
-        const double kj = mx / 2.0 - 0.5, ki = my / 2.0 - 0.5;
+        const double kj = g.mono ? mx - 0.5 : mx / 2.0 - 0.5, ki = g.mono ? my - 0.5 : my / 2.0 - 0.5;
         const double tkj = trunc(kj), tki = trunc(ki);
         const WT fx = (WT)(kj - tkj), fy = (WT)(ki - tki);  // signed modf fraction (D11)
         const int x0 = max((int)tkj, 0), y0 = max((int)tki, 0);
@@ -105,7 +106,7 @@ __device__ __forceinline__ void comp_contrib(const FramePtr f, const Geo& g, con
         for (int dj = -1; dj <= 1; ++dj) {
             const int j = cj + dj;
             if (j < 0 || j >= g.W || i < 0 || i >= g.H) continue;
-            const int ch = cfa.c[(i & 1) * 2 + (j & 1)];
+            const int ch = cfa.c[(i & 1) * 2 + (j & 1)];  // (monochrome: the host passes an all-zero pattern)
             const WT c = (WT)f.raw[(size_t)i * g.pitch + j];
             const WT dx = (WT)((double)j - mj);
             WT z;
@@ -192,11 +193,17 @@ __device__ __forceinline__ FrameGeo frame_geom(const float2 fl, const Geo& g, co
         q.valid = q.cj >= 0 && q.cj < g.W && q.ci >= 0 && q.ci < g.H;
         q.frx = (fl.x - fix) + (p.lfx - (float)cx);
         q.fry = (fl.y - fiy) + (p.lfy - (float)cy);
-        if (!ISO) {  // kmap = lr_mov/2 - 0.5, trunc toward zero + signed fraction (merge.py:349-361)
+        if (!ISO && !g.mono) {  // kmap = lr_mov/2 - 0.5, trunc toward zero + signed fraction (merge.py:349-361)
             if (q.cj >= 1) { q.x0 = (q.cj - 1) >> 1; q.fx = 0.5f * ((float)((q.cj - 1) & 1) + q.frx); }
             else           { q.x0 = 0;               q.fx = 0.5f * (q.frx - 1.f); }
             if (q.ci >= 1) { q.y0 = (q.ci - 1) >> 1; q.fy = 0.5f * ((float)((q.ci - 1) & 1) + q.fry); }
             else           { q.y0 = 0;               q.fy = 0.5f * (q.fry - 1.f); }
+        } else if (!ISO) {      // monochrome: kmap = lr_mov - 0.5 = c + fr - 0.5 (fr +- 0.5 is exact)
+            const bool hx = q.frx >= 0.5f, hy = q.fry >= 0.5f;
+            q.x0 = hx ? q.cj : max(q.cj - 1, 0);
+            q.fx = hx ? q.frx - 0.5f : (q.cj >= 1 ? q.frx + 0.5f : q.frx - 0.5f);
+            q.y0 = hy ? q.ci : max(q.ci - 1, 0);
+            q.fy = hy ? q.fry - 0.5f : (q.ci >= 1 ? q.fry + 0.5f : q.fry - 0.5f);
         }
     } else {
         const double mx = p.lr_x + (double)fl.x, my = p.lr_y + (double)fl.y;
@@ -206,7 +213,7 @@ __device__ __forceinline__ FrameGeo frame_geom(const float2 fl, const Geo& g, co
         q.frx = (float)(mx - (double)q.cj);
         q.fry = (float)(my - (double)q.ci);
         if (!ISO) {
-            const double kj = mx / 2.0 - 0.5, ki = my / 2.0 - 0.5;
+            const double kj = g.mono ? mx - 0.5 : mx / 2.0 - 0.5, ki = g.mono ? my - 0.5 : my / 2.0 - 0.5;
             const double tkj = trunc(kj), tki = trunc(ki);
             q.fx = (float)(kj - tkj);
             q.fy = (float)(ki - tki);
@@ -334,7 +341,8 @@ __device__ __forceinline__ void ref_accum_fast(const float* __restrict__ raw, co
     q.fx = q.fy = 0.f;
     int x1 = 0, y1 = 0;
     if (!ISO) {
-        const float gy = (pyf - 0.5f) * 0.5f, gx = (pxf - 0.5f) * 0.5f;  // == float32((pos - 0.5)/2)
+        const float gy = g.mono ? pyf : (pyf - 0.5f) * 0.5f;  // == float32((pos - 0.5)/2); monochrome: the position itself
+        const float gx = g.mono ? pxf : (pxf - 0.5f) * 0.5f;
         q.x0 = (int)fmaxf(floorf(gx), 0.f);
         q.y0 = (int)fmaxf(floorf(gy), 0.f);
         q.fx = gx - truncf(gx);
@@ -379,7 +387,8 @@ __device__ __forceinline__ bool ref_contrib(const float* __restrict__ raw, const
     const float pxf = (float)((double)oj / g.scale);
     float i00 = 1.f, i01 = 0.f, i10 = 0.f, i11 = 1.f;
     if (!ISO) {
-        const float gy = (float)(((double)pyf - 0.5) / 2.0), gx = (float)(((double)pxf - 0.5) / 2.0);
+        const float gy = g.mono ? pyf : (float)(((double)pyf - 0.5) / 2.0);
+        const float gx = g.mono ? pxf : (float)(((double)pxf - 0.5) / 2.0);
         const int x0 = (int)fmaxf(floorf(gx), 0.f), y0 = (int)fmaxf(floorf(gy), 0.f);
         const int x1 = min(x0 + 1, g.gw - 1), y1 = min(y0 + 1, g.gh - 1);
         const double rx = (double)(gx - truncf(gx)), ry = (double)(gy - truncf(gy));  // modf (signed)
@@ -474,6 +483,7 @@ __global__ void __launch_bounds__(256) k_accumulate_ref(const float* __restrict_
     const size_t o = ((size_t)oi * g.sW + oj) * 3;
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
+        if (g.mono && k > 0) break;  // one channel: the others are not even overwritten (merge.py:223-233)
         if (over) {
             num[o + k] = val[k];
             den[o + k] = acc[k];
@@ -1664,8 +1674,9 @@ static bool scale_is_pow2(double s) {  // 1, 2, 4, 8: (h + 0.5)/s is exact in fl
     return s == 1.0 || s == 2.0 || s == 4.0 || s == 8.0;
 }
 
-static int fill_geo(Geo& g, int H, int W, int pitch, int ny, int nx, int ts, double scale, int sH, int sW) {
-    g.H = H; g.W = W; g.pitch = pitch; g.gh = H / 2; g.gw = W / 2;
+static int fill_geo(Geo& g, int H, int W, int pitch, int ny, int nx, int ts, double scale, int sH, int sW, bool mono) {
+    g.H = H; g.W = W; g.pitch = pitch; g.mono = mono ? 1 : 0;
+    g.gh = mono ? H : H / 2; g.gw = mono ? W : W / 2;
     g.ny = ny; g.nx = nx; g.ts = ts; g.sH = sH; g.sW = sW; g.scale = scale;
     g.row0 = 0; g.row1 = sH;
     g.off_lr = g.off_hr = 0;
@@ -1694,15 +1705,16 @@ extern "C" int hhsr_accumulate(const float* raw, int H, int W, int pitch, const 
                                const float* covs, const float* r, const uint8_t cfa[4], double scale, int kflags,
                                float* num, float* den, int sH, int sW, void* stream) {
     const int iso = kflags & HHSR_KERNEL_ISO, f64 = kflags & HHSR_WEIGHT_F64;
-    HHSR_ARG(raw && flow && r && cfa && num && den && (iso || covs));
+    const bool mono = (kflags & HHSR_SENSOR_MONO) != 0;
+    HHSR_ARG(raw && flow && r && (cfa || mono) && num && den && (iso || covs));
     HHSR_ARG(H >= 2 && W >= 2 && pitch >= W && ts > 0 && scale >= 1.0 && sH > 0 && sW > 0);
     HHSR_ARG((int64_t)ny * ts >= H && (int64_t)nx * ts >= W);  // every LR position has a flow tile
     HHSR_ARG((double)sH <= scale * H + 0.5 && (double)sW <= scale * W + 0.5);
-    for (int k = 0; k < 4; ++k) HHSR_ARG(cfa[k] <= 2);
+    for (int k = 0; k < 4 && !mono; ++k) HHSR_ARG(cfa[k] <= 2);
     Geo g;
-    fill_geo(g, H, W, pitch, ny, nx, ts, scale, sH, sW);
+    fill_geo(g, H, W, pitch, ny, nx, ts, scale, sH, sW, mono);
     Cfa4 c;
-    for (int k = 0; k < 4; ++k) c.c[k] = cfa[k];
+    for (int k = 0; k < 4; ++k) c.c[k] = mono ? 0 : cfa[k];
     FramePtr f{raw, reinterpret_cast<const float2*>(flow), reinterpret_cast<const float4*>(covs), r};
     const dim3 grid(hhsr_cdiv(sW, 64), hhsr_cdiv(sH, 4)), block(256);
     hipStream_t s = (hipStream_t)stream;
@@ -1720,14 +1732,15 @@ extern "C" int hhsr_accumulate_ref(const float* raw, int H, int W, int pitch, co
                                    double max_multiplier, double max_frame_count, float* num, float* den, int sH,
                                    int sW, void* stream) {
     const int iso = kflags & HHSR_KERNEL_ISO;
-    HHSR_ARG(raw && cfa && num && den && (iso || covs));
+    const bool mono = (kflags & HHSR_SENSOR_MONO) != 0;
+    HHSR_ARG(raw && (cfa || mono) && num && den && (iso || covs));
     HHSR_ARG(H >= 2 && W >= 2 && pitch >= W && scale >= 1.0 && sH > 0 && sW > 0);
     HHSR_ARG(!acc_rob || (rad_max >= 0 && rad_max <= 8 && max_multiplier > 0.0));
-    for (int k = 0; k < 4; ++k) HHSR_ARG(cfa[k] <= 2);
+    for (int k = 0; k < 4 && !mono; ++k) HHSR_ARG(cfa[k] <= 2);
     Geo g;
-    fill_geo(g, H, W, pitch, 0, 0, 1, scale, sH, sW);
+    fill_geo(g, H, W, pitch, 0, 0, 1, scale, sH, sW, mono);
     Cfa4 c;
-    for (int k = 0; k < 4; ++k) c.c[k] = cfa[k];
+    for (int k = 0; k < 4; ++k) c.c[k] = mono ? 0 : cfa[k];
     const dim3 grid(hhsr_cdiv(sW, 64), hhsr_cdiv(sH, 4)), block(256);
     hipStream_t s = (hipStream_t)stream;
     const float4* cv = reinterpret_cast<const float4*>(covs);
@@ -1746,14 +1759,15 @@ extern "C" int hhsr_merge_burst(const float* const* raws, const float* const* fl
                                 double scale, int kflags, int flags, float* num, float* den, float* acc_r, int sH,
                                 int sW, int row0, int nrows, int lr_row_offset, void* stream) {
     const int iso = kflags & HHSR_KERNEL_ISO, f64 = kflags & HHSR_WEIGHT_F64;
-    HHSR_ARG(n_frames >= 0 && n_frames <= HHSR_MAX_FRAMES && cfa && num);
+    const bool mono = (kflags & HHSR_SENSOR_MONO) != 0;
+    HHSR_ARG(n_frames >= 0 && n_frames <= HHSR_MAX_FRAMES && (cfa || mono) && num);
     HHSR_ARG(n_frames == 0 || (raws && flows && rs && (iso || covs)));
     HHSR_ARG(H >= 2 && W >= 2 && pitch >= W && ts > 0 && scale >= 1.0 && sH > 0 && sW > 0);
     HHSR_ARG(n_frames == 0 || ((int64_t)ny * ts >= H && (int64_t)nx * ts >= W));
     HHSR_ARG((double)sH <= scale * H + 0.5 && (double)sW <= scale * W + 0.5);
     HHSR_ARG(!(flags & HHSR_MERGE_DO_REF) || (ref_raw && (iso || ref_covs)));
     HHSR_ARG(!(flags & (HHSR_MERGE_LOAD_ACC | HHSR_MERGE_STORE_DEN)) || den);
-    for (int k = 0; k < 4; ++k) HHSR_ARG(cfa[k] <= 2);
+    for (int k = 0; k < 4 && !mono; ++k) HHSR_ARG(cfa[k] <= 2);
     BurstArgs a;
     for (int n = 0; n < n_frames; ++n) {
         HHSR_ARG(raws[n] && flows[n] && rs[n] && (iso || covs[n]));
@@ -1769,7 +1783,7 @@ extern "C" int hhsr_merge_burst(const float* const* raws, const float* const* fl
     a.ref_cov = reinterpret_cast<const float4*>(ref_covs);
     a.flags = flags;
     Geo g;
-    fill_geo(g, H, W, pitch, ny, nx, ts, scale, sH, sW);
+    fill_geo(g, H, W, pitch, ny, nx, ts, scale, sH, sW, mono);
     HHSR_ARG(row0 >= 0 && nrows > 0 && row0 + nrows <= sH);
     HHSR_ARG(lr_row_offset >= 0 && lr_row_offset % ts == 0 && lr_row_offset % 2 == 0 &&
              (double)(int64_t)(lr_row_offset * scale) == lr_row_offset * scale);  // whole tiles, Bayer quads, output rows
@@ -1778,7 +1792,7 @@ extern "C" int hhsr_merge_burst(const float* const* raws, const float* const* fl
     g.row0 = row0;
     g.row1 = row0 + nrows;
     Cfa4 c;
-    for (int k = 0; k < 4; ++k) c.c[k] = cfa[k];
+    for (int k = 0; k < 4; ++k) c.c[k] = mono ? 0 : cfa[k];
     const dim3 grid(hhsr_cdiv(sW, 64), hhsr_cdiv(nrows, 4)), block(256);
     hipStream_t s = (hipStream_t)stream;
     const bool p2 = scale_is_pow2(scale);
@@ -1789,7 +1803,8 @@ extern "C" int hhsr_merge_burst(const float* const* raws, const float* const* fl
     static const int env_force = (getenv("HHSR_MERGE_NO_LDS") ? HHSR_MERGE_FORCE_GENERIC : 0) |
                                  (getenv("HHSR_MERGE_NO_QUAD") ? HHSR_MERGE_FORCE_TILE : 0) |
                                  (getenv("HHSR_MERGE_X2_V1") ? HHSR_MERGE_FORCE_X2V1 : 0);
-    const int force = kflags | env_force;
+    // monochrome sensors: the generic kernels only (the LDS-staged ones are laid out for the Bayer covariance grid)
+    const int force = kflags | env_force | (mono ? HHSR_MERGE_FORCE_GENERIC : 0);
     const int iscale = (int)scale;
     const bool tiled = !f64 && (double)iscale == scale && iscale >= 1 && ((int64_t)ts * iscale) % MT == 0 &&
                        n_frames > 0 && row0 % MT == 0 && !(force & HHSR_MERGE_FORCE_GENERIC);

@@ -27,16 +27,19 @@ __device__ __forceinline__ float dodgsonf(float x) {
     return 0.0f;
 }
 
-// Interpolates the three channels of a [3][lh][lw] map at raw pixel (y, x) displaced by (fx, fy).
-// Returns false (outside the guide image -> +inf, robustness.py:386-391) or true with out[3].
+// Interpolates the NC channels of a [NC][lh][lw] map at raw pixel (y, x) displaced by (fx, fy).
+// Returns false (outside the guide image -> +inf, robustness.py:386-391) or true with out[NC].
+template <int NC>
 __device__ __forceinline__ bool dodgson_sample(const float* __restrict__ LR, int lh, int lw, int y, int x, double fx,
-                                               double fy, float out[3]) {
+                                               double fy, float out[NC]) {
     const double ly = ((double)y + fy + 0.5) / 2.0 - 0.5;
     const double lx = ((double)x + fx + 0.5) / 2.0 - 0.5;
     if (!(ly >= 0.0 && ly < (double)lh && lx >= 0.0 && lx < (double)lw)) return false;
     const int cy = (int)rint(ly), cx = (int)rint(lx);  // round-half-even
     const size_t plane = (size_t)lh * lw;
-    float b0 = 0.f, b1 = 0.f, b2 = 0.f;
+    float b[NC];
+#pragma unroll
+    for (int c = 0; c < NC; ++c) b[c] = 0.f;
     double wacc = 0.0;
 #pragma unroll
     for (int i = -1; i <= 1; ++i) {
@@ -48,21 +51,14 @@ __device__ __forceinline__ bool dodgson_sample(const float* __restrict__ LR, int
             const double w = wy * dodgson((double)x_ - lx);
             const size_t o = (size_t)y_ * lw + x_;
             // float32 buffer += float32 * float64, rounded after every tap (robustness.py:414-415)
-            b0 = (float)((double)b0 + (double)LR[o] * w);
-            b1 = (float)((double)b1 + (double)LR[plane + o] * w);
-            b2 = (float)((double)b2 + (double)LR[2 * plane + o] * w);
+#pragma unroll
+            for (int c = 0; c < NC; ++c) b[c] = (float)((double)b[c] + (double)LR[c * plane + o] * w);
             wacc += w;
         }
     }
-    if (wacc == 1.0) {  // interior, un-warped or not: the Dodgson weights sum to exactly 1 there and x / 1.0 == x
-        out[0] = b0;
-        out[1] = b1;
-        out[2] = b2;
-        return true;
-    }
-    out[0] = (float)((double)b0 / wacc);
-    out[1] = (float)((double)b1 / wacc);
-    out[2] = (float)((double)b2 / wacc);
+    // interior, un-warped or not: the Dodgson weights sum to exactly 1 there and x / 1.0 == x
+#pragma unroll
+    for (int c = 0; c < NC; ++c) out[c] = wacc == 1.0 ? b[c] : (float)((double)b[c] / wacc);
     return true;
 }
 
@@ -79,7 +75,7 @@ __global__ void __launch_bounds__(256) k_rob_upscale(const float* __restrict__ L
     }
     float v[3];
     const size_t plane = (size_t)H * W, o = (size_t)y * W + x;
-    if (!dodgson_sample(LR, lh, lw, y, x, fx, fy, v)) v[0] = v[1] = v[2] = INFINITY;
+    if (!dodgson_sample<3>(LR, lh, lw, y, x, fx, fy, v)) v[0] = v[1] = v[2] = INFINITY;
     HR[o] = v[0];
     HR[plane + o] = v[1];
     HR[2 * plane + o] = v[2];
@@ -255,7 +251,7 @@ __global__ void __launch_bounds__(256) k_rob_frame(const float* __restrict__ cm,
     const int tix = x / ts, tiy = y / ts;
     const float2 f = flow[(size_t)tiy * nx + tix];
     float cmu[3];
-    const bool inb = dodgson_sample(cm, lh, lw, y, x, (double)f.x, (double)f.y, cmu);
+    const bool inb = dodgson_sample<3>(cm, lh, lw, y, x, (double)f.x, (double)f.y, cmu);
     if (!inb) cmu[0] = cmu[1] = cmu[2] = INFINITY;
     const size_t plane = (size_t)H * W, o = (size_t)y * W + x;
     double d_sq = 0.0;
@@ -836,5 +832,100 @@ extern "C" int hhsr_local_min5(const float* R, int H, int W, float* r, float* ac
     HHSR_ARG(R && r && H > 0 && W > 0 && R != r);
     hipLaunchKernelGGL(k_local_min5, dim3(hhsr_cdiv(W, LM_TX), hhsr_cdiv(H, LM_TY)), dim3(256), 0,
                        (hipStream_t)stream, R, H, W, r, acc_r);
+    HHSR_LAUNCHED();
+}
+
+// ---- monochrome sensors (`mode: grey`) ---------------------------------------------------------------------------
+// The frame itself is the one-channel guide image (robustness.py:62-66, 145-148); its 3x3 statistics come from
+// hhsr_mono_frame_stats.  The statistics map keeps its size in this mode (robustness.py:337-343) while the upscale
+// kernel still divides the position by its hard-coded s = 2 (robustness.py:358): every consumer sees the top-left
+// quadrant of the map stretched over the frame, the reference frame and the warped frames alike.  Deterministic, so
+// reproduced: the kernels below are the reference's float64 arithmetic on that geometry, one thread per pixel, the
+// Dodgson taps from L2 (a monochrome burst does not have the Bayer path's fused / LDS-staged variants).
+__global__ void __launch_bounds__(256) k_mono_rob_upscale(const float* __restrict__ LR, int H, int W,
+                                                           const float2* __restrict__ flow, int nx, int ts,
+                                                           float* __restrict__ HR) {
+    const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (x >= W || y >= H) return;
+    double fx = 0.0, fy = 0.0;
+    if (flow) {
+        const float2 f = flow[(size_t)(y / ts) * nx + x / ts];
+        fx = (double)f.x;
+        fy = (double)f.y;
+    }
+    float v[1];
+    if (!dodgson_sample<1>(LR, H, W, y, x, fx, fy, v)) v[0] = INFINITY;
+    HR[(size_t)y * W + x] = v[0];
+}
+
+extern "C" int hhsr_mono_rob_upscale(const float* stats, int H, int W, const float* flow, int ny, int nx, int ts,
+                                     float* out, void* stream) {
+    HHSR_ARG(stats && out && H > 0 && W > 0);
+    if (flow) HHSR_ARG(ts > 0 && (int64_t)ny * ts >= H && (int64_t)nx * ts >= W);
+    hipLaunchKernelGGL(k_mono_rob_upscale, dim3(hhsr_cdiv(W, 64), hhsr_cdiv(H, 4)), dim3(256), 0, (hipStream_t)stream,
+                       stats, H, W, reinterpret_cast<const float2*>(flow), nx, ts > 0 ? ts : 1, out);
+    HHSR_LAUNCHED();
+}
+
+__global__ void __launch_bounds__(256) k_mono_rob_sigma(const float* __restrict__ rmean, const float* __restrict__ rvar,
+                                                         const double* __restrict__ stdc, int ncurve,
+                                                         float* __restrict__ ssq, size_t n) {
+    const size_t o = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (o >= n) return;
+    int id = 0;
+    const double bb = 1000.0 * (double)rmean[o];
+    if (isfinite(bb)) id = clampi((int)rint(bb), 0, ncurve - 1);  // non-finite (D6 border): see k_rob_frame
+    const double s_t = stdc[id], st2 = s_t * s_t, sp = (double)rvar[o];
+    ssq[o] = (float)(0.0 + ((st2 > sp) ? st2 : sp));  // Python max(sigma_p_sq, sigma_t^2)
+}
+
+extern "C" int hhsr_mono_rob_sigma(const float* ref_means, const float* ref_vars, int H, int W,
+                                   const double* std_curve, int ncurve, float* sigma_sq, void* stream) {
+    HHSR_ARG(ref_means && ref_vars && std_curve && sigma_sq && H > 0 && W > 0 && ncurve > 0);
+    const size_t n = (size_t)H * W;
+    hipLaunchKernelGGL(k_mono_rob_sigma, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                       ref_means, ref_vars, std_curve, ncurve, sigma_sq, n);
+    HHSR_LAUNCHED();
+}
+
+// fused per-frame robustness -> R: k_rob_frame with one channel and the same-size statistics map
+__global__ void __launch_bounds__(256) k_mono_rob_frame(const float* __restrict__ cm, const float* __restrict__ rmean,
+                                                         const float* __restrict__ ssq,
+                                                         const float2* __restrict__ flow, int nx, int ts,
+                                                         const float* __restrict__ S, const double* __restrict__ difc,
+                                                         int ncurve, double t, float* __restrict__ R, int H, int W) {
+    const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (x >= W || y >= H) return;
+    const int tix = x / ts, tiy = y / ts;
+    const float2 f = flow[(size_t)tiy * nx + tix];
+    float cmu[1];
+    if (!dodgson_sample<1>(cm, H, W, y, x, (double)f.x, (double)f.y, cmu)) cmu[0] = INFINITY;
+    const size_t o = (size_t)y * W + x;
+    const float b = rmean[o];
+    const float dp = fabsf(b - cmu[0]);
+    int id = 0;
+    const double bb = 1000.0 * (double)b;
+    if (isfinite(bb)) id = clampi((int)rint(bb), 0, ncurve - 1);
+    const double d_t = difc[id];
+    const float dp2f = dp * dp;
+    const double dp2 = (double)dp2f;
+    const double shrink = dp2 / (dp2 + d_t * d_t);
+    const double d_sq = 0.0 + dp2 * shrink * shrink;
+    const float dsf = (float)d_sq, ssf = ssq[o];
+    const float e = expf(-dsf / ssf);
+    double v = (double)(S[(size_t)tiy * nx + tix] * e) - t;
+    v = v > 0.0 ? v : 0.0;  // NaN -> 0
+    v = v < 1.0 ? v : 1.0;
+    R[o] = (float)v;
+}
+
+extern "C" int hhsr_mono_rob_frame(const float* comp_means, int H, int W, const float* ref_means,
+                                   const float* sigma_sq, const float* flow, int ny, int nx, int ts, const float* S,
+                                   const double* diff_curve, int ncurve, double t, float* R, void* stream) {
+    HHSR_ARG(comp_means && ref_means && sigma_sq && flow && S && diff_curve && R);
+    HHSR_ARG(H > 0 && W > 0 && ts > 0 && ncurve > 0 && (int64_t)ny * ts >= H && (int64_t)nx * ts >= W);
+    hipLaunchKernelGGL(k_mono_rob_frame, dim3(hhsr_cdiv(W, 64), hhsr_cdiv(H, 4)), dim3(256), 0, (hipStream_t)stream,
+                       comp_means, ref_means, sigma_sq, reinterpret_cast<const float2*>(flow), nx, ts, S, diff_curve,
+                       ncurve, t, R, H, W);
     HHSR_LAUNCHED();
 }

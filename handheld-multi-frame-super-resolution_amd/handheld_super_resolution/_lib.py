@@ -45,6 +45,10 @@ _SIGS = {
     "hhsr_rob_frame": [P, I, I, P, P, P, P, I, I, I, P, P, I, D, P, P],
     "hhsr_rob_frames": [PP, I, I, I, P, P, P, PP, I, I, I, PP, P, I, D, PP, P],
     "hhsr_local_min5": [P, I, I, P, P, P],
+    "hhsr_mono_frame_stats": [P, I, I, I, P, P, P, D, D, D, D, D, D, D, D, I, P],
+    "hhsr_mono_rob_upscale": [P, I, I, P, I, I, I, P, P],
+    "hhsr_mono_rob_sigma": [P, P, I, I, P, I, P, P],
+    "hhsr_mono_rob_frame": [P, I, I, P, P, P, I, I, I, P, P, I, D, P, P],
     "hhsr_accumulate": [P, I, I, I, P, I, I, I, P, P, U8P, D, I, P, P, I, I, P],
     "hhsr_accumulate_ref": [P, I, I, I, P, U8P, D, I, P, I, D, D, P, P, I, I, P],
     "hhsr_divide": [P, P, L, P],

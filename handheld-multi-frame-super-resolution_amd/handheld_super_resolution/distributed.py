@@ -203,6 +203,10 @@ def main_sharded(ref_img, comp_imgs, config, group=None, engine=None, gather=Tru
         if not gather:
             debug = dict(debug, rows=(0, int(out.shape[0])))
         return out, debug
+    if config.mode != "bayer":
+        # the reference's one-channel robustness reads the statistics of row y / 2 for row y (robustness.py:358 with the
+        # same-size map of :337-343): a row slab is not self-contained there, so monochrome bursts run on one GPU
+        raise NotImplementedError("mode 'grey' is not sharded over GPUs (its robustness is not row-local); use main()")
     root = dist.get_global_rank(group, 0) if group is not None else 0
     eng.init_ref(ref_img)
     sH, sW, _ = eng.output_shape()

@@ -8,8 +8,6 @@ SEL_LINEAR = 1
 
 
 def _kernel_params(config):
-    if config.mode != "bayer":
-        raise NotImplementedError("grey mode is outside the MI355X hot path (bayer only)")
     law = config.merging.selection_law
     if law == "hard_threshold":
         sel = SEL_HARD_THRESHOLD
@@ -26,10 +24,13 @@ def _kernel_params(config):
 
 def estimate_kernels(img, config):
     """covs float32[H/2, W/2, 2, 2] sampled at the centre of every Bayer quad (kernels.py:29-137).
-    GAT, 2x2 decimation, the two gradient convolutions and the per-quad kernel are ONE HIP kernel."""
+    GAT, 2x2 decimation, the two gradient convolutions and the per-quad kernel are ONE HIP kernel.
+    `mode: grey` (monochrome sensors): no decimation, covs float32[H, W, 2, 2], one per pixel (kernels.py:83-87)."""
     params = _kernel_params(config)
     img = _lib.f32c(img)
     H, W = img.shape
+    if config.mode != "bayer":
+        return mono_frame_stats(img, config, stats=False)[2]
     if H % 2 or W % 2:
         raise ValueError(f"bayer frames need even dimensions, got {(H, W)}")
     covs = torch.empty((H // 2, W // 2, 2, 2), dtype=torch.float32, device=img.device)
@@ -43,6 +44,8 @@ def frame_stats(img, cfa_pattern, white_balance, config, want_vars=False):
     Returns (means [3, H/2, W/2], vars or None, covs [H/2, W/2, 2, 2])."""
     from .robustness import _wb3
 
+    if config.mode != "bayer":
+        return mono_frame_stats(img, config, want_vars=want_vars)
     params = _kernel_params(config)
     img = _lib.f32c(img)
     H, W = img.shape
@@ -55,3 +58,17 @@ def frame_stats(img, cfa_pattern, white_balance, config, want_vars=False):
               _lib.doubles(_wb3(white_balance)), _lib.ptr(means), _lib.ptr(vars_), _lib.ptr(covs), *params,
               _lib.stream())
     return means, vars_, covs
+
+
+def mono_frame_stats(img, config, stats=True, covs=True, want_vars=False):
+    """`mode: grey`: the per-frame pass of a monochrome frame — 3x3 local means (and variances) of the frame itself
+    [1, H, W] (robustness.py:62-66, 269-294) and / or the per-pixel kernel covariances [H, W, 2, 2] (kernels.py:83-137)."""
+    img = _lib.f32c(img)
+    H, W = img.shape
+    params = _kernel_params(config) if covs else (1.0, 0.0, 0.0, 0.0, 0.0, 1.0, 0.0, 1.0, 0)
+    means = torch.empty((1, H, W), dtype=torch.float32, device=img.device) if stats else None
+    vars_ = torch.empty_like(means) if stats and want_vars else None
+    cov = torch.empty((H, W, 2, 2), dtype=torch.float32, device=img.device) if covs else None
+    _lib.call("hhsr_mono_frame_stats", _lib.ptr(img), H, W, W, _lib.ptr(means), _lib.ptr(vars_), _lib.ptr(cov), *params,
+              _lib.stream())
+    return means, vars_, cov

@@ -7,7 +7,7 @@ from . import _lib
 
 
 # kflags of the C ABI (include/hhsr.h)
-KERNEL_ISO, WEIGHT_F64, FORCE_GENERIC, FORCE_TILE, FORCE_X2V1 = 1, 2, 4, 8, 16
+KERNEL_ISO, WEIGHT_F64, FORCE_GENERIC, FORCE_TILE, FORCE_X2V1, SENSOR_MONO = 1, 2, 4, 8, 16, 32
 _FORCE = {"auto": 0, "generic": FORCE_GENERIC, "tile": FORCE_TILE, "x2_v1": FORCE_X2V1}
 # process-wide A/B switches, read once like the library reads them
 _ENV_FORCE = ((FORCE_GENERIC if os.environ.get("HHSR_MERGE_NO_LDS") else 0) |
@@ -18,14 +18,13 @@ _ENV_FORCE = ((FORCE_GENERIC if os.environ.get("HHSR_MERGE_NO_LDS") else 0) |
 def _common(config):
     """(scale, kflags): bit 0 = iso kernel, bit 1 = float64 weight chain (config.hip.weight_fp64, the
     reference's Numba typing; default float32 weights with float64 geometry), bits 2-4 = restriction of
-    hhsr_merge_burst's kernel choice (config.hip.merge_kernel: auto | generic | tile | x2_v1; validation only)."""
-    if config.mode != "bayer":
-        raise NotImplementedError("grey mode is outside the MI355X hot path (bayer only)")
+    hhsr_merge_burst's kernel choice (config.hip.merge_kernel: auto | generic | tile | x2_v1; validation only),
+    bit 5 = `mode: grey` (one channel, per-pixel covariances)."""
     hip = config.get("hip", None) if hasattr(config, "get") else None
     f64 = bool(hip.get("weight_fp64", False)) if hip is not None else False
     force = _FORCE[str(hip.get("merge_kernel", "auto"))] if hip is not None else 0
     return float(config.scale), ((KERNEL_ISO if config.merging.kernel == "iso" else 0) | (WEIGHT_F64 if f64 else 0) |
-                                 force | _ENV_FORCE)
+                                 force | _ENV_FORCE | (SENSOR_MONO if config.mode != "bayer" else 0))
 
 
 def merge(comp_img, alignments, covs, r, num, den, cfa_pattern, config):
@@ -69,7 +68,7 @@ def can_fuse_local_min(config, shape):
     hhsr_merge_burst."""
     scale, kflags = _common(config)
     H, W = shape
-    ok = not (kflags & (WEIGHT_F64 | FORCE_GENERIC | FORCE_TILE)) and int(config.block_matching.tuning.tile_size) % 16 == 0
+    ok = not (kflags & (WEIGHT_F64 | FORCE_GENERIC | FORCE_TILE | SENSOR_MONO)) and int(config.block_matching.tuning.tile_size) % 16 == 0
     return ok and ((scale == 2.0 and H % 2 == 0 and W % 2 == 0) or (scale == 3.0 and W % 4 == 0))
 
 

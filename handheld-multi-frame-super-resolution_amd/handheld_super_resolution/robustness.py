@@ -32,6 +32,14 @@ def upscale_warp_stats(local_stats, tile_size=None, flow=None):
     (robustness.py:296-421).  +inf where the guide position falls outside the map."""
     local_stats = _lib.f32c(local_stats)
     nc, lh, lw = local_stats.shape
+    if nc == 1:
+        # `mode: grey`: the map keeps its size while the kernel keeps its hard-coded s = 2 (robustness.py:337-343, 358):
+        # the top-left quadrant stretched over the frame, for the reference and the warped frames alike (reproduced)
+        out = torch.empty_like(local_stats)
+        ny, nx = (0, 0) if flow is None else flow.shape[:2]
+        _lib.call("hhsr_mono_rob_upscale", _lib.ptr(local_stats), lh, lw, _lib.ptr(flow), ny, nx,
+                  0 if flow is None else int(tile_size), _lib.ptr(out), _lib.stream())
+        return out
     if nc != 3:
         raise ValueError("Incoherent number of channel : {}".format(nc))
     out = torch.empty((3, 2 * lh, 2 * lw), dtype=torch.float32, device=local_stats.device)
@@ -48,8 +56,11 @@ def init_robustness(ref_img, cfa_pattern, white_balance, config):
     """Reference-frame local means / variances at raw resolution (robustness.py:23-76)."""
     if not config.robustness.enabled:
         return None, None
-    if config.mode != "bayer":
-        raise NotImplementedError("grey mode is outside the MI355X hot path (bayer only)")
+    if config.mode != "bayer":  # the frame is its own one-channel guide image (robustness.py:62-66)
+        from .kernels import mono_frame_stats
+
+        m, v, _ = mono_frame_stats(ref_img, config, covs=False, want_vars=True)
+        return upscale_warp_stats(m), upscale_warp_stats(v)
     m, v = compute_local_stats_from_raw(ref_img, cfa_pattern, white_balance)
     return upscale_warp_stats(m), upscale_warp_stats(v)
 
@@ -117,14 +128,15 @@ def compute_robustness(comp_img, ref_local_means, ref_local_stds, flows, cfa_pat
         if accumulate_into is not None:
             accumulate_into += ones
         return ones
-    if config.mode != "bayer":
-        raise NotImplementedError("grey mode is outside the MI355X hot path (bayer only)")
     ts = config.block_matching.tuning.tile_size
     t = config.robustness.tuning
     std_curve, diff_curve = noise_model
     assert std_curve.dtype == torch.float64 and diff_curve.dtype == torch.float64 and std_curve.is_cuda
     H, W = comp_img.shape
     ny, nx, _ = flows.shape
+    if config.mode != "bayer":
+        return _compute_robustness_mono(comp_img, ref_local_means, ref_local_stds, flows, noise_model, config, return_R,
+                                        accumulate_into, ref_sigma_sq, comp_means)
     if ref_sigma_sq is None:  # a BurstPipeline passes the per-burst map; stand-alone callers get it here
         ref_sigma_sq = noise_sigma_sq(ref_local_means, ref_local_stds, std_curve)
     cm = comp_means  # a BurstPipeline gets them from the fused per-frame pass (kernels.frame_stats)
@@ -139,6 +151,37 @@ def compute_robustness(comp_img, ref_local_means, ref_local_stds, flows, cfa_pat
     if fuse_local_min:  # the caller's merge applies Alg. 9 itself (merge_burst(..., local_min=True))
         assert accumulate_into is None and not return_R
         return R
+    r = local_min(R, accumulate_into)
+    return (r, R) if return_R else r
+
+
+def mono_sigma_sq(ref_local_means, ref_local_stds, std_curve):
+    """noise_sigma_sq() of a monochrome burst: sigma^2 float32 [H, W] (robustness.py:505-528 with one channel)."""
+    _, H, W = ref_local_means.shape
+    out = torch.empty((H, W), dtype=torch.float32, device=ref_local_means.device)
+    _lib.call("hhsr_mono_rob_sigma", _lib.ptr(ref_local_means), _lib.ptr(ref_local_stds), H, W, _lib.ptr(std_curve),
+              int(std_curve.numel()), _lib.ptr(out), _lib.stream())
+    return out
+
+
+def _compute_robustness_mono(comp_img, ref_local_means, ref_local_stds, flows, noise_model, config, return_R,
+                             accumulate_into, ref_sigma_sq, comp_means):
+    """`mode: grey` (robustness.py:79-170 with the one-channel branches): 3x3 means of the frame itself, fused
+    warp / distance / noise model / threshold, 5x5 minimum."""
+    from .kernels import mono_frame_stats
+
+    ts = config.block_matching.tuning.tile_size
+    t = config.robustness.tuning
+    std_curve, diff_curve = noise_model
+    H, W = comp_img.shape
+    ny, nx, _ = flows.shape
+    sigma_sq = ref_sigma_sq if ref_sigma_sq is not None else mono_sigma_sq(ref_local_means, ref_local_stds, std_curve)
+    cm = comp_means if comp_means is not None else mono_frame_stats(comp_img, config, covs=False)[0]
+    S = compute_s(flows, t.Mt, t.s1, t.s2)
+    R = torch.empty((H, W), dtype=torch.float32, device=comp_img.device)
+    _lib.call("hhsr_mono_rob_frame", _lib.ptr(cm), H, W, _lib.ptr(ref_local_means), _lib.ptr(sigma_sq), _lib.ptr(flows),
+              ny, nx, int(ts), _lib.ptr(S), _lib.ptr(diff_curve), int(diff_curve.numel()), float(t.t), _lib.ptr(R),
+              _lib.stream())
     r = local_min(R, accumulate_into)
     return (r, R) if return_R else r
 

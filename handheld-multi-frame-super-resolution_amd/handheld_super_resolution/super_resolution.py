@@ -21,7 +21,7 @@ from .utils import divide, add, getTime, timer
 from .alignment import align, init_alignment, build_gaussian_pyramid
 from .params import sanitize_config, update_snr_config
 from .robustness import (init_robustness, compute_robustness, compute_robustness_group, noise_curves_to_device,
-                         ref_planes)
+                         ref_planes, upscale_warp_stats, mono_sigma_sq)
 from .kernels import estimate_kernels, frame_stats
 from .merge import merge, merge_ref, merge_burst, can_fuse_acc_r, can_fuse_local_min
 
@@ -69,8 +69,9 @@ class BurstPipeline:
     def __init__(self, config, device=None):
         self.config = config
         self.device = device or _device()
-        if config.mode != "bayer":
-            raise NotImplementedError("grey mode is outside the MI355X hot path (bayer only)")
+        # `mode: grey` (monochrome sensors): the frames are their own grey images (super_resolution.py:106-109, 144-147),
+        # one-channel robustness, per-pixel kernels, one-channel merge — the generic kernels of each stage
+        self.mono = config.mode != "bayer"
         self.cfa = [[int(v) for v in row] for row in config.exif.cfa_pattern]
         self.wb = [float(v) for v in config.exif.white_balance]
         self.curves = noise_curves_to_device(config.noise_model.std_curve, config.noise_model.diff_curve, self.device)
@@ -102,13 +103,20 @@ class BurstPipeline:
         self.align_state = self.grey_ref = None
         if alignment:
             sanitize_config(cfg, tuple(self.ref.shape))
-            grey = self._timed(compute_grey_images, 3, end_s="- Ref grey image estimated by {}".format(self.grey_method))(
+            grey = self.ref if self.mono else self._timed(
+                compute_grey_images, 3, end_s="- Ref grey image estimated by {}".format(self.grey_method))(
                 self.ref, self.grey_method)
             self.align_state = self._timed(init_alignment, 2, "\nInitializing alignment", "Alignment initialized (Total)")(
                 grey, cfg)
             self.grey_ref = grey
         self.ref_means = self.ref_vars = self.ref_covs = self.ref_sigma_sq = None
-        if robustness and cfg.robustness.enabled:  # init_robustness + the reference frame's kernels from one raw pass,
+        if robustness and cfg.robustness.enabled and self.mono:
+            m, v, self.ref_covs = self._timed(frame_stats, 2, "\nEstimating ref image local stats + kernels",
+                                              "Local stats + kernels estimated (Total)")(
+                self.ref, self.cfa, self.wb, cfg, want_vars=True)
+            self.ref_means, self.ref_vars = upscale_warp_stats(m), upscale_warp_stats(v)
+            self.ref_sigma_sq = mono_sigma_sq(self.ref_means, self.ref_vars, self.curves[0])
+        elif robustness and cfg.robustness.enabled:  # init_robustness + the reference frame's kernels from one raw pass,
             # then the upsampled means, sigma^2 and curve indices from one pass over the guide statistics
             m, v, self.ref_covs = self._timed(frame_stats, 2, "\nEstimating ref image local stats + kernels",
                                               "Local stats + kernels estimated (Total)")(
@@ -132,7 +140,7 @@ class BurstPipeline:
         """grey -> pyramid -> coarse-to-fine alignment of one comp frame: flow float32 [ny, nx, 2]."""
         cfg = self.config
         raw = _lib.f32c(img, self.device)
-        grey = compute_grey_images(raw, self.grey_method)
+        grey = raw if self.mono else compute_grey_images(raw, self.grey_method)
         pyramid = build_gaussian_pyramid(grey, cfg.block_matching.tuning.factors)
         if wait_ref is not None:
             torch.cuda.current_stream(self.device).wait_event(wait_ref)
@@ -156,8 +164,8 @@ class BurstPipeline:
             if wait_ref is not None:
                 torch.cuda.current_stream(self.device).wait_event(wait_ref)
         else:
-            grey = self._timed(compute_grey_images, 3, end_s="- grey images estimated by {}".format(self.grey_method))(
-                raw, self.grey_method)
+            grey = raw if self.mono else self._timed(
+                compute_grey_images, 3, end_s="- grey images estimated by {}".format(self.grey_method))(raw, self.grey_method)
             pyramid = build_gaussian_pyramid(grey, cfg.block_matching.tuning.factors)
             if wait_ref is not None:
                 torch.cuda.current_stream(self.device).wait_event(wait_ref)
@@ -174,7 +182,7 @@ class BurstPipeline:
         """Robustness of a group of frames of the burst (one launch per 4 frames shares the pass over the
         reference-frame planes): list of (raw, flow, covs, r)."""
         cfg = self.config
-        if not cfg.robustness.enabled or len(fronts) == 1:
+        if not cfg.robustness.enabled or len(fronts) == 1 or self.mono:
             rob = self._timed(compute_robustness, 2, "\nEstimating robustness", "Robustness estimated (Total)")
             return [(raw, flow, covs,
                      rob(raw, self.ref_means, self.ref_vars, flow, self.cfa, self.wb, self.curves, cfg,

@@ -169,6 +169,26 @@ int hhsr_rob_frames(const float* const* comp_means, int n_frames, int lh, int lw
  * (the accumulated robustness of super_resolution.py:158-159, fused to save a pass). */
 int hhsr_local_min5(const float* R, int H, int W, float* r, float* acc_r, void* stream);
 
+/* ---- monochrome sensors, `mode: grey` (super_resolution.py:106-109, 144-147; kernels.py:83-87; robustness.py:62-66,
+ * 145-148, 337-343; merge.py:131-137, 191-194, 349-354, 410): the frame is its own grey image (alignment unchanged), its
+ * own one-channel guide image (no white balance) and the kernel covariances are estimated per pixel.
+ * hhsr_mono_frame_stats: 3x3 local mean / variance [H][W] and / or covariances [H][W][2][2] in one pass
+ *   (means NULL: covariances only; covs NULL: statistics only; vars may be NULL).
+ * hhsr_mono_rob_upscale: robustness.py:296-421 on a one-channel map, which keeps its size while the kernel keeps its
+ *   hard-coded s = 2 — the top-left quadrant stretched over the frame (+inf outside), reproduced as it is;
+ *   flow NULL = the reference frame.
+ * hhsr_mono_rob_sigma / hhsr_mono_rob_frame: robustness.py:505-528 / the fused per-frame pass -> R, one channel. */
+int hhsr_mono_frame_stats(const float* raw, int H, int W, int pitch, float* means, float* vars, float* covs,
+                          double alpha, double beta, double k_detail, double k_denoise, double D_th, double D_tr,
+                          double k_stretch, double k_shrink, int law, void* stream);
+int hhsr_mono_rob_upscale(const float* stats, int H, int W, const float* flow, int ny, int nx, int ts, float* out,
+                          void* stream);
+int hhsr_mono_rob_sigma(const float* ref_means, const float* ref_vars, int H, int W, const double* std_curve,
+                        int ncurve, float* sigma_sq, void* stream);
+int hhsr_mono_rob_frame(const float* comp_means, int H, int W, const float* ref_means, const float* sigma_sq,
+                        const float* flow, int ny, int nx, int ts, const float* S, const double* diff_curve,
+                        int ncurve, double t, float* R, void* stream);
+
 /* kflags of the merge entry points */
 #define HHSR_KERNEL_ISO 1   /* merging.kernel == "iso": w = exp(-(dx^2+dy^2)) instead of the steerable kernel */
 #define HHSR_WEIGHT_F64 2   /* evaluate covariance interpolation / weights in float64 like the reference's
@@ -177,6 +197,10 @@ int hhsr_local_min5(const float* R, int H, int W, float* r, float* acc_r, void* 
 #define HHSR_MERGE_FORCE_GENERIC 4  /* no LDS staging: one thread per HR pixel, operands from global memory     */
 #define HHSR_MERGE_FORCE_TILE 8     /* no x2 kernel: the 16 x 16 HR tile kernel                                  */
 #define HHSR_MERGE_FORCE_X2V1 16    /* x2: first-generation kernel (per-pixel geometry) instead of k_merge_x2    */
+/* all three merge entry points: */
+#define HHSR_SENSOR_MONO 32  /* `mode: grey`: every sample goes to channel 0 (channels 1, 2 of num / den are left as they
+                                are), covs is [H][W][2][2] read at the position itself, cfa is ignored (may be NULL);
+                                hhsr_merge_burst then runs its generic kernel (no HHSR_MERGE_LOCAL_MIN)            */
 
 /* ---- merge, Alg. 4 / Alg. 11 (merge.py; utils.py:62-120) --------------------------------------
  * hhsr_accumulate: one comp frame, num/den += (merge.py:291-434).

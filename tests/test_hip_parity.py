@@ -1389,3 +1389,103 @@ def test_sharded_hip_engine_world2(tmp_path):
 
     o1, _ = hdist.main_sharded(ref, comp, base_config(ts=16, scale=2))
     assert_close(N(o1), N(want), 2e-5, 1e-6, "main_sharded(world=1) == main", max_bad_frac=1e-5)
+
+
+# ------------------------------------------------------------------------------------------ mode: grey (monochrome)
+MONO = ((1, 1), (1, 1))  # synthetic "CFA" that samples the scene's green plane everywhere
+
+
+def test_mono_stages_golden(golden):
+    """`mode: grey`: per-pixel covariances, one-channel robustness (with the reference's stretched statistics upscale)
+    and the one-channel merge / merge_ref against outputs of the reference's own functions and against the oracle."""
+    g = golden("grey_mode")
+    cfa, wb = [[0, 1], [1, 2]], [1.0, 1.0, 1.0]
+    cfg = base_config(mode="grey")
+    covs = N(kernels.estimate_kernels(T(g["k_raw"]), cfg))
+    assert covs.shape == g["k_raw"].shape + (2, 2)
+    assert_close(covs, g["k_cov"], 1e-4, 1e-6, "mono covs")
+    rm, rv = robustness.init_robustness(T(g["r_ref"]), cfa, wb, cfg)
+    assert tuple(rm.shape) == (1,) + g["r_ref"].shape
+    assert_close(N(rm), g["r_means"], 1e-6, 1e-8, "mono ref means")
+    assert_close(N(rv), g["r_vars"], 1e-4, 1e-9, "mono ref vars")
+    curves = robustness.noise_curves_to_device(np.array(cfg.noise_model.std_curve), np.array(cfg.noise_model.diff_curve), DEV)
+    r, R = robustness.compute_robustness(T(g["r_comp"]), T(g["r_means"]), T(g["r_vars"]), T(g["r_flow"]), cfa, wb, curves,
+                                         cfg, return_R=True)
+    assert_close(N(r), g["r_out"], 0, 1e-4, "mono r")
+    H, W = g["m_comp"].shape
+    for f64 in (False, True):
+        for tag, scale, kern in (("s2", 2, "steerable"), ("s15", 1.5, "steerable"), ("s3", 3, "steerable"),
+                                 ("s2iso", 2, "iso")):
+            cfg = base_config(ts=16, scale=scale, mode="grey")
+            cfg.hip = {"weight_fp64": f64}
+            cfg.merging.kernel = kern
+            oh, ow = round(scale * H), round(scale * W)
+            num, den = T(acc_pattern(oh, ow, 0)), T(acc_pattern(oh, ow, 5))
+            merge.merge(T(g["m_comp"]), T(g["m_flow"]), T(g["m_covs"]), T(g["m_r"]), num, den, cfa, cfg)
+            assert np.array_equal(N(num)[..., 1:], acc_pattern(oh, ow, 0)[..., 1:]), "channels 1, 2 untouched"
+            assert_close(N(num), g[f"m_{tag}_num"], 2e-5, 1e-6, f"mono {tag} num f64={f64}")
+            assert_close(N(den), g[f"m_{tag}_den"], 2e-5, 1e-6, f"mono {tag} den f64={f64}")
+            num, den = T(acc_pattern(oh, ow, 0)), T(acc_pattern(oh, ow, 5))
+            merge.merge_ref(T(g["m_ref"]), T(g["m_covs_ref"]), num, den, cfa, cfg)
+            assert_close(N(num), g[f"m_{tag}_numref"], 2e-5, 1e-6, f"mono {tag} numref")
+            assert_close(N(den), g[f"m_{tag}_denref"], 2e-5, 1e-6, f"mono {tag} denref")
+    cfg = base_config(ts=16, scale=2, mode="grey")
+    cfg.accumulated_robustness_denoiser.enabled = True
+    cfg.accumulated_robustness_denoiser.merge.enabled = True
+    num, den = T(acc_pattern(2 * H, 2 * W, 0)), T(acc_pattern(2 * H, 2 * W, 5))
+    merge.merge_ref(T(g["m_ref"]), T(g["m_covs_ref"]), num, den, cfa, cfg, T(g["m_acc_rob"]))
+    assert_close(N(num), g["m_den_numref"], 2e-5, 1e-6, "mono denoiser numref")  # channels 1, 2 NOT overwritten
+    assert_close(N(den), g["m_den_denref"], 2e-5, 1e-6, "mono denoiser denref")
+
+
+def test_e2e_mono_golden(golden):
+    """main() with `mode: grey` against the reference's own result on the same 128x128 x3 monochrome burst: channel 0
+    is the image, channels 1 and 2 are NaN (0/0: the accumulators always have three channels)."""
+    from test_oracle_golden import grey_e2e_inputs
+
+    g = golden("grey_mode")
+    ref, comp, cfg = grey_e2e_inputs(g)
+    cfg.debug = True
+    out, dbg = hsr.main(ref, comp, cfg)
+    assert_close(np.stack(dbg["flow"]), g["e_flow"], 0, 5e-5, "flow")
+    assert_close(np.stack(dbg["robustness"]), g["e_r"], 0, 1e-4, "r")
+    assert_close(N(dbg["accumulated robustness"]), g["e_acc_r"], 0, 1e-4, "acc r")
+    o = N(out)
+    assert np.isnan(o[..., 1:]).all()
+    assert_close(o, g["e_out"], 0, 5e-5, "output")
+    _, _, cfg2 = grey_e2e_inputs(g)  # fast path: multi-stream front end + fused burst merge
+    out2, dbg2 = hsr.main(ref, comp, cfg2)
+    assert_close(N(out2), o, 2e-5, 1e-6, "fast path == debug path")
+    assert_close(N(dbg2["accumulated robustness"]), g["e_acc_r"], 0, 1e-4, "acc r (fused)")
+    _, _, cfg3 = grey_e2e_inputs(g)  # sequential operator-API merge
+    cfg3.hip = {"fused_merge": False}
+    out3, _ = hsr.main(ref, comp, cfg3)
+    assert_close(N(out3), o, 2e-5, 1e-6, "sequential == fused")
+
+
+@pytest.mark.parametrize("shape,scale,iso", [((501, 619), 2, False), ((486, 520), 1.5, False), ((480, 640), 3, True)])
+def test_e2e_mono_vs_oracle(shape, scale, iso):
+    """Monochrome bursts of other sizes (odd dimensions are fine without a Bayer grid), scales and the iso kernel."""
+    H, W = shape
+    ref, comp, _ = synth.make_burst(H, W, 3, seed=66, cfa=MONO, max_shift=2.5, occluder=True)
+
+    def cfg_fn():
+        cfg = base_config(ts=16, scale=scale, mode="grey")
+        cfg.robustness.save_mask = True
+        if iso:
+            cfg.merging.kernel = "iso"
+        return cfg
+
+    o, want, flipped = _e2e_vs_oracle(ref, comp, cfg_fn, 16, f"mono {shape} x{scale}", 0)
+    assert np.isnan(o[..., 1:]).all() and np.isfinite(o[..., 0]).mean() > 0.99
+
+
+def test_mono_not_sharded():
+    from handheld_super_resolution import distributed as hdist
+
+    cfg = base_config(mode="grey")
+    cfg.block_matching.tuning.factors = [1, 2, 2, 2]
+    assert merge.can_fuse_local_min(cfg, (128, 128)) is False
+    ref, comp, _ = synth.make_burst(128, 128, 2, seed=1, cfa=MONO)
+    out, _ = hdist.main_sharded(ref, comp, cfg)  # world size 1 is main()
+    assert np.isfinite(N(out)[..., 0]).mean() > 0.99
