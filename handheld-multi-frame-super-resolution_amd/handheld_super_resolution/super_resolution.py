@@ -395,7 +395,8 @@ def process(burst_path, config):
     `burst_path` is either a burst held in memory / in an .npz file — a mapping with keys ``ref`` [H,W],
     ``comp`` [N-1,H,W], ``cfa_pattern`` [2,2], ``white_balance`` [>=3], ``alpha``, ``beta`` and optionally
     ``iso``, ``std_curve``, ``diff_curve``, ``orientation`` (EXIF 1..8), ``xyz2cam`` (3x3, DNG ColorMatrix1, for
-    ``postprocessing.do_color_correction``); ref / comp are either normalised white-balanced float RAW or integer
+    ``postprocessing.do_color_correction``) — ``cfa_pattern`` / ``white_balance`` may be left out with ``mode: grey``
+    (monochrome sensors: channel 0 of the result is the image, channels 1 and 2 are NaN like the reference's); ref / comp are either normalised white-balanced float RAW or integer
     sensor counts with ``black_levels`` and ``white_level`` (normalised on the GPU like utils_dng.py:149-160) —
     or a folder of .dng files, which needs rawpy + exifread like the reference (absent from this image:
     ImportError).  Noise curves: given in the burst, or ``config.noise_model.estimator``: "monte_carlo" (default — the
@@ -416,14 +417,22 @@ def process(burst_path, config):
     elif isinstance(burst_path, (str, os.PathLike)):
         ref_raw, raw_comp, iso, tags, cfa, _, white_balance, _ = load_dng_burst(burst_path)  # needs rawpy + exifread
         nm = tags["Image Tag 0xC761"].values  # DNG NoiseProfile, already scaled for the ISO (reference :232-238)
+        if config.mode == "grey":  # one (alpha, beta) pair (reference :233-235)
+            alpha_beta = {"alpha": nm[0][0], "beta": nm[1][0]}
+        else:                      # mean over the three colour planes (reference :236-238)
+            alpha_beta = {"alpha": sum(x[0] for x in nm[::2]) / 3, "beta": sum(x[0] for x in nm[1::2]) / 3}
         burst = {"ref": ref_raw, "comp": raw_comp, "iso": iso, "cfa_pattern": cfa, "white_balance": white_balance,
-                 "alpha": sum(x[0] for x in nm[::2]) / 3, "beta": sum(x[0] for x in nm[1::2]) / 3}
+                 **alpha_beta}
         if "Image Orientation" in tags:
             burst["orientation"] = tags["Image Orientation"].values[0]
         if "Image Tag 0xC621" in tags:  # DNG ColorMatrix1 (raw2rgb.py:12-27)
             burst["xyz2cam"] = np.array([x.decimal() for x in tags["Image Tag 0xC621"].values], np.float32).reshape(3, 3)
     else:
         burst = burst_path
+    if config.mode == "grey":  # monochrome sensor: no colour filter array, no white balance (both unused by main())
+        burst = dict(burst)
+        burst.setdefault("cfa_pattern", [[0, 1], [1, 2]])
+        burst.setdefault("white_balance", [1.0, 1.0, 1.0])
     ref_raw, raw_comp = burst["ref"], burst["comp"]
     if not torch.is_tensor(ref_raw) and np.issubdtype(np.asarray(ref_raw).dtype, np.integer):
         # sensor counts + metadata: the normalisation / white balance of utils_dng.py:149-160, on the GPU
