@@ -473,6 +473,107 @@ __global__ void __launch_bounds__(256) k_rob_frame_tile(const float* __restrict_
     }
 }
 
+// The 4 horizontally adjacent pixels x0 .. x0 + 3 (x0 % 4 == 0) of one row of a sub-tile, from the sub-tile's guide
+// window `win` ([3][RF_WN][RF_WN + 2], origin (wy0, wx0)): warped guide means -> colour distance -> shrink -> R.
+// Pixels k and k + 2 lie one guide pixel apart with the same sub-pixel phase (l = (p + f + 0.5) / 2 - 0.5), so they
+// share the Dodgson weights in x, the 9 weight products and their sum, and read a common 3 x 4 window per channel:
+// the geometry / weight part is evaluated per PHASE (2 per thread) instead of per pixel and a thread reads 72 window
+// values instead of 108.  Away from the left / right image border only (there the clamped taps differ per pixel and
+// the per-pixel form below is used); same operations in the same order either way: bit-identical results.
+__device__ __forceinline__ void rob_row4(const float (*win)[RF_WN][RF_WN + 2], const RobAxis& ay, const RobAxis& ax,
+                                         int wy0, int wx0, int y, int x0, int lh, int lw, const float rbk[4][3],
+                                         const float d_t2[4][3], const float iss[4], float Sv, float tf, float out[4]) {
+    int cy;
+    float ry, wyv[3];
+    const bool iny = rob_centre(ay, y, lh, cy, ry);
+    dodgson3(ry, cy, lh, wyv);
+    const int wi0 = cy - 1 - wy0;
+    float cmu[4][3];
+#pragma unroll
+    for (int ph = 0; ph < 2; ++ph) {  // pixels ph and ph + 2
+        int cx;
+        float rx;
+        const bool inx = rob_centre(ax, x0 + ph, lw, cx, rx);
+#pragma unroll
+        for (int c = 0; c < 3; ++c) cmu[ph][c] = cmu[ph + 2][c] = INFINITY;
+        // pixel ph + 2: l + 1, centre cx + 1, same offset rx; inside the image when cx + 2 <= lw - 1 (l + 1 <= cx + 1.5)
+        if (iny && inx && cx >= 1 && cx + 2 <= lw - 1) {  // no clamped tap in x for either pixel
+            float wxv[3], w[3][3], wacc = 0.f;
+            dodgson3(rx, cx, lw, wxv);
+#pragma unroll
+            for (int i = 0; i < 3; ++i)
+#pragma unroll
+                for (int j = 0; j < 3; ++j) {
+                    w[i][j] = wyv[i] * wxv[j];
+                    wacc += w[i][j];
+                }
+            const float iw = __builtin_amdgcn_rcpf(wacc);
+            const int wj0 = cx - 1 - wx0;
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                float g4[3][4];
+#pragma unroll
+                for (int i = 0; i < 3; ++i)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) g4[i][j] = win[c][wi0 + i][wj0 + j];
+#pragma unroll
+                for (int q = 0; q < 2; ++q) {
+                    float b = 0.f;
+#pragma unroll
+                    for (int i = 0; i < 3; ++i)
+#pragma unroll
+                        for (int j = 0; j < 3; ++j) b = fmaf(g4[i][j + q], w[i][j], b);
+                    cmu[ph + 2 * q][c] = b * iw;
+                }
+            }
+        } else {
+            int cx2;
+            float rx2;
+            const bool inx2 = rob_centre(ax, x0 + ph + 2, lw, cx2, rx2);
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                const int cxq = q ? cx2 : cx;
+                const float rxq = q ? rx2 : rx;
+                if (iny && (q ? inx2 : inx)) {
+                    float wxv[3], b0 = 0.f, b1 = 0.f, b2 = 0.f, wacc = 0.f;
+                    dodgson3(rxq, cxq, lw, wxv);
+                    const int wj0 = cxq - 1 - wx0;
+#pragma unroll
+                    for (int i = 0; i < 3; ++i) {
+#pragma unroll
+                        for (int j = 0; j < 3; ++j) {
+                            const float w = wyv[i] * wxv[j];
+                            b0 = fmaf(win[0][wi0 + i][wj0 + j], w, b0);
+                            b1 = fmaf(win[1][wi0 + i][wj0 + j], w, b1);
+                            b2 = fmaf(win[2][wi0 + i][wj0 + j], w, b2);
+                            wacc += w;
+                        }
+                    }
+                    const float iw = __builtin_amdgcn_rcpf(wacc);
+                    cmu[ph + 2 * q][0] = b0 * iw;
+                    cmu[ph + 2 * q][1] = b1 * iw;
+                    cmu[ph + 2 * q][2] = b2 * iw;
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        float d_sq = 0.f;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const float dp = fabsf(rbk[k][c] - cmu[k][c]);
+            const float dp2 = dp * dp;
+            const float shrink = dp2 * __builtin_amdgcn_rcpf(dp2 + d_t2[k][c]);
+            d_sq += dp2 * shrink * shrink;
+        }
+        const float e = __builtin_amdgcn_exp2f((-d_sq * iss[k]) * 1.44269504088896341f);
+        // R = clamp(S e - t, 0, 1) (robustness.py:636-639; the reference subtracts in float64 and rounds: <= 1 ulp of R
+        // apart); v_med3_f32 returns min(0, 1) for a NaN operand = the reference's NaN -> 0
+        out[k] = __builtin_amdgcn_fmed3f(Sv * e - tf, 0.f, 1.f);
+    }
+}
+
 // Same kernel with a ROW mapping: a thread owns 4 horizontally adjacent pixels of one row (one flow tile, one
 // sub-tile window).  The five reference-frame planes and R move as 16-byte vectors (1 KB per wave instruction
 // instead of 256 B: the dword version streamed at 3.5 TB/s), and the row part of the geometry — in-image test,
@@ -541,55 +642,17 @@ __global__ void __launch_bounds__(256) k_rob_frame_row4(const float* __restrict_
                              {rb4[0].z, rb4[1].z, rb4[2].z}, {rb4[0].w, rb4[1].w, rb4[2].w}};
     const float ssk[4] = {ss4.x, ss4.y, ss4.z, ss4.w};
     const uint32_t cik[4] = {ci4.x, ci4.y, ci4.z, ci4.w};
-    int cy;
-    float ry, wyv[3];
-    const bool iny = rob_centre(ay, y, lh, cy, ry);
-    dodgson3(ry, cy, lh, wyv);
-    const int wi0 = cy - 1 - wy0;
-    float out[4];
+    float d_t2[4][3], iss[4], out[4];
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
-        float d_t[3];
-#pragma unroll
-        for (int c = 0; c < 3; ++c) d_t[c] = (float)difc[(cik[k] >> (10 * c)) & 1023u];
-        int cx;
-        float rx;
-        const bool inx = rob_centre(ax, x0 + k, lw, cx, rx);
-        float cmu[3] = {INFINITY, INFINITY, INFINITY};
-        if (iny && inx) {
-            float wxv[3], b0 = 0.f, b1 = 0.f, b2 = 0.f, wacc = 0.f;
-            dodgson3(rx, cx, lw, wxv);
-            const int wj0 = cx - 1 - wx0;
-#pragma unroll
-            for (int i = 0; i < 3; ++i) {
-#pragma unroll
-                for (int j = 0; j < 3; ++j) {
-                    const float w = wyv[i] * wxv[j];
-                    b0 = fmaf(s_g[grp][v][0][wi0 + i][wj0 + j], w, b0);
-                    b1 = fmaf(s_g[grp][v][1][wi0 + i][wj0 + j], w, b1);
-                    b2 = fmaf(s_g[grp][v][2][wi0 + i][wj0 + j], w, b2);
-                    wacc += w;
-                }
-            }
-            const float iw = __builtin_amdgcn_rcpf(wacc);
-            cmu[0] = b0 * iw;
-            cmu[1] = b1 * iw;
-            cmu[2] = b2 * iw;
-        }
-        float d_sq = 0.f;
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
-            const float dp = fabsf(rbk[k][c] - cmu[c]);
-            const float dp2 = dp * dp;
-            const float shrink = dp2 * __builtin_amdgcn_rcpf(dp2 + d_t[c] * d_t[c]);
-            d_sq += dp2 * shrink * shrink;
+            const float d = (float)difc[(cik[k] >> (10 * c)) & 1023u];
+            d_t2[k][c] = d * d;
         }
-        const float e = __builtin_amdgcn_exp2f((-d_sq * __builtin_amdgcn_rcpf(ssk[k])) * 1.44269504088896341f);
-        double r = (double)(Sv * e) - t;
-        r = r > 0.0 ? r : 0.0;
-        r = r < 1.0 ? r : 1.0;
-        out[k] = (float)r;
+        iss[k] = __builtin_amdgcn_rcpf(ssk[k]);
     }
+    rob_row4(s_g[grp][v], ay, ax, wy0, wx0, y, x0, lh, lw, rbk, d_t2, iss, Sv, (float)t, out);
     *reinterpret_cast<float4*>(R + o) = make_float4(out[0], out[1], out[2], out[3]);
 }
 
@@ -682,52 +745,8 @@ __global__ void __launch_bounds__(256) k_rob_frames_row4(RobGroup gq, int lh, in
         }
         __syncthreads();
         if (!live) continue;
-        int cy;
-        float ry, wyv[3];
-        const bool iny = rob_centre(ay, y, lh, cy, ry);
-        dodgson3(ry, cy, lh, wyv);
-        const int wi0 = cy - 1 - wy0;
         float out[4];
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            int cx;
-            float rx;
-            const bool inx = rob_centre(ax, x0 + k, lw, cx, rx);
-            float cmu[3] = {INFINITY, INFINITY, INFINITY};
-            if (iny && inx) {
-                float wxv[3], b0 = 0.f, b1 = 0.f, b2 = 0.f, wacc = 0.f;
-                dodgson3(rx, cx, lw, wxv);
-                const int wj0 = cx - 1 - wx0;
-#pragma unroll
-                for (int i = 0; i < 3; ++i) {
-#pragma unroll
-                    for (int j = 0; j < 3; ++j) {
-                        const float w = wyv[i] * wxv[j];
-                        b0 = fmaf(s_g[grp][v][0][wi0 + i][wj0 + j], w, b0);
-                        b1 = fmaf(s_g[grp][v][1][wi0 + i][wj0 + j], w, b1);
-                        b2 = fmaf(s_g[grp][v][2][wi0 + i][wj0 + j], w, b2);
-                        wacc += w;
-                    }
-                }
-                const float iw = __builtin_amdgcn_rcpf(wacc);
-                cmu[0] = b0 * iw;
-                cmu[1] = b1 * iw;
-                cmu[2] = b2 * iw;
-            }
-            float d_sq = 0.f;
-#pragma unroll
-            for (int c = 0; c < 3; ++c) {
-                const float dp = fabsf(rbk[k][c] - cmu[c]);
-                const float dp2 = dp * dp;
-                const float shrink = dp2 * __builtin_amdgcn_rcpf(dp2 + d_t2[k][c]);
-                d_sq += dp2 * shrink * shrink;
-            }
-            const float e = __builtin_amdgcn_exp2f((-d_sq * iss[k]) * 1.44269504088896341f);
-            double r = (double)(Sv * e) - t;
-            r = r > 0.0 ? r : 0.0;
-            r = r < 1.0 ? r : 1.0;
-            out[k] = (float)r;
-        }
+        rob_row4(s_g[grp][v], ay, ax, wy0, wx0, y, x0, lh, lw, rbk, d_t2, iss, Sv, (float)t, out);
         *reinterpret_cast<float4*>(gq.R[fr] + o) = make_float4(out[0], out[1], out[2], out[3]);
     }
 }
