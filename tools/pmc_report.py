@@ -44,7 +44,22 @@ def main(root, needle):
     if "TCC_HIT_sum" in per and "TCC_REQ_sum" in per:
         print(f"L2 hit rate: {per['TCC_HIT_sum'] / per['TCC_REQ_sum']:.3f}")
     print("\n```json\n" + json.dumps(out) + "\n```")
+    return out
+
+
+def write_record(out, path, source, workload, note):
+    """The record bench.py's roofline.traffic is read from: keyed to the hash of the kernel's source file, so a later
+    edit of the kernel invalidates it instead of leaving a stale number."""
+    import hashlib
+
+    out = dict(out, workload=workload, source=source,
+               source_sha16=hashlib.sha256(open(source, "rb").read()).hexdigest()[:16], collected_by=note)
+    with open(path, "w") as f:
+        json.dump(out, f, indent=1)
+        f.write("\n")
 
 
 if __name__ == "__main__":
-    main(sys.argv[1], sys.argv[2])
+    rec = main(sys.argv[1], sys.argv[2])
+    if len(sys.argv) > 3:  # ... <record.json> <source file> <workload> <note>
+        write_record(rec, *sys.argv[3:7])
