@@ -16,7 +16,8 @@ all-gather of the flow fields, kernels / robustness / merge row-parallel; the ou
 
 Rank 0 prints ONE JSON line: metric "output Mpix/s" (scale^2 * H * W / time per burst), plus
   value_incl_h2d  the same with the frames starting as pinned host float32 arrays, uploaded on the frame pipeline's
-                  side streams (the reference's timer spans its uploads: super_resolution.py:103-195);
+                  side streams (the reference's timer spans its uploads: super_resolution.py:103-195); h2d.*_u16: the
+                  frames as uint16 sensor counts, normalised on the device (half the PCIe bytes);
   roofline        dominant kernel (hhsr_merge_burst): VALU issue and algorithmic bytes per launch / launch duration
                   measured with HIP events on the launch stream;
   cpu_baseline    the NumPy oracle (a golden-pinned port of the reference's algorithm; the reference itself has no CPU
@@ -207,6 +208,23 @@ def main():
                "pcie_floor_ms": round(nbytes / 63e9 * 1e3, 2),
                "note": "frames start as pinned host float32; every frame is uploaded once, on its pipeline stream "
                        "(hipMemcpyAsync), overlapping the other frames' kernels; PCIe Gen5 x16 spec 63 GB/s"}
+        # the same scope with the frames as the sensor's uint16 counts (what a DNG holds; the reference converts them
+        # to float32 on the host, utils_dng.py:149-160): half the PCIe bytes, normalised on the device per frame
+        if world == 1:
+            import copy
+
+            black, white = 64.0, 1023.0
+            to_counts = lambda t: torch.from_numpy(np.clip(np.rint(t.numpy() * (white - black) + black), 0, white)  # noqa: E731
+                                                   .astype(np.uint16)).pin_memory()
+            ref16, comp16 = to_counts(ref_h), [to_counts(c) for c in comp_h]
+            cfg16 = copy.deepcopy(cfg)
+            cfg16.hip = dict(cfg16.get("hip", None) or {}, raw_norm={"black_levels": [black] * 3, "white_level": white})
+            ms_16 = timed(lambda: hdist.main_sharded(ref16, comp16, cfg16, engine=engine_cls(cfg16), gather=args.gather)[0],
+                          steps_h, 2)
+            h2d.update(value_incl_h2d_u16=round(out_pix / (ms_16 * 1e-3) / 1e6, 2), ms_per_step_incl_h2d_u16=round(ms_16, 3),
+                       note_u16="frames start as pinned host uint16 sensor counts (10-bit, black 64): uploaded as "
+                                "counts, normalised on the device frame by frame (hhsr_normalize_raw_u16)")
+            del ref16, comp16
         del ref_h, comp_h
 
     # ---- dominant-kernel roofline -------------------------------------------------------------------------------------

@@ -81,6 +81,24 @@ class BurstPipeline:
         hip = config.get("hip", None) if hasattr(config, "get") else None
         # validation hook (bench.py's parity attribution, tests): per-frame flow fields that replace align()
         self._inject_flows = hip.get("inject_flows", None) if hip is not None else None
+        # frames given as integer sensor counts: {"black_levels": [R, G, B], "white_level": w} (see _ingest)
+        self._raw_norm = hip.get("raw_norm", None) if hip is not None else None
+
+    def _ingest(self, img):
+        """One frame -> float32 device tensor, on the current stream.  Float frames are the reference's call signature
+        (normalised, white-balanced RAW).  Integer frames are sensor counts as the DNG holds them: they are uploaded as
+        they are — half the PCIe bytes of the float32 frame — and normalised on the device with the reference loader's
+        arithmetic (utils_dng.py:149-160, hhsr_normalize_raw_u16) using config.hip.raw_norm and config.exif."""
+        t = img if torch.is_tensor(img) else torch.as_tensor(img)
+        if t.dtype.is_floating_point:
+            return _lib.f32c(t, self.device)
+        if t.is_cuda or self._raw_norm is None:
+            raise ValueError("integer frames are sensor counts: give config.hip.raw_norm = {black_levels, white_level} "
+                             "(host arrays), or pass normalised float frames")
+        from .utils_dng import normalize_burst
+
+        return normalize_burst(t, self._raw_norm["black_levels"], self._raw_norm["white_level"], self.wb, self.cfa,
+                               device=self.device)
 
     def _timed(self, func, level, start_s=None, end_s=None):
         """The reference's per-stage timers (super_resolution.py:72-81): synchronising wall-clock wrappers, active from
@@ -99,7 +117,7 @@ class BurstPipeline:
         main = torch.cuda.current_stream(self.device)
         self._entry = torch.cuda.Event()  # everything the caller enqueued before (e.g. the frames' upload) is done
         self._entry.record(main)
-        self.ref = _lib.f32c(ref_img, self.device)
+        self.ref = self._ingest(ref_img)
         self.align_state = self.grey_ref = None
         if alignment:
             sanitize_config(cfg, tuple(self.ref.shape))
@@ -139,7 +157,7 @@ class BurstPipeline:
     def align_frame(self, img, wait_ref=None):
         """grey -> pyramid -> coarse-to-fine alignment of one comp frame: flow float32 [ny, nx, 2]."""
         cfg = self.config
-        raw = _lib.f32c(img, self.device)
+        raw = self._ingest(img)
         grey = raw if self.mono else compute_grey_images(raw, self.grey_method)
         pyramid = build_gaussian_pyramid(grey, cfg.block_matching.tuning.factors)
         if wait_ref is not None:
@@ -156,7 +174,7 @@ class BurstPipeline:
         """grey -> pyramid -> alignment -> guide means + kernel covariances of one comp frame:
         (raw, flow, covs, guide means or None)."""
         cfg = self.config
-        raw = _lib.f32c(img, self.device)
+        raw = self._ingest(img)
         if flow is None and self._inject_flows is not None and index is not None:
             flow = self._inject_flows[index]
         if flow is not None:
@@ -435,11 +453,17 @@ def process(burst_path, config):
         burst.setdefault("white_balance", [1.0, 1.0, 1.0])
     ref_raw, raw_comp = burst["ref"], burst["comp"]
     if not torch.is_tensor(ref_raw) and np.issubdtype(np.asarray(ref_raw).dtype, np.integer):
-        # sensor counts + metadata: the normalisation / white balance of utils_dng.py:149-160, on the GPU
-        stack = normalize_burst(np.concatenate([np.asarray(ref_raw)[None], np.asarray(raw_comp)]),
-                                burst["black_levels"], burst["white_level"], burst["white_balance"],
-                                burst["cfa_pattern"])
-        ref_raw, raw_comp = stack[0], stack[1:]
+        # sensor counts + metadata: the normalisation / white balance of utils_dng.py:149-160, on the GPU.  The
+        # reference frame now (its brightness picks the SNR-based parameters); the other frames stay integer host arrays
+        # and are uploaded as counts — half the bytes of float32 frames — and normalised frame by frame on the pipeline
+        # streams (BurstPipeline._ingest), overlapping the other frames' kernels
+        ref_raw = normalize_burst(np.asarray(ref_raw), burst["black_levels"], burst["white_level"],
+                                  burst["white_balance"], burst["cfa_pattern"])
+        raw_comp = [np.asarray(f) for f in raw_comp]
+        hip = dict(config.get("hip", None) or {})
+        hip["raw_norm"] = {"black_levels": [float(v) for v in list(burst["black_levels"])[:3]],
+                           "white_level": float(burst["white_level"])}
+        config.hip = hip
         brightness_src = ref_raw.mean().item()
     else:
         ref_raw = np.asarray(ref_raw, dtype=np.float32) if not torch.is_tensor(ref_raw) else ref_raw

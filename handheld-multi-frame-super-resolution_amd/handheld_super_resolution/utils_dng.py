@@ -26,7 +26,7 @@ def normalize_burst(raw, black_levels, white_level, white_balance, cfa_pattern, 
         arr = arr[None]
     if arr.dim() != 3:
         raise ValueError("raw must be [H, W] or [n, H, W]")
-    arr = arr.contiguous().to(dev)
+    arr = arr.contiguous().to(dev, non_blocking=True)  # current stream; does not block the host for pinned memory
     n, H, W = arr.shape
     out = torch.empty((n, H, W), dtype=torch.float32, device=dev)
     bl = [float(v) for v in list(black_levels)[:3]]

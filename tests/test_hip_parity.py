@@ -1158,6 +1158,18 @@ def test_process_integer_burst_and_monte_carlo_estimator():
     img_i, _ = hsr.process({"ref": ref_c, "comp": comp_c, "black_levels": bl, "white_level": wl, **meta}, cfg0())
     img_f, _ = hsr.process({"ref": stack[0], "comp": stack[1:], **meta}, cfg0())
     assert_close(img_i, img_f, 0, 0, "integer burst == normalised burst")
+    # main() itself takes sensor counts when config.hip.raw_norm is given: pinned uint16 tensors, uploaded and
+    # normalised frame by frame on the pipeline streams — bit-identical to the normalised float frames
+    cm = cfg0()
+    hsr.prepare_config(cm, stack[0], synth.ALPHA_ISO100, synth.BETA_ISO100, cfa, wb)
+    cm.hip = {"raw_norm": {"black_levels": bl, "white_level": wl}}
+    out_c, _ = hsr.main(torch.from_numpy(ref_c).pin_memory(), [torch.from_numpy(c).pin_memory() for c in comp_c], cm)
+    cf = cfg0()
+    hsr.prepare_config(cf, stack[0], synth.ALPHA_ISO100, synth.BETA_ISO100, cfa, wb)
+    out_f, _ = hsr.main(stack[0], stack[1:], cf)
+    assert_close(N(out_c), N(out_f), 0, 0, "main(counts) == main(normalised)")
+    with pytest.raises(ValueError):
+        hsr.main(ref_c, comp_c, cf)  # counts without raw_norm
     c = cfg0()
     c.noise_model.estimator = "monte_carlo"
     c.noise_model.seed = 7
