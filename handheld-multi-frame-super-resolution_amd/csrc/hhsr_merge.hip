@@ -1338,6 +1338,10 @@ __global__ void __launch_bounds__(256, HHSR_X2_OCC) k_merge_x2(BurstArgs a, Geo 
 // h / S in FLOAT32 (merge.py:113-114), which is not the same for all l — its tap distances and covariance fractions are
 // therefore per-thread values here (only that one "frame" pays for it).
 // Tile = 16 x 16 LR = 16 S x 16 S HR pixels inside one flow tile (ts % 16 == 0); S^2 x 8 accumulators per thread.
+// (Measured alternative, round 2: one workgroup per tile AND output sub-row — 24 accumulators per thread, 3 waves per
+// SIMD without spills — is slower, 45.2 ms against 41.1 ms at C5: the per-frame work that does not depend on the
+// sub-row (staging, 5 x 5 minimum, wave-uniform float64 geometry) is then paid three times and outweighs the occupancy;
+// at 4 waves per SIMD it spills 46 dwords: 85 ms.)
 // Tiles with a window outside the image run the generic per-pixel code (merge_pixel) from global memory.
 template <int S>
 struct XsAxis {
