@@ -597,6 +597,63 @@ __global__ void __launch_bounds__(256) k_merge_border(BurstArgs a, Geo g, Cfa4 c
     merge_pixel<double, GEOM_F64, ISO>(a, g, cfa, hi, hj, num, den);
 }
 
+// The same with the frames of a pixel spread over lanes.  One thread per border pixel walks its 20 frames through the
+// float64 chain one after the other: ~70 k threads (1 100 waves on 1 024 SIMDs) with 15 k instructions each — the
+// launch is pure latency (158 us at 12 MP x 20).  Here lane = (pixel, frame): every lane evaluates ONE frame's
+// contribution to its pixel (the reference frame is the last "frame"), then the pixel's first lane adds the
+// contributions in frame order — the float32 additions of merge_pixel, in the same order: bit-identical.
+template <bool ISO>
+__global__ void __launch_bounds__(256) k_merge_border_wave(BurstArgs a, Geo g, Cfa4 cfa, float* __restrict__ num,
+                                                            float* __restrict__ den, int nf, int ppw) {
+    const int lane = threadIdx.x & 63, wave = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int pl = lane / nf, f = lane - pl * nf;  // pixel slot of the wave, frame (f == a.n: the reference frame)
+    const int t = wave * ppw + pl;
+    const int nrow = g.bt + g.bb, ncol = g.bl + g.br, mid = g.sH - nrow;
+    int hi = -1, hj = 0;
+    if (pl < ppw) {
+        if (t < nrow * g.sW) {
+            const int r = t / g.sW;
+            hj = t - r * g.sW;
+            hi = r < g.bt ? r : g.sH - g.bb + (r - g.bt);
+        } else if (ncol > 0 && t - nrow * g.sW < mid * ncol) {
+            const int u = t - nrow * g.sW;
+            const int r = u / ncol, c = u - r * ncol;
+            hi = g.bt + r;
+            hj = c < g.bl ? c : g.sW - g.br + (c - g.bl);
+        }
+    }
+    const bool live = hi >= g.row0 && hi < g.row1;
+    float val[3] = {0.f, 0.f, 0.f}, acc[3] = {0.f, 0.f, 0.f};
+    if (live) {
+        if (f < a.n) comp_contrib<double, ISO>(a.f[f], g, cfa, hi, hj, val, acc, (a.flags & HHSR_MERGE_LOCAL_MIN) != 0);
+        else ref_contrib<ISO>(a.ref_raw, a.ref_cov, g, cfa, hi, hj, nullptr, 0, 0.0, 0.0, val, acc);
+    }
+    const size_t o = live ? ((size_t)(hi - g.row0) * g.sW + hj) * 3 : 0;
+    float n3[3] = {0.f, 0.f, 0.f}, d3[3] = {0.f, 0.f, 0.f};
+    if (live && f == 0 && (a.flags & HHSR_MERGE_LOAD_ACC)) {
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            n3[k] = num[o + k];
+            d3[k] = den[o + k];
+        }
+    }
+    for (int q = 0; q < nf; ++q) {  // wave-uniform trip count; lane (pl, 0) accumulates in frame order
+        const int src = pl * nf + q;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            n3[k] += __shfl(val[k], src);
+            d3[k] += __shfl(acc[k], src);
+        }
+    }
+    if (live && f == 0) {
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            num[o + k] = (a.flags & HHSR_MERGE_DIVIDE) ? n3[k] / d3[k] : n3[k];
+            if (a.flags & HHSR_MERGE_STORE_DEN) den[o + k] = d3[k];
+        }
+    }
+}
+
 // ---- host entry points ----------------------------------------------------------------------------------
 // ---- fused burst kernel with LDS staging per flow tile ------------------------------------------------
 // For integer scales the HR tile of one flow vector is ts*scale pixels wide (a multiple of 16), so a 16x16
@@ -1865,10 +1922,24 @@ extern "C" int hhsr_merge_burst(const float* const* raws, const float* const* fl
         else { if (iso) HHSR_MB(float, GEOM_F64, true); else HHSR_MB(float, GEOM_F64, false); }
 #undef HHSR_MB
     }
-    if (!f64)  // the border bands the float32 kernels skipped, with the reference's float64 weight chain
-        launch_border(g, [&](dim3 bgrid, dim3 bblock) {
-            if (iso) hipLaunchKernelGGL((k_merge_border<true>), bgrid, bblock, 0, s, a, g, c, num, den);
-            else hipLaunchKernelGGL((k_merge_border<false>), bgrid, bblock, 0, s, a, g, c, num, den);
-        });
+    if (!f64) {  // the border bands the float32 kernels skipped, with the reference's float64 weight chain
+        const int nf = n_frames + ((flags & HHSR_MERGE_DO_REF) ? 1 : 0);
+        static const bool border_v1 = getenv("HHSR_MERGE_BORDER_V1") != nullptr;  // A/B switch, read once
+        if (nf >= 2 && nf <= 64 && !border_v1) {  // lane = (pixel, frame)
+            const int ppw = 64 / nf;
+            const int64_t npx = (int64_t)(g.bt + g.bb) * g.sW + (int64_t)(g.bl + g.br) * (g.sH - g.bt - g.bb);
+            const int64_t nwaves = (npx + ppw - 1) / ppw;
+            if (npx > 0) {
+                const dim3 bgrid((unsigned)((nwaves + 3) / 4)), bblock(256);
+                if (iso) hipLaunchKernelGGL((k_merge_border_wave<true>), bgrid, bblock, 0, s, a, g, c, num, den, nf, ppw);
+                else hipLaunchKernelGGL((k_merge_border_wave<false>), bgrid, bblock, 0, s, a, g, c, num, den, nf, ppw);
+            }
+        } else {
+            launch_border(g, [&](dim3 bgrid, dim3 bblock) {
+                if (iso) hipLaunchKernelGGL((k_merge_border<true>), bgrid, bblock, 0, s, a, g, c, num, den);
+                else hipLaunchKernelGGL((k_merge_border<false>), bgrid, bblock, 0, s, a, g, c, num, den);
+            });
+        }
+    }
     HHSR_LAUNCHED();
 }
