@@ -79,12 +79,26 @@ class HipEngine:
         self.denoiser_on = denoiser_enabled(config)
         self.accumulate_r = self.denoiser_on or bool(config.robustness.save_mask)
         self.pipe = None
+        self._runner = None  # HIP-graph replay of main() for device-resident bursts (graph.py)
 
     def single(self, ref_img, comp_imgs):
-        """world = 1: the single-GPU path itself."""
+        """world = 1: the single-GPU path itself.  An engine that is kept across bursts replays main() from a HIP graph
+        when the same device tensors come back (config.hip.graph, default on; the first call runs eagerly, the second
+        captures): the returned tensors then belong to the graph and are overwritten by the next call."""
         from .super_resolution import main
+        from .graph import GraphRunner, capturable
 
-        return main(ref_img, comp_imgs, self.config)
+        packed = torch.is_tensor(comp_imgs)
+        tensors = (ref_img, comp_imgs) if packed else (ref_img, *comp_imgs)
+        if not capturable(self.config, tensors):
+            return main(ref_img, comp_imgs, self.config)
+        if self._runner is None:
+            cfg = self.config
+            self._runner = GraphRunner(lambda ref, *comp: main(ref, comp[0] if packed else list(comp), cfg), ref_img.device)
+            self._packed = packed
+        if self._packed != packed:
+            return main(ref_img, comp_imgs, self.config)
+        return self._runner(*tensors)
 
     def init_ref(self, ref_img):
         """Replicated on every rank: the reference frame's alignment state (step A needs the whole frame)."""

@@ -82,11 +82,22 @@ def local_min(R, accumulate_into=None):
     return r
 
 
+_curves_cache = {}  # (device, content) -> device copies: a serving loop uploads a burst's curves once
+
+
 def noise_curves_to_device(std_curve, diff_curve, device):
-    """float64 device copies of the two noise curves (super_resolution.py:98-99)."""
-    s = torch.as_tensor(np.asarray(std_curve, dtype=np.float64), device=device)
-    d = torch.as_tensor(np.asarray(diff_curve, dtype=np.float64), device=device)
-    return s.contiguous(), d.contiguous()
+    """float64 device copies of the two noise curves (super_resolution.py:98-99), cached by content: repeated bursts
+    with the same curves do no host-to-device copy (which also keeps main() capturable in a HIP graph)."""
+    s = np.ascontiguousarray(np.asarray(std_curve, dtype=np.float64))
+    d = np.ascontiguousarray(np.asarray(diff_curve, dtype=np.float64))
+    key = (str(device), s.tobytes(), d.tobytes())
+    hit = _curves_cache.get(key)
+    if hit is None:
+        if len(_curves_cache) >= 8:
+            _curves_cache.pop(next(iter(_curves_cache)))
+        hit = _curves_cache[key] = (torch.as_tensor(s, device=device).contiguous(),
+                                    torch.as_tensor(d, device=device).contiguous())
+    return hit
 
 
 def noise_sigma_sq(ref_local_means, ref_local_stds, std_curve):

@@ -1527,3 +1527,71 @@ def test_process_mono_burst():
     assert np.abs(img[..., 0][ok] - want[..., 0][ok]).max() < 2e-6
     # the image is the super-resolved scene: close to the noise-free green plane at the output grid
     assert np.nanmean(np.abs(o[..., 0] - np.nanmean(o[..., 0]))) > 0.01
+
+
+# ------------------------------------------------------------------------------------------ HIP graph replay
+def test_graph_replay_equals_eager():
+    """An engine kept across bursts captures main() in a HIP graph on its second call with the same device tensors and
+    replays it afterwards: bit-identical to the eager path, also on new content in the same buffers; what cannot be
+    captured runs eagerly."""
+    from handheld_super_resolution import distributed as hdist
+    from handheld_super_resolution.graph import GraphRunner
+
+    def cfg_fn(**hip):
+        cfg = base_config(ts=16, scale=2)
+        cfg.robustness.save_mask = True
+        cfg.hip = hip
+        return cfg
+
+    ref, comp, _ = synth.make_burst_torch(512, 640, 6, torch.device(DEV), seed=11)
+    want, wdbg = hsr.main(ref, comp, cfg_fn())
+    want, wacc = want.clone(), wdbg["accumulated robustness"].clone()
+    eng = hdist.HipEngine(cfg_fn())
+    o1, _ = eng.single(ref, comp)  # eager (creates the per-stream plans)
+    assert not eng._runner.graphs
+    assert_close(N(o1), N(want), 0, 0, "first call (eager)")
+    o2, d2 = eng.single(ref, comp)  # capture + first replay
+    assert len(eng._runner.graphs) == 1 and not eng._runner.disabled
+    assert_close(N(o2), N(want), 0, 0, "capture + replay")
+    assert_close(N(d2["accumulated robustness"]), N(wacc), 0, 0, "accumulated robustness from the graph")
+    o3, _ = eng.single(ref, comp)
+    assert o3.data_ptr() == o2.data_ptr()  # static output of the graph
+    assert_close(N(o3), N(want), 0, 0, "replay")
+    ref2, comp2, _ = synth.make_burst_torch(512, 640, 6, torch.device(DEV), seed=12)
+    want2 = hsr.main(ref2, comp2, cfg_fn())[0].clone()
+    ref.copy_(ref2)
+    comp.copy_(comp2)
+    o4, _ = eng.single(ref, comp)
+    assert_close(N(o4), N(want2), 0, 0, "replay on new content in the same buffers")
+    assert not np.array_equal(N(want2), N(want), equal_nan=True)
+    o5, _ = eng.single(ref2, comp2)  # other tensors: eager again, then their own graph
+    assert_close(N(o5), N(want2), 0, 0, "other input tensors")
+    eng.single(ref2, comp2)
+    assert len(eng._runner.graphs) == 2
+    # lists of frames, host arrays, debug / verbose configurations and config.hip.graph = False stay eager
+    eng_l = hdist.HipEngine(cfg_fn())
+    frames = [comp2[i] for i in range(comp2.shape[0])]
+    for _ in range(3):
+        ol, _ = eng_l.single(ref2, frames)
+    assert len(eng_l._runner.graphs) == 1
+    assert_close(N(ol), N(want2), 0, 0, "list of frames")
+    eng_off = hdist.HipEngine(cfg_fn(graph=False))
+    for _ in range(3):
+        oo, _ = eng_off.single(ref2, comp2)
+    assert eng_off._runner is None
+    assert_close(N(oo), N(want2), 0, 0, "graph off")
+    eng_h = hdist.HipEngine(cfg_fn())
+    for _ in range(2):
+        oh, _ = eng_h.single(N(ref2), N(comp2))
+    assert eng_h._runner is None
+    assert_close(N(oh), N(want2), 0, 0, "host arrays")
+    # a function that reads back to the host cannot be captured: the runner falls back to eager execution
+    r = GraphRunner(lambda x: x * float(x.sum().item()), torch.device(DEV))
+    a = torch.ones(4, device=DEV)
+    r(a)
+    out = r(a)
+    assert r.disabled and torch.equal(out, a * 4)
+    assert torch.equal(r(a), a * 4)
+    torch.cuda.synchronize()
+    o6, _ = eng.single(ref, comp)  # the device is fine after the failed capture
+    assert_close(N(o6), N(want2), 0, 0, "replay after a failed capture elsewhere")
