@@ -80,6 +80,7 @@ class HipEngine:
         self.accumulate_r = self.denoiser_on or bool(config.robustness.save_mask)
         self.pipe = None
         self._runner = None  # HIP-graph replay of main() for device-resident bursts (graph.py)
+        self._runner_a, self._runners_b, self._flows_static = None, {}, None  # ... and of the two multi-GPU steps
 
     def single(self, ref_img, comp_imgs):
         """world = 1: the single-GPU path itself.  An engine that is kept across bursts replays main() from a HIP graph
@@ -109,6 +110,24 @@ class HipEngine:
         self.pipe.init_ref(ref_img, robustness=False)
         return self
 
+    def step_a(self, ref_img, my_frames):
+        """init_ref + align_frames; replayed from a HIP graph when an engine sees the same device tensors again.
+        Returns (flows [n, ny, nx, 2], the device-resident reference frame)."""
+        from .graph import GraphRunner, capturable
+
+        def fn(ref, *frames):
+            self.init_ref(ref)
+            return self.align_frames(list(frames)), self.pipe.ref
+
+        tensors = (ref_img, *my_frames)
+        if not capturable(self.config, tensors):
+            return fn(*tensors)
+        if self._runner_a is None:
+            self._runner_a = GraphRunner(fn, ref_img.device)
+        out = self._runner_a(*tensors)
+        self.device = ref_img.device
+        return out
+
     def shape(self):
         return tuple(self.pipe.ref.shape)
 
@@ -126,10 +145,35 @@ class HipEngine:
             return torch.empty((0, ny, nx, 2), dtype=torch.float32, device=self.device)
         return torch.stack(flows)
 
-    def merge_rows(self, comp_imgs, flows, r0, r1, max_flow_y):
+    def merge_rows(self, comp_imgs, flows, r0, r1, max_flow_y, ref_dev=None):
         """Step B: output rows [r0, r1) from ALL frames (flows: [N-1, ny, nx, 2]).  Returns (slab float32
         [r1 - r0, sW, 3], accumulated robustness of the raw rows [ceil(r0 / scale), ceil(r1 / scale)) — the rows whose
-        first output row lies in the slab: a disjoint cover over the slabs — or None)."""
+        first output row lies in the slab: a disjoint cover over the slabs — or None).  With the device-resident
+        reference frame of step_a (`ref_dev`) and device-resident frames the step is replayed from a HIP graph: the
+        gathered flows are copied into a static buffer, the flow bound is rounded up to a multiple of 8 rows (the result
+        does not depend on the halo, only the sub-image's extent does) and one graph is kept per (r0, r1, bound)."""
+        from .graph import GraphRunner, capturable
+
+        packed = torch.is_tensor(comp_imgs)
+        tensors = (comp_imgs,) if packed else tuple(comp_imgs)
+        if ref_dev is None or flows is None or not capturable(self.config, (ref_dev, flows, *tensors)):
+            return self._merge_rows(comp_imgs, flows, r0, r1, max_flow_y, self.pipe.ref if ref_dev is None else ref_dev)
+        bound = float(math.ceil(max_flow_y / 8.0) * 8)
+        if self._flows_static is None or self._flows_static.shape != flows.shape:
+            self._flows_static = torch.empty_like(flows)
+            self._runners_b = {}
+        self._flows_static.copy_(flows)
+        key = (int(r0), int(r1), bound, packed)
+        runner = self._runners_b.get(key)
+        if runner is None:
+            if len(self._runners_b) >= 4:
+                self._runners_b.pop(next(iter(self._runners_b)))
+            runner = self._runners_b[key] = GraphRunner(
+                lambda ref, fl, *comp: self._merge_rows(comp[0] if packed else list(comp), fl, r0, r1, bound, ref),
+                ref_dev.device)
+        return runner(ref_dev, self._flows_static, *tensors)
+
+    def _merge_rows(self, comp_imgs, flows, r0, r1, max_flow_y, ref_dev):
         from .super_resolution import BurstPipeline
         from .merge import merge, merge_ref, merge_burst, can_fuse_acc_r
         from .utils import divide
@@ -147,7 +191,7 @@ class HipEngine:
         nrows = r1 - r0
         t0, t1 = S0 // ts, -(-S1 // ts)
         sub = BurstPipeline(cfg, self.device)
-        sub.init_ref(self.pipe.ref[S0:S1], alignment=False)  # device-resident rows of the replicated reference frame
+        sub.init_ref(ref_dev[S0:S1], alignment=False)  # device-resident rows of the replicated reference frame
         n = len(comp_imgs)
         sub_flows = [flows[i, t0:t1].contiguous() for i in range(n)]
         out = torch.empty((nrows, sW, 3), dtype=torch.float32, device=self.device)
@@ -222,16 +266,19 @@ def main_sharded(ref_img, comp_imgs, config, group=None, engine=None, gather=Tru
         # same-size map of :337-343): a row slab is not self-contained there, so monochrome bursts run on one GPU
         raise NotImplementedError("mode 'grey' is not sharded over GPUs (its robustness is not row-local); use main()")
     root = dist.get_global_rank(group, 0) if group is not None else 0
-    eng.init_ref(ref_img)
-    sH, sW, _ = eng.output_shape()
-    H, W = eng.shape()
 
     # ---- A: frame-parallel alignment, then ONE all-gather of the flow fields ---------------------------------------
     mine = shard_indices(n, rank, world)
     per_rank = -(-n // world) if n else 0
-    flows = None
+    flows, ref_dev = None, None
+    if hasattr(eng, "step_a"):  # reference-frame state + alignment of this rank's frames (a HIP graph on replay)
+        local, ref_dev = eng.step_a(ref_img, [comp_imgs[i] for i in mine])
+    else:
+        eng.init_ref(ref_img)
+        local = eng.align_frames([comp_imgs[i] for i in mine]) if n else None  # [len(mine), ny, nx, 2]
+    sH, sW, _ = eng.output_shape()
+    H, W = eng.shape()
     if n:
-        local = eng.align_frames([comp_imgs[i] for i in mine])            # [len(mine), ny, nx, 2]
         padded = torch.zeros((per_rank, *local.shape[1:]), dtype=local.dtype, device=local.device)
         padded[: local.shape[0]] = local
         allf = _all_gather(padded, world, group)                            # [world, per_rank, ny, nx, 2]
@@ -250,7 +297,8 @@ def main_sharded(ref_img, comp_imgs, config, group=None, engine=None, gather=Tru
     debug = {"robustness": [], "flow": [], "rows": (r0, r1)}
     slab, acc_r = None, None
     if r1 > r0:
-        slab, acc_r = eng.merge_rows(comp_imgs, flows, r0, r1, max_flow)
+        slab, acc_r = (eng.merge_rows(comp_imgs, flows, r0, r1, max_flow, ref_dev=ref_dev) if ref_dev is not None
+                       else eng.merge_rows(comp_imgs, flows, r0, r1, max_flow))
     if not gather:
         if acc_r is not None:
             debug["accumulated robustness"] = acc_r

@@ -1360,6 +1360,23 @@ def _shard_worker(rank, world, port, out_path, scale=2, denoiser=False, n_frames
             np.savez(out_path, out=out.cpu().numpy(), acc_r=dbg["accumulated robustness"].cpu().numpy())
         else:
             assert out is None
+        # an engine kept across bursts with device-resident frames replays both steps from HIP graphs (eager, capture,
+        # replay, replay on new content): every step equals the host-array result above
+        cfg = _shard_cfg(scale, denoiser)
+        eng = hdist.HipEngine(cfg)
+        dref, dcomp = torch.as_tensor(ref).cuda(), torch.as_tensor(comp).cuda()
+        for it in range(4):
+            if it == 3:
+                ref2, comp2, _ = synth.make_burst(512, 512, n_frames, seed=18, max_shift=2.0)
+                want2, _ = hdist.main_sharded(ref2, comp2, _shard_cfg(scale, denoiser))
+                dref.copy_(torch.as_tensor(ref2))
+                dcomp.copy_(torch.as_tensor(comp2))
+            o, d = hdist.main_sharded(dref, dcomp, cfg, engine=eng)
+            if rank == 0:
+                w = out if it < 3 else want2
+                assert torch.equal(torch.nan_to_num(o.cpu()), torch.nan_to_num(w.cpu())), f"graph step {it}"
+        if n_frames > 1:
+            assert eng._runner_a.graphs and all(r.graphs for r in eng._runners_b.values()), "steps were not captured"
     finally:
         dist.destroy_process_group()
 
