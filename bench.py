@@ -201,7 +201,8 @@ def main():
     timed_call.on = False
     out_pix = round(scale * H) * round(scale * W)
     value = out_pix / (ms_per_step * 1e-3) / 1e6
-    graphed = on_gpu and getattr(getattr(engine, "_runner", None), "graphs", None)
+    graphed = bool(on_gpu and (getattr(getattr(engine, "_runner", None), "graphs", None) or
+                               getattr(getattr(engine, "_runner_a", None), "graphs", None)))
     ms_eager, ev_steps = None, args.steps
     if graphed:
         # the timed steps were graph replays: no Python launch to bracket with events.  The dominant kernel's launch
@@ -350,8 +351,10 @@ def main():
                        "parallelism": (f"{world} ranks: alignment frame-parallel, all-gather of flows, merge row-parallel, "
                                        f"output {'gathered to rank 0' if args.gather else 'sharded by rows'}")
                        if world > 1 else "single GPU"},
-            "launch": ("HIP graph replay: the step is captured once (stream capture incl. the frame pipeline's side "
-                       "streams) and replayed with one launch per burst; every kernel runs on every step"
+            "launch": (("HIP graph replay: the step is captured once (stream capture incl. the frame pipeline's side "
+                        "streams) and replayed with one launch per burst; every kernel runs on every step" if world == 1
+                        else "HIP graph replay of the two per-rank steps (alignment of the rank's frames; robustness + "
+                             "kernels + merge of its rows), the all-gather of the flow fields between them")
                        if graphed else "one launch per kernel from Python"),
             "ms_per_step_eager": round(ms_eager, 3) if ms_eager else None,
             "rccl_ranks": dist.get_world_size() if world > 1 else 1,
