@@ -24,11 +24,48 @@ __device__ __forceinline__ double div_by(double a, double b, double r) {
     return fma(fma(-b, q, a), r, q);
 }
 
+// sqrt of a non-negative double in the normal range (no sub-normal / infinite argument handling: the library sqrt
+// spends ~10 of its ~28 instructions on scaling by 2^+-256 and class tests).  v_rsq_f64 seed, one Goldschmidt
+// iteration and one residual correction: error <= 1 ulp (the library: correctly rounded); the callers round the
+// result to float32, where a 1-ulp float64 difference changes the float32 value with probability ~2^-29.
+#ifndef HHSR_FAST_SQRT
+#define HHSR_FAST_SQRT 1
+#endif
+__device__ __forceinline__ double sqrt_pos(double t) {
+#if HHSR_FAST_SQRT
+    const double y = __builtin_amdgcn_rsq(t);
+    double g = t * y, h = 0.5 * y;
+    const double r = fma(-h, g, 0.5);
+    g = fma(g, r, g);
+    h = fma(h, r, h);
+    const double d = fma(-g, g, t);
+    g = fma(d, h, g);
+    return t > 0.0 ? g : 0.0;  // rsq(0) = inf -> NaN above
+#else
+    return sqrt(t);
+#endif
+}
+
+// float32 quotient of operands in the normal range: v_rcp_f32 (1 ulp) + one residual correction — the correctly
+// rounded quotient except in rare double-rounding cases (the IEEE expansion spends ~10 instructions, most of them on
+// operand scaling); 0 / 0 and x / NaN stay NaN (D10), a zero divisor with a non-zero dividend does not occur here.
+#ifndef HHSR_FAST_DIV
+#define HHSR_FAST_DIV 1
+#endif
+__device__ __forceinline__ float div_f32(float x, float y) {
+#if HHSR_FAST_DIV
+    const float r = __builtin_amdgcn_rcpf(y), q = x * r;
+    return fmaf(fmaf(-y, q, x), r, q);
+#else
+    return x / y;
+#endif
+}
+
 __device__ __forceinline__ float gat1(float v, double alpha, double c0, double two_over_alpha) {
     // VST = alpha*I + 3/8*alpha^2 + beta ; max(0, .) ; 2/alpha * sqrt(.)   (utils_image.py:167-170)
     double t = alpha * (double)v + c0;
     t = t > 0.0 ? t : 0.0;
-    return (float)(two_over_alpha * sqrt(t));
+    return (float)(two_over_alpha * sqrt_pos(t));
 }
 
 // Per-quad kernel covariance from the variance-stabilised quad means `sg` (LDS tile with a one-quad halo,
@@ -63,7 +100,7 @@ __device__ __forceinline__ float4 quad_cov(const float* __restrict__ sg, int ly,
     const float bb = b * b;
     double delta = (double)bb - 4.0 * (double)c;
     delta = delta > 0.0 ? delta : 0.0;
-    const double sq = sqrt(delta);
+    const double sq = sqrt_pos(delta);
     const double r1 = (-(double)b + sq) / 2.0, r2 = (-(double)b - sq) / 2.0;
     float l1, l2;
     if (fabs(r1) >= fabs(r2)) {
@@ -85,15 +122,15 @@ __device__ __forceinline__ float4 quad_cov(const float* __restrict__ sg, int ly,
             e1x = 1.f; e1y = a1; e2x = 0.f; e2y = 1.f;
         } else {
             const float nrm = sqrtf(a0 * a0 + a1 * a1);
-            e1x = a0 / nrm;
-            e1y = a1 / nrm;
+            e1x = div_f32(a0, nrm);
+            e1y = div_f32(a1, nrm);
             const float sgn = copysignf(1.f, e1x);
             e2y = fabsf(e1x);
             e2x = -e1y * sgn;
         }
     }
     // k1, k2 (kernels.py:195-243): A, D float64 from float32 square roots; k stored float32
-    const double A = 1.0 + (double)sqrtf((l1 - l2) / (l1 + l2));
+    const double A = 1.0 + (double)sqrtf(div_f32(l1 - l2, l1 + l2));
     double D = 1.0 - div_by((double)sqrtf(l1), P.D_tr, P.r_D_tr) + P.D_th;
     D = D > 0.0 ? D : 0.0;  // clamp with Python max/min semantics (NaN -> 0)
     D = D < 1.0 ? D : 1.0;
