@@ -176,6 +176,8 @@ struct FrameStatsArgs {
     int pitch, gh, gw;
     FsCfa cfa;
     double rwb[3];  // 1 / white balance
+    double rwbk[4]; // ... of the colour at quad position k
+    int pat;        // 0 RGGB, 1 BGGR, 2 GRBG, 3 GBRG (compile-time channel routing per case); -1: any other 2 x 2 pattern
     float* means;   // [3][gh][gw] or NULL
     float* vars;    // [3][gh][gw] or NULL
     float4* covs;   // [gh][gw] or NULL
@@ -210,16 +212,31 @@ __global__ void __launch_bounds__(256) k_frame_stats(FrameStatsArgs A) {
             const int i = p / (FS_TX + 2), j = p - i * (FS_TX + 2);
             const float v[4] = {va[u].x, va[u].y, vb[u].x, vb[u].y};
             if (STATS) {
-                double g = 0.0;
+                // robustness.py:215-225: raw / wb[c] in float64; the two greens are added in (i, j) order and halved.
+                // The Bayer patterns route the four positions to their channels at compile time (a run-time colour
+                // index costs ~9 selects per pixel: 108 of this kernel's 173 v_cndmask)
                 float ch[3] = {0.f, 0.f, 0.f};
+                const double x0 = (double)v[0] * A.rwbk[0], x1 = (double)v[1] * A.rwbk[1];
+                const double x2 = (double)v[2] * A.rwbk[2], x3 = (double)v[3] * A.rwbk[3];
+                if (A.pat == 0) {         // R G / G B
+                    ch[0] = (float)x0; ch[1] = (float)(((0.0 + x1) + x2) / 2.0); ch[2] = (float)x3;
+                } else if (A.pat == 1) {  // B G / G R
+                    ch[2] = (float)x0; ch[1] = (float)(((0.0 + x1) + x2) / 2.0); ch[0] = (float)x3;
+                } else if (A.pat == 2) {  // G R / B G
+                    ch[0] = (float)x1; ch[1] = (float)(((0.0 + x0) + x3) / 2.0); ch[2] = (float)x2;
+                } else if (A.pat == 3) {  // G B / R G
+                    ch[2] = (float)x1; ch[1] = (float)(((0.0 + x0) + x3) / 2.0); ch[0] = (float)x2;
+                } else {
+                    double g = 0.0;
+                    const double x[4] = {x0, x1, x2, x3};
 #pragma unroll
-                for (int k = 0; k < 4; ++k) {  // robustness.py:215-225: raw / wb[c] in float64
-                    const int c = A.cfa.c[k];
-                    const double x = (double)v[k] * A.rwb[c];
-                    if (c == 1) g += x;
-                    else ch[c] = (float)x;
+                    for (int k = 0; k < 4; ++k) {
+                        const int c = A.cfa.c[k];
+                        if (c == 1) g += x[k];
+                        else ch[c] = (float)x[k];
+                    }
+                    ch[1] = (float)(g / 2.0);
                 }
-                ch[1] = (float)(g / 2.0);
                 s_ch[0][i][j] = ch[0];
                 s_ch[1][i][j] = ch[1];
                 s_ch[2][i][j] = ch[2];
@@ -274,6 +291,10 @@ static int frame_stats_launch(const float* raw, int H, int W, int pitch, const u
     A.raw = raw; A.pitch = pitch; A.gh = H / 2; A.gw = W / 2;
     for (int k = 0; k < 4; ++k) A.cfa.c[k] = cfa ? cfa[k] : 0;
     for (int k = 0; k < 3; ++k) A.rwb[k] = wb ? 1.0 / wb[k] : 1.0;
+    for (int k = 0; k < 4; ++k) A.rwbk[k] = A.rwb[A.cfa.c[k]];
+    const int code = A.cfa.c[0] * 27 + A.cfa.c[1] * 9 + A.cfa.c[2] * 3 + A.cfa.c[3];
+    A.pat = code == 0 * 27 + 1 * 9 + 1 * 3 + 2 ? 0 : code == 2 * 27 + 1 * 9 + 1 * 3 + 0 ? 1
+          : code == 1 * 27 + 0 * 9 + 2 * 3 + 1 ? 2 : code == 1 * 27 + 2 * 9 + 0 * 3 + 1 ? 3 : -1;
     A.means = means; A.vars = vars; A.covs = reinterpret_cast<float4*>(covs); A.P = P;
     A.P.r_D_tr = 1.0 / P.D_tr;
     A.P.inv_k_shrink = 1.0 / P.k_shrink;
