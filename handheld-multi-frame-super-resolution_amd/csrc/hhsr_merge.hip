@@ -985,6 +985,9 @@ __global__ void __launch_bounds__(256) k_merge_burst_quad(BurstArgs a, Geo g, Cf
 #ifndef HHSR_X2_PEEL
 #define HHSR_X2_PEEL 0   // 1: reference frame as a compile-time variant of the frame code (A/B: 160 VGPRs, 3.97 vs 3.54 ms); 0: run-time selects
 #endif
+#ifndef HHSR_X2_GEO
+#define HHSR_X2_GEO 1  // 1: per-frame geometry evaluated once per workgroup (lane = frame) and broadcast through LDS
+#endif
 #ifndef HHSR_XS_OCC
 #define HHSR_XS_OCC 2  // k_merge_xs<3>: 72 accumulators per thread; 3 waves per SIMD (168 VGPRs) spills 50 dwords
 #endif
@@ -1071,6 +1074,9 @@ __global__ void __launch_bounds__(256, HHSR_X2_OCC) k_merge_x2(BurstArgs a, Geo 
     __shared__ float4 s_cov[NB * COVSZ];
     __shared__ __align__(16) float s_R[NB * RAWSZ];                 // LMIN: un-filtered robustness, tile + 2-pixel border
     __shared__ __align__(16) float s_out[32 * X2_OP];
+#if HHSR_X2_GEO
+    __shared__ float4 s_geo[(HHSR_MAX_FRAMES + 1) * 8];             // per frame: [axis x, y][parity 0, 1] x 2 quads
+#endif
     const int tid = threadIdx.x;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;  // readfirstlane: known wave-uniform
     const int nbx = gridDim.x, nblk = gridDim.x * gridDim.y;
@@ -1093,6 +1099,28 @@ __global__ void __launch_bounds__(256, HHSR_X2_OCC) k_merge_x2(BurstArgs a, Geo 
         return;
     }
 
+#if HHSR_X2_GEO
+    // Per-frame geometry once per WORKGROUP: it only depends on the frame's flow vector and the parity class, so
+    // evaluating it in every thread and frame (~50 instructions, ~40 % of them half-rate, identical in all lanes of a
+    // wave) was 7 % of the kernel's VALU time.  Lane = frame here; the frame loop reads its entry back with four
+    // broadcast ds_read_b128.  (Visible to everybody after the first barrier of the frame loop.)
+    for (int n = tid; n < a.n + ((a.flags & HHSR_MERGE_DO_REF) ? 1 : 0); n += 256) {
+        const bool isref = n >= a.n;
+        float2 fl = make_float2(0.f, 0.f);
+        if (!isref) fl = a.f[n].flow[tile];
+#pragma unroll
+        for (int axis = 0; axis < 2; ++axis) {
+            const float f = axis ? fl.y : fl.x;
+            const int l0 = axis ? ly0 : lx0;
+#pragma unroll
+            for (int p = 0; p < 2; ++p) {
+                const X2Axis u = isref ? x2_ref_axis(l0, p) : x2_comp_axis(f, l0, p);
+                s_geo[n * 8 + axis * 4 + p * 2] = make_float4(__int_as_float(u.org), __int_as_float(u.e[1]), u.d0[0], u.d0[1]);
+                s_geo[n * 8 + axis * 4 + p * 2 + 1] = make_float4(__int_as_float(u.oc[0]), __int_as_float(u.oc[1]), u.f[0], u.f[1]);
+            }
+        }
+    }
+#endif
     const int py = wave >> 1, px = wave & 1;                        // this wave's parity class
     const int li = lane >> 3, lj = lane & 7;
     const int ty = 2 * li + py, tx = 2 * lj + px;                   // LR pixel inside the tile
@@ -1170,7 +1198,7 @@ __global__ void __launch_bounds__(256, HHSR_X2_OCC) k_merge_x2(BurstArgs a, Geo 
     // geometry, the identity fallback of the inverse and r = 1): as a run-time select it costs ~40 v_cndmask per frame,
     // and on gfx950 v_cndmask / v_min / v_cmp / v_floor / v_cvt issue at HALF the v_fma rate, v_exp / v_rcp at a quarter
     // (tools/ubench/valu_rate.hip) — the kernel is VALU-bound, so instruction classes are what to count.
-    auto frame = [&](auto isref_c, const bool isref_rt, const float2 fl, float local_r, const int bo) {
+    auto frame = [&](auto isref_c, const bool isref_rt, const float2 fl, float local_r, const int bo, const int n) {
         const bool isref = HHSR_X2_PEEL ? decltype(isref_c)::value : isref_rt;
         if (LMIN && !isref) {  // 5 x 5 minimum over rows ty .. ty + 4, columns tx .. tx + 4 of the R window
             // R is clamped to [0, 1] (never negative, never NaN): the order of its float32 bit patterns is the order of
@@ -1198,8 +1226,20 @@ __global__ void __launch_bounds__(256, HHSR_X2_OCC) k_merge_x2(BurstArgs a, Geo 
         }
         if (!isref) racc += local_r;
         if (local_r == 0.f) return;
+#if HHSR_X2_GEO
+        X2Axis ax, ay;
+        {
+            const float4 xa = lds_quad(s_geo + n * 8 + px * 2), xb = lds_quad(s_geo + n * 8 + px * 2 + 1);
+            const float4 ya = lds_quad(s_geo + n * 8 + 4 + py * 2), yb = lds_quad(s_geo + n * 8 + 4 + py * 2 + 1);
+            ax.org = __float_as_int(xa.x); ax.e[0] = 0; ax.e[1] = __float_as_int(xa.y); ax.d0[0] = xa.z; ax.d0[1] = xa.w;
+            ax.oc[0] = __float_as_int(xb.x); ax.oc[1] = __float_as_int(xb.y); ax.f[0] = xb.z; ax.f[1] = xb.w;
+            ay.org = __float_as_int(ya.x); ay.e[0] = 0; ay.e[1] = __float_as_int(ya.y); ay.d0[0] = ya.z; ay.d0[1] = ya.w;
+            ay.oc[0] = __float_as_int(yb.x); ay.oc[1] = __float_as_int(yb.y); ay.f[0] = yb.z; ay.f[1] = yb.w;
+        }
+#else
         const X2Axis ax = isref ? x2_ref_axis(lx0, px) : x2_comp_axis(fl.x, lx0, px);
         const X2Axis ay = isref ? x2_ref_axis(ly0, py) : x2_comp_axis(fl.y, ly0, py);
+#endif
 #pragma unroll
         for (int sa = 0; sa < 2; ++sa)
 #pragma unroll
@@ -1290,9 +1330,9 @@ __global__ void __launch_bounds__(256, HHSR_X2_OCC) k_merge_x2(BurstArgs a, Geo 
             }
     };
     auto frame_n = [&](int n, const float2 fl, float lr, int bo) {
-        if (!HHSR_X2_PEEL) frame(std::false_type{}, n >= a.n, fl, lr, bo);
-        else if (n >= a.n) frame(std::true_type{}, true, fl, lr, bo);
-        else frame(std::false_type{}, false, fl, lr, bo);
+        if (!HHSR_X2_PEEL) frame(std::false_type{}, n >= a.n, fl, lr, bo, n);
+        else if (n >= a.n) frame(std::true_type{}, true, fl, lr, bo, n);
+        else frame(std::false_type{}, false, fl, lr, bo, n);
     };
 #if HHSR_X2_DB
     // double-buffered windows: frame n is evaluated from buffer n & 1 while frame n + 1 is written into the other one
@@ -1395,6 +1435,8 @@ __global__ void __launch_bounds__(256, HHSR_X2_OCC) k_merge_x2(BurstArgs a, Geo 
 // h / S in FLOAT32 (merge.py:113-114), which is not the same for all l — its tap distances and covariance fractions are
 // therefore per-thread values here (only that one "frame" pays for it).
 // Tile = 16 x 16 LR = 16 S x 16 S HR pixels inside one flow tile (ts % 16 == 0); S^2 x 8 accumulators per thread.
+// (k_merge_x2's per-workgroup geometry table was tried here too: no change, 41.2 ms either way — at 2 waves per SIMD
+// this kernel waits on LDS latency, not on VALU issue.)
 // (Measured alternative, round 2: one workgroup per tile AND output sub-row — 24 accumulators per thread, 3 waves per
 // SIMD without spills — is slower, 45.2 ms against 41.1 ms at C5: the per-frame work that does not depend on the
 // sub-row (staging, 5 x 5 minimum, wave-uniform float64 geometry) is then paid three times and outweighs the occupancy;
