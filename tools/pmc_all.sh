@@ -6,7 +6,7 @@ NAME=$1
 cd /tmp && export TMPDIR=/tmp
 OUT=$GRAFT_REPO_ROOT/gpurun_out/$NAME
 rm -rf $OUT && mkdir -p $OUT
-ARGS="--no-cpu-baseline --no-h2d --streams 1 --steps 1 --warmup 1"
+ARGS="--no-cpu-baseline --no-h2d --no-graph --streams 1 --steps 1 --warmup 1"
 i=0
 for C in "SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS GRBM_GUI_ACTIVE" \
          "SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_LDS" \
