@@ -677,13 +677,14 @@ __global__ void __launch_bounds__(256) k_rob_frames_row4(RobGroup gq, int lh, in
                                                           const uint32_t* __restrict__ cidx, int nx, int ts,
                                                           const double* __restrict__ difc, double t, int H, int W) {
     __shared__ float s_g[2][2][3][RF_WN][RF_WN + 2];
+    __shared__ float4 s_tab[ROB_GROUP][2][2][2];  // per (frame, sub-tile): flow split, window origin, S — see below
     const int lx4 = threadIdx.x & 7, ly_ = threadIdx.x >> 3;  // 8 threads x 4 pixels per row, 32 rows
     const int grp = lx4 >> 2, v = ly_ >> 4;                   // the thread's 16 x 16 sub-tile
     const int bid = xcd_remap(blockIdx.y * gridDim.x + blockIdx.x, gridDim.x * gridDim.y);  // bands of tile rows per XCD
     const int bxi = bid % gridDim.x, byi = bid / gridDim.x;
     const int sx0 = bxi * RF_BX + grp * RF_T, sy0 = byi * RF_BY + v * RF_T;
     const int x0 = bxi * RF_BX + 4 * lx4, y = byi * RF_BY + ly_;
-    const int tix = min(sx0, W - 1) / ts, tiy = min(sy0, H - 1) / ts;
+    (void)sx0; (void)sy0;  // (tile indices now come from the per-workgroup table)
     const size_t gplane = (size_t)lh * lw, plane = (size_t)H * W;
     const int tg = (ly_ & (RF_T - 1)) * 4 + (lx4 & 3);  // 0..63 within the sub-tile
     constexpr int WSZ = 3 * RF_WN * RF_WN, NST = (WSZ + 63) / 64;
@@ -709,19 +710,35 @@ __global__ void __launch_bounds__(256) k_rob_frames_row4(RobGroup gq, int lh, in
         }
         iss[k] = __builtin_amdgcn_rcpf(ssk[k]);
     }
-    for (int fr = 0; fr < gq.n; ++fr) {
-        const float* __restrict__ cm = gq.cm[fr];
-        const float2 f = gq.flow[fr][(size_t)tiy * nx + tix];
-        const float Sv = gq.S[fr][(size_t)tiy * nx + tix];
+    // The flow split (float64 floor / compares), the window origin and S only depend on (frame, sub-tile): 16 lanes
+    // evaluate them once per workgroup instead of every thread for every frame (~150 cycles of half-rate work per thread
+    // and frame, 11 % of the kernel); the frame loop reads them back as two 16-byte LDS words.
+    if (threadIdx.x < gq.n * 4) {
+        const int fr = threadIdx.x >> 2, vv = (threadIdx.x >> 1) & 1, gg = threadIdx.x & 1;
+        const int tsx0 = bxi * RF_BX + gg * RF_T, tsy0 = byi * RF_BY + vv * RF_T;
+        const size_t tl = (size_t)(min(tsy0, H - 1) / ts) * nx + min(tsx0, W - 1) / ts;
+        const float2 f = gq.flow[fr][tl];
         const RobAxis ay = rob_axis(f.y), ax = rob_axis(f.x);
         int wy0, wx0;
-        {
-            float r_;
-            rob_centre(ay, sy0, lh, wy0, r_);
-            rob_centre(ax, sx0, lw, wx0, r_);
-            wy0 = clampi(wy0, -4, lh + 4) - 1;
-            wx0 = clampi(wx0, -4, lw + 4) - 1;
-        }
+        float r_;
+        rob_centre(ay, tsy0, lh, wy0, r_);
+        rob_centre(ax, tsx0, lw, wx0, r_);
+        wy0 = clampi(wy0, -4, lh + 4) - 1;
+        wx0 = clampi(wx0, -4, lw + 4) - 1;
+        const int flags = (ay.lt ? 1 : 0) | (ay.eq ? 2 : 0) | (ay.ok ? 4 : 0) | (ax.lt ? 8 : 0) | (ax.eq ? 16 : 0) | (ax.ok ? 32 : 0);
+        s_tab[fr][vv][gg][0] = make_float4(__int_as_float(ay.fi), ay.h, __int_as_float(wy0), __int_as_float(flags));
+        s_tab[fr][vv][gg][1] = make_float4(__int_as_float(ax.fi), ax.h, __int_as_float(wx0), gq.S[fr][tl]);
+    }
+    __syncthreads();
+    for (int fr = 0; fr < gq.n; ++fr) {
+        const float* __restrict__ cm = gq.cm[fr];
+        const float4 t0 = s_tab[fr][v][grp][0], t1 = s_tab[fr][v][grp][1];
+        const int flags = __float_as_int(t0.w);
+        RobAxis ay, ax;
+        ay.fi = __float_as_int(t0.x); ay.h = t0.y; ay.lt = flags & 1; ay.eq = flags & 2; ay.ok = flags & 4;
+        ax.fi = __float_as_int(t1.x); ax.h = t1.y; ax.lt = flags & 8; ax.eq = flags & 16; ax.ok = flags & 32;
+        const int wy0 = __float_as_int(t0.z), wx0 = __float_as_int(t1.z);
+        const float Sv = t1.w;
         float st[NST];
 #pragma unroll
         for (int u = 0; u < NST; ++u) {
