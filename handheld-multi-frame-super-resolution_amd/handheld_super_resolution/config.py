@@ -45,6 +45,16 @@ class Config(dict):
 
     def __setitem__(self, k, v):
         super().__setitem__(k, Config._wrap(v))
+        object.__setattr__(self, "_ver", self.version() + 1)
+
+    def __delitem__(self, k):
+        super().__delitem__(k)
+        object.__setattr__(self, "_ver", self.version() + 1)
+
+    def version(self):
+        """Number of in-place edits of THIS mapping (not of nested ones): lets a long-lived consumer — the HIP-graph
+        replay of distributed.HipEngine — notice that a configuration was mutated, as the reference's process() does."""
+        return self.__dict__.get("_ver", 0)
 
     def __getattr__(self, k):
         try:

@@ -93,6 +93,7 @@ class HipEngine:
         tensors = (ref_img, comp_imgs) if packed else (ref_img, *comp_imgs)
         if not capturable(self.config, tensors):
             return main(ref_img, comp_imgs, self.config)
+        self._check_config()
         if self._runner is None:
             cfg = self.config
             self._runner = GraphRunner(lambda ref, *comp: main(ref, comp[0] if packed else list(comp), cfg), ref_img.device)
@@ -100,6 +101,16 @@ class HipEngine:
         if self._packed != packed:
             return main(ref_img, comp_imgs, self.config)
         return self._runner(*tensors)
+
+    def _check_config(self):
+        """A graph holds what the captured Python code decided from the configuration: when the configuration was edited
+        in place since the graphs were captured, drop them."""
+        from .graph import ConfigWatch
+
+        if getattr(self, "_watch", None) is None:
+            self._watch = ConfigWatch()
+        if self._watch.changed(self.config):
+            self._runner, self._runner_a, self._runners_b, self._flows_static = None, None, {}, None
 
     def init_ref(self, ref_img):
         """Replicated on every rank: the reference frame's alignment state (step A needs the whole frame)."""
@@ -122,6 +133,7 @@ class HipEngine:
         tensors = (ref_img, *my_frames)
         if not capturable(self.config, tensors):
             return fn(*tensors)
+        self._check_config()
         if self._runner_a is None:
             self._runner_a = GraphRunner(fn, ref_img.device)
         out = self._runner_a(*tensors)

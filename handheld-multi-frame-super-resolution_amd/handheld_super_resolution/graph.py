@@ -93,6 +93,66 @@ def _leaves(x):
             yield from _leaves(v)
 
 
+def signature(config):
+    """Cheap fingerprint of everything in a configuration that the captured Python code may have decided from: all scalar
+    settings; long lists (the two 1001-entry noise curves) by identity, length and ends.  An engine drops its graphs
+    when the fingerprint of its configuration changes (the reference mutates configs in place)."""
+    def walk(v):
+        if isinstance(v, dict):
+            return tuple((k, walk(x)) for k, x in v.items())
+        if isinstance(v, (list, tuple)):
+            if len(v) > 32:  # the 1001-entry noise curves: identity + ends (a full walk would cost 0.2 ms per burst)
+                return ("list", id(v), len(v), repr(v[0]), repr(v[-1]))
+            return tuple(walk(x) for x in v)
+        if isinstance(v, (int, float, str, bool, type(None))):
+            return v
+        return ("object", id(v))
+
+    return walk(config)
+
+
+class ConfigWatch:
+    """O(#nested mappings) check that a configuration has not been edited in place since the last call: sums the edit
+    counters of the Config mappings of the tree (config.Config.version()); other mapping types (a real OmegaConf
+    DictConfig) are fingerprinted in full with signature()."""
+
+    def __init__(self):
+        self.nodes, self.state = None, None
+
+    def changed(self, config):
+        from .config import Config
+
+        if not isinstance(config, Config):
+            state = signature(config)
+        else:
+            if self.nodes is None or self.nodes[0] is not config:
+                self.nodes = self._collect(config)
+            state = sum(n.version() for n in self.nodes)
+        if state == self.state:
+            return False
+        if isinstance(config, Config):
+            self.nodes = self._collect(config)  # an edit may have replaced nested mappings
+            state = sum(n.version() for n in self.nodes)
+        first = self.state is None
+        self.state = state
+        return not first
+
+    @staticmethod
+    def _collect(config):
+        from .config import Config
+
+        out, stack = [], [config]
+        while stack:
+            c = stack.pop()
+            out.append(c)
+            for v in c.values():
+                if isinstance(v, Config):
+                    stack.append(v)
+                elif isinstance(v, list):
+                    stack.extend(x for x in v if isinstance(x, Config))
+        return out
+
+
 def capturable(config, tensors):
     """main() can be captured: no host-synchronising timers / debug copies / injected host arrays, device inputs."""
     hip = config.get("hip", None) if hasattr(config, "get") else None

@@ -1602,6 +1602,22 @@ def test_graph_replay_equals_eager():
         oh, _ = eng_h.single(N(ref2), N(comp2))
     assert eng_h._runner is None
     assert_close(N(oh), N(want2), 0, 0, "host arrays")
+    # the configuration edited in place (as the reference's process() does): the engine drops its graphs
+    eng.config.merging.tuning.k_detail = float(eng.config.merging.tuning.k_detail) * 1.25
+    cfg_k = cfg_fn()
+    cfg_k.merging.tuning.k_detail = eng.config.merging.tuning.k_detail
+    want_k = hsr.main(ref, comp, cfg_k)[0].clone()
+    ok_, _ = eng.single(ref, comp)
+    assert eng._runner is not None and not eng._runner.graphs
+    assert_close(N(ok_), N(want_k), 0, 0, "after an in-place edit of the configuration")
+    assert not np.array_equal(N(want_k), N(want2), equal_nan=True)
+    eng.single(ref, comp)
+    ok2, _ = eng.single(ref, comp)
+    assert eng._runner.graphs
+    assert_close(N(ok2), N(want_k), 0, 0, "re-captured with the edited configuration")
+    eng.config.merging.tuning.k_detail = cfg_fn().merging.tuning.k_detail
+    for _ in range(3):
+        eng.single(ref, comp)
     # a function that reads back to the host cannot be captured: the runner falls back to eager execution
     r = GraphRunner(lambda x: x * float(x.sum().item()), torch.device(DEV))
     a = torch.ones(4, device=DEV)
