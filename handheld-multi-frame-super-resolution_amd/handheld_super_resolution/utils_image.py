@@ -69,6 +69,17 @@ def compute_grey_images(img, method):
     raise NotImplementedError("Computation of gray level on GPU is only supported for FFT")
 
 
+_taps_c = {}  # factor -> (ctypes float array, number of taps): built once, passed by pointer at every launch
+
+
+def _taps_for_launch(factor):
+    hit = _taps_c.get(factor)
+    if hit is None:
+        taps = gaussian_taps(factor)
+        hit = _taps_c[factor] = (_lib.floats(taps), len(taps))
+    return hit
+
+
 def gaussian_taps(factor):
     """scipy.ndimage's 1-D Gaussian for sigma = factor/2, radius = int(2*factor + 0.5), as the reference
     requests it (utils_image.py:380), restated from its definition; float32 like the reference's tensor."""
@@ -90,14 +101,13 @@ def cuda_downsample(th_img, kernel="gaussian", factor=2):
     lead = th_img.shape[:-2]
     img = _lib.f32c(th_img.reshape(th_img.shape[-2:]))
     H, W = img.shape
-    taps = gaussian_taps(factor)
-    r = (len(taps) - 1) // 2
+    taps, ntaps = _taps_for_launch(factor)
+    r = (ntaps - 1) // 2
     h2, w2 = (H - 2 * r) // factor, (W - 2 * r) // factor
     if h2 < 1 or w2 < 1:
         raise ValueError(f"image of shape {(H, W)} is too small to be downsampled by {factor}")
     out = torch.empty((h2, w2), dtype=torch.float32, device=img.device)
-    _lib.call("hhsr_gauss_decimate", _lib.ptr(img), H, W, W, _lib.ptr(out), w2, factor, _lib.floats(taps),
-              len(taps), _lib.stream())
+    _lib.call("hhsr_gauss_decimate", _lib.ptr(img), H, W, W, _lib.ptr(out), w2, factor, taps, ntaps, _lib.stream())
     return out.reshape(*lead, h2, w2)
 
 
