@@ -127,6 +127,12 @@ class BurstPipeline:
             self.align_state = self._timed(init_alignment, 2, "\nInitializing alignment", "Alignment initialized (Total)")(
                 grey, cfg)
             self.grey_ref = grey
+        # two milestones of the reference precompute: the frames' alignment only needs the first (grey image, pyramid,
+        # gradients, Hessians: ~0.25 ms); the robustness state behind it (raw pass + upsampled planes, another ~0.25 ms)
+        # is first needed after a frame's alignment and raw pass — the side streams do not sit out the second half
+        # (measured: no change of the 12 MP step, the other frames' FFTs already fill that time; kept for short bursts)
+        self._align_ready = torch.cuda.Event()
+        self._align_ready.record(main)
         self.ref_means = self.ref_vars = self.ref_covs = self.ref_sigma_sq = None
         if robustness and cfg.robustness.enabled and self.mono:
             m, v, self.ref_covs = self._timed(frame_stats, 2, "\nEstimating ref image local stats + kernels",
@@ -161,7 +167,7 @@ class BurstPipeline:
         grey = raw if self.mono else compute_grey_images(raw, self.grey_method)
         pyramid = build_gaussian_pyramid(grey, cfg.block_matching.tuning.factors)
         if wait_ref is not None:
-            torch.cuda.current_stream(self.device).wait_event(wait_ref)
+            torch.cuda.current_stream(self.device).wait_event(self._align_ready)
         return align(*self.align_state, grey, cfg, moving_pyramid=pyramid)
 
     def align_frames(self, comp_imgs, n_streams=None):
@@ -178,15 +184,13 @@ class BurstPipeline:
         if flow is None and self._inject_flows is not None and index is not None:
             flow = self._inject_flows[index]
         if flow is not None:
-            flow = _lib.f32c(flow, self.device)
-            if wait_ref is not None:
-                torch.cuda.current_stream(self.device).wait_event(wait_ref)
+            flow = _lib.f32c(flow, self.device)  # (nothing here needs the reference frame: the caller waits before the robustness)
         else:
             grey = raw if self.mono else self._timed(
                 compute_grey_images, 3, end_s="- grey images estimated by {}".format(self.grey_method))(raw, self.grey_method)
             pyramid = build_gaussian_pyramid(grey, cfg.block_matching.tuning.factors)
             if wait_ref is not None:
-                torch.cuda.current_stream(self.device).wait_event(wait_ref)
+                torch.cuda.current_stream(self.device).wait_event(self._align_ready)
             flow = self._timed(align, 2, "\nBeginning alignment", "Image aligned (Total)")(
                 *self.align_state, grey, cfg, moving_pyramid=pyramid)
         if cfg.robustness.enabled:  # guide means + kernel covariances from one pass over the raw frame
@@ -220,7 +224,10 @@ class BurstPipeline:
         (latency-bound) reference precompute.
         `flow`: a flow field that replaces the alignment (multi-GPU step B; validation hook
         config.hip.inject_flows via `index`)."""
-        return self._robustness([self._front(img, wait_ref, index, flow)], accumulate_r, fuse_local_min)[0]
+        front = self._front(img, wait_ref, index, flow)
+        if wait_ref is not None:
+            torch.cuda.current_stream(self.device).wait_event(wait_ref)
+        return self._robustness([front], accumulate_r, fuse_local_min)[0]
 
     def fuses_local_min(self):
         """True when the fused merge can take the un-filtered robustness maps (see merge.can_fuse_local_min)."""
@@ -246,6 +253,8 @@ class BurstPipeline:
 
             def work(ci, wait):
                 fronts = [self._front(comp_imgs[i], wait, i, None if flows is None else flows[i]) for i in chunks[ci]]
+                if wait is not None:  # the robustness needs the second half of the reference precompute
+                    torch.cuda.current_stream(self.device).wait_event(wait)
                 return self._robustness(fronts, accumulate_r if wait is None else None, fuse_local_min)
 
             out = self._on_streams(len(chunks), n_streams, accumulate_r is not None, work)
