@@ -674,8 +674,9 @@ struct RobGroup {
 
 __global__ void __launch_bounds__(256) k_rob_frames_row4(RobGroup gq, int lh, int lw, const float* __restrict__ rmean,
                                                           const float* __restrict__ ssq,
-                                                          const uint32_t* __restrict__ cidx, int nx, int ts,
-                                                          const double* __restrict__ difc, double t, int H, int W) {
+                                                          const uint32_t* __restrict__ cidx, int ny, int nx, int ts,
+                                                          const double* __restrict__ difc, double t, int H, int W,
+                                                          double Mt2, float s1, float s2) {
     __shared__ float s_g[2][2][3][RF_WN][RF_WN + 2];
     __shared__ float4 s_tab[ROB_GROUP][2][2][2];  // per (frame, sub-tile): flow split, window origin, S — see below
     const int lx4 = threadIdx.x & 7, ly_ = threadIdx.x >> 3;  // 8 threads x 4 pixels per row, 32 rows
@@ -727,7 +728,26 @@ __global__ void __launch_bounds__(256) k_rob_frames_row4(RobGroup gq, int lh, in
         wx0 = clampi(wx0, -4, lw + 4) - 1;
         const int flags = (ay.lt ? 1 : 0) | (ay.eq ? 2 : 0) | (ay.ok ? 4 : 0) | (ax.lt ? 8 : 0) | (ax.eq ? 16 : 0) | (ax.ok ? 32 : 0);
         s_tab[fr][vv][gg][0] = make_float4(__int_as_float(ay.fi), ay.h, __int_as_float(wy0), __int_as_float(flags));
-        s_tab[fr][vv][gg][1] = make_float4(__int_as_float(ax.fi), ax.h, __int_as_float(wx0), gq.S[fr][tl]);
+        float Sv;
+        if (gq.S[fr]) {
+            Sv = gq.S[fr][tl];
+        } else {  // the flow-irregularity weight of the tile (k_rob_s, robustness.py:570-612), evaluated here
+            const int tiy = (int)(tl / nx), tix = (int)(tl - (size_t)tiy * nx);
+            float mnx = INFINITY, mny = INFINITY, mxx = -INFINITY, mxy = -INFINITY;
+            for (int i = -1; i <= 1; ++i)
+                for (int j = -1; j <= 1; ++j) {
+                    const int yy = tiy + i, xx = tix + j;
+                    if (yy >= 0 && yy < ny && xx >= 0 && xx < nx) {
+                        const float2 q = gq.flow[fr][(size_t)yy * nx + xx];
+                        mxx = fmaxf(mxx, q.x); mxy = fmaxf(mxy, q.y);
+                        mnx = fminf(mnx, q.x); mny = fminf(mny, q.y);
+                    }
+                }
+            const float d0 = mxx - mnx, d1 = mxy - mny;
+            const float m = d0 * d0 + d1 * d1;
+            Sv = ((double)m > Mt2) ? s1 : s2;
+        }
+        s_tab[fr][vv][gg][1] = make_float4(__int_as_float(ax.fi), ax.h, __int_as_float(wx0), Sv);
     }
     __syncthreads();
     for (int fr = 0; fr < gq.n; ++fr) {
@@ -796,10 +816,10 @@ extern "C" int hhsr_rob_frame(const float* comp_means, int lh, int lw, const flo
 
 extern "C" int hhsr_rob_frames(const float* const* comp_means, int n_frames, int lh, int lw, const float* ref_means,
                                const float* ref_sigma_sq, const uint32_t* ref_curve_index, const float* const* flows,
-                               int ny, int nx, int ts, const float* const* S, const double* diff_curve, int ncurve,
-                               double t, float* const* R, void* stream) {
-    HHSR_ARG(comp_means && flows && S && R && n_frames >= 0);
-    for (int n = 0; n < n_frames; ++n) HHSR_ARG(comp_means[n] && flows[n] && S[n] && R[n]);
+                               int ny, int nx, int ts, const float* const* S, float Mt, float s1, float s2,
+                               const double* diff_curve, int ncurve, double t, float* const* R, void* stream) {
+    HHSR_ARG(comp_means && flows && R && n_frames >= 0);
+    for (int n = 0; n < n_frames; ++n) HHSR_ARG(comp_means[n] && flows[n] && (!S || S[n]) && R[n]);
     HHSR_ARG(ref_means && ref_sigma_sq && diff_curve && lh > 0 && lw > 0 && ts > 0 && ncurve > 0);
     const int H = 2 * lh, W = 2 * lw;
     HHSR_ARG(ny * ts >= H && nx * ts >= W);
@@ -807,6 +827,11 @@ extern "C" int hhsr_rob_frames(const float* const* comp_means, int n_frames, int
     bool vec4 = W % 4 == 0 && (((uintptr_t)ref_means | (uintptr_t)ref_sigma_sq | (uintptr_t)ref_curve_index) & 15) == 0;
     for (int n = 0; n < n_frames; ++n) vec4 = vec4 && ((uintptr_t)R[n] & 15) == 0;
     if (no_group || !(ts % RF_T == 0 && ref_curve_index && ncurve <= 1024 && vec4)) {
+        if (!S) {
+            hhsr_set_error("hhsr_rob_frames: S = NULL (weights evaluated inside the kernel) needs the grouped kernel: "
+                           "ts %% 16 == 0, W %% 4 == 0, packed curve indices, 16-byte aligned planes");
+            return -3;
+        }
         for (int n = 0; n < n_frames; ++n) {
             const int rc = hhsr_rob_frame(comp_means[n], lh, lw, ref_means, ref_sigma_sq, ref_curve_index, flows[n], ny, nx,
                                           ts, S[n], diff_curve, ncurve, t, R[n], stream);
@@ -821,11 +846,12 @@ extern "C" int hhsr_rob_frames(const float* const* comp_means, int n_frames, int
             const int n = n0 + (k < g.n ? k : 0);
             g.cm[k] = comp_means[n];
             g.flow[k] = reinterpret_cast<const float2*>(flows[n]);
-            g.S[k] = S[n];
+            g.S[k] = S ? S[n] : nullptr;
             g.R[k] = R[n];
         }
         hipLaunchKernelGGL(k_rob_frames_row4, dim3(hhsr_cdiv(W, RF_BX), hhsr_cdiv(H, RF_BY)), dim3(256), 0,
-                           (hipStream_t)stream, g, lh, lw, ref_means, ref_sigma_sq, ref_curve_index, nx, ts, diff_curve, t, H, W);
+                           (hipStream_t)stream, g, lh, lw, ref_means, ref_sigma_sq, ref_curve_index, ny, nx, ts, diff_curve, t,
+                           H, W, (double)Mt * (double)Mt, s1, s2);
     }
     HHSR_LAUNCHED();
 }

@@ -43,7 +43,7 @@ _SIGS = {
     "hhsr_rob_sigma": [P, P, I, I, P, I, P, P, P],
     "hhsr_ref_planes": [P, P, I, I, P, I, P, P, P, P],
     "hhsr_rob_frame": [P, I, I, P, P, P, P, I, I, I, P, P, I, D, P, P],
-    "hhsr_rob_frames": [PP, I, I, I, P, P, P, PP, I, I, I, PP, P, I, D, PP, P],
+    "hhsr_rob_frames": [PP, I, I, I, P, P, P, PP, I, I, I, PP, F, F, F, P, I, D, PP, P],
     "hhsr_local_min5": [P, I, I, P, P, P],
     "hhsr_mono_frame_stats": [P, I, I, I, P, P, P, D, D, D, D, D, D, D, D, I, P],
     "hhsr_mono_rob_upscale": [P, I, I, P, I, I, I, P, P],

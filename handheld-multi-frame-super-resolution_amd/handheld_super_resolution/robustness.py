@@ -5,6 +5,11 @@ import torch
 from . import _lib
 
 
+import os as _os
+
+_NO_GROUP = bool(_os.environ.get("HHSR_ROB_NO_GROUP"))  # the library's A/B switch, read once like the library reads it
+
+
 def _wb3(white_balance):
     wb = [float(v) for v in (white_balance.tolist() if hasattr(white_balance, "tolist") else white_balance)]
     if len(wb) < 3:
@@ -210,10 +215,15 @@ def compute_robustness_group(comp_imgs, ref_local_means, flows, noise_model, con
     H, W = comp_imgs[0].shape
     ny, nx, _ = flows[0].shape
     sigma_sq, curve_index = ref_sigma_sq
-    S = [compute_s(f, t.Mt, t.s1, t.s2) for f in flows]
+    # the grouped kernel evaluates the per-tile flow-irregularity weight S itself (one launch less per frame); the
+    # per-frame fall-back kernels of hhsr_rob_frames need the S maps — same test as in the library
+    inline_s = (int(ts) % 16 == 0 and W % 4 == 0 and curve_index is not None and diff_curve.numel() <= 1024
+                and not _NO_GROUP)
+    S = None if inline_s else [compute_s(f, t.Mt, t.s1, t.s2) for f in flows]
     R = [torch.empty((H, W), dtype=torch.float32, device=comp_imgs[0].device) for _ in flows]
     _lib.call("hhsr_rob_frames", _lib.ptr_array(comp_means), len(flows), H // 2, W // 2, _lib.ptr(ref_local_means),
-              _lib.ptr(sigma_sq), _lib.ptr(curve_index), _lib.ptr_array(flows), ny, nx, int(ts), _lib.ptr_array(S),
+              _lib.ptr(sigma_sq), _lib.ptr(curve_index), _lib.ptr_array(flows), ny, nx, int(ts),
+              None if S is None else _lib.ptr_array(S), float(t.Mt), float(t.s1), float(t.s2),
               _lib.ptr(diff_curve), int(diff_curve.numel()), float(t.t), _lib.ptr_array(R), _lib.stream())
     if fuse_local_min:
         assert accumulate_into is None

@@ -160,11 +160,14 @@ int hhsr_rob_frame(const float* comp_means, int lh, int lw, const float* ref_mea
                    const uint32_t* ref_curve_index, const float* flow, int ny, int nx, int ts, const float* S,
                    const double* diff_curve, int ncurve, double t, float* R, void* stream);
 /* hhsr_rob_frame for n_frames frames of one burst (HOST arrays of device pointers): groups of 4 frames share one pass
- * over the reference-frame planes (20 of the 27 bytes per pixel and frame); per frame bit-identical to hhsr_rob_frame. */
+ * over the reference-frame planes (20 of the 27 bytes per pixel and frame); per frame bit-identical to hhsr_rob_frame.
+ * S = NULL: the per-tile weights of hhsr_rob_s are evaluated inside the kernel from (Mt, s1, s2) — one launch less per
+ * frame; only with the grouped kernel (ts % 16 == 0, W % 4 == 0, packed curve indices, 16-byte aligned planes; error -3
+ * otherwise).  With S given, Mt / s1 / s2 are ignored. */
 int hhsr_rob_frames(const float* const* comp_means, int n_frames, int lh, int lw, const float* ref_means,
                     const float* ref_sigma_sq, const uint32_t* ref_curve_index, const float* const* flows, int ny,
-                    int nx, int ts, const float* const* S, const double* diff_curve, int ncurve, double t,
-                    float* const* R, void* stream);
+                    int nx, int ts, const float* const* S, float Mt, float s1, float s2, const double* diff_curve,
+                    int ncurve, double t, float* const* R, void* stream);
 /* 5x5 clamp-border minimum (robustness.py:670-686).  acc_r != NULL additionally does acc_r += r
  * (the accumulated robustness of super_resolution.py:158-159, fused to save a pass). */
 int hhsr_local_min5(const float* R, int H, int W, float* r, float* acc_r, void* stream);
