@@ -22,3 +22,13 @@ for s in range(len(ends) - nlast, len(ends)):
         depth += d; last = t
     print(f"step: span {(t1 - t0) / 1e6:.3f} ms, busy {busy / 1e6:.3f} ms, idle {(t1 - t0 - busy) / 1e6:.3f} ms, "
           f"sum of durations {sum(r[2] - r[1] for r in ks) / 1e6:.3f} ms, mean kernels in flight {area / max(busy, 1):.2f}, kernels {len(ks)}")
+
+# kernel census of the last step
+import collections
+lo, hi = ends[-2] + 1, ends[-1]
+cnt = collections.Counter(r[0].split("(")[0][:70] for r in rows[lo:hi + 1])
+dur = collections.Counter()
+for r in rows[lo:hi + 1]:
+    dur[r[0].split("(")[0][:70]] += r[2] - r[1]
+for k, v in cnt.most_common():
+    print(f"{v:4d}  {dur[k] / 1e3:8.1f} us  {k}")
