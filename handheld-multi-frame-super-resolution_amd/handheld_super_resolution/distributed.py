@@ -96,8 +96,7 @@ class HipEngine:
         self._check_config()
         if self._runner is None:
             cfg = self.config
-            dev = ref_img.device if ref_img.is_cuda else torch.device("cuda", torch.cuda.current_device())
-            self._runner = GraphRunner(lambda ref, *comp: main(ref, comp[0] if packed else list(comp), cfg), dev)
+            self._runner = GraphRunner(lambda ref, *comp: main(ref, comp[0] if packed else list(comp), cfg), ref_img.device)
             self._packed = packed
         if self._packed != packed:
             return main(ref_img, comp_imgs, self.config)

@@ -47,7 +47,7 @@ class GraphRunner:
         return out
 
     def __call__(self, *tensors):
-        if self.disabled or not all(_static_buffer(t) for t in tensors):
+        if self.disabled or not all(torch.is_tensor(t) and t.is_cuda for t in tensors):
             return self.fn(*tensors)
         key = _key(tensors)
         hit = self.graphs.get(key)
@@ -80,12 +80,6 @@ class GraphRunner:
             self.graphs.pop(next(iter(self.graphs)))
         self.graphs[key] = (graph, out, tensors)
         return self.graphs[key]
-
-
-def _static_buffer(t):
-    """A tensor whose address a graph may bake in: device memory, or page-locked host memory (its upload is captured as a
-    memcpy node of the graph: a serving loop refills the same pinned staging buffers for every burst)."""
-    return torch.is_tensor(t) and (t.is_cuda or t.is_pinned())
 
 
 def _leaves(x):
@@ -164,4 +158,4 @@ def capturable(config, tensors):
     hip = config.get("hip", None) if hasattr(config, "get") else None
     if hip is not None and (hip.get("inject_flows", None) is not None or not hip.get("graph", True)):
         return False
-    return config.verbose == 0 and not config.debug and all(_static_buffer(t) for t in tensors)
+    return config.verbose == 0 and not config.debug and all(torch.is_tensor(t) and t.is_cuda for t in tensors)
