@@ -203,6 +203,10 @@ def main():
     value = out_pix / (ms_per_step * 1e-3) / 1e6
     graphed = bool(on_gpu and (getattr(getattr(engine, "_runner", None), "graphs", None) or
                                getattr(getattr(engine, "_runner_a", None), "graphs", None)))
+    if world > 1:  # the eager section below runs collectives: every rank takes it when any rank replayed a graph
+        g_any = torch.tensor([int(graphed)], dtype=torch.int32, device=dev)
+        dist.all_reduce(g_any, op=dist.ReduceOp.MAX)
+        graphed = bool(int(g_any.item()))
     ms_eager, ev_steps = None, args.steps
     if graphed:
         # the timed steps were graph replays: no Python launch to bracket with events.  The dominant kernel's launch
