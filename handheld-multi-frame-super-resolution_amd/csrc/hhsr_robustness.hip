@@ -191,6 +191,25 @@ __global__ void __launch_bounds__(256) k_ref_planes(const float* __restrict__ gm
         if (!(ly >= 0.0 && ly < (double)lh && lx >= 0.0 && lx < (double)lw)) {
 #pragma unroll
             for (int c = 0; c < 6; ++c) v[c] = INFINITY;
+        } else if (y >= 2 && (y >> 1) + 1 <= lh - 1 && x >= 2 && (x >> 1) + 1 <= lw - 1) {
+            // interior, no flow: l = p/2 -+ 0.25 by the parity of p, centre p >> 1, tap offsets (-0.75, 0.25, 1.25) or
+            // (-1.25, -0.25, 0.75): the Dodgson weights are the dyadic constants 3/16, 7/8, -1/16, their products are exact
+            // in float32 and sum to exactly 1, and fmaf(v, w, b) rounds the exact v w + b once — the very value the generic
+            // path's float64 multiply-add followed by the float32 rounding produces.  Bit-identical, no float64.
+            const int cy = y >> 1, cx = x >> 1;
+            const float wyv[3] = {(y & 1) ? -0.0625f : 0.1875f, 0.875f, (y & 1) ? 0.1875f : -0.0625f};
+            const float wxv[3] = {(x & 1) ? -0.0625f : 0.1875f, 0.875f, (x & 1) ? 0.1875f : -0.0625f};
+            float b[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int i = 0; i < 3; ++i)
+#pragma unroll
+                for (int j = 0; j < 3; ++j) {
+                    const float w = wyv[i] * wxv[j];
+#pragma unroll
+                    for (int c = 0; c < 6; ++c) b[c] = fmaf(s_w[c][cy + i - 1 - wy0][cx + j - 1 - wx0], w, b[c]);
+                }
+#pragma unroll
+            for (int c = 0; c < 6; ++c) v[c] = b[c];
         } else {
             const int cy = (int)rint(ly), cx = (int)rint(lx);
             float b[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
