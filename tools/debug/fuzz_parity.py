@@ -110,4 +110,13 @@ for k in range(n_cases):
                 dr4 = np.abs(np.stack(dbg4["robustness"]) - np.stack(cap["r"]))
                 print(f"        same on the per-frame (debug) path: max {float(d4.max()):.2e}; r max {float(dr4.max()):.2e} at "
                       f"{tuple(int(v) for v in np.unravel_index(dr4.argmax(), dr4.shape))}")
+                r4, ro = np.stack(dbg4["robustness"]), np.stack(cap["r"])
+                for f_ in range(r4.shape[0]):
+                    print(f"        frame {f_}: r at the pixel's LR position gpu {float(r4[f_, int(lry), int(lrx)])!r} oracle "
+                          f"{float(ro[f_, int(lry), int(lrx)])!r}; image at the pixel gpu {float(o4[y, x, ch])!r} oracle {float(want[y, x, ch])!r}")
+                # contribution test: the same burst without the comp frames (reference frame only)
+                c5 = cfg_fn()
+                o5 = hsr.main(ref, comp[:0], c5)[0].cpu().numpy()
+                w5, _ = oracle.main(ref, comp[:0], cfg_fn())
+                print(f"        reference frame alone at the pixel: gpu {float(o5[y, x, ch])!r} oracle {float(w5[y, x, ch])!r}")
 print("worst image difference outside flipped-tile footprints:", worst)
