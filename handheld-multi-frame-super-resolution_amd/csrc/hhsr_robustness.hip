@@ -111,10 +111,10 @@ __global__ void __launch_bounds__(256) k_rob_s(const float2* __restrict__ flow, 
     S[(size_t)y * nx + x] = ((double)m > Mt2) ? s1 : s2;
 }
 
-extern "C" int hhsr_rob_s(const float* flow, int ny, int nx, float Mt, float s1, float s2, float* S, void* stream) {
+extern "C" int hhsr_rob_s(const float* flow, int ny, int nx, double Mt, float s1, float s2, float* S, void* stream) {
     HHSR_ARG(flow && S && ny > 0 && nx > 0);
     hipLaunchKernelGGL(k_rob_s, dim3(hhsr_cdiv(nx, 256), ny), dim3(256), 0, (hipStream_t)stream,
-                       reinterpret_cast<const float2*>(flow), ny, nx, (double)Mt * (double)Mt, s1, s2, S);
+                       reinterpret_cast<const float2*>(flow), ny, nx, Mt * Mt, s1, s2, S);  // float64 like the reference's M_th
     HHSR_LAUNCHED();
 }
 
@@ -835,7 +835,7 @@ extern "C" int hhsr_rob_frame(const float* comp_means, int lh, int lw, const flo
 
 extern "C" int hhsr_rob_frames(const float* const* comp_means, int n_frames, int lh, int lw, const float* ref_means,
                                const float* ref_sigma_sq, const uint32_t* ref_curve_index, const float* const* flows,
-                               int ny, int nx, int ts, const float* const* S, float Mt, float s1, float s2,
+                               int ny, int nx, int ts, const float* const* S, double Mt, float s1, float s2,
                                const double* diff_curve, int ncurve, double t, float* const* R, void* stream) {
     HHSR_ARG(comp_means && flows && R && n_frames >= 0);
     for (int n = 0; n < n_frames; ++n) HHSR_ARG(comp_means[n] && flows[n] && (!S || S[n]) && R[n]);
@@ -870,7 +870,7 @@ extern "C" int hhsr_rob_frames(const float* const* comp_means, int n_frames, int
         }
         hipLaunchKernelGGL(k_rob_frames_row4, dim3(hhsr_cdiv(W, RF_BX), hhsr_cdiv(H, RF_BY)), dim3(256), 0,
                            (hipStream_t)stream, g, lh, lw, ref_means, ref_sigma_sq, ref_curve_index, ny, nx, ts, diff_curve, t,
-                           H, W, (double)Mt * (double)Mt, s1, s2);
+                           H, W, Mt * Mt, s1, s2);
     }
     HHSR_LAUNCHED();
 }

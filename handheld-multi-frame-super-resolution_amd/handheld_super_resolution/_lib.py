@@ -39,11 +39,11 @@ _SIGS = {
     "hhsr_frame_stats": [P, I, I, I, U8P, DP, P, P, P, D, D, D, D, D, D, D, D, I, P],
     "hhsr_normalize_raw_u16": [P, I, I, I, I, U8P, DP, D, DP, P, P],
     "hhsr_rob_upscale": [P, I, I, P, I, I, I, P, P],
-    "hhsr_rob_s": [P, I, I, F, F, F, P, P],
+    "hhsr_rob_s": [P, I, I, D, F, F, P, P],
     "hhsr_rob_sigma": [P, P, I, I, P, I, P, P, P],
     "hhsr_ref_planes": [P, P, I, I, P, I, P, P, P, P],
     "hhsr_rob_frame": [P, I, I, P, P, P, P, I, I, I, P, P, I, D, P, P],
-    "hhsr_rob_frames": [PP, I, I, I, P, P, P, PP, I, I, I, PP, F, F, F, P, I, D, PP, P],
+    "hhsr_rob_frames": [PP, I, I, I, P, P, P, PP, I, I, I, PP, D, F, F, P, I, D, PP, P],
     "hhsr_local_min5": [P, I, I, P, P, P],
     "hhsr_mono_frame_stats": [P, I, I, I, P, P, P, D, D, D, D, D, D, D, D, I, P],
     "hhsr_mono_rob_upscale": [P, I, I, P, I, I, I, P, P],

@@ -138,7 +138,7 @@ int hhsr_frame_stats(const float* raw, int H, int W, int pitch, const uint8_t cf
 int hhsr_rob_upscale(const float* stats, int lh, int lw, const float* flow, int ny, int nx, int ts,
                      float* out, void* stream);
 /* Per-tile flow-irregularity map S (robustness.py:570-612). */
-int hhsr_rob_s(const float* flow, int ny, int nx, float Mt, float s1, float s2, float* S, void* stream);
+int hhsr_rob_s(const float* flow, int ny, int nx, double Mt, float s1, float s2, float* S, void* stream);
 /* Frame-independent noise-model terms (robustness.py:505-528, once per burst):
  * sigma_sq[p] = sum_c max(ref_vars[c][p], std_curve[round(1000 ref_means[c][p])]^2), float32 [H][W];
  * curve_index[p] (optional, NULL to skip; needs ncurve <= 1024) = the three curve indices
@@ -166,7 +166,7 @@ int hhsr_rob_frame(const float* comp_means, int lh, int lw, const float* ref_mea
  * otherwise).  With S given, Mt / s1 / s2 are ignored. */
 int hhsr_rob_frames(const float* const* comp_means, int n_frames, int lh, int lw, const float* ref_means,
                     const float* ref_sigma_sq, const uint32_t* ref_curve_index, const float* const* flows, int ny,
-                    int nx, int ts, const float* const* S, float Mt, float s1, float s2, const double* diff_curve,
+                    int nx, int ts, const float* const* S, double Mt, float s1, float s2, const double* diff_curve,
                     int ncurve, double t, float* const* R, void* stream);
 /* 5x5 clamp-border minimum (robustness.py:670-686).  acc_r != NULL additionally does acc_r += r
  * (the accumulated robustness of super_resolution.py:158-159, fused to save a pass). */
