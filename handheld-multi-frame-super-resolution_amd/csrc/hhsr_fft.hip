@@ -275,10 +275,19 @@ __device__ __forceinline__ bool fft_kept(int u, int n) {
     return i >= n / 4 && i < n - (n + 3) / 4;
 }
 
-// Layout of the kept half spectrum T: x-bins in blocks of 8, element (kx, y) at ((kx/8)*H + y)*8 + kx%8 — the
-// row kernels then move 64-byte runs (8 consecutive bins of one row) and a column is a 64-byte-strided walk
-// whose cache lines are shared by the 8 columns of its block (placed on one XCD, see k_cols).
-__device__ __forceinline__ size_t t_index(int kx, int y, int H) { return ((size_t)(kx >> 3) * H + y) * 8 + (kx & 7); }
+// Layout of the kept half spectrum T: x-bins in blocks of TB, element (kx, y) at ((kx/TB)*H + y)*TB + kx%TB — the
+// row kernels move runs of TB consecutive bins of one row (two adjacent rows of a workgroup are adjacent in memory) and a
+// column pair is a walk at a stride of TB elements whose cache lines are shared by the columns of its block (placed on
+// one XCD, see k_cols).
+// x-bins per block.  The row kernels want long runs of consecutive bins of a row (8: 64 bytes), the column kernel wants its
+// column pair contiguous over y (2).  Timed per phase with wall_clock64: at 8 the column kernel spends 6 + 14-19 us of its
+// 57 us in its 16-byte accesses at a 64-byte stride (the transforms themselves: 14 us).  Measured at 12 MP, us per
+// frame (rows fwd / cols / rows inv): 8: 39 / 57 / 39 = 135;  4: 40 / 43 / 44 = 127;  2: 43 / 35 / 59 = 137.
+#ifndef HHSR_FFT_TB
+#define HHSR_FFT_TB 4
+#endif
+constexpr int TB = HHSR_FFT_TB;
+__device__ __forceinline__ size_t t_index(int kx, int y, int H) { return ((size_t)(kx / TB) * H + y) * TB + (kx % TB); }
 
 constexpr int FFT_NT = 512;          // threads per workgroup
 constexpr int FFT_ROWS_WPE = 6;     // row kernels: 48 KB of LDS -> three workgroups per CU need <= 85 VGPRs
@@ -338,16 +347,16 @@ __global__ void __launch_bounds__(FFT_NT, FFT_COLS_WPE) k_cols(float2* __restric
     if (kx >= Wk) return;
     float2* tw = fl;
     float2* buf = tw + ((twlen + 1) & ~1);  // 16-byte aligned
-    float2* colb = T + ((size_t)(kx >> 3) * H) * 8 + (kx & 7);  // row y at colb[8 y]
-    float4* col = reinterpret_cast<float4*>(colb);               // NC = 2: row y at col[4 y]
+    float2* colb = T + ((size_t)(kx / TB) * H) * TB + (kx % TB);  // row y at colb[TB y]
+    float4* col = reinterpret_cast<float4*>(colb);                 // NC = 2: row y at col[(TB / 2) y]
     for (int k = tid; k < twlen; k += FFT_NT) tw[k] = twH[k];
     for (int k = tid; k < H; k += FFT_NT) {
         if (NC == 2) {
-            const float4 v = col[(size_t)4 * k];
+            const float4 v = col[(size_t)(TB / 2) * k];
             buf[k] = make_float2(v.x, v.y);
             buf[H + k] = make_float2(v.z, v.w);
         } else {
-            buf[k] = colb[(size_t)8 * k];
+            buf[k] = colb[(size_t)TB * k];
         }
     }
     fft_lds(buf, H, NC, tw, H, rad, tid, FFT_NT);
@@ -363,9 +372,9 @@ __global__ void __launch_bounds__(FFT_NT, FFT_COLS_WPE) k_cols(float2* __restric
     for (int y = tid; y < H; y += FFT_NT) {
         if (NC == 2) {
             const float2 a = cconj(buf[y]), b2 = cconj(buf[H + y]);
-            col[(size_t)4 * y] = make_float4(a.x, a.y, b2.x, b2.y);
+            col[(size_t)(TB / 2) * y] = make_float4(a.x, a.y, b2.x, b2.y);
         } else {
-            colb[(size_t)8 * y] = cconj(buf[y]);
+            colb[(size_t)TB * y] = cconj(buf[y]);
         }
     }
 }
