@@ -282,9 +282,11 @@ __device__ __forceinline__ bool fft_kept(int u, int n) {
 // x-bins per block.  The row kernels want long runs of consecutive bins of a row (8: 64 bytes), the column kernel wants its
 // column pair contiguous over y (2).  Timed per phase with wall_clock64: at 8 the column kernel spends 6 + 14-19 us of its
 // 57 us in its 16-byte accesses at a 64-byte stride (the transforms themselves: 14 us).  Measured at 12 MP, us per
-// frame (rows fwd / cols / rows inv): 8: 39 / 57 / 39 = 135;  4: 40 / 43 / 44 = 127;  2: 43 / 35 / 59 = 137.
+// frame (rows fwd / cols / rows inv): 8: 39 / 57 / 39 = 135;  4: 40 / 43 / 44 = 127;  2: 43 / 35 / 59 = 137 — and with
+// the row kernels walking T in memory order and k_rows_inv reading every bin once (pairs Z[k], Z[M-k]):
+// 4: 40 / 44 / 40 = 124;  2: 42 / 35 / 44 = 121 (step 8.92 vs 8.99 ms).
 #ifndef HHSR_FFT_TB
-#define HHSR_FFT_TB 4
+#define HHSR_FFT_TB 2
 #endif
 constexpr int TB = HHSR_FFT_TB;
 __device__ __forceinline__ size_t t_index(int kx, int y, int H) { return ((size_t)(kx / TB) * H + y) * TB + (kx % TB); }
@@ -321,9 +323,12 @@ __global__ void __launch_bounds__(FFT_NT, FFT_ROWS_WPE) k_rows_fwd(const float* 
     }
     fft_lds(buf, M, nrows, tw, M, rad, tid, FFT_NT);
     // X[k] = 1/2 [(Z[k] + conj Z[M-k]) - i w_k (Z[k] - conj Z[M-k])],  w_k = exp(-2 pi i k / W); kept bins only,
-    // straight from LDS to the blocked-transposed spectrum (8 consecutive lanes = one 64-byte run)
-    for (int idx = tid; idx < nrows * Wk; idx += FFT_NT) {
-        const int rb = idx / Wk, k = idx - rb * Wk;
+    // straight from LDS to the blocked-transposed spectrum
+    const int nblk = (Wk + TB - 1) / TB;
+    for (int idx = tid; idx < nblk * nrows * TB; idx += FFT_NT) {  // in the order the bins lie in T (see k_rows_inv)
+        const int b = idx / (nrows * TB), q = idx - b * (nrows * TB);
+        const int rb = q / TB, k = b * TB + (q - rb * TB);
+        if (k >= Wk) continue;
         const float2* Z = buf + rb * M;
         const float2 zk = Z[k == M ? 0 : k], zm = cconj(Z[k == 0 ? 0 : M - k]);
         const float2 s = cadd(zk, zm), d = mul_mi(cmul(twW[k], csub(zk, zm)));
@@ -391,16 +396,28 @@ __global__ void __launch_bounds__(FFT_NT, FFT_ROWS_WPE) k_rows_inv(const float2*
     for (int k = tid; k < twlen; k += FFT_NT) tw[k] = twM[k];
     const int y0 = blockIdx.x * RB;
     const int nrows = min(RB, H - y0);
-    // Z[k] = 1/2 [(X[k] + conj X[M-k]) + i conj(w_k) (X[k] - conj X[M-k])] with X = 0 above the kept band, built
-    // straight from the spectrum in global memory (each kept bin is read by the threads of k and M-k; the second
-    // read hits L1/L2) and stored conjugated for the conj(FFT(conj(.))) inverse
-    for (int idx = tid; idx < nrows * M; idx += FFT_NT) {
-        const int rb = idx / M, k = idx - rb * M;
-        const int mk = M - k;  // in 1..M
-        const float2 xk = k < Wk ? T[t_index(k, y0 + rb, H)] : make_float2(0.f, 0.f);
-        const float2 xm = mk < Wk ? cconj(T[t_index(mk, y0 + rb, H)]) : make_float2(0.f, 0.f);
-        const float2 s = cadd(xk, xm), d = mul_pi(cmul(cconj(twW[k]), csub(xk, xm)));
-        buf[rb * M + k] = cconj(cscale(cadd(s, d), 0.5f));
+    // Z[k] = 1/2 [(X[k] + conj X[M-k]) + i conj(w_k) (X[k] - conj X[M-k])] with X = 0 above the kept band, stored
+    // conjugated for the conj(FFT(conj(.))) inverse.  One thread builds the PAIR Z[k], Z[M-k] (k <= M/2) from X[k] and
+    // X[M-k]: every kept bin is read from global memory exactly once, in the order it lies there — blocks of TB bins,
+    // the workgroup's rows adjacent (the former element-wise loop read every bin twice, the second time in descending k).
+    const int half = M / 2 + 1, nblk = (half + TB - 1) / TB;
+    for (int idx = tid; idx < nblk * nrows * TB; idx += FFT_NT) {
+        const int b = idx / (nrows * TB), q = idx - b * (nrows * TB);
+        const int rb = q / TB, k = b * TB + (q - rb * TB);
+        if (k >= half) continue;
+        const int mk = M - k;  // in M/2 .. M
+        const float2 xa = k < Wk ? T[t_index(k, y0 + rb, H)] : make_float2(0.f, 0.f);
+        const float2 xb = (mk < Wk && mk != k) ? T[t_index(mk, y0 + rb, H)] : (mk == k ? xa : make_float2(0.f, 0.f));
+        {
+            const float2 xk = xa, xm = cconj(xb);
+            const float2 s = cadd(xk, xm), d = mul_pi(cmul(cconj(twW[k]), csub(xk, xm)));
+            buf[rb * M + k] = cconj(cscale(cadd(s, d), 0.5f));
+        }
+        if (mk != k && mk < M) {
+            const float2 xk = xb, xm = cconj(xa);
+            const float2 s = cadd(xk, xm), d = mul_pi(cmul(cconj(twW[mk]), csub(xk, xm)));
+            buf[rb * M + mk] = cconj(cscale(cadd(s, d), 0.5f));
+        }
     }
     fft_lds(buf, M, nrows, tw, M, rad, tid, FFT_NT);
     if ((M & 1) == 0 && (W & 3) == 0) {
