@@ -327,7 +327,11 @@ __global__ void __launch_bounds__(FFT_NT, FFT_ROWS_WPE) k_rows_fwd(const float* 
     float2* tw = fl;
     float2* buf = tw + ((twlen + 1) & ~1);  // 16-byte aligned
     batched_for<float2>(twlen, tid, [&](int k) { return twM[k]; }, [&](int k, float2 v) { tw[k] = v; });
-    const int y0 = blockIdx.x * RB;
+    // persistent workgroups: the grid is one resident round (HHSR_FFT_PERSIST), every workgroup walks the row blocks
+    // blockIdx.x, blockIdx.x + gridDim.x, ...: one twiddle copy and one dispatch per workgroup slot instead of per block
+    for (int blk = blockIdx.x; blk * RB < H; blk += gridDim.x) {
+    if (blk != (int)blockIdx.x) __syncthreads();  // the previous block's stores have read the buffer
+    const int y0 = blk * RB;
     const int nrows = min(RB, H - y0);
     if ((M & 1) == 0 && (W & 3) == 0) {  // two complex samples (16 bytes) per lane
         const int Mh = M / 2;
@@ -358,6 +362,7 @@ __global__ void __launch_bounds__(FFT_NT, FFT_ROWS_WPE) k_rows_fwd(const float* 
         const float2 zk = Z[k == M ? 0 : k], zm = cconj(Z[k == 0 ? 0 : M - k]);
         const float2 s = cadd(zk, zm), d = mul_mi(cmul(twW[k], csub(zk, zm)));
         T[t_index(k, y0 + rb, H)] = cscale(cadd(s, d), 0.5f);
+    }
     }
 }
 
@@ -419,7 +424,9 @@ __global__ void __launch_bounds__(FFT_NT, FFT_ROWS_WPE) k_rows_inv(const float2*
     float2* tw = fl;
     float2* buf = tw + ((twlen + 1) & ~1);  // 16-byte aligned
     batched_for<float2>(twlen, tid, [&](int k) { return twM[k]; }, [&](int k, float2 v) { tw[k] = v; });
-    const int y0 = blockIdx.x * RB;
+    for (int blk = blockIdx.x; blk * RB < H; blk += gridDim.x) {  // persistent workgroups, see k_rows_fwd
+    if (blk != (int)blockIdx.x) __syncthreads();
+    const int y0 = blk * RB;
     const int nrows = min(RB, H - y0);
     // Z[k] = 1/2 [(X[k] + conj X[M-k]) + i conj(w_k) (X[k] - conj X[M-k])] with X = 0 above the kept band, stored
     // conjugated for the conj(FFT(conj(.))) inverse.  One thread builds the PAIR Z[k], Z[M-k] (k <= M/2) from X[k] and
@@ -457,6 +464,7 @@ __global__ void __launch_bounds__(FFT_NT, FFT_ROWS_WPE) k_rows_inv(const float2*
             const int rb = idx / M, n = idx - rb * M;
             reinterpret_cast<float2*>(dst + (size_t)(y0 + rb) * W)[n] = cconj(buf[rb * M + n]);
         }
+    }
     }
 }
 
@@ -623,7 +631,10 @@ void hhsr_fft_destroy(HhsrFft& f) {
 }
 
 int hhsr_fft_lowpass(const HhsrFft& f, const float* src, float* dst, hipStream_t s) {
-    const int nrb = hhsr_cdiv(f.H, f.rb);
+    // row kernels: at most one resident round of workgroups (3 per CU by their 48 kB of LDS), each walking several blocks
+    static const int persist = getenv("HHSR_FFT_PERSIST") ? atoi(getenv("HHSR_FFT_PERSIST")) : 768;
+    const int nrb_all = hhsr_cdiv(f.H, f.rb);
+    const int nrb = persist > 0 && persist < nrb_all ? persist : nrb_all;
     // unnormalised inverse transforms multiply by (W/2) and H
     const float norm = (float)(1.0 / ((double)(f.W / 2) * (double)f.H));
 #define ROWS_FWD(RB) hipLaunchKernelGGL(k_rows_fwd<RB>, dim3(nrb), dim3(FFT_NT), f.lds_rows, s, src, f.H, f.W, f.T, f.Wk, \
