@@ -68,7 +68,9 @@ class GraphRunner:
         self.stream.wait_stream(cur)
         graph = torch.cuda.CUDAGraph()
         try:
-            with torch.cuda.graph(graph, stream=self.stream):
+            # thread_local: only this thread's calls are checked — the RCCL watchdog thread of a multi-GPU job queries
+            # events while we capture
+            with torch.cuda.graph(graph, stream=self.stream, capture_error_mode="thread_local"):
                 out = self.fn(*tensors)
         except Exception as e:  # not capturable in this configuration: stay eager
             self.disabled = True
