@@ -315,6 +315,26 @@ __device__ __forceinline__ void batched_for(int n, int tid, Load load, Store sto
     }
 }
 
+// Row block of persistent workgroup `wg` in its round `it` (< 0: none left).  A 128-byte line of the blocked spectrum
+// holds one column block of 16 / TB consecutive rows, i.e. of G = 16 / (TB RB) consecutive row blocks: they go to
+// consecutive workgroups of ONE XCD (workgroup b runs on XCD b % 8 — observed; locality only), so that one L2 gathers /
+// serves the line instead of G of them (k_rows_inv fetched 4.6 x the spectrum's bytes with the plain round-robin walk).
+#ifndef HHSR_FFT_XCD
+#define HHSR_FFT_XCD 1
+#endif
+template <int RB>
+__device__ __forceinline__ int row_block(int it, int H) {
+    constexpr int G = (16 / (TB * RB)) > 0 ? 16 / (TB * RB) : 1;
+    int blk;
+    if (HHSR_FFT_XCD && (gridDim.x & 7) == 0) {
+        const int v = (int)(blockIdx.x >> 3) + it * (int)(gridDim.x >> 3);
+        blk = ((v / G) * 8 + (int)(blockIdx.x & 7)) * G + v % G;  // increasing in `it`
+    } else {
+        blk = (int)blockIdx.x + it * (int)gridDim.x;
+    }
+    return blk * RB < H ? blk : -1;
+}
+
 // Row kernels: RB rows per workgroup, transformed SIMULTANEOUSLY (RB x fewer barriers, RB x more independent
 // butterflies per thread).  LDS: tw[twlen] | RB x row[M]  (float2 each).
 template <int RB>
@@ -328,9 +348,9 @@ __global__ void __launch_bounds__(FFT_NT, FFT_ROWS_WPE) k_rows_fwd(const float* 
     float2* buf = tw + ((twlen + 1) & ~1);  // 16-byte aligned
     batched_for<float2>(twlen, tid, [&](int k) { return twM[k]; }, [&](int k, float2 v) { tw[k] = v; });
     // persistent workgroups: the grid is one resident round (HHSR_FFT_PERSIST), every workgroup walks the row blocks
-    // blockIdx.x, blockIdx.x + gridDim.x, ...: one twiddle copy and one dispatch per workgroup slot instead of per block
-    for (int blk = blockIdx.x; blk * RB < H; blk += gridDim.x) {
-    if (blk != (int)blockIdx.x) __syncthreads();  // the previous block's stores have read the buffer
+    // (row_block): one twiddle copy and one dispatch per workgroup slot instead of per block
+    for (int it = 0, blk; (blk = row_block<RB>(it, H)) >= 0; ++it) {
+    if (it) __syncthreads();  // the previous block's stores have read the buffer
     const int y0 = blk * RB;
     const int nrows = min(RB, H - y0);
     if ((M & 1) == 0 && (W & 3) == 0) {  // two complex samples (16 bytes) per lane
@@ -424,8 +444,8 @@ __global__ void __launch_bounds__(FFT_NT, FFT_ROWS_WPE) k_rows_inv(const float2*
     float2* tw = fl;
     float2* buf = tw + ((twlen + 1) & ~1);  // 16-byte aligned
     batched_for<float2>(twlen, tid, [&](int k) { return twM[k]; }, [&](int k, float2 v) { tw[k] = v; });
-    for (int blk = blockIdx.x; blk * RB < H; blk += gridDim.x) {  // persistent workgroups, see k_rows_fwd
-    if (blk != (int)blockIdx.x) __syncthreads();
+    for (int it = 0, blk; (blk = row_block<RB>(it, H)) >= 0; ++it) {  // persistent workgroups, see k_rows_fwd
+    if (it) __syncthreads();
     const int y0 = blk * RB;
     const int nrows = min(RB, H - y0);
     // Z[k] = 1/2 [(X[k] + conj X[M-k]) + i conj(w_k) (X[k] - conj X[M-k])] with X = 0 above the kept band, stored
