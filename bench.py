@@ -235,8 +235,8 @@ def main():
         h2d = {"value_incl_h2d": round(out_pix / (ms_h * 1e-3) / 1e6, 2), "ms_per_step_incl_h2d": round(ms_h, 3),
                "steps": steps_h, "host_bytes_per_step": nbytes,
                "pcie_floor_ms": round(nbytes / 63e9 * 1e3, 2),
-               "note": "frames start as pinned host float32; every frame is uploaded once, on its pipeline stream "
-                       "(hipMemcpyAsync), overlapping the other frames' kernels; PCIe Gen5 x16 spec 63 GB/s"}
+               "note": "frames start as pinned host float32; all uploads are queued up front, back to back on one "
+                       "upload stream (hipMemcpyAsync), each frame's kernels wait for its copy; PCIe Gen5 x16 spec 63 GB/s"}
         # the same scope with the frames as the sensor's uint16 counts (what a DNG holds; the reference converts them
         # to float32 on the host, utils_dng.py:149-160): half the PCIe bytes, normalised on the device per frame
         if world == 1:

@@ -1546,6 +1546,39 @@ def test_process_mono_burst():
     assert np.nanmean(np.abs(o[..., 0] - np.nanmean(o[..., 0]))) > 0.01
 
 
+@pytest.mark.parametrize("scale,mode", [(2, "bayer"), (1.5, "bayer"), (2, "grey")])
+def test_host_bursts_prefetch(scale, mode):
+    """Page-locked host frames: all uploads are queued up front on the upload stream instead of frame by frame —
+    bit-identical to device-resident frames and to pageable NumPy frames, float32 and uint16 counts."""
+    ref, comp, _ = synth.make_burst_torch(512, 640, 8, torch.device(DEV), seed=21)
+    ref_p, comp_p = ref.cpu().pin_memory(), [comp[i].cpu().pin_memory() for i in range(comp.shape[0])]
+
+    def cfg_fn(**hip):
+        cfg = base_config(ts=16, scale=scale)
+        cfg.mode = mode
+        cfg.robustness.save_mask = True
+        cfg.hip = hip
+        return cfg
+
+    want, wdbg = hsr.main(ref, comp, cfg_fn())  # device-resident
+    for hip in ({}, {"streams": 1}):
+        for r_, c_ in ((ref_p, comp_p), (ref_p, torch.stack(comp_p).pin_memory()), (N(ref), N(comp))):
+            got, dbg = hsr.main(r_, c_, cfg_fn(**hip))
+            assert_close(N(got), N(want), 0, 0, f"x{scale} {mode} {hip}")
+            assert_close(N(dbg["accumulated robustness"]), N(wdbg["accumulated robustness"]), 0, 0, "accumulated robustness")
+    # uint16 counts: uploaded as counts, normalised on the device
+    black, white = 64.0, 1023.0
+    counts = lambda t: torch.from_numpy(np.clip(np.rint(N(t) * (white - black) + black), 0, white).astype(np.uint16))  # noqa: E731
+    ref16, comp16 = counts(ref), [counts(comp[i]) for i in range(comp.shape[0])]
+    outs = []
+    for pin in (False, True):
+        cfg = cfg_fn(raw_norm={"black_levels": [black] * 3, "white_level": white})
+        r_ = ref16.pin_memory() if pin else ref16
+        c_ = [c.pin_memory() for c in comp16] if pin else comp16
+        outs.append(N(hsr.main(r_, c_, cfg)[0]))
+    assert_close(outs[1], outs[0], 0, 0, "uint16 counts: prefetched vs per-frame uploads")
+
+
 # ------------------------------------------------------------------------------------------ HIP graph replay
 def test_graph_replay_equals_eager():
     """An engine kept across bursts captures main() in a HIP graph on its second call with the same device tensors and
