@@ -70,8 +70,18 @@ def parse_args():
     ap.add_argument("--no-graph", action="store_true", help="launch every kernel from Python instead of replaying the "
                                                             "step from a HIP graph")
     ap.add_argument("--engine", default=None, help="FILE.py:CLASS replacing distributed.HipEngine (plumbing tests "
-                                                   "without a GPU; implies host tensors)")
-    return ap.parse_args()
+                                                   "without a GPU; implies host tensors; only with --backend gloo)")
+    ap.add_argument("--strategy", default="rows", choices=["rows", "reduce"],
+                    help="N > 1: rows = frame-parallel alignment, all-gather of flows, row-parallel merge (default); "
+                         "reduce = frames one per rank, ONE reduce-scatter of the float32 accumulators (north star)")
+    ap.add_argument("--max-flow", type=float, default=None,
+                    help="N > 1, rows: bound on |flow_y| in pixels for the sub-image halo (no host read in the step); "
+                         "default: measured from the gathered flows (one scalar read per burst)")
+    ap.add_argument("--cpu-cores", type=int, default=None, help="worker processes of the CPU baseline (default: all cores)")
+    args = ap.parse_args()
+    if args.engine is not None and args.backend != "gloo":
+        ap.error("--engine (a foreign per-rank engine: launch-plumbing tests) is only accepted with --backend gloo")
+    return args
 
 
 def respawn_under_torchrun(args):
@@ -169,7 +179,8 @@ def main():
     engine = engine_cls(cfg)
 
     def step(r=ref, c=comp):
-        return hdist.main_sharded(r, c, cfg, engine=engine, gather=args.gather)[0]
+        return hdist.main_sharded(r, c, cfg, engine=engine, gather=args.gather, strategy=args.strategy,
+                                  max_flow=args.max_flow)[0]
 
     def barrier():
         if world > 1:
@@ -217,7 +228,8 @@ def main():
         cfg_e.hip = dict(cfg_e.hip, graph=False)
         eng_e = engine_cls(cfg_e)
         ev_steps = max(3, min(10, args.steps))
-        fn_e = lambda: hdist.main_sharded(ref, comp, cfg_e, engine=eng_e, gather=args.gather)[0]  # noqa: E731
+        fn_e = lambda: hdist.main_sharded(ref, comp, cfg_e, engine=eng_e, gather=args.gather, strategy=args.strategy,  # noqa: E731
+                                          max_flow=args.max_flow)[0]
         fn_e()
         barrier()
         timed_call.on = True
@@ -227,33 +239,60 @@ def main():
     # ---- H2D-inclusive leg: the reference's scope (frames are host arrays when the timer starts) ---------------------
     h2d = None
     if on_gpu and not args.no_h2d:
+        import copy
+
+        steps_h = max(3, args.steps // 2)
+        nbytes = 4.0 * H * W * NF
+        PCIE_GBS = 63.0  # PCIe Gen5 x16 spec, one direction
+
+        def host_leg(r_h, c_h, cfg_h, what):
+            """`what` starting in host memory: one engine kept across the bursts (graph.HostBurstRunner: eager uploads
+            into static staging, per-chunk HIP graphs of the front end, one merge graph)."""
+            eng_h = engine_cls(cfg_h)
+            fn = lambda: hdist.main_sharded(r_h, c_h, cfg_h, engine=eng_h, gather=args.gather, strategy=args.strategy,  # noqa: E731
+                                            max_flow=args.max_flow)[0]
+            ms = timed(fn, steps_h, 3)  # eager, capture, one replay; then the timed replays
+            runner = getattr(eng_h, "_host", None)
+            graphs = bool(runner is not None and not runner.disabled and any(s != "seen" for s in runner.states.values()))
+            del eng_h
+            return ms, graphs
+
         ref_h = ref.cpu().pin_memory()
         comp_h = [comp[i].cpu().pin_memory() for i in range(NF - 1)]  # one pinned float32 array per frame
-        steps_h = max(3, args.steps // 2)
-        ms_h = timed(lambda: step(ref_h, comp_h), steps_h, 2)
-        nbytes = 4.0 * H * W * NF
+        ms_h, g_h = host_leg(ref_h, comp_h, cfg, "pinned float32 frames")
+        floor = nbytes / (PCIE_GBS * 1e9) * 1e3
         h2d = {"value_incl_h2d": round(out_pix / (ms_h * 1e-3) / 1e6, 2), "ms_per_step_incl_h2d": round(ms_h, 3),
-               "steps": steps_h, "host_bytes_per_step": nbytes,
-               "pcie_floor_ms": round(nbytes / 63e9 * 1e3, 2),
-               "note": "frames start as pinned host float32; all uploads are queued up front, back to back on one "
-                       "upload stream (hipMemcpyAsync), each frame's kernels wait for its copy; PCIe Gen5 x16 spec 63 GB/s"}
-        # the same scope with the frames as the sensor's uint16 counts (what a DNG holds; the reference converts them
-        # to float32 on the host, utils_dng.py:149-160): half the PCIe bytes, normalised on the device per frame
+               "steps": steps_h, "host_bytes_per_step": nbytes, "pcie_floor_ms": round(floor, 2),
+               "pcie_floor_frac": round(floor / ms_h, 3), "graphs": g_h,
+               "note": "frames start as pinned host float32 (the reference's timer scope, super_resolution.py:103-195): "
+                       "uploads are eager hipMemcpyAsync calls back to back on one upload stream into static staging "
+                       "buffers, the kernels replay as per-chunk HIP graphs that wait for their frames' copies "
+                       "(graph.HostBurstRunner); pcie_floor = bytes / 63 GB/s (PCIe Gen5 x16 spec)"}
         if world == 1:
-            import copy
-
+            # the same scope with the frames as the sensor's uint16 counts (what a DNG holds; the reference converts them
+            # to float32 on the host, utils_dng.py:149-160): half the PCIe bytes, normalised on the device per frame
             black, white = 64.0, 1023.0
             to_counts = lambda t: torch.from_numpy(np.clip(np.rint(t.numpy() * (white - black) + black), 0, white)  # noqa: E731
                                                    .astype(np.uint16)).pin_memory()
             ref16, comp16 = to_counts(ref_h), [to_counts(c) for c in comp_h]
             cfg16 = copy.deepcopy(cfg)
             cfg16.hip = dict(cfg16.get("hip", None) or {}, raw_norm={"black_levels": [black] * 3, "white_level": white})
-            ms_16 = timed(lambda: hdist.main_sharded(ref16, comp16, cfg16, engine=engine_cls(cfg16), gather=args.gather)[0],
-                          steps_h, 2)
+            ms_16, g_16 = host_leg(ref16, comp16, cfg16, "pinned uint16 counts")
             h2d.update(value_incl_h2d_u16=round(out_pix / (ms_16 * 1e-3) / 1e6, 2), ms_per_step_incl_h2d_u16=round(ms_16, 3),
+                       pcie_floor_ms_u16=round(floor / 2, 2), pcie_floor_frac_u16=round(floor / 2 / ms_16, 3), graphs_u16=g_16,
                        note_u16="frames start as pinned host uint16 sensor counts (10-bit, black 64): uploaded as "
                                 "counts, normalised on the device frame by frame (hhsr_normalize_raw_u16)")
             del ref16, comp16
+            # the reference's literal call: main(ref, comp, config) with plain (pageable) NumPy float32 arrays
+            ref_np, comp_np = ref_h.numpy().copy(), np.stack([c.numpy() for c in comp_h])
+            cfg_np = copy.deepcopy(cfg)
+            fn_np = lambda: hsr.main(ref_np, comp_np, cfg_np)[0]  # noqa: E731
+            ms_np = timed(fn_np, steps_h, 3)
+            h2d.update(value_numpy_pageable=round(out_pix / (ms_np * 1e-3) / 1e6, 2), ms_per_step_numpy_pageable=round(ms_np, 3),
+                       note_numpy="hsr.main(ref, comp, config) on pageable NumPy float32 arrays, the same config object "
+                                  "call after call: 8 host threads copy the frames into page-locked staging while "
+                                  "earlier frames cross PCIe; fresh result tensor per call (one device copy)")
+            del ref_np, comp_np
         del ref_h, comp_h
 
     # ---- dominant-kernel roofline -------------------------------------------------------------------------------------
@@ -265,7 +304,10 @@ def main():
         # whole-image launch on one GPU; on N ranks each launch covers 1/N of the output rows (+ halo rows of input)
         nbytes = merge_burst_bytes(NF - 1, P, S) / world
         achieved = nbytes / (avg_ms * 1e-3) / 1e9
-        kernel = "k_merge_x2" if float(scale) == 2.0 else "k_merge_burst_tile"
+        # the kernel hhsr_merge_burst picks for this scale (csrc/hhsr_merge.hip: x2 and x3 have wave-per-parity-class
+        # kernels, other integer scales the tile kernel, non-integer scales the generic one)
+        kernel = ("k_merge_x2" if float(scale) == 2.0 else "k_merge_xs<3>" if float(scale) == 3.0 and W % 4 == 0
+                  else "k_merge_burst_tile" if float(scale).is_integer() else "k_merge_burst")
         traffic, valu, pmc_note = None, None, None
         try:  # HBM bytes / VALU instructions per launch from the committed rocprofv3 --pmc passes of this exact kernel
             with open(os.path.join(ROOT, "profiles", "r02_pmc_merge.json")) as f:
@@ -352,9 +394,15 @@ def main():
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"{H}x{W} Bayer burst, {NF} frames, x{scale} SR, Ts={cfg.block_matching.tuning.tile_size}, "
                                    f"metrics={cfg.block_matching.tuning.metrics}, robustness on, frames resident in HBM",
-                       "parallelism": (f"{world} ranks: alignment frame-parallel, all-gather of flows, merge row-parallel, "
-                                       f"output {'gathered to rank 0' if args.gather else 'sharded by rows'}")
+                       "l1_semantics": "intended (SAD argmin; the reference's level-0 L1 kernel is undefined behaviour "
+                                       "upstream, SURVEY.md App. A D1: block_matching.py:168-180; oracle-defined, unpinned)",
+                       "parallelism": ((f"{world} ranks, strategy rows: alignment frame-parallel, all-gather of flows, merge "
+                                        f"row-parallel" if args.strategy == "rows" else
+                                        f"{world} ranks, strategy reduce: frames one per rank, reduce-scatter of the float32 "
+                                        f"accumulators over row slabs") +
+                                       f", output {'gathered to rank 0' if args.gather else 'sharded by rows'}")
                        if world > 1 else "single GPU"},
+            "strategy": args.strategy if world > 1 else None,
             "launch": (("HIP graph replay: the step is captured once (stream capture incl. the frame pipeline's side "
                         "streams) and replayed with one launch per burst; every kernel runs on every step" if world == 1
                         else "HIP graph replay of the two per-rank steps (alignment of the rank's frames; robustness + "

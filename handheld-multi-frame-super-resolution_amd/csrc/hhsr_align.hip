@@ -587,14 +587,23 @@ struct Stage2D {  // N x N window, lane -> (row lane / CW + k * (64 / CW), colum
     static constexpr int RPP = HHSR_WAVE / CW, NK = (N + RPP - 1) / RPP;
 };
 
+struct AlignFrames {  // blockIdx.y = frame of the batch (the frames share the reference level)
+    const float* mov[HHSR_MAX_BATCH];
+    float* flow[HHSR_MAX_BATCH];
+    const float2* coarse[HHSR_MAX_BATCH];  // all NULL or all set
+};
+
 template <int TS, int R, bool L1>
 __global__ void __launch_bounds__(256) k_align_wave(const float* __restrict__ ref, int rh, int rw, int ref_pitch,
-                                                     const float* __restrict__ hess, const float* __restrict__ mov,
-                                                     int mh, int mw, int mov_pitch, float* __restrict__ flow, int nx,
+                                                     const float* __restrict__ hess, AlignFrames fr,
+                                                     int mh, int mw, int mov_pitch, int nx,
                                                      int ntiles, int mode, int n_iter,
-                                                     const float2* __restrict__ coarse, int cny, int cnx, int rep,
+                                                     int cny, int cnx, int rep,
                                                      float mult) {
     constexpr int r = R;
+    const float* __restrict__ mov = fr.mov[blockIdx.y];
+    float* __restrict__ flow = fr.flow[blockIdx.y];
+    const float2* __restrict__ coarse = fr.coarse[blockIdx.y];
     extern __shared__ __attribute__((aligned(16))) float lds[];
     constexpr int M = ICA_M;
     constexpr int RS = TS + 2, RP = RS | 1;            // reference tile + halo
@@ -851,38 +860,59 @@ static size_t align_wave_lds(int ts, int r) {
     return (size_t)4 * ((RS * RP + WS * WP + 3) & ~3) * sizeof(float);
 }
 
-extern "C" int hhsr_align_level(const float* ref, int rh, int rw, int ref_pitch, const float* hess, const float* mov,
-                                int mh, int mw, int mov_pitch, float* flow, int ny, int nx, int ts, int r, int metric,
-                                int n_iter, const float* coarse_flow, int cny, int cnx, int rep, float mult,
-                                void* stream) {
-    HHSR_ARG(ref && hess && mov && flow && rh > 0 && rw > 0 && mh > 0 && mw > 0 && ny > 0 && nx > 0);
+extern "C" int hhsr_align_level_batch(const float* ref, int rh, int rw, int ref_pitch, const float* hess,
+                                      const float* const* movs, int n_frames, int mh, int mw, int mov_pitch,
+                                      float* const* flows, int ny, int nx, int ts, int r, int metric, int n_iter,
+                                      const float* const* coarse_flows, int cny, int cnx, int rep, float mult,
+                                      void* stream) {
+    HHSR_ARG(ref && hess && movs && flows && n_frames >= 0 && rh > 0 && rw > 0 && mh > 0 && mw > 0 && ny > 0 && nx > 0);
+    for (int n = 0; n < n_frames; ++n) HHSR_ARG(movs[n] && flows[n] && (!coarse_flows || coarse_flows[n]));
     HHSR_ARG(r >= 0 && n_iter > 0 && metric >= 0 && metric <= 2);  // 0 = L2, 1 = L1 (intended), 2 = L1_ref_effective
     HHSR_ARG(ts == 8 || ts == 16 || ts == 32);
     HHSR_ARG(metric == 0 || ts >= 16);  // block_matching.py:87: no L1 search for 8-pixel tiles
     HHSR_ARG(ny * ts <= rh && nx * ts <= rw);
     HHSR_ARG(r == 1 || r == 2 || r == 4);  // compiled search radii (other radii: hhsr_bm_* + hhsr_ica)
-    HHSR_ARG(!coarse_flow || (cny > 0 && cnx > 0 && rep > 0));
+    HHSR_ARG(!coarse_flows || (cny > 0 && cnx > 0 && rep > 0));
     const size_t l = align_wave_lds(ts, r);
     HHSR_ARG(l <= 64 * 1024);
     const int ntiles = nx * ny;
-    const dim3 g(hhsr_cdiv(ntiles, 4)), b(256);
+    const dim3 b(256);
     hipStream_t s = (hipStream_t)stream;
     const int mode = metric == 2 ? 1 : 0;
-#define ALW(TS, R, L1) hipLaunchKernelGGL((k_align_wave<TS, R, L1>), g, b, l, s, ref, rh, rw, ref_pitch, hess, mov, mh, \
-                                          mw, mov_pitch, flow, nx, ntiles, mode, n_iter, \
-                                          reinterpret_cast<const float2*>(coarse_flow), cny, cnx, rep, mult)
+    for (int n0 = 0; n0 < n_frames; n0 += HHSR_MAX_BATCH) {
+        const int nb = n_frames - n0 < HHSR_MAX_BATCH ? n_frames - n0 : HHSR_MAX_BATCH;
+        AlignFrames fr;
+        for (int k = 0; k < HHSR_MAX_BATCH; ++k) {
+            const int n = n0 + (k < nb ? k : 0);
+            fr.mov[k] = movs[n];
+            fr.flow[k] = flows[n];
+            fr.coarse[k] = coarse_flows ? reinterpret_cast<const float2*>(coarse_flows[n]) : nullptr;
+        }
+        const dim3 g(hhsr_cdiv(ntiles, 4), nb);
+#define ALW(TS, R, L1) hipLaunchKernelGGL((k_align_wave<TS, R, L1>), g, b, l, s, ref, rh, rw, ref_pitch, hess, fr, mh, \
+                                          mw, mov_pitch, nx, ntiles, mode, n_iter, cny, cnx, rep, mult)
 #define ALW_R(TS, L1) do { if (r == 1) ALW(TS, 1, L1); else if (r == 2) ALW(TS, 2, L1); else ALW(TS, 4, L1); } while (0)
-    if (metric == 0) {
-        if (ts == 8) ALW_R(8, false);
-        else if (ts == 16) ALW_R(16, false);
-        else ALW_R(32, false);
-    } else {
-        if (ts == 16) ALW_R(16, true);
-        else ALW_R(32, true);
-    }
+        if (metric == 0) {
+            if (ts == 8) ALW_R(8, false);
+            else if (ts == 16) ALW_R(16, false);
+            else ALW_R(32, false);
+        } else {
+            if (ts == 16) ALW_R(16, true);
+            else ALW_R(32, true);
+        }
 #undef ALW_R
 #undef ALW
+    }
     HHSR_LAUNCHED();
+}
+
+extern "C" int hhsr_align_level(const float* ref, int rh, int rw, int ref_pitch, const float* hess, const float* mov,
+                                int mh, int mw, int mov_pitch, float* flow, int ny, int nx, int ts, int r, int metric,
+                                int n_iter, const float* coarse_flow, int cny, int cnx, int rep, float mult,
+                                void* stream) {
+    HHSR_ARG(mov && flow);
+    return hhsr_align_level_batch(ref, rh, rw, ref_pitch, hess, &mov, 1, mh, mw, mov_pitch, &flow, ny, nx, ts, r, metric,
+                                  n_iter, coarse_flow ? &coarse_flow : nullptr, cny, cnx, rep, mult, stream);
 }
 
 // ---- flow upscaling (nearest) ---------------------------------------------------------------------

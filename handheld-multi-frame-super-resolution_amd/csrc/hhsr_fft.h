@@ -20,8 +20,11 @@ struct HhsrFft {
     int twlenM = 0, twlenH = 0;     // lengths of the per-pass twiddle tables
     int rb = 0;                     // rows per workgroup of the row kernels (4, 2 or 1 by LDS budget)
     int nc = 0;                     // kept columns per workgroup of the column kernel (2 or 1)
+    int batch = 1;                  // frames one launch may carry: T holds this many spectra, tstride elements apart
+    size_t tstride = 0;
 };
 
-bool hhsr_fft_create(HhsrFft& f, int H, int W);   // false: sizes unsupported (caller uses the library plans)
+bool hhsr_fft_create(HhsrFft& f, int H, int W, int batch);   // false: sizes unsupported (caller uses the library plans)
 void hhsr_fft_destroy(HhsrFft& f);
-int hhsr_fft_lowpass(const HhsrFft& f, const float* src, float* dst, hipStream_t s);
+// n frames: one launch per phase for every f.batch of them (row blocks of all frames walked by one resident round of workgroups)
+int hhsr_fft_lowpass(const HhsrFft& f, const float* const* srcs, float* const* dsts, int n, hipStream_t s);

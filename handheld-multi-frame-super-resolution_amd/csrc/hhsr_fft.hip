@@ -323,7 +323,7 @@ __device__ __forceinline__ void batched_for(int n, int tid, Load load, Store sto
 #define HHSR_FFT_XCD 1
 #endif
 template <int RB>
-__device__ __forceinline__ int row_block(int it, int H) {
+__device__ __forceinline__ int row_block(int it, int nblocks) {
     constexpr int G = (16 / (TB * RB)) > 0 ? 16 / (TB * RB) : 1;
     int blk;
     if (HHSR_FFT_XCD && (gridDim.x & 7) == 0) {
@@ -332,14 +332,23 @@ __device__ __forceinline__ int row_block(int it, int H) {
     } else {
         blk = (int)blockIdx.x + it * (int)gridDim.x;
     }
-    return blk * RB < H ? blk : -1;
+    return blk < nblocks ? blk : -1;
 }
 
 // Row kernels: RB rows per workgroup, transformed SIMULTANEOUSLY (RB x fewer barriers, RB x more independent
 // butterflies per thread).  LDS: tw[twlen] | RB x row[M]  (float2 each).
+// Frames of a batch: the row kernels walk the row blocks of ALL frames of the launch (block b of frame f is virtual block
+// f * nb + b), the column kernel takes the frame from blockIdx.y; frame f's spectrum is T + f * tstride.
+struct FftFrames {
+    const float* src[HHSR_MAX_BATCH];
+    float* dst[HHSR_MAX_BATCH];
+    int n;
+    size_t tstride;  // float2 elements between the spectra of consecutive frames
+};
+
 template <int RB>
-__global__ void __launch_bounds__(FFT_NT, FFT_ROWS_WPE) k_rows_fwd(const float* __restrict__ src, int H, int W,
-                                                                        float2* __restrict__ T, int Wk, HhsrRadices rad,
+__global__ void __launch_bounds__(FFT_NT, FFT_ROWS_WPE) k_rows_fwd(FftFrames fr, int H, int W,
+                                                                        float2* __restrict__ Tall, int Wk, HhsrRadices rad,
                                                                         const float2* __restrict__ twM, int twlen,
                                                                         const float2* __restrict__ twW) {
     extern __shared__ __attribute__((aligned(16))) float2 fl[];
@@ -349,8 +358,12 @@ __global__ void __launch_bounds__(FFT_NT, FFT_ROWS_WPE) k_rows_fwd(const float* 
     batched_for<float2>(twlen, tid, [&](int k) { return twM[k]; }, [&](int k, float2 v) { tw[k] = v; });
     // persistent workgroups: the grid is one resident round (HHSR_FFT_PERSIST), every workgroup walks the row blocks
     // (row_block): one twiddle copy and one dispatch per workgroup slot instead of per block
-    for (int it = 0, blk; (blk = row_block<RB>(it, H)) >= 0; ++it) {
+    const int nb = (H + RB - 1) / RB;
+    for (int it = 0, vblk; (vblk = row_block<RB>(it, nb * fr.n)) >= 0; ++it) {
     if (it) __syncthreads();  // the previous block's stores have read the buffer
+    const int frame = vblk / nb, blk = vblk - frame * nb;
+    const float* __restrict__ src = fr.src[frame];
+    float2* __restrict__ T = Tall + (size_t)frame * fr.tstride;
     const int y0 = blk * RB;
     const int nrows = min(RB, H - y0);
     if ((M & 1) == 0 && (W & 3) == 0) {  // two complex samples (16 bytes) per lane
@@ -389,7 +402,7 @@ __global__ void __launch_bounds__(FFT_NT, FFT_ROWS_WPE) k_rows_fwd(const float* 
 // Column kernel: TWO adjacent kept columns per workgroup (one 16-byte load per row serves both), transformed
 // simultaneously.  LDS: tw[twlen] | 2 x col[H]
 template <int NC>  // kept columns per workgroup: 2 (one 16-byte load per row serves both) or 1 (long columns)
-__global__ void __launch_bounds__(FFT_NT, FFT_COLS_WPE) k_cols(float2* __restrict__ T, int H, int W, int Wk,
+__global__ void __launch_bounds__(FFT_NT, FFT_COLS_WPE) k_cols(float2* __restrict__ Tall, size_t tstride, int H, int W, int Wk,
                                                                     HhsrRadices rad, const float2* __restrict__ twH,
                                                                     int twlen, float norm) {
     extern __shared__ __attribute__((aligned(16))) float2 fl[];
@@ -400,6 +413,7 @@ __global__ void __launch_bounds__(FFT_NT, FFT_COLS_WPE) k_cols(float2* __restric
     const int per = 8 / NC;  // workgroups per 8-column block
     const int kx = 8 * (xcd + 8 * (loc / per)) + NC * (loc % per);
     if (kx >= Wk) return;
+    float2* __restrict__ T = Tall + (size_t)blockIdx.y * tstride;  // blockIdx.y: frame of the batch
     float2* tw = fl;
     float2* buf = tw + ((twlen + 1) & ~1);  // 16-byte aligned
     float2* colb = T + ((size_t)(kx / TB) * H) * TB + (kx % TB);  // row y at colb[TB y]
@@ -435,8 +449,8 @@ __global__ void __launch_bounds__(FFT_NT, FFT_COLS_WPE) k_cols(float2* __restric
 }
 
 template <int RB>
-__global__ void __launch_bounds__(FFT_NT, FFT_ROWS_WPE) k_rows_inv(const float2* __restrict__ T, int H, int W, int Wk,
-                                                                        float* __restrict__ dst, HhsrRadices rad,
+__global__ void __launch_bounds__(FFT_NT, FFT_ROWS_WPE) k_rows_inv(const float2* __restrict__ Tall, int H, int W, int Wk,
+                                                                        FftFrames fr, HhsrRadices rad,
                                                                         const float2* __restrict__ twM, int twlen,
                                                                         const float2* __restrict__ twW) {
     extern __shared__ __attribute__((aligned(16))) float2 fl[];
@@ -444,8 +458,12 @@ __global__ void __launch_bounds__(FFT_NT, FFT_ROWS_WPE) k_rows_inv(const float2*
     float2* tw = fl;
     float2* buf = tw + ((twlen + 1) & ~1);  // 16-byte aligned
     batched_for<float2>(twlen, tid, [&](int k) { return twM[k]; }, [&](int k, float2 v) { tw[k] = v; });
-    for (int it = 0, blk; (blk = row_block<RB>(it, H)) >= 0; ++it) {  // persistent workgroups, see k_rows_fwd
+    const int nb = (H + RB - 1) / RB;
+    for (int it = 0, vblk; (vblk = row_block<RB>(it, nb * fr.n)) >= 0; ++it) {  // persistent workgroups, see k_rows_fwd
     if (it) __syncthreads();
+    const int frame = vblk / nb, blk = vblk - frame * nb;
+    const float2* __restrict__ T = Tall + (size_t)frame * fr.tstride;
+    float* __restrict__ dst = fr.dst[frame];
     const int y0 = blk * RB;
     const int nrows = min(RB, H - y0);
     // Z[k] = 1/2 [(X[k] + conj X[M-k]) + i conj(w_k) (X[k] - conj X[M-k])] with X = 0 above the kept band, stored
@@ -596,8 +614,9 @@ static int pick_rb(int M, HhsrRadices& rad) {
     return 0;
 }
 
-bool hhsr_fft_create(HhsrFft& f, int H, int W) {
+bool hhsr_fft_create(HhsrFft& f, int H, int W, int batch) {
     f = HhsrFft();
+    if (batch < 1 || batch > HHSR_MAX_BATCH) return false;
     if (W % 2 || H < 2 || W < 4) return false;
     const int M = W / 2;
     if (M >= 65536 || H >= 65536) return false;
@@ -633,7 +652,9 @@ bool hhsr_fft_create(HhsrFft& f, int H, int W) {
     f.twM = upload(hM);
     f.twH = upload(hH);
     f.twW = upload(plain_twiddles(M, (double)W));  // exp(-2 pi i k / W), k < M
-    if (hipMalloc((void**)&f.T, sizeof(float2) * (size_t)((Wk + 7) / 8) * 8 * H) != hipSuccess) f.T = nullptr;
+    f.batch = batch;
+    f.tstride = (size_t)((Wk + 7) / 8) * 8 * H;  // one spectrum per frame of a batch
+    if (hipMalloc((void**)&f.T, sizeof(float2) * f.tstride * batch) != hipSuccess) f.T = nullptr;
     if (!f.twM || !f.twH || !f.twW || !f.T) {
         hhsr_fft_destroy(f);
         return false;
@@ -650,26 +671,35 @@ void hhsr_fft_destroy(HhsrFft& f) {
     f = HhsrFft();
 }
 
-int hhsr_fft_lowpass(const HhsrFft& f, const float* src, float* dst, hipStream_t s) {
+int hhsr_fft_lowpass(const HhsrFft& f, const float* const* srcs, float* const* dsts, int n, hipStream_t s) {
     // row kernels: at most one resident round of workgroups (3 per CU by their 48 kB of LDS), each walking several blocks
     static const int persist = getenv("HHSR_FFT_PERSIST") ? atoi(getenv("HHSR_FFT_PERSIST")) : 768;
-    const int nrb_all = hhsr_cdiv(f.H, f.rb);
-    const int nrb = persist > 0 && persist < nrb_all ? persist : nrb_all;
     // unnormalised inverse transforms multiply by (W/2) and H
     const float norm = (float)(1.0 / ((double)(f.W / 2) * (double)f.H));
-#define ROWS_FWD(RB) hipLaunchKernelGGL(k_rows_fwd<RB>, dim3(nrb), dim3(FFT_NT), f.lds_rows, s, src, f.H, f.W, f.T, f.Wk, \
+    for (int n0 = 0; n0 < n; n0 += f.batch) {  // the plan holds f.batch spectra: longer lists run in rounds
+        FftFrames fr;
+        fr.n = n - n0 < f.batch ? n - n0 : f.batch;
+        fr.tstride = f.tstride;
+        for (int k = 0; k < HHSR_MAX_BATCH; ++k) {
+            fr.src[k] = srcs[n0 + (k < fr.n ? k : 0)];
+            fr.dst[k] = dsts[n0 + (k < fr.n ? k : 0)];
+        }
+        const int nrb_all = hhsr_cdiv(f.H, f.rb) * fr.n;
+        const int nrb = persist > 0 && persist < nrb_all ? persist : nrb_all;
+#define ROWS_FWD(RB) hipLaunchKernelGGL(k_rows_fwd<RB>, dim3(nrb), dim3(FFT_NT), f.lds_rows, s, fr, f.H, f.W, f.T, f.Wk, \
                                         f.radM, f.twM, f.twlenM, f.twW)
-#define ROWS_INV(RB) hipLaunchKernelGGL(k_rows_inv<RB>, dim3(nrb), dim3(FFT_NT), f.lds_rows, s, f.T, f.H, f.W, f.Wk, dst, \
+#define ROWS_INV(RB) hipLaunchKernelGGL(k_rows_inv<RB>, dim3(nrb), dim3(FFT_NT), f.lds_rows, s, f.T, f.H, f.W, f.Wk, fr, \
                                         f.radM, f.twM, f.twlenM, f.twW)
-    if (f.rb == 4) ROWS_FWD(4); else if (f.rb == 2) ROWS_FWD(2); else ROWS_FWD(1);
-    if (f.nc == 2)
-        hipLaunchKernelGGL(k_cols<2>, dim3(((f.Wk + 63) / 64) * 32), dim3(FFT_NT), f.lds_cols, s, f.T, f.H, f.W, f.Wk,
-                           f.radH, f.twH, f.twlenH, norm);
-    else
-        hipLaunchKernelGGL(k_cols<1>, dim3(((f.Wk + 63) / 64) * 64), dim3(FFT_NT), f.lds_cols, s, f.T, f.H, f.W, f.Wk,
-                           f.radH, f.twH, f.twlenH, norm);
-    if (f.rb == 4) ROWS_INV(4); else if (f.rb == 2) ROWS_INV(2); else ROWS_INV(1);
+        if (f.rb == 4) ROWS_FWD(4); else if (f.rb == 2) ROWS_FWD(2); else ROWS_FWD(1);
+        if (f.nc == 2)
+            hipLaunchKernelGGL(k_cols<2>, dim3(((f.Wk + 63) / 64) * 32, fr.n), dim3(FFT_NT), f.lds_cols, s, f.T, f.tstride,
+                               f.H, f.W, f.Wk, f.radH, f.twH, f.twlenH, norm);
+        else
+            hipLaunchKernelGGL(k_cols<1>, dim3(((f.Wk + 63) / 64) * 64, fr.n), dim3(FFT_NT), f.lds_cols, s, f.T, f.tstride,
+                               f.H, f.W, f.Wk, f.radH, f.twH, f.twlenH, norm);
+        if (f.rb == 4) ROWS_INV(4); else if (f.rb == 2) ROWS_INV(2); else ROWS_INV(1);
 #undef ROWS_FWD
 #undef ROWS_INV
+    }
     return hhsr_launch_status("hhsr_grey_lowpass");
 }

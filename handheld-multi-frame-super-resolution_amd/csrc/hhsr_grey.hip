@@ -110,7 +110,13 @@ extern "C" int hhsr_grey_plan_create(int H, int W, int flags, void** plan_out) {
     p->Wk = 0;
     for (int x = 0; x < p->Wh; ++x)
         if (host_kept(x, W) || host_kept(x == 0 ? 0 : W - x, W)) p->Wk = x + 1;
-    if ((flags & 4) && hhsr_fft_create(p->fft, H, W)) {  // fused kernels: no library plans needed
+    const int batch = (flags >> 8) & 0xff ? (flags >> 8) & 0xff : 1;  // HHSR_GREY_BATCH(n)
+    if (batch > HHSR_MAX_BATCH) {
+        hhsr_set_error("hhsr_grey_plan_create: batch %d > HHSR_MAX_BATCH", batch);
+        delete p;
+        return -1;
+    }
+    if ((flags & 4) && hhsr_fft_create(p->fft, H, W, batch)) {  // fused kernels: no library plans needed
         *plan_out = p;
         return 0;
     }
@@ -168,11 +174,23 @@ extern "C" int hhsr_grey_plan_destroy(void* plan) {
     return 0;
 }
 
+extern "C" int hhsr_grey_lowpass_batch(void* plan, const float* const* srcs, float* const* dsts, int n_frames, void* stream) {
+    HHSR_ARG(plan && srcs && dsts && n_frames >= 0);
+    for (int n = 0; n < n_frames; ++n) HHSR_ARG(srcs[n] && dsts[n]);
+    GreyPlan* p = static_cast<GreyPlan*>(plan);
+    if (p->fft.ok) return n_frames ? hhsr_fft_lowpass(p->fft, srcs, dsts, n_frames, (hipStream_t)stream) : 0;
+    for (int n = 0; n < n_frames; ++n) {  // library plans: one spectrum buffer, frame by frame
+        const int rc = hhsr_grey_lowpass(plan, srcs[n], dsts[n], stream);
+        if (rc) return rc;
+    }
+    return 0;
+}
+
 extern "C" int hhsr_grey_lowpass(void* plan, const float* src, float* dst, void* stream) {
     HHSR_ARG(plan && src && dst);
     GreyPlan* p = static_cast<GreyPlan*>(plan);
     hipStream_t s = (hipStream_t)stream;
-    if (p->fft.ok) return hhsr_fft_lowpass(p->fft, src, dst, s);
+    if (p->fft.ok) return hhsr_fft_lowpass(p->fft, &src, &dst, 1, s);
     hipfftComplex* sp = reinterpret_cast<hipfftComplex*>(p->spec);
     hipfftResult r = hipfftSetStream(p->r2c, s);
     if (r == HIPFFT_SUCCESS) r = hipfftSetStream(p->c2r, s);

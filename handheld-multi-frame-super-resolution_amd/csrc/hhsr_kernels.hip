@@ -171,6 +171,13 @@ constexpr int FS_IT = (FS_N + 255) / 256;
 struct FsCfa {
     uint8_t c[4];
 };
+struct FsFrames {  // blockIdx.z = frame of the batch
+    const float* raw[HHSR_MAX_BATCH];
+    float* means[HHSR_MAX_BATCH];   // [3][gh][gw] or NULL
+    float* vars[HHSR_MAX_BATCH];    // [3][gh][gw] or NULL
+    float4* covs[HHSR_MAX_BATCH];   // [gh][gw] or NULL
+};
+
 struct FrameStatsArgs {
     const float* raw;
     int pitch, gh, gw;
@@ -185,7 +192,11 @@ struct FrameStatsArgs {
 };
 
 template <bool STATS, bool COV>
-__global__ void __launch_bounds__(256) k_frame_stats(FrameStatsArgs A) {
+__global__ void __launch_bounds__(256) k_frame_stats(FrameStatsArgs A, FsFrames fr) {
+    A.raw = fr.raw[blockIdx.z];
+    A.means = fr.means[blockIdx.z];
+    A.vars = fr.vars[blockIdx.z];
+    A.covs = fr.covs[blockIdx.z];
     __shared__ float s_ch[STATS ? 3 : 1][STATS ? FS_TY + 2 : 1][FS_P];
     __shared__ float s_g[COV ? (FS_TY + 2) * FS_P : 1];
     const int bid = xcd_remap(blockIdx.y * gridDim.x + blockIdx.x, gridDim.x * gridDim.y);  // bands of tile rows per XCD
@@ -285,25 +296,43 @@ __global__ void __launch_bounds__(256) k_frame_stats(FrameStatsArgs A) {
     }
 }
 
-static int frame_stats_launch(const float* raw, int H, int W, int pitch, const uint8_t* cfa, const double* wb,
-                              float* means, float* vars, float* covs, const CovParams& P, void* stream) {
+static int frame_stats_launch_batch(const float* const* raws, int n_frames, int H, int W, int pitch, const uint8_t* cfa,
+                                    const double* wb, float* const* means, float* const* vars, float* const* covs,
+                                    const CovParams& P, void* stream) {
     FrameStatsArgs A;
-    A.raw = raw; A.pitch = pitch; A.gh = H / 2; A.gw = W / 2;
+    A.raw = nullptr; A.pitch = pitch; A.gh = H / 2; A.gw = W / 2;
     for (int k = 0; k < 4; ++k) A.cfa.c[k] = cfa ? cfa[k] : 0;
     for (int k = 0; k < 3; ++k) A.rwb[k] = wb ? 1.0 / wb[k] : 1.0;
     for (int k = 0; k < 4; ++k) A.rwbk[k] = A.rwb[A.cfa.c[k]];
     const int code = A.cfa.c[0] * 27 + A.cfa.c[1] * 9 + A.cfa.c[2] * 3 + A.cfa.c[3];
     A.pat = code == 0 * 27 + 1 * 9 + 1 * 3 + 2 ? 0 : code == 2 * 27 + 1 * 9 + 1 * 3 + 0 ? 1
           : code == 1 * 27 + 0 * 9 + 2 * 3 + 1 ? 2 : code == 1 * 27 + 2 * 9 + 0 * 3 + 1 ? 3 : -1;
-    A.means = means; A.vars = vars; A.covs = reinterpret_cast<float4*>(covs); A.P = P;
+    A.means = nullptr; A.vars = nullptr; A.covs = nullptr; A.P = P;
     A.P.r_D_tr = 1.0 / P.D_tr;
     A.P.inv_k_shrink = 1.0 / P.k_shrink;
-    const dim3 grid(hhsr_cdiv(A.gw, FS_TX), hhsr_cdiv(A.gh, FS_TY)), block(256);
     hipStream_t s = (hipStream_t)stream;
-    if (means && covs) hipLaunchKernelGGL((k_frame_stats<true, true>), grid, block, 0, s, A);
-    else if (means) hipLaunchKernelGGL((k_frame_stats<true, false>), grid, block, 0, s, A);
-    else hipLaunchKernelGGL((k_frame_stats<false, true>), grid, block, 0, s, A);
+    for (int n0 = 0; n0 < n_frames; n0 += HHSR_MAX_BATCH) {
+        const int nb = n_frames - n0 < HHSR_MAX_BATCH ? n_frames - n0 : HHSR_MAX_BATCH;
+        FsFrames fr;
+        for (int k = 0; k < HHSR_MAX_BATCH; ++k) {
+            const int n = n0 + (k < nb ? k : 0);
+            fr.raw[k] = raws[n];
+            fr.means[k] = means ? means[n] : nullptr;
+            fr.vars[k] = vars ? vars[n] : nullptr;
+            fr.covs[k] = covs ? reinterpret_cast<float4*>(covs[n]) : nullptr;
+        }
+        const dim3 grid(hhsr_cdiv(A.gw, FS_TX), hhsr_cdiv(A.gh, FS_TY), nb), block(256);
+        if (means && covs) hipLaunchKernelGGL((k_frame_stats<true, true>), grid, block, 0, s, A, fr);
+        else if (means) hipLaunchKernelGGL((k_frame_stats<true, false>), grid, block, 0, s, A, fr);
+        else hipLaunchKernelGGL((k_frame_stats<false, true>), grid, block, 0, s, A, fr);
+    }
     return hhsr_launch_status("hhsr_frame_stats");
+}
+
+static int frame_stats_launch(const float* raw, int H, int W, int pitch, const uint8_t* cfa, const double* wb,
+                              float* means, float* vars, float* covs, const CovParams& P, void* stream) {
+    return frame_stats_launch_batch(&raw, 1, H, W, pitch, cfa, wb, means ? &means : nullptr, vars ? &vars : nullptr,
+                                    covs ? &covs : nullptr, P, stream);
 }
 
 extern "C" int hhsr_cov_from_raw(const float* raw, int H, int W, int pitch, float* covs, double alpha, double beta,
@@ -338,6 +367,20 @@ extern "C" int hhsr_frame_stats(const float* raw, int H, int W, int pitch, const
     for (int k = 0; k < 3; ++k) HHSR_ARG(wb[k] != 0.0);
     CovParams P{alpha, beta, k_detail, k_denoise, D_th, D_tr, k_stretch, k_shrink, law};
     return frame_stats_launch(raw, H, W, pitch, cfa, wb, means, vars, covs, P, stream);
+}
+
+extern "C" int hhsr_frame_stats_batch(const float* const* raws, int n_frames, int H, int W, int pitch, const uint8_t cfa[4],
+                                      const double* wb, float* const* means, float* const* covs, double alpha,
+                                      double beta, double k_detail, double k_denoise, double D_th, double D_tr,
+                                      double k_stretch, double k_shrink, int law, void* stream) {
+    HHSR_ARG(raws && cfa && wb && means && covs && n_frames >= 0 && H >= 2 && W >= 2 && pitch >= W && (pitch & 1) == 0);
+    for (int n = 0; n < n_frames; ++n)
+        HHSR_ARG(raws[n] && means[n] && covs[n] && ((uintptr_t)raws[n] & 7) == 0 && ((uintptr_t)covs[n] & 15) == 0);
+    HHSR_ARG(alpha > 0.0 && (law == 0 || law == 1));
+    for (int k = 0; k < 4; ++k) HHSR_ARG(cfa[k] <= 2);
+    for (int k = 0; k < 3; ++k) HHSR_ARG(wb[k] != 0.0);
+    CovParams P{alpha, beta, k_detail, k_denoise, D_th, D_tr, k_stretch, k_shrink, law};
+    return frame_stats_launch_batch(raws, n_frames, H, W, pitch, cfa, wb, means, nullptr, covs, P, stream);
 }
 
 // ---- monochrome sensors (`mode: grey`) ---------------------------------------------------------------------------

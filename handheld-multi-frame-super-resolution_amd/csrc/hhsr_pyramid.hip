@@ -84,10 +84,17 @@ constexpr int GD_TX = 32, GD_TY = 16;  // output tile per 256-thread workgroup
 // tap order — the association of the reference's two chained valid conv2d calls.  F and the tap count
 // NT = 4F+1 are compile-time so that the tile loads are issued back to back (a runtime-bound load->LDS
 // loop serialises on memory latency) and the tap loops unroll.
+struct GdFrames {  // blockIdx.z = frame of the batch
+    const float* src[HHSR_MAX_BATCH];
+    float* dst[HHSR_MAX_BATCH];
+};
+
 template <int F>
-__global__ void __launch_bounds__(256) k_gauss_decimate(const float* __restrict__ src, int H, int W, int sp,
-                                                         float* __restrict__ dst, int h2, int w2, int dp, Taps taps) {
+__global__ void __launch_bounds__(256) k_gauss_decimate(GdFrames fr, int H, int W, int sp,
+                                                         int h2, int w2, int dp, Taps taps) {
     extern __shared__ float lds[];
+    const float* __restrict__ src = fr.src[blockIdx.z];
+    float* __restrict__ dst = fr.dst[blockIdx.z];
     constexpr int f = F, nt = 4 * F + 1;
     constexpr int IH = (GD_TY - 1) * f + nt, IW = (GD_TX - 1) * f + nt;
     constexpr int IWp = IW | 1;  // odd pitch: the strided column reads below stay <= 2-way conflicted
@@ -135,10 +142,12 @@ __global__ void __launch_bounds__(256) k_gauss_decimate(const float* __restrict_
     }
 }
 
-extern "C" int hhsr_gauss_decimate(const float* src, int H, int W, int src_pitch, float* dst, int dst_pitch,
-                                   int factor, const float* taps, int ntaps, void* stream) {
-    HHSR_ARG(src && dst && taps && H > 0 && W > 0 && src_pitch >= W);
+extern "C" int hhsr_gauss_decimate_batch(const float* const* srcs, int n_frames, int H, int W, int src_pitch,
+                                         float* const* dsts, int dst_pitch, int factor, const float* taps, int ntaps,
+                                         void* stream) {
+    HHSR_ARG(srcs && dsts && taps && n_frames >= 0 && H > 0 && W > 0 && src_pitch >= W);
     HHSR_ARG((factor == 2 || factor == 4) && ntaps == 4 * factor + 1);  // the reference's kernels: radius int(2f + 0.5)
+    for (int n = 0; n < n_frames; ++n) HHSR_ARG(srcs[n] && dsts[n]);
     const int r = (ntaps - 1) / 2;
     const int h2 = (H - 2 * r) / factor, w2 = (W - 2 * r) / factor;
     HHSR_ARG(h2 > 0 && w2 > 0 && dst_pitch >= w2);
@@ -146,12 +155,26 @@ extern "C" int hhsr_gauss_decimate(const float* src, int H, int W, int src_pitch
     for (int i = 0; i < HHSR_MAX_TAPS; ++i) t.g[i] = i < ntaps ? taps[i] : 0.f;
     const int IH = (GD_TY - 1) * factor + ntaps, IWp = ((GD_TX - 1) * factor + ntaps) | 1;
     const size_t lds = (size_t)(IH + GD_TY) * IWp * sizeof(float);
-    const dim3 g(hhsr_cdiv(w2, GD_TX), hhsr_cdiv(h2, GD_TY));
-    if (factor == 2)
-        hipLaunchKernelGGL(k_gauss_decimate<2>, g, dim3(256), lds, (hipStream_t)stream, src, H, W, src_pitch, dst, h2, w2,
-                           dst_pitch, t);
-    else
-        hipLaunchKernelGGL(k_gauss_decimate<4>, g, dim3(256), lds, (hipStream_t)stream, src, H, W, src_pitch, dst, h2, w2,
-                           dst_pitch, t);
+    for (int n0 = 0; n0 < n_frames; n0 += HHSR_MAX_BATCH) {
+        const int nb = n_frames - n0 < HHSR_MAX_BATCH ? n_frames - n0 : HHSR_MAX_BATCH;
+        GdFrames fr;
+        for (int k = 0; k < HHSR_MAX_BATCH; ++k) {
+            fr.src[k] = srcs[n0 + (k < nb ? k : 0)];
+            fr.dst[k] = dsts[n0 + (k < nb ? k : 0)];
+        }
+        const dim3 g(hhsr_cdiv(w2, GD_TX), hhsr_cdiv(h2, GD_TY), nb);
+        if (factor == 2)
+            hipLaunchKernelGGL(k_gauss_decimate<2>, g, dim3(256), lds, (hipStream_t)stream, fr, H, W, src_pitch, h2, w2,
+                               dst_pitch, t);
+        else
+            hipLaunchKernelGGL(k_gauss_decimate<4>, g, dim3(256), lds, (hipStream_t)stream, fr, H, W, src_pitch, h2, w2,
+                               dst_pitch, t);
+    }
     HHSR_LAUNCHED();
+}
+
+extern "C" int hhsr_gauss_decimate(const float* src, int H, int W, int src_pitch, float* dst, int dst_pitch,
+                                   int factor, const float* taps, int ntaps, void* stream) {
+    HHSR_ARG(src && dst);
+    return hhsr_gauss_decimate_batch(&src, 1, H, W, src_pitch, &dst, dst_pitch, factor, taps, ntaps, stream);
 }

@@ -92,16 +92,19 @@ extern "C" int hhsr_rob_upscale(const float* stats, int lh, int lw, const float*
 }
 
 // ---- flow irregularity S (robustness.py:570-612) ------------------------------------------------
+// rows_lo / rows_hi: tile rows that lie in memory before flow[0] / after flow[ny - 1] — `flow` is then a row slice of a
+// larger field (the row slabs of the multi-GPU path) and the 3 x 3 neighbourhood reads them, so that the weights of the
+// slice's first and last rows are those of the full field.
 __global__ void __launch_bounds__(256) k_rob_s(const float2* __restrict__ flow, int ny, int nx, double Mt2, float s1,
-                                                float s2, float* __restrict__ S) {
+                                                float s2, float* __restrict__ S, int rows_lo, int rows_hi) {
     const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
     if (x >= nx) return;
     float mnx = INFINITY, mny = INFINITY, mxx = -INFINITY, mxy = -INFINITY;
     for (int i = -1; i <= 1; ++i)
         for (int j = -1; j <= 1; ++j) {
             const int yy = y + i, xx = x + j;
-            if (yy >= 0 && yy < ny && xx >= 0 && xx < nx) {
-                const float2 f = flow[(size_t)yy * nx + xx];
+            if (yy >= -rows_lo && yy < ny + rows_hi && xx >= 0 && xx < nx) {
+                const float2 f = flow[(ptrdiff_t)yy * nx + xx];
                 mxx = fmaxf(mxx, f.x); mxy = fmaxf(mxy, f.y);
                 mnx = fminf(mnx, f.x); mny = fminf(mny, f.y);
             }
@@ -111,10 +114,12 @@ __global__ void __launch_bounds__(256) k_rob_s(const float2* __restrict__ flow, 
     S[(size_t)y * nx + x] = ((double)m > Mt2) ? s1 : s2;
 }
 
-extern "C" int hhsr_rob_s(const float* flow, int ny, int nx, double Mt, float s1, float s2, float* S, void* stream) {
-    HHSR_ARG(flow && S && ny > 0 && nx > 0);
+extern "C" int hhsr_rob_s(const float* flow, int ny, int nx, double Mt, float s1, float s2, float* S, int rows_before,
+                          int rows_after, void* stream) {
+    HHSR_ARG(flow && S && ny > 0 && nx > 0 && rows_before >= 0 && rows_after >= 0);
     hipLaunchKernelGGL(k_rob_s, dim3(hhsr_cdiv(nx, 256), ny), dim3(256), 0, (hipStream_t)stream,
-                       reinterpret_cast<const float2*>(flow), ny, nx, Mt * Mt, s1, s2, S);  // float64 like the reference's M_th
+                       reinterpret_cast<const float2*>(flow), ny, nx, Mt * Mt, s1, s2, S, rows_before,
+                       rows_after);  // float64 like the reference's M_th
     HHSR_LAUNCHED();
 }
 
@@ -695,7 +700,7 @@ __global__ void __launch_bounds__(256) k_rob_frames_row4(RobGroup gq, int lh, in
                                                           const float* __restrict__ ssq,
                                                           const uint32_t* __restrict__ cidx, int ny, int nx, int ts,
                                                           const double* __restrict__ difc, double t, int H, int W,
-                                                          double Mt2, float s1, float s2) {
+                                                          double Mt2, float s1, float s2, int rows_lo, int rows_hi) {
     __shared__ float s_g[2][2][3][RF_WN][RF_WN + 2];
     __shared__ float4 s_tab[ROB_GROUP][2][2][2];  // per (frame, sub-tile): flow split, window origin, S — see below
     const int lx4 = threadIdx.x & 7, ly_ = threadIdx.x >> 3;  // 8 threads x 4 pixels per row, 32 rows
@@ -756,8 +761,8 @@ __global__ void __launch_bounds__(256) k_rob_frames_row4(RobGroup gq, int lh, in
             for (int i = -1; i <= 1; ++i)
                 for (int j = -1; j <= 1; ++j) {
                     const int yy = tiy + i, xx = tix + j;
-                    if (yy >= 0 && yy < ny && xx >= 0 && xx < nx) {
-                        const float2 q = gq.flow[fr][(size_t)yy * nx + xx];
+                    if (yy >= -rows_lo && yy < ny + rows_hi && xx >= 0 && xx < nx) {  // (see k_rob_s)
+                        const float2 q = gq.flow[fr][(ptrdiff_t)yy * nx + xx];
                         mxx = fmaxf(mxx, q.x); mxy = fmaxf(mxy, q.y);
                         mnx = fminf(mnx, q.x); mny = fminf(mny, q.y);
                     }
@@ -836,8 +841,9 @@ extern "C" int hhsr_rob_frame(const float* comp_means, int lh, int lw, const flo
 extern "C" int hhsr_rob_frames(const float* const* comp_means, int n_frames, int lh, int lw, const float* ref_means,
                                const float* ref_sigma_sq, const uint32_t* ref_curve_index, const float* const* flows,
                                int ny, int nx, int ts, const float* const* S, double Mt, float s1, float s2,
-                               const double* diff_curve, int ncurve, double t, float* const* R, void* stream) {
-    HHSR_ARG(comp_means && flows && R && n_frames >= 0);
+                               const double* diff_curve, int ncurve, double t, float* const* R, int flow_rows_before,
+                               int flow_rows_after, void* stream) {
+    HHSR_ARG(comp_means && flows && R && n_frames >= 0 && flow_rows_before >= 0 && flow_rows_after >= 0);
     for (int n = 0; n < n_frames; ++n) HHSR_ARG(comp_means[n] && flows[n] && (!S || S[n]) && R[n]);
     HHSR_ARG(ref_means && ref_sigma_sq && diff_curve && lh > 0 && lw > 0 && ts > 0 && ncurve > 0);
     const int H = 2 * lh, W = 2 * lw;
@@ -870,7 +876,7 @@ extern "C" int hhsr_rob_frames(const float* const* comp_means, int n_frames, int
         }
         hipLaunchKernelGGL(k_rob_frames_row4, dim3(hhsr_cdiv(W, RF_BX), hhsr_cdiv(H, RF_BY)), dim3(256), 0,
                            (hipStream_t)stream, g, lh, lw, ref_means, ref_sigma_sq, ref_curve_index, ny, nx, ts, diff_curve, t,
-                           H, W, Mt * Mt, s1, s2);
+                           H, W, Mt * Mt, s1, s2, flow_rows_before, flow_rows_after);
     }
     HHSR_LAUNCHED();
 }

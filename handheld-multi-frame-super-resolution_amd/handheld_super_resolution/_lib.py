@@ -25,25 +25,29 @@ _SIGS = {
     "hhsr_lowpass_mask_r2c": [P, I, I, L, L, P],
     "hhsr_grey_plan_create": [I, I, I, PP],
     "hhsr_grey_lowpass": [P, P, P, P],
+    "hhsr_grey_lowpass_batch": [P, PP, PP, I, P],
     "hhsr_grey_plan_destroy": [P],
     "hhsr_pad_circular": [P, I, I, I, P, I, I, I, P],
     "hhsr_gauss_decimate": [P, I, I, I, P, I, I, FP, I, P],
+    "hhsr_gauss_decimate_batch": [PP, I, I, I, I, PP, I, I, FP, I, P],
     "hhsr_grad_hessian": [P, I, I, I, I, P, P, P, P],
     "hhsr_bm_l2": [P, I, P, I, I, I, P, I, I, I, I, P],
     "hhsr_bm_l1": [P, I, P, I, I, I, P, I, I, I, I, I, P],
     "hhsr_ica": [P, P, P, I, P, P, I, I, I, P, I, I, I, I, I, P],
     "hhsr_align_level": [P, I, I, I, P, P, I, I, I, P, I, I, I, I, I, I, P, I, I, I, F, P],
+    "hhsr_align_level_batch": [P, I, I, I, P, PP, I, I, I, I, PP, I, I, I, I, I, I, PP, I, I, I, F, P],
     "hhsr_flow_upscale_nearest": [P, I, I, P, I, I, I, F, P],
     "hhsr_cov_from_raw": [P, I, I, I, P, D, D, D, D, D, D, D, D, I, P],
     "hhsr_rob_stats": [P, I, I, I, U8P, DP, P, P, P],
     "hhsr_frame_stats": [P, I, I, I, U8P, DP, P, P, P, D, D, D, D, D, D, D, D, I, P],
+    "hhsr_frame_stats_batch": [PP, I, I, I, I, U8P, DP, PP, PP, D, D, D, D, D, D, D, D, I, P],
     "hhsr_normalize_raw_u16": [P, I, I, I, I, U8P, DP, D, DP, P, P],
     "hhsr_rob_upscale": [P, I, I, P, I, I, I, P, P],
-    "hhsr_rob_s": [P, I, I, D, F, F, P, P],
+    "hhsr_rob_s": [P, I, I, D, F, F, P, I, I, P],
     "hhsr_rob_sigma": [P, P, I, I, P, I, P, P, P],
     "hhsr_ref_planes": [P, P, I, I, P, I, P, P, P, P],
     "hhsr_rob_frame": [P, I, I, P, P, P, P, I, I, I, P, P, I, D, P, P],
-    "hhsr_rob_frames": [PP, I, I, I, P, P, P, PP, I, I, I, PP, D, F, F, P, I, D, PP, P],
+    "hhsr_rob_frames": [PP, I, I, I, P, P, P, PP, I, I, I, PP, D, F, F, P, I, D, PP, I, I, P],
     "hhsr_local_min5": [P, I, I, P, P, P],
     "hhsr_mono_frame_stats": [P, I, I, I, P, P, P, D, D, D, D, D, D, D, D, I, P],
     "hhsr_mono_rob_upscale": [P, I, I, P, I, I, I, P, P],
@@ -61,6 +65,7 @@ _SIGS = {
 
 MERGE_LOAD_ACC, MERGE_DO_REF, MERGE_DIVIDE, MERGE_STORE_DEN = 1, 2, 4, 8
 MAX_FRAMES = 64
+MAX_BATCH = 8  # HHSR_MAX_BATCH: frames per launch of the batched front-end entry points
 
 _lib = None
 

@@ -8,7 +8,7 @@ import torch.nn.functional as F
 from . import _lib
 from .ICA import init_ica, align_lvl_ica
 from .block_matching import align_lvl_block_matching_L2, align_lvl_block_matching_L1
-from .utils_image import cuda_downsample
+from .utils_image import cuda_downsample, cuda_downsample_batch
 
 
 def build_gaussian_pyramid(image, factors=[1, 2, 4, 4], kernel="gaussian"):
@@ -18,6 +18,14 @@ def build_gaussian_pyramid(image, factors=[1, 2, 4, 4], kernel="gaussian"):
         pyramid.append(cuda_downsample(pyramid[-1], kernel, factor))
     pyramid = [lvl.reshape(lvl.shape[-2:]) for lvl in pyramid]
     return pyramid[::-1]
+
+
+def build_gaussian_pyramids(images, factors=[1, 2, 4, 4]):
+    """build_gaussian_pyramid() of several frames of one shape, one launch per level (coarse first per frame)."""
+    levels = [cuda_downsample_batch(images, factors[0])]
+    for factor in factors[1:]:
+        levels.append(cuda_downsample_batch(levels[-1], factor))
+    return [[lvl[i] for lvl in levels[::-1]] for i in range(len(images))]
 
 
 def init_alignment(ref_img, config):
@@ -162,3 +170,48 @@ def align(ref_pyramid, tyled_pyr, ref_tiled_fft, ref_gradx, ref_grady, ref_hessi
         align_lvl(ref_pyramid[i], tyled_pyr[i], ref_tiled_fft[i], ref_gradx[i], ref_grady[i], ref_hessian[i],
                   moving_pyramid[i], alignments, l, config, coarse=coarse)
     return alignments
+
+
+def can_align_batch(config):
+    """Every level runs on the fused level kernel with the coarser flow read in place (see align())."""
+    bm = config.block_matching.tuning
+    n = len(bm.factors)
+    for l in range(n):
+        if _fused_level(l, config) is None:
+            return False
+        if l + 1 < n:
+            q = bm.tile_sizes[l] // bm.tile_sizes[l + 1]
+            if q <= 0 or bm.factors[l + 1] // q <= 0 or bm.flow_upscale_mode != "nearest":
+                return False
+    return True
+
+
+def align_batch(ref_pyramid, ref_hessian, moving_pyramids, config):
+    """align() of several frames against one reference pyramid: ONE launch per level for the whole chunk
+    (hhsr_align_level_batch) — the coarse levels are 7-27 us launches of a few hundred workgroups that cannot fill the
+    GPU one frame at a time.  Needs can_align_batch(config); per frame bit-identical to align().
+    Returns the list of finest-level flow fields (views of one [n, ny, nx, 2] tensor)."""
+    bm = config.block_matching.tuning
+    n_lvl, nf = len(ref_pyramid), len(moving_pyramids)
+    dev = moving_pyramids[0][0].device
+    prev = None
+    for i in range(n_lvl):
+        l = n_lvl - i - 1
+        code, ts, r = _fused_level(l, config)
+        ref_lvl = ref_pyramid[i]
+        rh, rw = ref_lvl.shape
+        ny, nx = rh // ts, rw // ts
+        movs = [p[i] for p in moving_pyramids]
+        mh, mw = movs[0].shape
+        flows = list(torch.empty((nf, ny, nx, 2), dtype=torch.float32, device=dev).unbind(0))
+        if prev is None:
+            cptr, cny, cnx, rep, mult = None, 0, 0, -1, 1.0
+        else:
+            q = bm.tile_sizes[l] // bm.tile_sizes[l + 1]
+            rep, mult = bm.factors[l + 1] // q, float(bm.factors[l + 1])
+            cptr, (cny, cnx) = _lib.ptr_array(prev), prev[0].shape[:2]
+        _lib.call("hhsr_align_level_batch", _lib.ptr(ref_lvl), rh, rw, rw, _lib.ptr(ref_hessian[i]), _lib.ptr_array(movs),
+                  nf, mh, mw, mw, _lib.ptr_array(flows), ny, nx, ts, r, code, int(config.ica.tuning.n_iter), cptr,
+                  int(cny), int(cnx), int(rep), float(mult), _lib.stream())
+        prev = flows
+    return prev

@@ -51,6 +51,29 @@ class Config(dict):
         super().__delitem__(k)
         object.__setattr__(self, "_ver", self.version() + 1)
 
+    # every mutating dict method goes through the edit counter (a graph replay must notice ANY in-place edit)
+    def setdefault(self, k, default=None):
+        if k not in self:
+            self[k] = default
+        return self[k]
+
+    def pop(self, k, *default):
+        if k in self:
+            v = self[k]
+            del self[k]
+            return v
+        if default:
+            return default[0]
+        raise KeyError(k)
+
+    def popitem(self):
+        k = next(reversed(self))
+        return k, self.pop(k)
+
+    def clear(self):
+        for k in list(self):
+            del self[k]
+
     def version(self):
         """Number of in-place edits of THIS mapping (not of nested ones): lets a long-lived consumer — the HIP-graph
         replay of distributed.HipEngine — notice that a configuration was mutated, as the reference's process() does."""

@@ -60,6 +60,24 @@ def frame_stats(img, cfa_pattern, white_balance, config, want_vars=False):
     return means, vars_, covs
 
 
+def frame_stats_batch(imgs, cfa_pattern, white_balance, config):
+    """frame_stats() of several comp frames of one shape in one launch (hhsr_frame_stats_batch): list of
+    (means [3, H/2, W/2], None, covs [H/2, W/2, 2, 2]); per frame bit-identical."""
+    from .robustness import _wb3
+
+    params = _kernel_params(config)
+    imgs = [_lib.f32c(i) for i in imgs]
+    H, W = imgs[0].shape
+    if H % 2 or W % 2:
+        raise ValueError(f"bayer frames need even dimensions, got {(H, W)}")
+    n, dev = len(imgs), imgs[0].device
+    means = list(torch.empty((n, 3, H // 2, W // 2), dtype=torch.float32, device=dev).unbind(0))
+    covs = list(torch.empty((n, H // 2, W // 2, 2, 2), dtype=torch.float32, device=dev).unbind(0))
+    _lib.call("hhsr_frame_stats_batch", _lib.ptr_array(imgs), n, H, W, W, _lib.cfa_bytes(cfa_pattern),
+              _lib.doubles(_wb3(white_balance)), _lib.ptr_array(means), _lib.ptr_array(covs), *params, _lib.stream())
+    return [(m, None, c) for m, c in zip(means, covs)]
+
+
 def mono_frame_stats(img, config, stats=True, covs=True, want_vars=False):
     """`mode: grey`: the per-frame pass of a monochrome frame — 3x3 local means (and variances) of the frame itself
     [1, H, W] (robustness.py:62-66, 269-294) and / or the per-pixel kernel covariances [H, W, 2, 2] (kernels.py:83-137)."""

@@ -70,11 +70,14 @@ def init_robustness(ref_img, cfa_pattern, white_balance, config):
     return upscale_warp_stats(m), upscale_warp_stats(v)
 
 
-def compute_s(flows, M_th, s1, s2):
-    """Per-tile flow-irregularity weight (robustness.py:530-612)."""
+def compute_s(flows, M_th, s1, s2, flow_rows=(0, 0)):
+    """Per-tile flow-irregularity weight (robustness.py:530-612).  `flow_rows` = (before, after): `flows` is a row
+    slice (a VIEW) of a larger field with that many tile rows around it in memory — the multi-GPU row slabs — and the
+    3 x 3 tile neighbourhood reads them, so the slice's first and last rows get the full field's weights."""
     ny, nx, _ = flows.shape
     S = torch.empty((ny, nx), dtype=torch.float32, device=flows.device)
-    _lib.call("hhsr_rob_s", _lib.ptr(flows), ny, nx, float(M_th), float(s1), float(s2), _lib.ptr(S), _lib.stream())
+    _lib.call("hhsr_rob_s", _lib.ptr(flows), ny, nx, float(M_th), float(s1), float(s2), _lib.ptr(S),
+              int(flow_rows[0]), int(flow_rows[1]), _lib.stream())
     return S
 
 
@@ -135,7 +138,7 @@ def ref_planes(guide_means, guide_vars, std_curve):
 
 def compute_robustness(comp_img, ref_local_means, ref_local_stds, flows, cfa_pattern, white_balance, noise_model,
                        config, return_R=False, accumulate_into=None, ref_sigma_sq=None, comp_means=None,
-                       fuse_local_min=False):
+                       fuse_local_min=False, flow_rows=(0, 0)):
     """Alg. 6 (robustness.py:79-170): r float32 [H, W].  3 kernels instead of the reference's 8:
     guide + local stats; fused warp-upsample / colour distance / noise model / threshold; 5x5 min."""
     comp_img = _lib.f32c(comp_img)
@@ -158,7 +161,7 @@ def compute_robustness(comp_img, ref_local_means, ref_local_stds, flows, cfa_pat
     cm = comp_means  # a BurstPipeline gets them from the fused per-frame pass (kernels.frame_stats)
     if cm is None:
         cm, _ = compute_local_stats_from_raw(comp_img, cfa_pattern, white_balance, want_vars=False)
-    S = compute_s(flows, t.Mt, t.s1, t.s2)
+    S = compute_s(flows, t.Mt, t.s1, t.s2, flow_rows)
     R = torch.empty((H, W), dtype=torch.float32, device=comp_img.device)
     sigma_sq, curve_index = ref_sigma_sq
     _lib.call("hhsr_rob_frame", _lib.ptr(cm), H // 2, W // 2, _lib.ptr(ref_local_means), _lib.ptr(sigma_sq),
@@ -203,7 +206,7 @@ def _compute_robustness_mono(comp_img, ref_local_means, ref_local_stds, flows, n
 
 
 def compute_robustness_group(comp_imgs, ref_local_means, flows, noise_model, config, ref_sigma_sq, comp_means,
-                             accumulate_into=None, fuse_local_min=False):
+                             accumulate_into=None, fuse_local_min=False, flow_rows=(0, 0)):
     """compute_robustness() for several frames of one burst: the fused kernel runs once per 4 frames and reads the
     reference-frame planes (20 of the 27 bytes per pixel and frame) once per group (hhsr_rob_frames); per frame the
     result is bit-identical to compute_robustness().  Needs the per-burst (sigma_sq, curve_index) and the frames' guide
@@ -219,12 +222,13 @@ def compute_robustness_group(comp_imgs, ref_local_means, flows, noise_model, con
     # per-frame fall-back kernels of hhsr_rob_frames need the S maps — same test as in the library
     inline_s = (int(ts) % 16 == 0 and W % 4 == 0 and curve_index is not None and diff_curve.numel() <= 1024
                 and not _NO_GROUP)
-    S = None if inline_s else [compute_s(f, t.Mt, t.s1, t.s2) for f in flows]
+    S = None if inline_s else [compute_s(f, t.Mt, t.s1, t.s2, flow_rows) for f in flows]
     R = [torch.empty((H, W), dtype=torch.float32, device=comp_imgs[0].device) for _ in flows]
     _lib.call("hhsr_rob_frames", _lib.ptr_array(comp_means), len(flows), H // 2, W // 2, _lib.ptr(ref_local_means),
               _lib.ptr(sigma_sq), _lib.ptr(curve_index), _lib.ptr_array(flows), ny, nx, int(ts),
               None if S is None else _lib.ptr_array(S), float(t.Mt), float(t.s1), float(t.s2),
-              _lib.ptr(diff_curve), int(diff_curve.numel()), float(t.t), _lib.ptr_array(R), _lib.stream())
+              _lib.ptr(diff_curve), int(diff_curve.numel()), float(t.t), _lib.ptr_array(R), int(flow_rows[0]),
+              int(flow_rows[1]), _lib.stream())
     if fuse_local_min:
         assert accumulate_into is None
         return R

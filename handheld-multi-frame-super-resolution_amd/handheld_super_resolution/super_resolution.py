@@ -16,13 +16,14 @@ import numpy as np
 import torch
 
 from . import _lib
-from .utils_image import compute_grey_images
+from .utils_image import compute_grey_images, compute_grey_images_batch
 from .utils import divide, add, getTime, timer
-from .alignment import align, init_alignment, build_gaussian_pyramid
+from .alignment import (align, init_alignment, build_gaussian_pyramid, build_gaussian_pyramids, align_batch,
+                        can_align_batch)
 from .params import sanitize_config, update_snr_config
 from .robustness import (init_robustness, compute_robustness, compute_robustness_group, noise_curves_to_device,
                          ref_planes, upscale_warp_stats, mono_sigma_sq)
-from .kernels import estimate_kernels, frame_stats
+from .kernels import estimate_kernels, frame_stats, frame_stats_batch
 from .merge import merge, merge_ref, merge_burst, can_fuse_acc_r, can_fuse_local_min
 
 
@@ -94,6 +95,13 @@ class BurstPipeline:
         self._inject_flows = hip.get("inject_flows", None) if hip is not None else None
         # frames given as integer sensor counts: {"black_levels": [R, G, B], "white_level": w} (see _ingest)
         self._raw_norm = hip.get("raw_norm", None) if hip is not None else None
+        # chunk-batched front end (one launch per stage for a chunk of frames, see _front_chunk); config.hip.batch: false
+        # keeps the per-frame launches (A/B, tests)
+        # (before, after): the flow fields handed to this pipeline are row slices (views) of larger fields with that many
+        # tile rows around them — the sub-image pipelines of distributed.py; see robustness.compute_s
+        self.flow_rows = (0, 0)
+        self._batch = (True if hip is None else bool(hip.get("batch", True))) and not self.mono \
+            and self.grey_method == "FFT" and config.verbose < 2
 
     def _ingest(self, img):
         """One frame -> float32 device tensor, on the current stream.  Float frames are the reference's call signature
@@ -102,9 +110,10 @@ class BurstPipeline:
         arithmetic (utils_dng.py:149-160, hhsr_normalize_raw_u16) using config.hip.raw_norm and config.exif."""
         staged = isinstance(img, _Staged)
         if staged:  # prefetch(): the copy was queued on the upload stream
-            cur = torch.cuda.current_stream(self.device)
-            cur.wait_event(img.event)
-            img.tensor.record_stream(cur)
+            if img.event is not None:  # (None: a static staging buffer of graph.HostBurstRunner, ordered by the runner)
+                cur = torch.cuda.current_stream(self.device)
+                cur.wait_event(img.event)
+                img.tensor.record_stream(cur)
             img = img.tensor
         t = img if torch.is_tensor(img) else torch.as_tensor(img)
         if t.dtype.is_floating_point:
@@ -210,12 +219,50 @@ class BurstPipeline:
             torch.cuda.current_stream(self.device).wait_event(self._align_ready)
         return align(*self.align_state, grey, cfg, moving_pyramid=pyramid)
 
+    def _align_chunk(self, imgs, wait_ref=None):
+        """align_frame() of a chunk of frames with ONE launch per stage (grey transform phases, pyramid levels,
+        alignment levels) when the configuration allows it; per frame bit-identical to align_frame()."""
+        cfg = self.config
+        if len(imgs) < 2 or not self._batch or not can_align_batch(cfg):
+            return [self.align_frame(img, wait_ref) for img in imgs]
+        raws = [self._ingest(img) for img in imgs]
+        pyramids = build_gaussian_pyramids(compute_grey_images_batch(raws, self.grey_method),
+                                           cfg.block_matching.tuning.factors)
+        if wait_ref is not None:
+            torch.cuda.current_stream(self.device).wait_event(self._align_ready)
+        return align_batch(self.align_state[0], self.align_state[5], pyramids, cfg)
+
     def align_frames(self, comp_imgs, n_streams=None):
-        """align_frame() over a list of frames, round-robin on the side streams (like process_frames)."""
+        """align_frame() over a list of frames: chunks of frames round-robin on the side streams (like process_frames)."""
         with torch.cuda.device(self.device):
             comp_imgs = self.prefetch([comp_imgs[i] for i in range(len(comp_imgs))])
-            return [f[0] for f in self._on_streams(len(comp_imgs), n_streams, False,
-                                                   lambda i, wait: (self.align_frame(comp_imgs[i], wait_ref=wait),))]
+            chunks = self._chunks(len(comp_imgs), n_streams)
+            out = self._on_streams(len(chunks), n_streams, False,
+                                   lambda ci, wait: self._align_chunk([comp_imgs[i] for i in chunks[ci]], wait_ref=wait))
+            return [f for chunk in out for f in chunk]
+
+    def _front_chunk(self, imgs, wait_ref, indices, flows):
+        """_front() of a chunk of frames.  With the default configuration (Bayer frames, FFT grey image, fused level
+        kernels) every stage is ONE launch for the whole chunk — 3 transform phases, 3 pyramid levels, 4 alignment
+        levels, 1 raw pass: 11 launches per chunk instead of per frame — and the latency-bound stages (FFT phases,
+        coarse pyramid / alignment levels: a few hundred workgroups per frame) see enough work to fill the GPU.
+        Results per frame are bit-identical to _front() (tests: batch == single)."""
+        cfg = self.config
+        inj = [None if flows is None else flows[i] for i in indices]
+        if flows is None and self._inject_flows is not None:
+            inj = [self._inject_flows[i] for i in indices]
+        if len(imgs) < 2 or not self._batch or not can_align_batch(cfg) or any(f is not None for f in inj):
+            return [self._front(img, wait_ref, i, f) for img, i, f in zip(imgs, indices, inj)]
+        raws = [self._ingest(img) for img in imgs]
+        pyramids = build_gaussian_pyramids(compute_grey_images_batch(raws, self.grey_method),
+                                           cfg.block_matching.tuning.factors)
+        if wait_ref is not None:
+            torch.cuda.current_stream(self.device).wait_event(self._align_ready)
+        fl = align_batch(self.align_state[0], self.align_state[5], pyramids, cfg)
+        if cfg.robustness.enabled:
+            stats = frame_stats_batch(raws, self.cfa, self.wb, cfg)
+            return [(raw, f, st[2], st[0]) for raw, f, st in zip(raws, fl, stats)]
+        return [(raw, f, estimate_kernels(raw, cfg), None) for raw, f in zip(raws, fl)]
 
     def _front(self, img, wait_ref=None, index=None, flow=None):
         """grey -> pyramid -> alignment -> guide means + kernel covariances of one comp frame:
@@ -250,11 +297,12 @@ class BurstPipeline:
             return [(raw, flow, covs,
                      rob(raw, self.ref_means, self.ref_vars, flow, self.cfa, self.wb, self.curves, cfg,
                                         accumulate_into=accumulate_r, ref_sigma_sq=self.ref_sigma_sq, comp_means=means,
-                                        fuse_local_min=fuse_local_min and cfg.robustness.enabled))
+                                        fuse_local_min=fuse_local_min and cfg.robustness.enabled,
+                                        flow_rows=self.flow_rows))
                     for raw, flow, covs, means in fronts]
         rs = compute_robustness_group([f[0] for f in fronts], self.ref_means, [f[1] for f in fronts], self.curves, cfg,
                                       self.ref_sigma_sq, [f[3] for f in fronts], accumulate_into=accumulate_r,
-                                      fuse_local_min=fuse_local_min)
+                                      fuse_local_min=fuse_local_min, flow_rows=self.flow_rows)
         return [(f[0], f[1], f[2], r) for f, r in zip(fronts, rs)]
 
     def process_frame(self, img, accumulate_r=None, wait_ref=None, fuse_local_min=False, index=None, flow=None):
@@ -283,24 +331,32 @@ class BurstPipeline:
         with torch.cuda.device(self.device):
             n = len(comp_imgs)
             comp_imgs = self.prefetch(comp_imgs)
-            streams = self._n_streams(n_streams)
-            # chunks of up to ROB_GROUP frames stay together on a stream: their robustness is one launch that reads the
-            # reference-frame planes once (hhsr_rob_frames); chunk sizes are balanced over the streams
-            n_chunks = min(n, streams * -(-n // (streams * ROB_GROUP))) if n else 0
-            chunks, i = [], 0
-            for c in range(n_chunks):
-                size = n // n_chunks + (1 if c < n % n_chunks else 0)
-                chunks.append(list(range(i, i + size)))
-                i += size
+            chunks = self._chunks(n, n_streams)
 
             def work(ci, wait):
-                fronts = [self._front(comp_imgs[i], wait, i, None if flows is None else flows[i]) for i in chunks[ci]]
+                fronts = self._front_chunk([comp_imgs[i] for i in chunks[ci]], wait, chunks[ci], flows)
                 if wait is not None:  # the robustness needs the second half of the reference precompute
                     torch.cuda.current_stream(self.device).wait_event(wait)
                 return self._robustness(fronts, accumulate_r if wait is None else None, fuse_local_min)
 
             out = self._on_streams(len(chunks), n_streams, accumulate_r is not None, work)
             return [f for chunk in out for f in chunk]
+
+    def _chunks(self, n, n_streams=None):
+        """Frame indices per chunk.  Chunks of up to `config.hip.chunk` (default ROB_GROUP) frames stay together on a
+        stream: their robustness is one launch per ROB_GROUP frames that reads the reference-frame planes once
+        (hhsr_rob_frames), and with the batched front end every stage is one launch per chunk; chunk sizes are balanced
+        over the streams."""
+        streams = self._n_streams(n_streams)
+        hip = self.config.get("hip", None) if hasattr(self.config, "get") else None
+        size = max(1, min(int(hip.get("chunk", ROB_GROUP)) if hip is not None else ROB_GROUP, _lib.MAX_BATCH))
+        n_chunks = min(n, streams * -(-n // (streams * size))) if n else 0
+        chunks, i = [], 0
+        for c in range(n_chunks):
+            k = n // n_chunks + (1 if c < n % n_chunks else 0)
+            chunks.append(list(range(i, i + k)))
+            i += k
+        return chunks
 
     def _n_streams(self, n_streams):
         if n_streams is None:
@@ -342,13 +398,50 @@ class BurstPipeline:
         return round(s * H), round(s * W)
 
 
-def main(ref_img, comp_imgs, config):
+_main_runners = []  # [(config, ConfigWatch, HostBurstRunner)], most recently used last
+
+
+def _host_runner(config, device):
+    """The HostBurstRunner of a configuration object that main() is called with again and again (a serving loop); a
+    configuration edited in place gets a new one.  At most two are kept (each holds a burst's intermediates)."""
+    from .graph import ConfigWatch, HostBurstRunner
+
+    for k, (cfg, watch, runner) in enumerate(_main_runners):
+        if cfg is config and runner.device == device:
+            _main_runners.append(_main_runners.pop(k))
+            if watch.changed(config):
+                _main_runners.pop()
+                break
+            return runner
+    watch = ConfigWatch()
+    watch.changed(config)
+    runner = HostBurstRunner(config, device)
+    _main_runners.append((config, watch, runner))
+    del _main_runners[:-2]
+    return runner
+
+
+def main(ref_img, comp_imgs, config, *, _no_runner=False):
     """Alg. 1 (reference super_resolution.py:41-200).
 
     ref_img [H, W], comp_imgs [N-1, H, W]: float32 NumPy arrays (as in the reference) or torch tensors
     (host or already device-resident).  Returns (num, debug_dict): num is the normalised RGB image,
     a float32 GPU tensor [sH, sW, 3] WITHOUT post-processing; debug_dict has 'flow' / 'robustness' lists
-    (NumPy, only if config.debug) and 'accumulated robustness' (GPU tensor) when the mask is requested."""
+    (NumPy, only if config.debug) and 'accumulated robustness' (GPU tensor) when the mask is requested.
+
+    Host-resident bursts (the reference's signature) that come back with the same configuration object, shapes and
+    dtype — a serving loop — run through graph.HostBurstRunner from the third call on: uploads as eager copies, the
+    kernels as per-chunk HIP graphs, bit-identical results; main() then returns when the host buffers may be refilled
+    (all uploads done) and hands out fresh tensors like the reference (one device copy of the result).
+    `config.hip.graph: false` keeps the eager path."""
+    if not _no_runner and torch.cuda.is_available():
+        from .graph import HostBurstRunner
+
+        if HostBurstRunner.usable(config, ref_img, comp_imgs):
+            out, dbg = _host_runner(config, _device())(ref_img, comp_imgs)
+            if "accumulated robustness" in dbg and dbg["accumulated robustness"] is not None:
+                dbg = dict(dbg, **{"accumulated robustness": dbg["accumulated robustness"].clone()})
+            return out.clone(), dbg
     verbose = config.verbose >= 1
     debug_mode = bool(config.debug)
     debug_dict = {"robustness": [], "flow": []}

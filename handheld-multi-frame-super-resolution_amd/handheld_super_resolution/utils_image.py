@@ -6,15 +6,18 @@ from . import _lib
 
 
 class _GreyPlan:
-    """Owner of one C-side hipFFT plan (H, W, device); destroyed with the object."""
+    """Owner of one C-side hipFFT plan (H, W, device); destroyed with the object.  `batch`: spectra the plan holds =
+    frames one launch per phase may carry (HHSR_GREY_BATCH)."""
 
-    def __init__(self, H, W):
+    def __init__(self, H, W, batch=1):
         import ctypes
         import os
 
         h = ctypes.c_void_p()
-        _lib.call("hhsr_grey_plan_create", H, W, int(os.environ.get("HHSR_GREY_PLAN", "4")), ctypes.byref(h))
+        _lib.call("hhsr_grey_plan_create", H, W, int(os.environ.get("HHSR_GREY_PLAN", "4")) | (int(batch) << 8),
+                  ctypes.byref(h))
         self.handle = h
+        self.batch = int(batch)
 
     def __del__(self):
         try:
@@ -28,16 +31,38 @@ _grey_plans = {}  # (H, W, device, stream) -> plan, least recently used first
 _GREY_PLAN_CACHE = 16  # e.g. 4 streams x 2 image sizes (bench.py: full size, then the parity crop) x 2 devices
 
 
-def _grey_plan(H, W, device):
+def _grey_plan(H, W, device, batch=1):
+    """The plan of (size, device, stream); one that holds fewer spectra than `batch` is replaced by a larger one."""
     key = (H, W, device.index, torch.cuda.current_stream(device).cuda_stream)
     p = _grey_plans.pop(key, None)
+    if p is not None and p.batch < batch:
+        p = None
     if p is None:
         while len(_grey_plans) >= _GREY_PLAN_CACHE:  # evict the least recently used plan only
             _grey_plans.pop(next(iter(_grey_plans)))
         with torch.cuda.device(device):
-            p = _GreyPlan(H, W)
+            p = _GreyPlan(H, W, batch)
     _grey_plans[key] = p  # most recently used last
     return p
+
+
+def compute_grey_images_batch(imgs, method="FFT"):
+    """compute_grey_images() of several frames of one shape: ONE launch per transform phase for up to
+    _lib.MAX_BATCH frames (hhsr_grey_lowpass_batch) instead of three per frame — the per-frame launches are
+    latency-bound (row / column transforms that sit at barriers half of the time), a chunk of frames keeps one
+    resident round of workgroups busy across the frames' row blocks.  Per frame bit-identical.  Returns a list of
+    [H, W] views of one [n, H, W] tensor."""
+    imgs = [_lib.f32c(i) for i in imgs]
+    if method != "FFT" or len(imgs) < 2:
+        return [compute_grey_images(i, method) for i in imgs]
+    H, W = imgs[0].shape
+    dev = imgs[0].device
+    out = torch.empty((len(imgs), H, W), dtype=torch.float32, device=dev)
+    outs = list(out.unbind(0))
+    plan = _grey_plan(H, W, dev, min(len(imgs), _lib.MAX_BATCH))
+    _lib.call("hhsr_grey_lowpass_batch", plan.handle, _lib.ptr_array(imgs), _lib.ptr_array(outs), len(imgs),
+              _lib.stream(dev))
+    return outs
 
 
 def compute_grey_images(img, method):
@@ -109,6 +134,25 @@ def cuda_downsample(th_img, kernel="gaussian", factor=2):
     out = torch.empty((h2, w2), dtype=torch.float32, device=img.device)
     _lib.call("hhsr_gauss_decimate", _lib.ptr(img), H, W, W, _lib.ptr(out), w2, factor, taps, ntaps, _lib.stream())
     return out.reshape(*lead, h2, w2)
+
+
+def cuda_downsample_batch(imgs, factor=2):
+    """cuda_downsample() of several [H, W] levels of one shape in one launch (hhsr_gauss_decimate_batch); per frame
+    bit-identical.  Returns a list of views of one [n, h2, w2] tensor."""
+    if factor == 1:
+        return list(imgs)
+    imgs = [_lib.f32c(i) for i in imgs]
+    H, W = imgs[0].shape
+    taps, ntaps = _taps_for_launch(factor)
+    r = (ntaps - 1) // 2
+    h2, w2 = (H - 2 * r) // factor, (W - 2 * r) // factor
+    if h2 < 1 or w2 < 1:
+        raise ValueError(f"image of shape {(H, W)} is too small to be downsampled by {factor}")
+    out = torch.empty((len(imgs), h2, w2), dtype=torch.float32, device=imgs[0].device)
+    outs = list(out.unbind(0))
+    _lib.call("hhsr_gauss_decimate_batch", _lib.ptr_array(imgs), len(imgs), H, W, W, _lib.ptr_array(outs), w2, factor,
+              taps, ntaps, _lib.stream())
+    return outs
 
 
 # ---- after the path (SURVEY.md 8f-4) ------------------------------------------------------------------------------------

@@ -35,6 +35,7 @@ extern "C" {
 
 #define HHSR_MAX_TAPS 33      /* Gaussian taps: 4*factor+1, factor <= 8 */
 #define HHSR_MAX_FRAMES 64    /* frames per hhsr_merge_burst launch */
+#define HHSR_MAX_BATCH 8      /* frames per launch of the batched front-end entry points (hhsr_*_batch) */
 
 const char* hhsr_version(void);
 const char* hhsr_last_error(void);
@@ -59,8 +60,14 @@ int hhsr_lowpass_mask_r2c(float* spec, int H, int W, int64_t stride_y, int64_t s
 #define HHSR_GREY_FUSED 4    /* three in-LDS kernels (rows, columns + mask, rows) when W is even and W/2, H factor
                                 into {2,3,5,7} and fit LDS; otherwise the library plans are used */
 #define HHSR_GREY_TPRUNED 2  /* row plans with a transposed spectrum + contiguous column plans on the kept bins */
+#define HHSR_GREY_BATCH(n) ((n) << 8)  /* the plan holds n (<= HHSR_MAX_BATCH) spectra: hhsr_grey_lowpass_batch then
+                                          transforms n frames with ONE launch per phase (default 1) */
 int hhsr_grey_plan_create(int H, int W, int flags, void** plan_out);
 int hhsr_grey_lowpass(void* plan, const float* src, float* dst, void* stream);
+/* The same transform for n_frames frames (HOST arrays of device pointers): per-frame results are bit-identical to
+ * hhsr_grey_lowpass; with the fused kernels the row blocks / kept columns of all frames of a plan-batch share one
+ * launch per phase (the per-frame launches are latency-bound: 3 x 19 launches of ~40 us per 12 MP burst). */
+int hhsr_grey_lowpass_batch(void* plan, const float* const* srcs, float* const* dsts, int n_frames, void* stream);
 int hhsr_grey_plan_destroy(void* plan);
 
 /* ---- pyramid (alignment.py:27-37, 74-82; utils_image.py:360-391) ------------------------------ */
@@ -72,6 +79,10 @@ int hhsr_pad_circular(const float* src, int H, int W, int src_pitch,
 int hhsr_gauss_decimate(const float* src, int H, int W, int src_pitch,
                         float* dst, int dst_pitch, int factor,
                         const float* taps, int ntaps, void* stream);
+/* n_frames levels of the same shape in one launch (HOST arrays of device pointers); per frame bit-identical. */
+int hhsr_gauss_decimate_batch(const float* const* srcs, int n_frames, int H, int W, int src_pitch,
+                              float* const* dsts, int dst_pitch, int factor,
+                              const float* taps, int ntaps, void* stream);
 
 /* ---- Lucas-Kanade precompute (ICA.py:15-76) ---------------------------------------------------
  * gx = I[x+1]-I[x-1], gy likewise (zero border, no 1/2 factor); hess[ty][tx] = sum over the tile of
@@ -108,6 +119,13 @@ int hhsr_align_level(const float* ref, int rh, int rw, int ref_pitch, const floa
                      const float* mov, int mh, int mw, int mov_pitch,
                      float* flow, int ny, int nx, int ts, int r, int metric, int n_iter,
                      const float* coarse_flow, int cny, int cnx, int rep, float mult, void* stream);
+/* The same level step for n_frames moving frames against ONE reference level in one launch (HOST arrays of device
+ * pointers; coarse_flows NULL or one pointer per frame): the coarse levels are 7-27 us launches of a few hundred
+ * workgroups each — a chunk of frames fills the GPU where one frame cannot.  Per frame bit-identical. */
+int hhsr_align_level_batch(const float* ref, int rh, int rw, int ref_pitch, const float* hess,
+                           const float* const* movs, int n_frames, int mh, int mw, int mov_pitch,
+                           float* const* flows, int ny, int nx, int ts, int r, int metric, int n_iter,
+                           const float* const* coarse_flows, int cny, int cnx, int rep, float mult, void* stream);
 
 /* ---- flow upscaling, nearest mode (alignment.py:150-172): dst[y][x] = mult*src[y/rep][x/rep],
  * zero where y/rep >= sny or x/rep >= snx. */
@@ -133,12 +151,22 @@ int hhsr_frame_stats(const float* raw, int H, int W, int pitch, const uint8_t cf
                      float* means, float* vars, float* covs, double alpha, double beta, double k_detail,
                      double k_denoise, double D_th, double D_tr, double k_stretch, double k_shrink, int law,
                      void* stream);
+/* The same pass for n_frames comp frames (guide means + covariances, no variances) in one launch: HOST arrays of
+ * device pointers; per frame bit-identical to hhsr_frame_stats. */
+int hhsr_frame_stats_batch(const float* const* raws, int n_frames, int H, int W, int pitch, const uint8_t cfa[4],
+                           const double* wb, float* const* means, float* const* covs, double alpha, double beta,
+                           double k_detail, double k_denoise, double D_th, double D_tr, double k_stretch,
+                           double k_shrink, int law, void* stream);
 /* Dodgson-quadratic x2 upsampling of a [3][lh][lw] map to [3][2lh][2lw], optionally warped by the
  * per-tile flow (NULL = reference frame; robustness.py:359-421).  +inf outside. */
 int hhsr_rob_upscale(const float* stats, int lh, int lw, const float* flow, int ny, int nx, int ts,
                      float* out, void* stream);
-/* Per-tile flow-irregularity map S (robustness.py:570-612). */
-int hhsr_rob_s(const float* flow, int ny, int nx, double Mt, float s1, float s2, float* S, void* stream);
+/* Per-tile flow-irregularity map S (robustness.py:570-612): spread of the flow over the 3 x 3 TILE neighbourhood.
+ * rows_before / rows_after (0 for a whole field): tile rows that lie in memory before flow[0] / after flow[ny - 1] —
+ * `flow` is then a row slice of a larger field (the row slabs of the multi-GPU path, distributed.py) and the
+ * neighbourhood reads them, so that the first and last rows of the slice get the weights of the full field. */
+int hhsr_rob_s(const float* flow, int ny, int nx, double Mt, float s1, float s2, float* S, int rows_before,
+               int rows_after, void* stream);
 /* Frame-independent noise-model terms (robustness.py:505-528, once per burst):
  * sigma_sq[p] = sum_c max(ref_vars[c][p], std_curve[round(1000 ref_means[c][p])]^2), float32 [H][W];
  * curve_index[p] (optional, NULL to skip; needs ncurve <= 1024) = the three curve indices
@@ -163,11 +191,12 @@ int hhsr_rob_frame(const float* comp_means, int lh, int lw, const float* ref_mea
  * over the reference-frame planes (20 of the 27 bytes per pixel and frame); per frame bit-identical to hhsr_rob_frame.
  * S = NULL: the per-tile weights of hhsr_rob_s are evaluated inside the kernel from (Mt, s1, s2) — one launch less per
  * frame; only with the grouped kernel (ts % 16 == 0, W % 4 == 0, packed curve indices, 16-byte aligned planes; error -3
- * otherwise).  With S given, Mt / s1 / s2 are ignored. */
+ * otherwise).  With S given, Mt / s1 / s2 are ignored.  flow_rows_before / flow_rows_after: as in hhsr_rob_s, for the
+ * weights evaluated inside the kernel (every flows[n] is a row slice with that many tile rows around it). */
 int hhsr_rob_frames(const float* const* comp_means, int n_frames, int lh, int lw, const float* ref_means,
                     const float* ref_sigma_sq, const uint32_t* ref_curve_index, const float* const* flows, int ny,
                     int nx, int ts, const float* const* S, double Mt, float s1, float s2, const double* diff_curve,
-                    int ncurve, double t, float* const* R, void* stream);
+                    int ncurve, double t, float* const* R, int flow_rows_before, int flow_rows_after, void* stream);
 /* 5x5 clamp-border minimum (robustness.py:670-686).  acc_r != NULL additionally does acc_r += r
  * (the accumulated robustness of super_resolution.py:158-159, fused to save a pass). */
 int hhsr_local_min5(const float* R, int H, int W, float* r, float* acc_r, void* stream);

@@ -179,8 +179,9 @@ def init_robustness(ref, cfa, wb, config):
     return upscale_warp_stats(m), upscale_warp_stats(v)
 
 
-def compute_robustness(comp, ref_means, ref_vars, flow, cfa, wb, noise_model, config, debug=None):
-    """Alg. 6 (robustness.py:79-170)."""
+def compute_robustness(comp, ref_means, ref_vars, flow, cfa, wb, noise_model, config, debug=None, S=None):
+    """Alg. 6 (robustness.py:79-170).  `S`: precomputed flow-irregularity weights for `flow` (the multi-GPU tests pass
+    the rows of the full frame's map that belong to a sub-image: S is the one stage that is not row-local)."""
     comp = np.asarray(comp, dtype=F32)
     if not config.robustness.enabled:
         return np.ones_like(comp, F32)
@@ -191,7 +192,8 @@ def compute_robustness(comp, ref_means, ref_vars, flow, cfa, wb, noise_model, co
     with np.errstate(all="ignore"):
         d_p = np.abs(ref_means - cmu).astype(F32)
     d_sq, s_sq = apply_noise_model(d_p, ref_means, ref_vars, noise_model[0], noise_model[1])
-    S = compute_s(flow, t.Mt, t.s1, t.s2)
+    if S is None:
+        S = compute_s(flow, t.Mt, t.s1, t.s2)
     R = robustness_threshold(d_sq, s_sq, S, t.t, ts)
     if debug is not None:
         debug.update(comp_means_up=cmu, d_sq=d_sq, sigma_sq=s_sq, S=S, R=R)

@@ -72,10 +72,13 @@ class OracleEngine:
         num = np.zeros((round(s * Hs), round(s * W), 3), np.float32)
         den = np.zeros_like(num)
         acc_r = np.zeros((Hs, W), np.float32)
+        t = cfg.robustness.tuning
         for i, img in enumerate(comps):
             img_s = np.asarray(img, np.float32)[S0:S1]
             flow_s = flows[i, t0:t1].numpy()
-            r = oracle.compute_robustness(img_s, *stats, flow_s, self.cfa, self.wb, self.curves, cfg)
+            # the flow-irregularity weight is the one stage that is not row-local: full field, then the sub-image's rows
+            S = oracle.compute_s(flows[i].numpy(), t.Mt, t.s1, t.s2)[t0:t1]
+            r = oracle.compute_robustness(img_s, *stats, flow_s, self.cfa, self.wb, self.curves, cfg, S=S)
             acc_r += r
             oracle.merge(img_s, flow_s, oracle.estimate_kernels(img_s, cfg), r, num, den, self.cfa, cfg)
         oracle.merge_ref(ref_s, oracle.estimate_kernels(ref_s, cfg), num, den, self.cfa, cfg)
@@ -85,20 +88,71 @@ class OracleEngine:
         return torch.from_numpy(np.ascontiguousarray(num[row0:row0 + (r1 - r0)])), torch.from_numpy(acc_r[L0:L1].copy())
 
 
-def _burst():
-    ref, comp, _ = synth.make_burst(128, 128, 4, seed=9, max_shift=1.5)
+    # ---- strategy "reduce" --------------------------------------------------------------------------------------------
+    def partial(self, ref, my_frames, padded_rows):
+        cfg = self.cfg
+        self.init_ref(ref)
+        H, W = self.ref.shape
+        sH, sW, _ = self.output_shape()
+        stats = oracle.init_robustness(self.ref, self.cfa, self.wb, cfg)
+        acc = np.zeros((2, padded_rows, sW, 3), np.float32)
+        acc_r = np.zeros((H, W), np.float32)
+        for img in my_frames:
+            img = np.asarray(img, np.float32)
+            flow = oracle.align(*self.al, oracle.compute_grey_images(img, "FFT"), cfg)
+            r = oracle.compute_robustness(img, *stats, flow, self.cfa, self.wb, self.curves, cfg)
+            acc_r += r
+            oracle.merge(img, flow, oracle.estimate_kernels(img, cfg), r, acc[0, :sH], acc[1, :sH], self.cfa, cfg)
+        return torch.from_numpy(acc), torch.from_numpy(acc_r), self.ref, oracle.estimate_kernels(self.ref, cfg)
+
+    def finish_rows(self, acc_slab, r0, r1, ref, ref_covs):
+        cfg = self.cfg
+        sH, sW, _ = self.output_shape()
+        num = np.zeros((sH, sW, 3), np.float32)
+        den = np.zeros_like(num)
+        num[r0:r1], den[r0:r1] = acc_slab[0, : r1 - r0].numpy(), acc_slab[1, : r1 - r0].numpy()
+        oracle.merge_ref(ref, ref_covs, num, den, self.cfa, cfg)  # (whole image: only rows [r0, r1) are kept)
+        oracle.divide(num, den)
+        return torch.from_numpy(np.ascontiguousarray(num[r0:r1]))
+
+
+def _burst(seam=False):
+    ref, comp, _ = synth.make_burst(128, 128, 4, seed=9, max_shift=0.0 if seam else 1.5)
+    if seam:  # frame 1 is brighter around raw rows 80-100: its robustness there sits in the band where S decides
+        comp = comp.copy()
+        yy = np.arange(128, dtype=np.float32)[:, None]
+        comp[1] = np.clip(comp[1] + 0.06 * np.exp(-(((yy - 90) / 8.0) ** 2)), 0, 1).astype(np.float32)
     cfg = base_config(ts=16, scale=2)
     cfg.block_matching.tuning.factors = [1, 2, 2, 2]
     return ref, comp, cfg
 
 
-def _worker(rank, world, port, out_path):
+class SeamEngine(OracleEngine):
+    """OracleEngine whose "alignment" returns a crafted flow field: zero everywhere except 3 px in y in tile row 4 of
+    frame 1 — irregular flow directly ABOVE the sub-image of slab 1 (world 2: output rows [192, 256) -> raw rows from
+    96 - (3 + HALO) -> tile row 5 on).  The flow-irregularity weight S of tile row 5 depends on tile row 4
+    (robustness.py:587-612), which a row slice of the flow field does not contain."""
+
+    def align_frames(self, comps):
+        H, W = self.ref.shape
+        ts = self.tile_size()
+        fl = np.zeros((len(comps), -(-H // ts), -(-W // ts), 2), np.float32)
+        if len(comps) and getattr(self, "_has_frame1", True):
+            fl[self._frame1, 4, :, 1] = 3.0
+        return torch.from_numpy(fl)
+
+
+def _worker(rank, world, port, out_path, strategy="rows", seam=False):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
-        ref, comp, cfg = _burst()
-        out, dbg = hdist.main_sharded(ref, comp, cfg, engine=OracleEngine(cfg))
+        ref, comp, cfg = _burst(seam)
+        eng = OracleEngine(cfg)
+        if seam:  # frame 1 of the burst is aligned by rank 1 % world as its (1 // world)-th frame
+            eng = SeamEngine(cfg)
+            eng._has_frame1, eng._frame1 = (1 % world == rank), 1 // world
+        out, dbg = hdist.main_sharded(ref, comp, cfg, engine=eng, strategy=strategy)
         if rank == 0:
             np.savez(out_path, out=out.numpy(), acc_r=dbg["accumulated robustness"].numpy())
         else:
@@ -143,6 +197,63 @@ def test_sharded_equals_sequential(tmp_path, world):
     # bit for bit (no partial sums are exchanged, so there is no summation-order difference either)
     assert np.nanmax(d) == 0.0
     assert np.array_equal(got["acc_r"], dbg["accumulated robustness"].astype(np.float32))
+
+
+@pytest.mark.timeout(300)
+def test_moving_object_at_seam(tmp_path):
+    """S of a tile is the flow spread over its 3 x 3 TILE neighbourhood — not row-local.  A burst
+    whose flow is irregular directly above a sub-image must still reproduce the sequential result bit for bit — and the
+    case must be real: with S recomputed from the row slice (round 2) the slab differs."""
+    ref, comp, cfg = _burst(seam=True)
+    flows = np.zeros((3, 8, 8, 2), np.float32)
+    flows[1, 4, :, 1] = 3.0
+    # sequential result with the same injected flows (oracle stages as in oracle.main)
+    cfa, wb = np.array(cfg.exif.cfa_pattern), np.array(cfg.exif.white_balance, np.float64)
+    curves = (np.array(cfg.noise_model.std_curve), np.array(cfg.noise_model.diff_curve))
+
+    def sequential(slice_rows=None):
+        r0s = 0 if slice_rows is None else slice_rows[0] * 16
+        r1s = 128 if slice_rows is None else min(128, slice_rows[1] * 16)
+        rs, imgs = ref[r0s:r1s], comp[:, r0s:r1s]
+        stats = oracle.init_robustness(rs, cfa, wb, cfg)
+        num = np.zeros((2 * (r1s - r0s), 256, 3), np.float32)
+        den = np.zeros_like(num)
+        for i in range(3):
+            f = flows[i] if slice_rows is None else flows[i, slice_rows[0]:slice_rows[1]]
+            r = oracle.compute_robustness(imgs[i], *stats, f, cfa, wb, curves, cfg)
+            oracle.merge(imgs[i], f, oracle.estimate_kernels(imgs[i], cfg), r, num, den, cfa, cfg)
+        oracle.merge_ref(rs, oracle.estimate_kernels(rs, cfg), num, den, cfa, cfg)
+        oracle.divide(num, den)
+        return num
+
+    want = sequential()
+    S0, S1, row0 = hdist.sub_image_rows(192, 256, 2, 128, 16, 3.0)
+    assert S0 == 80 and S1 == 128 and row0 == 32
+    naive = sequential((5, 8))[row0:row0 + 64]  # round 2's sub-image: S from the slice
+    with np.errstate(all="ignore"):
+        assert np.nanmax(np.abs(naive - want[192:256])) > 1e-4, "the burst does not exercise the seam case"
+    out_path = str(tmp_path / "out.npz")
+    mp.spawn(_worker, args=(2, _free_port(), out_path, "rows", True), nprocs=2, join=True)
+    got = np.load(out_path)
+    assert np.array_equal(got["out"], want, equal_nan=True)
+
+
+@pytest.mark.timeout(300)
+@pytest.mark.parametrize("world", [2, 3])
+def test_reduce_strategy_matches_sequential(tmp_path, world):
+    """strategy="reduce" (north star: frames sharded one per rank, ONE reduce of the float32 accumulators, reference
+    merge.py:432-434): partial sums are added in a different order than the sequential merge, so the result agrees to
+    float32 summation noise instead of bit for bit."""
+    out_path = str(tmp_path / "out.npz")
+    mp.spawn(_worker, args=(world, _free_port(), out_path, "reduce"), nprocs=world, join=True)
+    got = np.load(out_path)
+    ref, comp, cfg = _burst()
+    want, dbg = oracle.main(ref, comp, cfg)
+    assert (np.isnan(got["out"]) == np.isnan(want)).all()
+    with np.errstate(all="ignore"):
+        d = np.abs(got["out"] - want)
+    assert np.nanmax(d) < 2e-6  # measured 2.4e-7
+    np.testing.assert_allclose(got["acc_r"], dbg["accumulated robustness"].astype(np.float32), rtol=0, atol=2e-6)
 
 
 def test_single_process_path_is_main():

@@ -1661,3 +1661,215 @@ def test_graph_replay_equals_eager():
     torch.cuda.synchronize()
     o6, _ = eng.single(ref, comp)  # the device is fine after the failed capture
     assert_close(N(o6), N(want2), 0, 0, "replay after a failed capture elsewhere")
+
+
+# ------------------------------------------------------------------------------------------ chunk-batched front end
+def test_batched_operators_equal_single():
+    """The *_batch entry points (one launch per stage for a chunk of frames: FFT phases, pyramid levels, alignment
+    levels, raw pass) give every frame the bits of the single-frame entry points — also for lists longer than
+    HHSR_MAX_BATCH (rounds) and through a plan that holds fewer spectra than frames."""
+    from handheld_super_resolution import _lib
+
+    n = _lib.MAX_BATCH + 3
+    ref, comp, _ = synth.make_burst_torch(384, 512, n + 1, torch.device(DEV), seed=33)
+    frames = [comp[i] for i in range(n)]
+    cfg = base_config(ts=16, scale=2, metrics=("L1", "L2", "L2", "L2"))
+    cfg.block_matching.tuning.factors = [1, 2, 2, 2]
+    greys = utils_image.compute_grey_images_batch(frames, "FFT")
+    for g, f in zip(greys, frames):
+        assert torch.equal(g, utils_image.compute_grey_images(f, "FFT"))
+    assert torch.equal(utils_image.compute_grey_images_batch(frames[:3], "FFT")[2], greys[2])  # (a smaller batch, same plan)
+    pyrs = alignment.build_gaussian_pyramids(greys, cfg.block_matching.tuning.factors)
+    for p, g in zip(pyrs, greys):
+        for a, b in zip(p, alignment.build_gaussian_pyramid(g, cfg.block_matching.tuning.factors)):
+            assert torch.equal(a, b)
+    state = alignment.init_alignment(utils_image.compute_grey_images(ref, "FFT"), cfg)
+    assert alignment.can_align_batch(cfg)
+    flows = alignment.align_batch(state[0], state[5], pyrs, cfg)
+    for fl, g, p in zip(flows, greys, pyrs):
+        assert torch.equal(fl, alignment.align(*state, g, cfg, moving_pyramid=p))
+    cfa, wb = [[0, 1], [1, 2]], [1.9, 1.0, 1.6]
+    stats = kernels.frame_stats_batch(frames, cfa, wb, cfg)
+    for (m, _, c), f in zip(stats, frames):
+        m1, _, c1 = kernels.frame_stats(f, cfa, wb, cfg)
+        assert torch.equal(m, m1) and torch.equal(torch.nan_to_num(c), torch.nan_to_num(c1))
+
+
+@pytest.mark.parametrize("hip", [{"chunk": 8}, {"chunk": 3, "streams": 2}, {"streams": 1}])
+def test_batched_front_end_equals_per_frame(hip):
+    """main() with the chunk-batched front end (default) == main() with one launch per frame and stage
+    (config.hip.batch: false), bit for bit, for several chunk sizes / stream counts."""
+    ref, comp, _ = synth.make_burst_torch(512, 640, 10, torch.device(DEV), seed=44, max_shift=3.0)
+
+    def run(**h):
+        cfg = base_config(ts=16, scale=2, metrics=("L1", "L2", "L2", "L2"))
+        cfg.robustness.save_mask = True
+        cfg.hip = h
+        out, dbg = hsr.main(ref, comp, cfg)
+        return torch.nan_to_num(out, nan=-1.0), dbg["accumulated robustness"]
+
+    want = run(batch=False)
+    got = run(**hip)
+    assert torch.equal(got[0], want[0]) and torch.equal(got[1], want[1])
+
+
+# ------------------------------------------------------------------------------------------ host-resident bursts
+@pytest.mark.parametrize("kind", ["f32_pinned", "f32_numpy", "u16_pinned", "u16_numpy"])
+def test_host_burst_runner_equals_eager(kind):
+    """Bursts that start in host memory (the reference's signature / timer scope): graph.HostBurstRunner — eager uploads
+    into static staging, per-chunk HIP graphs — gives the eager path's bits on every call (eager, capture, replay,
+    replay on new content), for page-locked and pageable frames, float32 frames and uint16 sensor counts."""
+    from handheld_super_resolution import distributed as hdist
+
+    black, white = 64.0, 1023.0
+
+    def burst(seed):
+        ref, comp, _ = synth.make_burst(512, 640, 9, seed=seed, max_shift=2.5)
+        if kind.startswith("u16"):
+            c = lambda a: np.clip(np.rint(a * (white - black) + black), 0, white).astype(np.uint16)  # noqa: E731
+            ref, comp = c(ref), c(comp)
+        return ref, comp
+
+    def cfg_fn(graph):
+        cfg = base_config(ts=16, scale=2, metrics=("L1", "L2", "L2", "L2"))
+        cfg.robustness.save_mask = True
+        cfg.hip = {"graph": graph}
+        if kind.startswith("u16"):
+            cfg.hip["raw_norm"] = {"black_levels": [black] * 3, "white_level": white}
+        return cfg
+
+    def host(a):
+        t = torch.from_numpy(a)
+        return t.pin_memory() if kind.endswith("pinned") else a
+
+    ref0, comp0 = burst(5)
+    ref_h, comp_h = host(ref0), [host(comp0[i]) for i in range(comp0.shape[0])]
+    want, wdbg = hsr.main(ref0, comp0, cfg_fn(False))  # eager
+    eng = hdist.HipEngine(cfg_fn(True))
+    for it in range(4):
+        if it == 3:  # new content in the same host buffers
+            ref1, comp1 = burst(6)
+            want, wdbg = hsr.main(ref1, comp1, cfg_fn(False))
+            for dst, src in zip([ref_h, *comp_h], [ref1, *comp1]):
+                (dst if not torch.is_tensor(dst) else dst.numpy())[...] = src
+        got, dbg = eng.single(ref_h, comp_h)
+        assert torch.equal(torch.nan_to_num(got, nan=-1.0), torch.nan_to_num(want, nan=-1.0)), f"{kind} call {it}"
+        assert torch.equal(dbg["accumulated robustness"], wdbg["accumulated robustness"])
+    st = eng._host.states[next(iter(eng._host.states))]
+    assert not eng._host.disabled and st != "seen" and len(st.g_chunks) >= 2, getattr(eng._host, "error", None)
+
+
+def test_main_numpy_serving_loop():
+    """main() itself, called again and again with NumPy arrays and the same configuration object (the reference's
+    signature in a serving loop), goes through the runner from the third call on and still hands out fresh tensors."""
+    from handheld_super_resolution import super_resolution as sr
+
+    ref, comp, _ = synth.make_burst(384, 512, 6, seed=8, max_shift=2.0)
+    cfg = base_config(ts=16, scale=2)
+    outs = [hsr.main(ref, comp, cfg)[0] for _ in range(4)]
+    for o in outs[1:]:
+        assert torch.equal(torch.nan_to_num(o), torch.nan_to_num(outs[0]))
+    assert len({o.data_ptr() for o in outs}) == 4
+    runner = [r for c, _, r in sr._main_runners if c is cfg][0]
+    assert not runner.disabled and any(s != "seen" for s in runner.states.values())
+    cfg.scale = 1  # edited in place: a new runner, the eager result of the new configuration
+    o1 = hsr.main(ref, comp, cfg)[0]
+    assert tuple(o1.shape) == (384, 512, 3)
+    cfg2 = base_config(ts=16, scale=1)
+    assert torch.equal(torch.nan_to_num(o1), torch.nan_to_num(hsr.main(ref, comp, cfg2)[0]))
+
+
+# ------------------------------------------------------------------------------------------ multi-GPU: seam, reduce
+def _seam_burst():
+    ref, comp, _ = synth.make_burst(512, 512, 4, seed=17, max_shift=0.0)
+    comp = comp.copy()
+    yy = np.arange(512, dtype=np.float32)[:, None]
+    comp[1] = np.clip(comp[1] + 0.06 * np.exp(-(((yy - 250) / 8.0) ** 2)), 0, 1).astype(np.float32)
+    flows = np.zeros((3, 32, 32, 2), np.float32)
+    flows[1, 14, :, 1] = 3.0  # irregular flow directly above slab 1's sub-image (raw rows from 240 = tile row 15 on)
+    return ref, comp, flows
+
+
+def _shard_worker2(rank, world, port, out_path, strategy, seam):
+    import os
+    import torch.distributed as dist
+    from handheld_super_resolution import distributed as hdist
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        torch.cuda.set_device(0)
+        cfg = base_config(ts=16, scale=2)
+        cfg.robustness.save_mask = True
+        if seam:
+            ref, comp, flows = _seam_burst()
+
+            class SeamEngine(hdist.HipEngine):  # "alignment" returns the crafted field (this rank's frames of it)
+                def align_frames(self, comp_imgs):
+                    mine = hdist.shard_indices(3, rank, world)
+                    return torch.as_tensor(flows[mine], device="cuda")
+
+            eng = SeamEngine(cfg)
+        else:
+            ref, comp, _ = synth.make_burst(512, 512, 6, seed=17, max_shift=2.0)
+            eng = hdist.HipEngine(cfg)
+        dref, dcomp = torch.as_tensor(ref).cuda(), torch.as_tensor(comp).cuda()
+        outs = []
+        for it in range(3):  # eager, capture, replay
+            o, d = hdist.main_sharded(dref, dcomp, cfg, engine=eng, strategy=strategy)
+            if rank == 0:
+                outs.append((o.cpu().numpy().copy(), d["accumulated robustness"].cpu().numpy().copy()))
+        if rank == 0:
+            for o, a in outs[1:]:
+                assert np.array_equal(o, outs[0][0], equal_nan=True) and np.array_equal(a, outs[0][1])
+            np.savez(out_path, out=outs[0][0], acc_r=outs[0][1])
+    finally:
+        dist.destroy_process_group()
+
+
+def _spawn2(tmp_path, world, strategy, seam):
+    import socket
+    import torch.multiprocessing as mp
+
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    out_path = str(tmp_path / "o.npz")
+    mp.spawn(_shard_worker2, args=(world, port, out_path, strategy, seam), nprocs=world, join=True)
+    return np.load(out_path)
+
+
+def test_sharded_seam_flow_irregularity(tmp_path):
+    """irregular flow directly above a sub-image.  S (3 x 3 TILE neighbourhood) is evaluated on the
+    full gathered field (flow_rows of hhsr_rob_frames), so the row-sharded HIP result is the single-GPU one bit for bit;
+    the slice-only evaluation of round 2 differs on this burst."""
+    ref, comp, flows = _seam_burst()
+    cfg = base_config(ts=16, scale=2)
+    cfg.robustness.save_mask = True
+    cfg.hip = {"inject_flows": [f for f in flows]}
+    want, wdbg = hsr.main(ref, comp, cfg)
+    got = _spawn2(tmp_path, 2, "rows", True)
+    assert np.array_equal(got["out"], N(want), equal_nan=True)
+    assert np.array_equal(got["acc_r"], N(wdbg["accumulated robustness"]))
+    # the case is real: the sub-image of slab 1 with S from the slice (no rows around it) differs
+    sub = hsr.BurstPipeline(base_config(ts=16, scale=2)).init_ref(T(ref[240:]), alignment=False)
+    f1 = T(flows[1])
+    a = sub.process_frame(T(comp[1, 240:]), flow=f1[15:].contiguous().clone())[3]
+    sub.flow_rows = (15, 0)
+    b = sub.process_frame(T(comp[1, 240:]), flow=f1[15:])[3]
+    assert float((a - b).abs().max()) > 1e-3
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_sharded_reduce_strategy(tmp_path, world):
+    """strategy="reduce" (north star): frames one per rank through the whole chain, reduce-scatter of the float32
+    accumulators over row slabs, reference frame + normalisation per slab — equals the single-GPU result up to the
+    summation order of the partial sums; replayed from HIP graphs on the second / third burst."""
+    ref, comp, _ = synth.make_burst(512, 512, 6, seed=17, max_shift=2.0)
+    cfg = base_config(ts=16, scale=2)
+    cfg.robustness.save_mask = True
+    want, wdbg = hsr.main(ref, comp, cfg)
+    got = _spawn2(tmp_path, world, "reduce", False)
+    assert_close(got["out"], N(want), 0, 2e-6, "reduce strategy == single")
+    assert_close(got["acc_r"], N(wdbg["accumulated robustness"]), 0, 2e-6, "acc_r")

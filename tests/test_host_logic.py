@@ -125,3 +125,42 @@ def test_monte_carlo_noise_curves_cpu():
     for i in (0, 3, 998, 1000):
         dm, sm = oracle.frontend.unitary_mc(a, b, i / 1000, 20000, rng)
         assert abs(s1[i] / sm - 1) < 0.03 and abs(d1[i] / dm - 1) < 0.05
+
+
+# ------------------------------------------------------------------------------------------ graph-replay guards
+def test_config_watch_sees_every_in_place_edit():
+    """a sum of per-node edit counters can cancel out (a nested mapping replaced by a fresh one), and
+    dict.setdefault / pop / clear and in-place list edits bypass __setitem__.  ConfigWatch compares (identity, counter)
+    per node plus the content of short lists, and Config routes every mutating method through its counter."""
+    from handheld_super_resolution.graph import ConfigWatch
+    from handheld_super_resolution.config import Config
+
+    def fresh():
+        cfg = base_config()
+        w = ConfigWatch()
+        assert not w.changed(cfg) and not w.changed(cfg)  # first look never counts as a change
+        return cfg, w
+
+    cfg, w = fresh()
+    cfg.scale = 3
+    assert w.changed(cfg) and not w.changed(cfg)
+    cfg, w = fresh()  # nested mapping replaced by a fresh one with FEWER edits: a counter sum would not move
+    cfg.robustness.tuning.t = 0.2
+    cfg.robustness.tuning.t = 0.3
+    assert w.changed(cfg)
+    before = sum(n.version() for n in (cfg, cfg.robustness, cfg.robustness.tuning))
+    cfg.robustness["tuning"] = Config({"t": 0.5, "s1": 2, "s2": 12, "Mt": 0.8})
+    object.__setattr__(cfg.robustness, "_ver", cfg.robustness.version() - 1)  # even with the parent's counter rolled back
+    assert w.changed(cfg), before
+    cfg, w = fresh()
+    cfg.block_matching.tuning.tile_sizes[0] = 8  # in-place list edit
+    assert w.changed(cfg)
+    for edit in (lambda c: c.setdefault("new_key", 1), lambda c: c.pop("grey_method"), lambda c: c.robustness.clear(),
+                 lambda c: c.merging.popitem()):
+        cfg, w = fresh()
+        edit(cfg)
+        assert w.changed(cfg)
+    a, b = base_config(), base_config()
+    w = ConfigWatch()
+    w.changed(a)
+    assert not w.changed(b)  # another object: a first look again
