@@ -107,12 +107,50 @@ class HostBurstRunner:
     The call returns when the host buffers may be refilled (all uploads done); the result tensor is produced
     asynchronously on the current stream as usual and belongs to the runner: valid until its next call."""
 
-    COPY_THREADS = 8
+    COPY_THREADS = 16
 
     def __init__(self, config, device):
         self.config, self.device = config, device
         self.states = {}
         self.disabled = False
+        # the eager calls run on the stream the graphs are captured on and replayed on later: the per-stream FFT plans
+        # (which allocate: not capturable) then exist when the capture needs them
+        self.main = torch.cuda.Stream(device)
+        # HIGH priority: HIP streams share a few hardware queues (GPU_MAX_HW_QUEUES, default 4) per priority level.  A
+        # stream with 20 copies queued holds its queue with one barrier packet per copy, and every compute stream mapped
+        # to the same queue starts after the LAST copy (tools/debug/hwqueue_probe.py: 7 of 8 compute streams blocked for
+        # 8.7 ms; with the upload stream in the high-priority queue set: none)
+        self.up = torch.cuda.Stream(device, priority=-1)
+
+    def _eager(self, ref_img, comp_imgs):
+        from .super_resolution import main
+
+        cur = torch.cuda.current_stream(self.device)
+        self.main.wait_stream(cur)
+        with torch.cuda.stream(self.main):
+            out, dbg = main(ref_img, comp_imgs, self.config, _no_runner=True)
+        cur.wait_stream(self.main)
+        for t in _leaves((out, dbg)):
+            t.record_stream(cur)
+        return out, dbg
+
+    def close(self):
+        """Drop the captured states in a defined order: device idle first, then graphs, staging, copy threads."""
+        try:
+            torch.cuda.synchronize(self.device)
+        except Exception:
+            pass
+        for st in list(self.states.values()):
+            pool = getattr(st, "pool", None)
+            if pool is not None:
+                pool.shutdown(wait=True)
+        self.states.clear()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
     @staticmethod
     def usable(config, ref_img, comp_imgs):
@@ -148,12 +186,13 @@ class HostBurstRunner:
         frames = [f if f.is_contiguous() else f.contiguous() for f in frames]
         key = (tuple(frames[0].shape), frames[0].dtype, len(frames))
         st = self.states.get(key)
-        if self.disabled or st is None:
-            if not self.disabled:
-                self.states[key] = "seen"
-                while len(self.states) > 4:
-                    self.states.pop(next(iter(self.states)))
+        if self.disabled:
             return main(ref_img, comp_imgs, self.config, _no_runner=True)
+        if st is None:
+            self.states[key] = "seen"
+            while len(self.states) > 4:
+                self.states.pop(next(iter(self.states)))
+            return self._eager(ref_img, comp_imgs)
         if st == "seen":
             try:
                 st = self.states[key] = self._capture(frames)
@@ -175,8 +214,7 @@ class HostBurstRunner:
         with torch.cuda.device(dev):
             st.stage = torch.empty((n + 1, H, W), dtype=frames[0].dtype, device=dev)
             st.pin = None
-            st.main = torch.cuda.Stream(dev)
-            st.up = torch.cuda.Stream(dev)
+            st.main, st.up = self.main, self.up
             for i, f in enumerate(frames):  # valid content for the capture-time launches' validation paths
                 st.stage[i].copy_(f)
             torch.cuda.synchronize(dev)
@@ -196,8 +234,15 @@ class HostBurstRunner:
             pool = _stream_pool.setdefault(dev.index, [])
             if len(pool) < ns:
                 pool += [torch.cuda.Stream(dev) for _ in range(ns - len(pool))]
-            st.chunks = pipe._chunks(n, None)
-            st.streams = [pool[c % ns] for c in range(len(st.chunks))]  # the eager path's stream of chunk c: its FFT plans
+            st.chunks = host_chunks(n, pipe._chunk_size())
+            st.streams = [pool[c % ns] for c in range(len(st.chunks))]  # (FFT plans exist per pool stream: eager call)
+            if cfg.grey_method == "FFT":  # plans allocate: they have to exist before their stream is captured
+                from . import _lib
+                from .utils_image import _grey_plan
+
+                for idx, s in zip(st.chunks, st.streams):
+                    with torch.cuda.stream(s):
+                        _grey_plan(H, W, dev, _lib.MAX_BATCH if len(idx) > 1 else 1)
             st.g_chunks, results = [], []
             for idx, s in zip(st.chunks, st.streams):
                 g = torch.cuda.CUDAGraph()
@@ -221,19 +266,33 @@ class HostBurstRunner:
 
     # ---- replay ---------------------------------------------------------------------------------------------------
     def _replay(self, st, frames):
+        import numpy as np
+
         dev = self.device
         cur = torch.cuda.current_stream(dev)
         n = len(frames) - 1
         pinned = all(f.is_pinned() for f in frames)
         futs = None
-        if not pinned:  # pageable frames -> page-locked staging, COPY_THREADS memcpys in flight
+        if not pinned:
+            # pageable frames -> page-locked staging.  Every frame is cut into COPY_THREADS row slabs that the pool copies
+            # in frame order (np.copyto releases the GIL): frame i is complete after (i + 1) x 48 MB / (aggregate memcpy
+            # bandwidth) and starts crossing PCIe while the threads are on frame i + 1
             from concurrent.futures import ThreadPoolExecutor
 
             if st.pin is None:
                 st.pin = torch.empty(tuple(st.stage.shape), dtype=st.stage.dtype, pin_memory=True)
+                st.pin_np = st.pin.numpy()
                 st.pool = ThreadPoolExecutor(self.COPY_THREADS)
             # (the previous burst's DMA out of the staging finished before its call returned)
-            futs = [st.pool.submit(st.pin[i].copy_, f) if not f.is_pinned() else None for i, f in enumerate(frames)]
+            H = st.stage.shape[1]
+            cuts = [H * k // self.COPY_THREADS for k in range(self.COPY_THREADS + 1)]
+            futs = []
+            for i, f in enumerate(frames):
+                if f.is_pinned():
+                    futs.append(None)
+                    continue
+                src = f.numpy()
+                futs.append([st.pool.submit(np.copyto, st.pin_np[i, a:b], src[a:b]) for a, b in zip(cuts[:-1], cuts[1:]) if b > a])
         with torch.cuda.device(dev):
             st.up.wait_stream(st.main)   # the previous burst's kernels are done with the device staging buffers
             st.main.wait_stream(cur)
@@ -241,7 +300,8 @@ class HostBurstRunner:
             def upload(i):
                 src = frames[i]
                 if futs is not None and futs[i] is not None:
-                    futs[i].result()
+                    for f in futs[i]:
+                        f.result()
                     src = st.pin[i]
                 with torch.cuda.stream(st.up):
                     st.stage[i].copy_(src, non_blocking=True)
@@ -251,29 +311,54 @@ class HostBurstRunner:
             if futs is None:  # page-locked frames: all copies queued up front, back to back
                 for i in range(1, n + 1):
                     upload(i)
+            # The graphs are launched HOST-PACED: the host waits for a chunk's last copy, then launches its graph.  Queued
+            # up front behind event waits they did not start before the LAST copy had finished (measured: first kernel at
+            # 9.0 ms of a 9.0 ms upload sequence) — HIP streams share a few hardware queues, and a barrier packet that
+            # waits for a late copy blocks everything behind it in its queue, other streams' runnable work included.  The
+            # call blocks until the uploads are done anyway (the host buffers are the caller's again when it returns).
+            st.e_up[0].synchronize()
             with torch.cuda.stream(st.main):
-                st.main.wait_event(st.e_up[0])
                 st.g_ref.replay()
                 st.e_ref.record(st.main)
             for idx, s, g in zip(st.chunks, st.streams, st.g_chunks):
                 if futs is not None:
                     for i in idx:
                         upload(1 + i)
+                st.e_up[1 + idx[-1]].synchronize()  # copies complete in order: the chunk's frames are all there
                 with torch.cuda.stream(s):
                     s.wait_event(st.e_ref)
-                    for i in idx:
-                        s.wait_event(st.e_up[1 + i])
                     g.replay()
             with torch.cuda.stream(st.main):
                 for s in set(st.streams):
                     st.main.wait_stream(s)
                 st.g_merge.replay()
             cur.wait_stream(st.main)
-        st.e_up[n].synchronize()  # the caller may refill its host buffers when this returns
         debug = {"robustness": [], "flow": []}
         if st.acc_r is not None:
             debug["accumulated robustness"] = st.acc_r
         return st.num, debug
+
+
+def host_chunks(n, size):
+    """Chunk sizes for frames that arrive one after the other over PCIe: chunks of `size` first (one launch per stage and
+    chunk: efficient while later frames are still in flight), then 3, 2, 1, 1 — what runs after the LAST frame has arrived
+    is on the critical path of the burst, so the last chunks are short.  Returns lists of frame indices."""
+    tail = []
+    for t in (1, 1, 2, 3):
+        if n - sum(tail) - t >= size:
+            tail.append(t)
+    body, rem = [], n - sum(tail)
+    while rem > 0:
+        body.append(min(size, rem))
+        rem -= body[-1]
+    if len(body) > 1 and body[-1] < body[-2]:  # the remainder chunk goes first of the short ones: sizes never grow
+        pass
+    sizes = body + tail[::-1]
+    out, i = [], 0
+    for k in sizes:
+        out.append(list(range(i, i + k)))
+        i += k
+    return out
 
 
 def _leaves(x):

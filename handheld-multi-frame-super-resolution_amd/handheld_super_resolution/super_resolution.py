@@ -141,7 +141,8 @@ class BurstPipeline:
             if stream is None:
                 stream = _upload_streams.get(self.device.index)
                 if stream is None:
-                    stream = _upload_streams[self.device.index] = torch.cuda.Stream(self.device)
+                    # (high priority = its own hardware queue: see graph.HostBurstRunner)
+                    stream = _upload_streams[self.device.index] = torch.cuda.Stream(self.device, priority=-1)
             with torch.cuda.stream(stream):
                 d = t.contiguous().to(self.device, non_blocking=True)
                 ev = torch.cuda.Event()
@@ -348,8 +349,7 @@ class BurstPipeline:
         (hhsr_rob_frames), and with the batched front end every stage is one launch per chunk; chunk sizes are balanced
         over the streams."""
         streams = self._n_streams(n_streams)
-        hip = self.config.get("hip", None) if hasattr(self.config, "get") else None
-        size = max(1, min(int(hip.get("chunk", ROB_GROUP)) if hip is not None else ROB_GROUP, _lib.MAX_BATCH))
+        size = self._chunk_size()
         n_chunks = min(n, streams * -(-n // (streams * size))) if n else 0
         chunks, i = [], 0
         for c in range(n_chunks):
@@ -357,6 +357,10 @@ class BurstPipeline:
             chunks.append(list(range(i, i + k)))
             i += k
         return chunks
+
+    def _chunk_size(self):
+        hip = self.config.get("hip", None) if hasattr(self.config, "get") else None
+        return max(1, min(int(hip.get("chunk", ROB_GROUP)) if hip is not None else ROB_GROUP, _lib.MAX_BATCH))
 
     def _n_streams(self, n_streams):
         if n_streams is None:
@@ -401,6 +405,19 @@ class BurstPipeline:
 _main_runners = []  # [(config, ConfigWatch, HostBurstRunner)], most recently used last
 
 
+def _drop_host_runners():
+    """Interpreter exit: release the cached runners (HIP graphs, page-locked staging, copy threads) while the HIP runtime
+    is still up instead of in whatever order module teardown picks."""
+    while _main_runners:
+        _, _, runner = _main_runners.pop()
+        runner.close()
+
+
+import atexit as _atexit  # noqa: E402
+
+_atexit.register(_drop_host_runners)
+
+
 def _host_runner(config, device):
     """The HostBurstRunner of a configuration object that main() is called with again and again (a serving loop); a
     configuration edited in place gets a new one.  At most two are kept (each holds a burst's intermediates)."""
@@ -417,7 +434,8 @@ def _host_runner(config, device):
     watch.changed(config)
     runner = HostBurstRunner(config, device)
     _main_runners.append((config, watch, runner))
-    del _main_runners[:-2]
+    while len(_main_runners) > 2:
+        _main_runners.pop(0)[2].close()
     return runner
 
 

@@ -38,6 +38,10 @@ def _grey_plan(H, W, device, batch=1):
     if p is not None and p.batch < batch:
         p = None
     if p is None:
+        if torch.cuda.is_current_stream_capturing():
+            # a plan allocates (twiddle tables, spectra): it has to exist before its stream is captured — graph.py's
+            # runners do one eager call on the capture streams first
+            raise RuntimeError(f"no FFT plan for {H}x{W} x{batch} on this stream yet: cannot create one during stream capture")
         while len(_grey_plans) >= _GREY_PLAN_CACHE:  # evict the least recently used plan only
             _grey_plans.pop(next(iter(_grey_plans)))
         with torch.cuda.device(device):
@@ -59,7 +63,9 @@ def compute_grey_images_batch(imgs, method="FFT"):
     dev = imgs[0].device
     out = torch.empty((len(imgs), H, W), dtype=torch.float32, device=dev)
     outs = list(out.unbind(0))
-    plan = _grey_plan(H, W, dev, min(len(imgs), _lib.MAX_BATCH))
+    # (a plan that serves more than one frame per launch always holds MAX_BATCH spectra — 24 MB each at 12 MP: the
+    # callers' chunk sizes vary, e.g. graph.host_chunks, and a plan cannot be replaced while its stream is captured)
+    plan = _grey_plan(H, W, dev, _lib.MAX_BATCH)
     _lib.call("hhsr_grey_lowpass_batch", plan.handle, _lib.ptr_array(imgs), _lib.ptr_array(outs), len(imgs),
               _lib.stream(dev))
     return outs

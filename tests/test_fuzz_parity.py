@@ -1,0 +1,192 @@
+"""Randomised end-to-end parity sweep as a test: HIP main() against oracle.main() on 64 random bursts —
+sizes (also odd multiples of 2), 2-4 frames, scales 1 / 1.5 / 2 / 3, the four Bayer patterns, white balances, tile sizes
+16 / 32, iso kernel, robustness and merge denoiser on / off, moving occluders, level-0 metric L2 / L1 / L1_ref_effective.
+
+Asserted per case (every case also runs with the oracle's flow fields injected, config.hip.inject_flows — that run
+exercises kernels + robustness + merge on identical geometry, the flow comparison exercises the alignment):
+  * identical NaN pattern; at most one tile whose flow differs by > 0.05 px (a float32 near-tie of ONE block-matching
+    decision somewhere in the pyramid; measured: 1 tile in the 64 cases) and at most FLIPPED_PER_BATCH per batch;
+  * everywhere else flow <= 1e-4 px and robustness r <= 1e-4;
+  * oracle flows injected: image <= 1e-4 everywhere EXCEPT at most MAX_INJ_OUTLIERS isolated values per case, each <=
+    INJECTED_ATOL (measured over the 64 cases: 61 cases <= 9.6e-5, one case with 2 values at 1.01e-4; round 2's batches:
+    one case at 1.6e-4 under a diverged alignment — the moving occluder, |flow| > DIVERGED_PX);
+  * own flows: image <= 1e-4 outside the footprint of a flipped tile EXCEPT
+      (a) isolated pixels in diverged tiles: at most MAX_OUTLIERS values per case, each <= MAX_OUTLIER;
+      (b) flow-sensitive pixels — pixels that agree (<= 1e-4) once the oracle's flows are injected, i.e. whose whole
+          difference comes from the <= 1e-4 px by which the flows differ: at most two tiles' worth per case.
+
+Why those pixels exist — conditioning of the reference algorithm, not arithmetic differences:
+(a) under a diverged flow the merged content is wrong in both implementations; with robustness off the image
+derivative with respect to the flow is large there (8e-5 px of float32 ICA noise become 3e-4), with robustness on r sits
+in its transition band (~1e-5) where R = S e - t cancels to 1e-4 of its operands while the comp sample outweighs the
+reference sample ~100x: a relative 1e-6 in e becomes 1e-3 in the image — the reference's own float32 buffers carry the
+same rounding noise.  (b) the 3 x 3 tap window is centred on round(position) (merge.py:343-361): the output is
+DISCONTINUOUS in the flow where a tile's position (h + 0.5) / s + flow crosses a rounding boundary — a 1e-5 px flow
+difference then swaps a row of taps for the opposite one for every pixel of the tile with that sub-pixel phase (measured:
+one tile of one case, 6.9e-2 with own flows, 1.8e-7 with the oracle's flows).
+
+The oracle runs are independent: a fork pool computes them on the host cores while the GPU works through the cases."""
+import multiprocessing as mp
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import oracle
+from helpers import base_config, flipped_tiles
+from handheld_super_resolution import synthetic as synth
+import handheld_super_resolution as hsr
+
+pytestmark = pytest.mark.gpu
+
+CFAS = [((0, 1), (1, 2)), ((2, 1), (1, 0)), ((1, 0), (2, 1)), ((1, 2), (0, 1))]
+BATCHES = [(0, 22), (1, 22), (2, 20)]  # (generator seed, cases): the 64 cases
+FLIPPED_PER_BATCH = 2   # tiles with a flipped block-matching decision                (measured: 0, 0, 1)
+MAX_OUTLIERS = 64       # own flows, diverged tiles: values (pixel x channel) > 1e-4   (measured: 3 and 2 in two cases)
+MAX_OUTLIER = 5e-3      # ... the largest of them                                      (measured: 2.8e-3)
+DIVERGED_PX = 30.0      # |flow| beyond which a tile's alignment counts as diverged (the pyramid's honest range is ~10 px here)
+MAX_INJ_OUTLIERS = 16   # oracle flows injected: values > 1e-4                         (measured: 2, at 1.01e-4)
+INJECTED_ATOL = 3e-4    # ... the largest of them             (round 2's batches: one case at 1.6e-4)
+
+
+def cases(gen_seed, n):
+    rng = np.random.default_rng(gen_seed)
+    out = []
+    for k in range(n):
+        ts = int(rng.choice([16, 16, 32]))
+        lo, hi = (576, 760) if ts == 16 else (384, 640)  # (default pyramid factors need >= 36 tiles of 16; ts 32: factors 2)
+        c = dict(ts=ts, H=int(rng.integers(lo, hi)) // 2 * 2, W=int(rng.integers(lo, hi + 64)) // 2 * 2,
+                 nf=int(rng.integers(2, 5)), scale=[1, 1.5, 2, 2, 3][int(rng.integers(0, 5))], cfa=CFAS[int(rng.integers(0, 4))])
+        c["wb"] = (float(rng.uniform(1.0, 2.2)), 1.0, float(rng.uniform(1.0, 2.0))) if rng.random() < 0.7 else (1.0, 1.0, 1.0)
+        c["iso"] = bool(rng.random() < 0.2)
+        c["rob"] = bool(rng.random() < 0.85)
+        c["den"] = bool(c["rob"] and rng.random() < 0.25)
+        c["seed"] = int(rng.integers(0, 10000))
+        c["max_shift"], c["occ"] = float(rng.uniform(0.5, 3.5)), bool(rng.random() < 0.5)
+        c["metric0"] = ["L2", "L1", "L1_ref_effective"][(gen_seed + k) % 3] if ts == 16 else "L2"
+        c["id"] = f"{gen_seed}.{k}"
+        out.append(c)
+    return out
+
+
+def config(c, **hip):
+    cfg = base_config(ts=c["ts"], scale=c["scale"], snr=30.0 if c["ts"] == 16 else 18.0,
+                      metrics=(c["metric0"], "L2", "L2", "L2"))
+    if c["ts"] == 32:
+        cfg.block_matching.tuning.factors = [1, 2, 2, 2]
+    cfg.exif = {"cfa_pattern": [list(r) for r in c["cfa"]], "iso": 100, "white_balance": list(c["wb"])}
+    cfg.robustness.enabled = c["rob"]
+    cfg.robustness.save_mask = c["rob"]
+    if c["iso"]:
+        cfg.merging.kernel = "iso"
+    if c["den"]:
+        cfg.accumulated_robustness_denoiser.enabled = True
+        cfg.accumulated_robustness_denoiser.merge.enabled = True
+    if hip:
+        cfg.hip = hip
+    return cfg
+
+
+def burst(c):
+    return synth.make_burst(c["H"], c["W"], c["nf"], seed=c["seed"], max_shift=c["max_shift"], occluder=c["occ"],
+                            cfa=c["cfa"], wb=c["wb"])[:2]
+
+
+def _oracle_case(c):
+    os.environ["OMP_NUM_THREADS"] = "1"
+    torch.set_num_threads(1)
+    ref, comp = burst(c)
+    cap = {}
+    want, _ = oracle.main(ref, comp, config(c), capture=cap)
+    return ref, comp, want, np.stack(cap["flow"]), (np.stack(cap["r"]) if c["rob"] else None)
+
+
+def check(c, ref, comp, want, oflow, o_r, report=None):
+    """Returns the number of flipped tiles of the case."""
+    from helpers import footprint
+
+    cfg = config(c)
+    cfg.debug = True
+    out, dbg = hsr.main(ref, comp, cfg)
+    o = out.cpu().numpy()
+    cfg_i = config(c, inject_flows=[f for f in oflow])
+    cfg_i.debug = True
+    out_i, dbg_i = hsr.main(ref, comp, cfg_i)
+    oi = out_i.cpu().numpy()
+    H, W, ts, scale = c["H"], c["W"], c["ts"], c["scale"]
+    tag = f"case {c['id']} ({H}x{W} x{c['nf']} s={scale} ts={ts} {c['metric0']} rob={c['rob']} den={c['den']} occ={c['occ']})"
+    gflow = np.stack(dbg["flow"])
+    flipped = flipped_tiles(gflow, oflow)
+    nflip = int(flipped.sum())
+    nan_mis = int((np.isnan(o) != np.isnan(want)).sum()) + int((np.isnan(oi) != np.isnan(want)).sum())
+    dflow = float(np.abs(gflow - oflow).max(-1)[~flipped].max())
+    dr = dr_i = 0.0
+    if c["rob"]:
+        m1 = np.stack([footprint(f, ts, (H, W), 1.0) for f in flipped])
+        dr = float(np.where(m1, 0, np.abs(np.stack(dbg["robustness"]) - o_r)).max())
+        dr_i = float(np.abs(np.stack(dbg_i["robustness"]) - o_r).max())
+    with np.errstate(all="ignore"):
+        d = np.where(np.isnan(want), 0.0, np.abs(o.astype(np.float64) - want))
+        di = np.where(np.isnan(want), 0.0, np.abs(oi.astype(np.float64) - want))
+    d = np.where(footprint(flipped, ts, (H, W), scale)[..., None], 0.0, d)
+    # tiles with a diverged alignment in some frame, grown by one tile (a sample's kernel reaches into the neighbour)
+    big = np.abs(oflow).max(-1).max(0) > DIVERGED_PX
+    grown = np.zeros_like(big)
+    for dy in (-1, 0, 1):
+        for dx in (-1, 0, 1):
+            grown |= np.roll(np.roll(big, dy, 0), dx, 1)
+    yy = np.minimum(((np.arange(o.shape[0]) + 0.5) / scale).astype(int) // ts, big.shape[0] - 1)
+    xx = np.minimum(((np.arange(o.shape[1]) + 0.5) / scale).astype(int) // ts, big.shape[1] - 1)
+    div = grown[np.ix_(yy, xx)][..., None]
+    bad_i = di > 1e-4
+    n_inj, inj_max, inj_outside = int(bad_i.sum()), float(di.max()), int((bad_i & ~div).sum())
+    bad = d > 1e-4
+    sens = bad & ~bad_i                      # (b) agree once the flows agree
+    rest = bad & bad_i                       # (a) must be diverged-tile outliers
+    n_sens, sens_max = int(sens.sum()), float(np.where(sens, d, 0).max())
+    n_rest, rest_max, rest_outside = int(rest.sum()), float(np.where(rest, d, 0).max()), int((rest & ~div).sum())
+    if report is not None:
+        report.append(f"{tag}: flipped {nflip}, nan {nan_mis}, flow {dflow:.1e}, r {dr:.1e} / injected {dr_i:.1e}; injected "
+                      f"image max {inj_max:.2e} ({n_inj} > 1e-4, {inj_outside} outside diverged tiles); own flows: flow-"
+                      f"sensitive {n_sens} (max {sens_max:.1e}), other {n_rest} (max {rest_max:.1e}, {rest_outside} outside "
+                      f"diverged tiles)")
+        return nflip
+    assert nan_mis == 0 and nflip <= 1, f"{tag}: {nflip} flipped tiles, {nan_mis} NaN mismatches"
+    assert dflow <= 1e-4 and dr <= 1e-4 and dr_i <= 1e-4, f"{tag}: flow {dflow:.2e} px, r {dr:.2e} / {dr_i:.2e}"
+    assert n_inj <= MAX_INJ_OUTLIERS and inj_max <= INJECTED_ATOL, \
+        f"{tag}: oracle flows injected: {n_inj} values above 1e-4 (max {inj_max:.2e}), {inj_outside} outside diverged tiles"
+    assert n_rest <= MAX_OUTLIERS and rest_max <= MAX_OUTLIER and rest_outside == 0, \
+        f"{tag}: {n_rest} values above 1e-4 (max {rest_max:.2e}), {rest_outside} outside diverged tiles"
+    assert n_sens <= 2 * 3 * int(round(ts * scale)) ** 2, f"{tag}: {n_sens} flow-sensitive values (max {sens_max:.2e})"
+    return nflip
+
+
+_pool, _jobs = None, {}
+
+
+@pytest.fixture(scope="module")
+def oracle_jobs():
+    """All 64 oracle runs are submitted at once to a fork pool (NumPy-only children: they never touch the GPU) and the
+    batches consume them as they finish: the sweep takes about as long as the slowest oracle case."""
+    all_cases = [c for gs, n in BATCHES for c in cases(gs, n)]
+    workers = max(1, min(len(all_cases), (os.cpu_count() or 2) // 2))
+    pool = mp.get_context("fork").Pool(workers)
+    jobs = {c["id"]: pool.apply_async(_oracle_case, (c,)) for c in all_cases}
+    yield jobs
+    pool.terminate()
+    pool.join()
+
+
+@pytest.mark.timeout(1800)
+@pytest.mark.parametrize("gen_seed,n", BATCHES)
+def test_fuzz_sweep(oracle_jobs, gen_seed, n):
+    report = [] if os.environ.get("HHSR_FUZZ_REPORT") else None
+    flipped = 0
+    for c in cases(gen_seed, n):
+        flipped += check(c, *oracle_jobs[c["id"]].get(timeout=1500), report=report)
+    if report is not None:
+        with open(os.environ["HHSR_FUZZ_REPORT"], "a") as f:
+            f.write("\n".join(report) + "\n")
+    else:
+        assert flipped <= FLIPPED_PER_BATCH, f"batch {gen_seed}: {flipped} flipped tiles"

@@ -1764,7 +1764,7 @@ def test_main_numpy_serving_loop():
     signature in a serving loop), goes through the runner from the third call on and still hands out fresh tensors."""
     from handheld_super_resolution import super_resolution as sr
 
-    ref, comp, _ = synth.make_burst(384, 512, 6, seed=8, max_shift=2.0)
+    ref, comp, _ = synth.make_burst(512, 640, 6, seed=8, max_shift=2.0)
     cfg = base_config(ts=16, scale=2)
     outs = [hsr.main(ref, comp, cfg)[0] for _ in range(4)]
     for o in outs[1:]:
@@ -1774,7 +1774,7 @@ def test_main_numpy_serving_loop():
     assert not runner.disabled and any(s != "seen" for s in runner.states.values())
     cfg.scale = 1  # edited in place: a new runner, the eager result of the new configuration
     o1 = hsr.main(ref, comp, cfg)[0]
-    assert tuple(o1.shape) == (384, 512, 3)
+    assert tuple(o1.shape) == (512, 640, 3)
     cfg2 = base_config(ts=16, scale=1)
     assert torch.equal(torch.nan_to_num(o1), torch.nan_to_num(hsr.main(ref, comp, cfg2)[0]))
 

@@ -20,13 +20,17 @@ def run(split):
     cfg.verbose = 0
     cfg.scale = 2
     black, white = 64.0, 1023.0
-    cfg.hip = {"raw_norm": {"black_levels": [black] * 3, "white_level": white}}
-    if split != "auto":
-        cfg.hip["merge_split"] = split == "on"
+    cfg.hip = {"raw_norm": {"black_levels": [black] * 3, "white_level": white}} if split != "f32" else {}
+    if os.environ.get("HHSR_CHUNK"):
+        cfg.hip["chunk"] = int(os.environ["HHSR_CHUNK"])
+    if os.environ.get("HHSR_STREAMS"):
+        cfg.hip["streams"] = int(os.environ["HHSR_STREAMS"])
     hsr.prepare_config(cfg, np.full((H, W), float(ref.mean()), np.float32), synth.ALPHA_ISO100, synth.BETA_ISO100,
                        [[0, 1], [1, 2]], [1.0, 1.0, 1.0])
     to_counts = lambda t: torch.from_numpy(np.clip(np.rint(t.cpu().numpy() * (white - black) + black), 0, white)
                                            .astype(np.uint16)).pin_memory()
+    if split == "f32":
+        to_counts = lambda t: t.cpu().pin_memory()
     ref16, comp16 = to_counts(ref), [to_counts(comp[i]) for i in range(NF - 1)]
     del ref, comp
     eng = hdist.HipEngine(cfg)
@@ -64,7 +68,7 @@ def report(db):
     for e in big:
         print(f"  copy {(e[0] - t0) / 1e6:7.3f} .. {(e[1] - t0) / 1e6:7.3f} ms  {int(e[2].split()[1]) / 1e6:.1f} MB")
     for e in step:
-        if "k_merge" in e[2] or "k_ref_planes" in e[2]:
+        if "k_merge" in e[2] or "k_ref_planes" in e[2] or "k_rows_fwd" in e[2] or "k_rob_frames" in e[2]:
             print(f"  {e[2]:40s} {(e[0] - t0) / 1e6:7.3f} .. {(e[1] - t0) / 1e6:7.3f} ms")
     kk = sorted((e[0], e[1]) for e in step if not e[2].startswith("COPY"))
     busy, last = 0, t0
