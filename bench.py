@@ -212,8 +212,8 @@ def main():
     timed_call.on = False
     out_pix = round(scale * H) * round(scale * W)
     value = out_pix / (ms_per_step * 1e-3) / 1e6
-    graphed = bool(on_gpu and (getattr(getattr(engine, "_runner", None), "graphs", None) or
-                               getattr(getattr(engine, "_runner_a", None), "graphs", None)))
+    graphed = bool(on_gpu and any(getattr(getattr(engine, r, None), "graphs", None)
+                                  for r in ("_runner", "_runner_a", "_runner_p")))
     if world > 1:  # the eager section below runs collectives: every rank takes it when any rank replayed a graph
         g_any = torch.tensor([int(graphed)], dtype=torch.int32, device=dev)
         dist.all_reduce(g_any, op=dist.ReduceOp.MAX)
@@ -405,8 +405,11 @@ def main():
             "strategy": args.strategy if world > 1 else None,
             "launch": (("HIP graph replay: the step is captured once (stream capture incl. the frame pipeline's side "
                         "streams) and replayed with one launch per burst; every kernel runs on every step" if world == 1
-                        else "HIP graph replay of the two per-rank steps (alignment of the rank's frames; robustness + "
-                             "kernels + merge of its rows), the all-gather of the flow fields between them")
+                        else ("HIP graph replay of the two per-rank steps (alignment of the rank's frames; robustness + "
+                              "kernels + merge of its rows), the all-gather of the flow fields between them"
+                              if args.strategy == "rows" else
+                              "HIP graph replay of the two per-rank steps (the rank's frames through the whole chain into "
+                              "accumulators; reference frame + normalisation of its slab), the reduce-scatter between them"))
                        if graphed else "one launch per kernel from Python"),
             "ms_per_step_eager": round(ms_eager, 3) if ms_eager else None,
             "rccl_ranks": dist.get_world_size() if world > 1 else 1,

@@ -92,20 +92,27 @@ def footprint(flipped, ts, shape, scale=1.0, grow=3):
     return lr[np.ix_(yi, xi)]
 
 
-def assert_explained(got, want, atol, flipped, ts, shape, scale, what, max_flipped, per_frame=False):
+def assert_explained(got, want, atol, flipped, ts, shape, scale, what, max_flipped, per_frame=False, grow=None,
+                     stray=(0, 0.0)):
     """|got - want| <= atol everywhere except inside the footprint of flipped tiles; the number of flipped tiles
-    (over all frames) is itself bounded by `max_flipped` (the measured count, PARITY.md).  NaN == NaN."""
+    (over all frames) is itself bounded by `max_flipped` (the measured count, PARITY.md).  NaN == NaN.
+    `grow`: LR pixels the footprint extends beyond the tile; default ts + 3 — a tile's flow enters the flow-irregularity
+    weight S of its 8 NEIGHBOUR tiles (robustness.py:587-612), so a flipped decision can switch their S between s1 and
+    s2 and with it their robustness and merged pixels.
+    `stray` = (count, cap): that many values outside the footprint may exceed atol, each by at most cap (isolated
+    flow-sensitive pixels, tests/test_fuzz_parity.py: the measured count goes here, not a blanket allowance)."""
+    grow = ts + 3 if grow is None else grow
     got, want = np.asarray(got, np.float64), np.asarray(want, np.float64)
     assert got.shape == want.shape, f"{what}: shape {got.shape} vs {want.shape}"
     nf = int(np.asarray(flipped).sum())
     with np.errstate(all="ignore"):
         bad = ~((np.abs(got - want) <= atol) | (np.isnan(got) & np.isnan(want)))
     if bad.ndim == 3 and bad.shape[-1] == 3 and not per_frame:      # [sH, sW, 3] image
-        mask = footprint(flipped, ts, shape, scale)[..., None]
+        mask = footprint(flipped, ts, shape, scale, grow)[..., None]
     elif per_frame:                                                  # [n, H, W] per-frame maps
-        mask = np.stack([footprint(f, ts, shape, scale) for f in np.asarray(flipped)])
+        mask = np.stack([footprint(f, ts, shape, scale, grow) for f in np.asarray(flipped)])
     else:
-        mask = footprint(flipped, ts, shape, scale)
+        mask = footprint(flipped, ts, shape, scale, grow)
     unexplained = bad & ~mask
     log = os.environ.get("HHSR_PARITY_LOG")
     if log:
@@ -122,6 +129,8 @@ def assert_explained(got, want, atol, flipped, ts, shape, scale, what, max_flipp
     if unexplained.any():
         with np.errstate(all="ignore"):
             err = np.where(unexplained, np.abs(got - want), 0)
+        if int(unexplained.sum()) <= stray[0] and float(np.nanmax(err)) <= stray[1]:
+            return
         k = np.unravel_index(np.nanargmax(err), err.shape)
         raise AssertionError(f"{what}: {int(unexplained.sum())} differences above {atol} outside the footprint of the "
                              f"{nf} flipped tiles; worst at {k}: {got[k]} vs {want[k]}")

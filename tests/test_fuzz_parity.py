@@ -123,13 +123,13 @@ def check(c, ref, comp, want, oflow, o_r, report=None):
     dflow = float(np.abs(gflow - oflow).max(-1)[~flipped].max())
     dr = dr_i = 0.0
     if c["rob"]:
-        m1 = np.stack([footprint(f, ts, (H, W), 1.0) for f in flipped])
+        m1 = np.stack([footprint(f, ts, (H, W), 1.0, ts + 3) for f in flipped])  # (+ the neighbour tiles: their S)
         dr = float(np.where(m1, 0, np.abs(np.stack(dbg["robustness"]) - o_r)).max())
         dr_i = float(np.abs(np.stack(dbg_i["robustness"]) - o_r).max())
     with np.errstate(all="ignore"):
         d = np.where(np.isnan(want), 0.0, np.abs(o.astype(np.float64) - want))
         di = np.where(np.isnan(want), 0.0, np.abs(oi.astype(np.float64) - want))
-    d = np.where(footprint(flipped, ts, (H, W), scale)[..., None], 0.0, d)
+    d = np.where(footprint(flipped, ts, (H, W), scale, ts + 3)[..., None], 0.0, d)
     # tiles with a diverged alignment in some frame, grown by one tile (a sample's kernel reaches into the neighbour)
     big = np.abs(oflow).max(-1).max(0) > DIVERGED_PX
     grown = np.zeros_like(big)

@@ -25,7 +25,11 @@ DEV = "cuda"
 # budgets are zero and every image / robustness difference has to be within tolerance everywhere.  Should a future
 # kernel change flip a near-tie, the footprint rule of helpers.assert_explained keeps the image check meaningful.
 FLIP_BUDGET = {"c1": 0, "ts32": 0, "ts64": 0, "ragged2": 0, "ragged1.5": 0, "ragged3": 0, "matrix": 0,
-               "c2_full": 0, "c4_crop": 0}
+               "c2_full": 0, "c4_crop": 0,
+               # L1_ref_effective rounds the incoming level-0 flow (flow <- round_half_even(flow)): a tile whose upscaled
+               # level-1 flow lies within float32 ICA noise (1e-6 px) of k + 0.5 rounds the other way — measured: 1 of the
+               # 94 000 tile-frames of the 12 MP burst
+               "c2_full_eff": 2}
 
 
 def T(a, dtype=torch.float32):
@@ -814,7 +818,7 @@ def test_e2e_golden_x1_denoiser(golden):
 
 
 def _e2e_vs_oracle(ref, comp, cfg_fn, ts, what, max_flipped, out_atol=1e-4, flow_atol=1e-4, r_atol=1e-4, acc_atol=3e-4,
-                   parallel=False):
+                   parallel=False, stray=(0, 0.0)):
     """HIP main() against the oracle on one burst, every difference accounted for (tolerances ~10x the measured
     differences of PARITY.md: flow 8e-6 px, r 7e-6, accumulated r 1.4e-5, image 6.4e-5): flows equal to `flow_atol` except on
     tiles whose block-matching decision flipped (count <= max_flipped, the measured number); robustness, accumulated
@@ -837,7 +841,7 @@ def _e2e_vs_oracle(ref, comp, cfg_fn, ts, what, max_flipped, out_atol=1e-4, flow
                      max_flipped, per_frame=True)
     o = N(out)
     assert o.shape == want.shape
-    assert_explained(o, want, out_atol, flipped, ts, (H, W), scale, what + " output", max_flipped)
+    assert_explained(o, want, out_atol, flipped, ts, (H, W), scale, what + " output", max_flipped, stray=stray)
     if "accumulated robustness" in wdbg:
         assert_explained(N(dbg["accumulated robustness"]), wdbg["accumulated robustness"], acc_atol, flipped, ts, (H, W),
                          1.0, what + " acc r", max_flipped)
@@ -1221,13 +1225,21 @@ def test_full_size_properties():
     assert float((inner - 0.4).abs().max()) < 1e-5
 
 
-def test_c2_full_size_against_oracle():
+@pytest.mark.parametrize("metric0", ["L1", "L1_ref_effective"])
+def test_c2_full_size_against_oracle(metric0):
     """BASELINE config C2 geometry at FULL size — 3000x4000, x2 -> 48 MP — against the oracle (2 comp frames: ~1 min of
-    NumPy on two host cores), every difference attributed to a flipped block-matching tile."""
+    NumPy on two host cores), every difference attributed to a flipped block-matching tile.  Both readings of the
+    headline configuration's level-0 metric (configs/default.yaml:17 `L1`; upstream's L1 kernels are undefined
+    behaviour): the intended SAD argmin, and `L1_ref_effective` = what the hardware most likely
+    does with the uninitialised shift (flow <- round(flow))."""
     H, W = 3000, 4000
     ref, comp, _ = synth.make_burst(H, W, 3, seed=1234)
-    _e2e_vs_oracle(ref, comp, lambda: base_config(ts=16, scale=2, metrics=("L1", "L2", "L2", "L2")), 16, "C2 full size",
-                   max_flipped=FLIP_BUDGET["c2_full"], parallel=True)
+    _e2e_vs_oracle(ref, comp, lambda: base_config(ts=16, scale=2, metrics=(metric0, "L2", "L2", "L2")), 16,
+                   f"C2 full size {metric0}",
+                   max_flipped=FLIP_BUDGET["c2_full" if metric0 == "L1" else "c2_full_eff"], parallel=True,
+                   # (L1_ref_effective: ONE of the 144 M output values at 2.1e-4 away from any flipped tile — an isolated
+                   # flow-sensitive pixel, see tests/test_fuzz_parity.py)
+                   stray=(0, 0.0) if metric0 == "L1" else (4, 1e-3))
 
 
 def test_c4_substitute_13_frames_sensor_size():
@@ -1873,3 +1885,29 @@ def test_sharded_reduce_strategy(tmp_path, world):
     got = _spawn2(tmp_path, world, "reduce", False)
     assert_close(got["out"], N(want), 0, 2e-6, "reduce strategy == single")
     assert_close(got["acc_r"], N(wdbg["accumulated robustness"]), 0, 2e-6, "acc_r")
+
+
+@pytest.mark.timeout(900)
+@pytest.mark.parametrize("strategy", ["rows", "reduce"])
+def test_bench_two_ranks_share_the_gpu(strategy):
+    """`bench.py --gpus 2` with the real HipEngine: the script re-executes itself under torch.distributed.run, two ranks
+    rendezvous over gloo (RCCL needs one GPU per rank; HHSR_BENCH_SHARE_GPU=1 puts both on device 0), run
+    main_sharded with the chosen strategy from HIP graphs and rank 0 prints ONE JSON line with n_gpus = 2."""
+    import json
+    import os
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, HHSR_BENCH_SHARE_GPU="1")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT"):
+        env.pop(k, None)
+    p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--backend", "gloo", "--strategy",
+                        strategy, "--height", "768", "--width", "1024", "--frames", "6", "--steps", "3", "--warmup", "2",
+                        "--no-cpu-baseline", "--no-h2d"], capture_output=True, text=True, env=env, timeout=850)
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert p.returncode == 0 and len(lines) == 1, p.stderr[-3000:]
+    rec = json.loads(lines[0])
+    assert rec["n_gpus"] == 2 and rec["rccl_ranks"] == 2 and rec["backend"] == "gloo" and rec["value"] > 0
+    assert rec["strategy"] == strategy and strategy in rec["config"]["parallelism"]
+    assert rec["engine"].startswith("HipEngine") and "HIP graph replay" in rec["launch"]
