@@ -61,5 +61,31 @@ def build(force=False, verbose=True):
     return OUT
 
 
+def build_asan(out_dir, verbose=False):
+    """AddressSanitizer build of the HOST side of the library: every translation unit with
+    -fsanitize=address -fno-gpu-sanitize (the device code is untouched), linked against the shared ASan runtime, into
+    `out_dir`/libhhsr_hip_asan.so.  Used by tests/test_abi.py with a C driver built by the same compiler; not shipped."""
+    os.makedirs(out_dir, exist_ok=True)
+    flags = ["--offload-arch=" + ARCH, "-O1", "-g", "-std=c++17", "-fPIC", "-fsanitize=address", "-fno-gpu-sanitize",
+             "-shared-libsan", "-fno-omit-frame-pointer"]
+    objs, jobs = [], []
+    for src, extra in SOURCES.items():
+        o = os.path.join(out_dir, src.replace(".hip", ".o"))
+        objs.append(o)
+        jobs.append([HIPCC, *flags, *extra, "-c", os.path.join(CSRC, src), "-o", o])
+
+    def run(cmd):
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        subprocess.run(cmd, check=True)
+
+    with ThreadPoolExecutor(max_workers=max(1, min(len(jobs), os.cpu_count() or 1))) as ex:
+        list(ex.map(run, jobs))
+    out = os.path.join(out_dir, "libhhsr_hip_asan.so")
+    run([HIPCC, "--offload-arch=" + ARCH, "-shared", "-fPIC", "-fsanitize=address", "-shared-libsan", "-o", out, *objs,
+         "-L/opt/rocm/lib", "-lhipfft", "-Wl,-rpath,/opt/rocm/lib"])
+    return out
+
+
 if __name__ == "__main__":
     print(build(force="--force" in sys.argv))

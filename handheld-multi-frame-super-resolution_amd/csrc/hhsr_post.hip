@@ -8,9 +8,11 @@
 
 // ---- accumulated-robustness sample an output pixel reads (utils_image.py:205-206, 262-263) ---------------------------
 // half_index = 1: int(round((y - 0.5) / (2 scale))), the reference's expression (it addresses the [H][W] map as if it
-// had half that resolution — a deterministic upstream quirk, reproduced by default); 0: the nearest raw pixel.
+// had half that resolution — a deterministic upstream quirk, reproduced by default); 0: the nearest raw pixel;
+// 2: int(round(y / scale)), the reference's `mode: grey` branch (utils_image.py:203-204, 260-261).
 __device__ __forceinline__ int acc_index(int i, double scale, int half_index, int n) {
-    const double v = half_index ? ((double)i - 0.5) / (2.0 * scale) : ((double)i + 0.5) / scale - 0.5;
+    const double v = half_index == 2 ? (double)i / scale
+                   : half_index ? ((double)i - 0.5) / (2.0 * scale) : ((double)i + 0.5) / scale - 0.5;
     return min(max((int)rint(v), 0), n - 1);  // rint: half to even, like Python's round()
 }
 

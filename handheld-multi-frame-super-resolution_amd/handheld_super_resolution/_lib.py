@@ -162,6 +162,6 @@ def f32c(t, device=None):
     if not isinstance(t, torch.Tensor):
         t = torch.as_tensor(t)
     dev = device if device is not None else (t.device if t.is_cuda else torch.device("cuda", torch.cuda.current_device()))
-    if not t.is_cuda and t.dtype not in (torch.float32, torch.float64, torch.float16, torch.bfloat16):
-        t = t.to(torch.float32)
+    if not t.is_cuda and t.dtype not in (torch.float32, torch.float16, torch.bfloat16):
+        t = t.to(torch.float32)  # (float64 host data too: half the PCIe bytes, the kernels work on float32)
     return t.to(device=dev, non_blocking=True).to(dtype=torch.float32).contiguous()

@@ -8,7 +8,11 @@ MI355X design notes (vs the reference's per-frame Python loop):
     20-frame burst is <3 GB of the 288 GB) and the merge of the whole burst is ONE kernel with the
     accumulators in registers (merge.merge_burst), instead of a read-modify-write of the 2x576 MB
     accumulators per frame;
-  * frames shard across GPUs with one RCCL sum-reduce of num/den (distributed.py).
+  * the front end (grey FFT, pyramid, alignment levels, raw pass) runs one launch per STAGE AND CHUNK of frames, chunks
+    round-robin on three HIP streams; bursts that start in host memory run as eager uploads + per-chunk HIP graphs
+    (graph.HostBurstRunner), device-resident bursts as one graph per burst (graph.GraphRunner);
+  * multi-GPU (distributed.py): alignment frame-parallel, one all-gather of the flow fields, robustness / kernels /
+    merge row-parallel (default), or frames one per GPU with one reduce-scatter of the num / den accumulators.
 """
 import time
 
@@ -143,12 +147,22 @@ class BurstPipeline:
                 if stream is None:
                     # (high priority = its own hardware queue: see graph.HostBurstRunner)
                     stream = _upload_streams[self.device.index] = torch.cuda.Stream(self.device, priority=-1)
+            if t.dtype == torch.float64:  # (half the PCIe bytes: the kernels work on float32 frames anyway)
+                t = t.to(torch.float32).pin_memory()
             with torch.cuda.stream(stream):
                 d = t.contiguous().to(self.device, non_blocking=True)
                 ev = torch.cuda.Event()
                 ev.record(stream)
+            self._last_upload = ev
             out.append(_Staged(d, ev))
         return out
+
+    def uploads_done(self):
+        """Block until the last queued upload has left the host: the caller's page-locked buffers may be refilled."""
+        ev = getattr(self, "_last_upload", None)
+        if ev is not None:
+            ev.synchronize()
+            self._last_upload = None
 
     def _timed(self, func, level, start_s=None, end_s=None):
         """The reference's per-stage timers (super_resolution.py:72-81): synchronising wall-clock wrappers, active from
@@ -532,6 +546,10 @@ def main(ref_img, comp_imgs, config, *, _no_runner=False):
         print(s, " " * (50 - len(s)), ": ", round((time.perf_counter() - t1), 2), "seconds")
     if accumulate_r:
         debug_dict["accumulated robustness"] = accumulated_r
+    # host-buffer contract: main() returns when the caller's (page-locked) frames have been read — the uploads were
+    # queued asynchronously (BurstPipeline.prefetch) and a serving loop refills its staging buffers right after the
+    # call; the kernels keep running asynchronously on the current stream as before
+    pipe.uploads_done()
     return num, debug_dict
 
 
@@ -655,10 +673,10 @@ def process(burst_path, config):
     half_index = bool(compat.get("post_denoiser_half_index", True))
     if den.median.enabled:
         out = frame_count_denoising_median(out, debug_dict["accumulated robustness"], den.median, scale=config.scale,
-                                           half_index=half_index)
+                                           half_index=half_index, mode=config.mode)
     if den.gauss.enabled:
         out = frame_count_denoising_gauss(out, debug_dict["accumulated robustness"], den.gauss, scale=config.scale,
-                                          half_index=half_index)
+                                          half_index=half_index, mode=config.mode)
     ori = int(burst.get("orientation", 1))  # EXIF 'Image Orientation' (reference :346-352); 1 when the burst has none
     pp = config.postprocessing
     if pp.enabled:

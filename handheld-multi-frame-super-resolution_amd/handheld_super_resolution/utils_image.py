@@ -196,9 +196,13 @@ def apply_orientation(img, ori):
     return t(img).contiguous()
 
 
-def _frame_count_denoise(image, r_acc, config, kind, strength, scale, half_index):
-    if str(config.get("mode", "bayer")) == "grey":
-        raise NotImplementedError("grey mode is outside the MI355X hot path (bayer only)")
+def _frame_count_denoise(image, r_acc, config, kind, strength, scale, half_index, mode=None):
+    # `mode: grey` (monochrome sensors): the reference indexes the accumulated robustness with int(round(y / scale))
+    # (utils_image.py:203-204, 260-261) instead of the Bayer branch's half-resolution index.  Upstream reads `mode` (and
+    # `scale`) from the denoiser's own sub-block, which process() never fills: here process() passes both.
+    mode = str(config.get("mode", "bayer") if mode is None else mode)
+    if mode == "grey":
+        half_index = 2
     scale = config.get("scale", scale)
     if scale is None:
         raise ValueError("the frame-count denoisers need the scale (config.scale or the scale argument)")
@@ -208,20 +212,20 @@ def _frame_count_denoise(image, r_acc, config, kind, strength, scale, half_index
     assert C == 3
     out = torch.empty_like(img)
     _lib.call("hhsr_frame_count_denoise", _lib.ptr(img), _lib.ptr(out), H, W, _lib.ptr(acc), acc.shape[0], acc.shape[1],
-              float(scale), kind, float(strength), float(config.max_frame_count), 1 if half_index else 0,
+              float(scale), kind, float(strength), float(config.max_frame_count), int(half_index),
               _lib.stream(img.device))
     return out
 
 
-def frame_count_denoising_median(image, r_acc, config, scale=None, half_index=True):
+def frame_count_denoising_median(image, r_acc, config, scale=None, half_index=True, mode=None):
     """Median filter whose radius grows where few frames were merged (utils_image.py:236-286).  `config`: the
     accumulated_robustness_denoiser.median block (radius_max <= 7, max_frame_count); the reference reads `scale` and
     `mode` from the same block although process() never puts them there — pass `scale`.  `half_index`: keep the
     reference's index into the accumulated robustness (it addresses the [H, W] map at half resolution)."""
-    return _frame_count_denoise(image, r_acc, config, 0, config.radius_max, scale, half_index)
+    return _frame_count_denoise(image, r_acc, config, 0, config.radius_max, scale, half_index, mode)
 
 
-def frame_count_denoising_gauss(image, r_acc, config, scale=None, half_index=True):
+def frame_count_denoising_gauss(image, r_acc, config, scale=None, half_index=True, mode=None):
     """Gaussian blur whose sigma grows where few frames were merged (utils_image.py:174-234).  Upstream this kernel does
     not compile (range() of the float 3 sigma); the build's window is |i|, |j| <= ceil(3 sigma)."""
-    return _frame_count_denoise(image, r_acc, config, 1, config.sigma_max, scale, half_index)
+    return _frame_count_denoise(image, r_acc, config, 1, config.sigma_max, scale, half_index, mode)

@@ -289,7 +289,8 @@ int hhsr_normalize_raw_u16(const uint16_t* raw, int n_frames, int H, int W, int 
  * [ah][aw] (accumulated robustness).  kind 0 = median (strength_max = radius_max <= 7: the reference's 16 x 16 sample
  * buffer overflows beyond that, error -2), kind 1 = gauss (strength_max = sigma_max; window |i|, |j| <= ceil(3 sigma) —
  * the reference's range() of a float does not type under Numba, so the build defines it).  half_index 1 = the
- * reference's index int(round((y - 0.5) / (2 scale))) into acc_r, 0 = the nearest raw pixel. */
+ * reference's index int(round((y - 0.5) / (2 scale))) into acc_r, 0 = the nearest raw pixel, 2 = int(round(y / scale)),
+ * the reference's `mode: grey` branch (utils_image.py:203-204, 260-261). */
 int hhsr_frame_count_denoise(const float* image, float* out, int H, int W, const float* acc_r, int ah, int aw,
                              double scale, int kind, double strength_max, double max_frame_count, int half_index,
                              void* stream);

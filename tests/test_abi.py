@@ -102,3 +102,87 @@ def test_c_client_runs(tmp_path):
     r = subprocess.run([_build_c_demo(tmp_path)], capture_output=True, text=True)
     assert r.returncode == 0, r.stdout + r.stderr
     assert "bit-exact" in r.stdout and "rejected factor 3" in r.stdout
+
+
+# ---- AddressSanitizer build of the host shim ---------------------------------------------------------------
+CLANG = "/opt/rocm/lib/llvm/bin/clang"
+
+
+def _asan_env():
+    import glob
+
+    rt = glob.glob("/opt/rocm/lib/llvm/lib/clang/*/lib/linux/libclang_rt.asan-x86_64.so")
+    if not rt or not os.path.exists(CLANG):
+        pytest.skip("ROCm clang / ASan runtime not available")
+    # protect_shadow_gap=0: the HIP runtime maps memory inside ASan's shadow gap; leaks: the runtime's own singletons
+    return dict(os.environ, ASAN_OPTIONS="protect_shadow_gap=0:detect_leaks=0:abort_on_error=0",
+                LD_LIBRARY_PATH=os.path.dirname(rt[0]) + ":" + os.environ.get("LD_LIBRARY_PATH", ""))
+
+
+@pytest.fixture(scope="module")
+def asan_lib(tmp_path_factory):
+    import importlib.util
+
+    out = str(tmp_path_factory.mktemp("asan"))
+    spec = importlib.util.spec_from_file_location("hhsr_build_asan", os.path.join(
+        ROOT, "handheld-multi-frame-super-resolution_amd", "build.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return out, mod.build_asan(out)
+
+
+def _asan_exe(out, src, extra=(), libs=()):
+    import subprocess
+
+    exe = os.path.join(out, os.path.splitext(os.path.basename(src))[0] + "_asan")
+    cmd = [CLANG, "-std=c11", "-Wall", "-g", "-fsanitize=address", "-shared-libsan", "-I" + os.path.join(ROOT, "include"),
+           *extra, src, "-L" + out, "-lhhsr_hip_asan", *libs, "-Wl,-rpath," + out, "-Wl,-rpath,/opt/rocm/lib", "-lm", "-o", exe]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    return exe
+
+
+@pytest.mark.timeout(900)
+def test_asan_host_shim_argument_paths(asan_lib):
+    """Every translation unit rebuilt with -fsanitize=address (host side; device code untouched) and driven by
+    tests/asan_host_driver.c: the HOST arrays of the C ABI (pointer tables of the batched entry points, CFA bytes, tap /
+    white-balance vectors) are exact-length heap allocations, the calls pass every table check and fail a later
+    validation — no GPU needed.  ASan reports abort the driver; a deliberately short table is caught (checked once by
+    hand: heap-buffer-overflow READ in hhsr_gauss_decimate_batch)."""
+    import subprocess
+
+    env = _asan_env()
+    out, _ = asan_lib
+    exe = _asan_exe(out, os.path.join(ROOT, "tests", "asan_host_driver.c"))
+    r = subprocess.run([exe], capture_output=True, text=True, env=env, timeout=300)
+    assert r.returncode == 0 and "all argument paths returned their error codes" in r.stdout, r.stdout + r.stderr[-3000:]
+    assert "AddressSanitizer" not in r.stderr
+
+
+@pytest.mark.gpu
+@pytest.mark.timeout(900)
+def test_asan_c_client_runs_on_the_gpu(asan_lib):
+    """The plain-C client of examples/ against the ASan build of the library, on the GPU: launches included."""
+    import subprocess
+
+    env = _asan_env()
+    out, _ = asan_lib
+    exe = _asan_exe(out, os.path.join(ROOT, "examples", "hhsr_c_demo.c"),
+                    extra=("-D__HIP_PLATFORM_AMD__", "-I/opt/rocm/include"), libs=("-L/opt/rocm/lib", "-lamdhip64"))
+    r = subprocess.run([exe], capture_output=True, text=True, env=env, timeout=600)
+    assert r.returncode == 0 and "bit-exact" in r.stdout, r.stdout + r.stderr[-3000:]
+    assert "AddressSanitizer" not in r.stderr
+
+
+def test_library_is_newer_than_its_sources():
+    """The in-tree .so travels to the GPU box as it is: a source edited after the last build would be tested stale."""
+    from handheld_super_resolution import _lib
+
+    csrc = os.path.join(ROOT, "handheld-multi-frame-super-resolution_amd", "csrc")
+    newest = max(os.path.getmtime(os.path.join(csrc, f)) for f in os.listdir(csrc))
+    newest = max(newest, os.path.getmtime(HDR))
+    if os.path.getmtime(_lib.LIB_PATH) < newest:
+        import __graft_entry__
+
+        __graft_entry__.build()
+    assert os.path.getmtime(_lib.LIB_PATH) >= newest

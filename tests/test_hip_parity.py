@@ -765,6 +765,23 @@ def test_divide_add():
     ta = T(a[..., 0])
     utils.add(ta, T(b[..., 0]))
     assert_close(N(ta), a[..., 0] + b[..., 0], 0, 0, "add")
+    # pointers that are not 16-byte aligned (contiguous views at odd offsets): same misalignment -> scalar head +
+    # float4 body, different misalignments -> scalar kernel
+    flat_a, flat_b = a.ravel(), b.ravel()
+    for oa, ob, n in ((1, 1, 1001), (3, 3, 2), (2, 1, 777), (0, 3, 640), (1, 0, 5)):
+        base_a, base_b = T(flat_a), T(flat_b)
+        va, vb = base_a[oa:oa + n], base_b[ob:ob + n]
+        utils.divide(va, vb)
+        with np.errstate(all="ignore"):
+            want = flat_a.copy()
+            want[oa:oa + n] = flat_a[oa:oa + n] / flat_b[ob:ob + n]
+        assert_close(N(base_a), want, 0, 0, f"divide at offsets {oa}, {ob}")  # (and nothing outside the view touched)
+        base_a = T(flat_a)
+        va = base_a[oa:oa + n]
+        utils.add(va, vb)
+        want = flat_a.copy()
+        want[oa:oa + n] = flat_a[oa:oa + n] + flat_b[ob:ob + n]
+        assert_close(N(base_a), want, 0, 0, f"add at offsets {oa}, {ob}")
 
 
 def test_abi_error_reporting():
@@ -1074,6 +1091,39 @@ def test_process_frame_count_denoisers():
         fn = post.frame_count_denoising_median if which == "median" else post.frame_count_denoising_gauss
         want = fn(N(out), N(mdbg["accumulated robustness"]), sub, 2)
         assert_close(img, want, 0, 1e-6 if which == "gauss" else 0, f"process with the {which} denoiser")
+
+
+def test_frame_count_denoisers_grey_index():
+    """`mode: grey`: the post-hoc denoisers index the accumulated robustness with int(round(y / scale))
+    (utils_image.py:203-204, 260-261), not with the Bayer branch's half-resolution index — at the operator level and
+    through process() on a monochrome burst."""
+    from oracle import post
+
+    rng = np.random.default_rng(2)
+    img = rng.random((96, 128, 3), dtype=np.float32)
+    acc = (rng.random((48, 64)) * 4).astype(np.float32)
+    cfg = hsr.default_config().accumulated_robustness_denoiser
+    for which, fn, ofn, tol in (("median", utils_image.frame_count_denoising_median, post.frame_count_denoising_median, 0),
+                                ("gauss", utils_image.frame_count_denoising_gauss, post.frame_count_denoising_gauss, 1e-6)):
+        got = N(fn(T(img), T(acc), cfg[which], scale=2, mode="grey"))
+        assert_close(got, ofn(img, acc, cfg[which], 2, half_index=2), 0, tol, f"{which}, grey index")
+        bayer = N(fn(T(img), T(acc), cfg[which], scale=2))
+        assert_close(bayer, ofn(img, acc, cfg[which], 2, half_index=True), 0, tol, f"{which}, bayer index")
+        assert not np.array_equal(got, bayer)
+    ref, comp, _ = synth.make_burst(512, 512, 3, seed=8, cfa=MONO, occluder=True)
+    c = hsr.default_config()
+    c.verbose = 0
+    c.mode = "grey"
+    c.block_matching.tuning.tile_size = 16
+    c.block_matching.tuning.metrics = ["L2"] * 4
+    c.postprocessing.enabled = False
+    c.accumulated_robustness_denoiser.median.enabled = True
+    burst = {"ref": ref, "comp": comp, "alpha": synth.ALPHA_ISO100, "beta": synth.BETA_ISO100}
+    out, dbg = hsr.process(burst, c)
+    o, mdbg = hsr.main(ref, comp, c)
+    want = post.frame_count_denoising_median(N(o), N(mdbg["accumulated robustness"]), c.accumulated_robustness_denoiser.median,
+                                             c.scale, half_index=2)
+    assert_close(out[..., 0], want[..., 0], 0, 0, "process(mode: grey) with the median denoiser")
 
 
 # ------------------------------------------------------------------------------------------ burst front end
