@@ -310,7 +310,8 @@ def main():
                   else "k_merge_burst_tile" if float(scale).is_integer() else "k_merge_burst")
         traffic, valu, pmc_note = None, None, None
         try:  # HBM bytes / VALU instructions per launch from the committed rocprofv3 --pmc passes of this exact kernel
-            with open(os.path.join(ROOT, "profiles", "r02_pmc_merge.json")) as f:
+            pmc_file = "r03_pmc_merge_x3.json" if float(scale) == 3.0 else "r03_pmc_merge.json"
+            with open(os.path.join(ROOT, "profiles", pmc_file)) as f:
                 pm = json.load(f)
             sha = hashlib.sha256(open(MERGE_SRC, "rb").read()).hexdigest()[:16]
             if pm.get("workload") == f"{H}x{W}x{NF} x{scale}" and world == 1:
@@ -321,7 +322,7 @@ def main():
                     valu = {"wave_insts_per_launch": insts, "achieved_Tlaneops": round(lane_ops / 1e12, 2),
                             "peak_Tlaneops": VALU_PEAK_TLANEOPS, "frac": round(lane_ops / 1e12 / VALU_PEAK_TLANEOPS, 3)}
                 else:
-                    pmc_note = (f"profiles/r02_pmc_merge.json was collected for kernel source {pm.get('source_sha16')}, "
+                    pmc_note = (f"profiles/{pmc_file} was collected for kernel source {pm.get('source_sha16')}, "
                                 f"the source is now {sha}: counters not reported (re-run tools/pmc_merge.sh)")
         except Exception as e:  # noqa: BLE001
             pmc_note = f"no PMC record: {e}"
@@ -342,17 +343,21 @@ def main():
 
         c = min(args.cpu_crop, H, W)
         c -= c % 32
+        # as many disjoint crops of the same burst as the host has cores for (one worker process per comp frame and crop),
+        # all processed at the same time; crop 0 (the centre) doubles as the parity sample
+        cores = args.cpu_cores or os.cpu_count() or 1
+        k_crops = max(1, min(cores // max(1, NF - 1), (H // c) * (W // c)))
         y0, x0 = ((H - c) // 64) * 32, ((W - c) // 64) * 32
-        ref_c = ref[y0:y0 + c, x0:x0 + c].cpu().numpy()
-        comp_c = comp[:, y0:y0 + c, x0:x0 + c].cpu().numpy()
+        origins = [(y0, x0)] + [(gy * c, gx * c) for gy in range(H // c) for gx in range(W // c)][:k_crops - 1]
+        crops = [(ref[y:y + c, x:x + c].cpu().numpy(), comp[:, y:y + c, x:x + c].cpu().numpy()) for y, x in origins]
+        ref_c, comp_c = crops[0]
         cap = {}
-        t1 = time.perf_counter()
-        want, _, cores = oracle.main_parallel(ref_c, comp_c, cfg, capture=cap)
-        tc = time.perf_counter() - t1
-        cpu = {"value": round(round(scale * c) ** 2 / tc / 1e6, 4), "unit": "output Mpix/s", "cores": cores,
+        want, _, tc, cores_used = oracle.throughput_all_cores(crops, cfg, cores=cores, capture=cap)
+        cpu = {"value": round(len(crops) * round(scale * c) ** 2 / tc / 1e6, 4), "unit": "output Mpix/s", "cores": cores_used,
                "host_cores": os.cpu_count(), "kind": "port",
-               "sample": f"{c}x{c} crop of the same burst, all {NF} frames, x{scale}, NumPy oracle (golden-pinned port; "
-                         f"the reference has no CPU path), one worker process per comp frame, {tc:.1f} s wall"}
+               "sample": f"{len(crops)} crops of {c}x{c} of the same burst processed concurrently, all {NF} frames each, "
+                         f"x{scale}, NumPy oracle (golden-pinned port; the reference has no CPU path), one worker process "
+                         f"per comp frame and crop = {cores_used} processes, {tc:.1f} s wall"}
 
         def diff(cfg_run):
             got = hsr.main(ref_c, comp_c, cfg_run)

@@ -72,5 +72,8 @@ def load_dng_burst(burst_path):
     else:
         raise AttributeError("ISO value could not be found in both EXIF and Image type.")
     iso = min(3200, max(100, iso))
+    xyz2cam = None
+    if "Image Tag 0xC621" in tags:  # DNG ColorMatrix1 (raw2rgb.py:11-26)
+        xyz2cam = np.array([x.decimal() for x in tags["Image Tag 0xC621"].values]).reshape(3, 3).astype(np.float32)
     stack = normalize_burst(np.stack(frames), black_levels, white_level, white_balance, cfa)
-    return stack[0], stack[1:], iso, tags, cfa, None, white_balance, paths[0]
+    return stack[0], stack[1:], iso, tags, cfa, xyz2cam, white_balance, paths[0]

@@ -2,8 +2,10 @@
 
 normalize_burst : reference utils_dng.py:149-160 (float32 array arithmetic with Python scalars).
 unitary_mc / run_fast_mc : reference fast_monte_carlo.py:44-84, 126-214 (NumPy, seeded generator instead of the
-global unseeded one).  Pinning: the normalisation is checked against hand-computed values in
-tests/test_host_logic.py; the Monte-Carlo only statistically (the reference's own draws are unseeded, SURVEY.md
+global unseeded one).  Pinning: the normalisation against what the reference's own load_dng_burst returned for three
+synthetic sensors (golden `frontend`, tools/refsim/make_goldens.py::stage_frontend: the .dng DECODER is a stand-in —
+rawpy is absent — the loader is upstream code) and against hand-computed values (tests/test_host_logic.py); the
+Monte-Carlo only statistically (the reference's own draws are unseeded, SURVEY.md
 App. A D18) — against the analytic un-clipped limits and against the product's GPU estimator.
 """
 import numpy as np

@@ -105,3 +105,40 @@ def main_parallel(ref_img, comp_imgs, config, workers=None, capture=None):
     if accumulate_r:
         debug["accumulated robustness"] = acc_r
     return num, debug, workers
+
+
+def _timed_crop(ref, comp, config, workers, conn):
+    import time
+
+    t0 = time.perf_counter()
+    main_parallel(ref, comp, config, workers=workers)
+    conn.send(time.perf_counter() - t0)
+    conn.close()
+
+
+def throughput_all_cores(crops, config, cores=None, capture=None):
+    """The oracle on ALL host cores: `crops` = list of (ref, comp) of one shape, processed CONCURRENTLY — crop 0 in this
+    process (its result is returned for the parity check), every other crop in a forked process of its own; each of them
+    runs main_parallel with one worker per comp frame.  The crops are independent bursts for the timing's purpose (a
+    production CPU deployment would serve independent bursts side by side the same way); frames x row slabs inside one
+    burst would leave the per-frame alignment — which needs whole frames — on n_frames cores.
+    Returns (output of crop 0, its debug dict, wall seconds until the LAST crop finished, worker processes used)."""
+    import time
+
+    n = max(1, len(crops[0][1]))
+    cores = cores or os.cpu_count() or 1
+    k = max(1, min(len(crops), cores // n))
+    ctx = mp.get_context("fork")
+    procs = []
+    t0 = time.perf_counter()
+    for ref, comp in crops[1:k]:
+        parent, child = ctx.Pipe(duplex=False)
+        p = ctx.Process(target=_timed_crop, args=(ref, comp, config, n, child))  # (non-daemonic: it forks its own pool)
+        p.start()
+        child.close()
+        procs.append((p, parent))
+    out, dbg, used = main_parallel(crops[0][0], crops[0][1], config, workers=n, capture=capture)
+    for p, conn in procs:
+        conn.recv()
+        p.join()
+    return out, dbg, time.perf_counter() - t0, used * k

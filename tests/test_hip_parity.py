@@ -1127,6 +1127,61 @@ def test_frame_count_denoisers_grey_index():
 
 
 # ------------------------------------------------------------------------------------------ burst front end
+@pytest.mark.parametrize("sensor", ["rggb10", "bggr14", "grbg12"])
+def test_load_dng_burst_golden(golden, sensor, tmp_path, monkeypatch):
+    """The product's load_dng_burst (normalisation on the GPU) against what the reference's own loader returned for the
+    same synthetic sensor (golden `frontend`): same stand-in decoder objects in the place of rawpy / exifread, every
+    return value equal — frames bit for bit."""
+    import sys
+    import types
+    from handheld_super_resolution import utils_dng
+
+    g = golden("frontend")
+    t = sensor
+    counts = g[f"{t}_counts"]
+    paths = []
+    for i in range(counts.shape[0]):
+        p = tmp_path / f"im_{i:02d}.dng"
+        p.write_bytes(b"stand-in")
+        paths.append(str(p))
+
+    class FakeRaw:
+        def __init__(self, path):
+            self.raw_image = counts[paths.index(str(path))]
+            self.white_level = int(g[f"{t}_white"])
+            self.black_level_per_channel = g[f"{t}_black"].tolist()
+            self.camera_whitebalance = g[f"{t}_wb"].tolist()
+            self.raw_pattern = g[f"{t}_pattern"].astype(np.uint8)
+
+        def __enter__(self):
+            return self
+
+        def __exit__(self, *a):
+            return False
+
+    class Tag:
+        def __init__(self, values):
+            self.values = values
+
+        def __str__(self):
+            return str(self.values[0])
+
+    class Ratio:
+        def __init__(self, v):
+            self.v = v
+
+        def decimal(self):
+            return float(self.v)
+
+    tags = {"EXIF ISOSpeedRatings": Tag([int(g[f"{t}_iso_in"])]), "Image Tag 0xC621": Tag([Ratio(v) for v in g[f"{t}_ccm_in"]])}
+    monkeypatch.setitem(sys.modules, "rawpy", types.SimpleNamespace(imread=lambda p: FakeRaw(p)))
+    monkeypatch.setitem(sys.modules, "exifread", types.SimpleNamespace(process_file=lambda f, **kw: dict(tags)))
+    ref_raw, raw_comp, iso, _, cfa, xyz2cam, wb, ref_path = utils_dng.load_dng_burst(str(tmp_path))
+    assert np.array_equal(N(ref_raw), g[f"{t}_ref"]) and np.array_equal(N(raw_comp), g[f"{t}_comp"])
+    assert iso == int(g[f"{t}_iso"]) and np.array_equal(cfa, g[f"{t}_cfa"]) and ref_path.endswith("im_00.dng")
+    assert np.array_equal(xyz2cam, g[f"{t}_xyz2cam"]) and list(wb) == g[f"{t}_wb"].tolist()
+
+
 @pytest.mark.parametrize("shape", [(3, 64, 96), (2, 50, 70)])
 def test_normalize_raw_bit_exact(shape):
     """hhsr_normalize_raw_u16 == the NumPy expression of utils_dng.py:149-160, bit for bit (incl. a width that is

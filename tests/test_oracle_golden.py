@@ -322,3 +322,23 @@ def test_e2e_grey_mode(golden):
     assert_close(np.stack(cap["r"]), g["e_r"], 0, 5e-5, "r")
     assert_close(dbg["accumulated robustness"], g["e_acc_r"], 0, 5e-5, "acc r")
     assert_close(out, g["e_out"], 0, 5e-5, "output")
+
+
+SENSORS = ("rggb10", "bggr14", "grbg12")
+
+
+def test_frontend_golden(golden):
+    """oracle.frontend.normalize_burst against what the reference's own load_dng_burst
+    (utils_dng.py:50-164) returned for three synthetic sensors (tools/refsim: the decoder is a stand-in, the loader's
+    arithmetic, CFA relabelling and ISO clipping are upstream code) — bit for bit."""
+    g = golden("frontend")
+    for t in SENSORS:
+        cfa = g[f"{t}_pattern"].copy()
+        cfa[cfa == 3] = 1
+        assert np.array_equal(cfa, g[f"{t}_cfa"])
+        got = oracle.frontend.normalize_burst(g[f"{t}_counts"], g[f"{t}_black"].tolist(), int(g[f"{t}_white"]),
+                                              g[f"{t}_wb"].tolist(), cfa)
+        assert got.dtype == np.float32
+        assert np.array_equal(got[0], g[f"{t}_ref"]) and np.array_equal(got[1:], g[f"{t}_comp"]), t
+        assert int(g[f"{t}_iso"]) == min(3200, max(100, int(g[f"{t}_iso_in"])))
+        assert np.array_equal(g[f"{t}_xyz2cam"], g[f"{t}_ccm_in"].reshape(3, 3).astype(np.float32))

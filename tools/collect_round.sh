@@ -1,6 +1,6 @@
 #!/bin/bash
 # Everything the round's profiles / PARITY.md are made from, in one GPU call.  usage: tools/collect_round.sh <name>
-NAME=${1:-r02}
+NAME=${1:-r03}
 OUT=gpurun_out/$NAME
 mkdir -p $OUT
 HHSR_PARITY_LOG=$PWD/$OUT/parity.jsonl timeout 2400 python -m pytest tests -q -m gpu --timeout 1200 > $OUT/tests.log 2>&1
@@ -12,12 +12,18 @@ MSRC=handheld-multi-frame-super-resolution_amd/csrc/hhsr_merge.hip
 python tools/pmc_report.py $OUT/pmc_x2 k_merge_x2 profiles/${NAME}_pmc_merge.json $MSRC "3000x4000x20 x2" \
   "tools/pmc_merge.sh k_merge_x2 (bench.py --no-cpu-baseline --no-h2d --steps 1 --warmup 0), profiles/${NAME}_pmc_merge_x2.md" > $OUT/pmc_x2.md
 cp profiles/${NAME}_pmc_merge.json $OUT/pmc_merge.json
+# ... and the x3 kernel's on the C5 geometry (48 MP x 20 x3 on one GPU)
+bash tools/pmc_merge.sh "k_merge_xs" $NAME/pmc_x3 --no-h2d --steps 1 --warmup 0 --height 6000 --width 8000 --scale 3 > /dev/null 2>&1
+python tools/pmc_report.py $OUT/pmc_x3 k_merge_xs profiles/${NAME}_pmc_merge_x3.json $MSRC "6000x8000x20 x3" \
+  "tools/pmc_merge.sh k_merge_xs (bench.py --no-cpu-baseline --no-h2d --steps 1 --warmup 0 --height 6000 --width 8000 --scale 3), profiles/${NAME}_pmc_merge_x3.md" > $OUT/pmc_x3.md
+cp profiles/${NAME}_pmc_merge_x3.json $OUT/pmc_merge_x3.json
 python bench.py > $OUT/bench_n1.json 2> $OUT/bench_n1.err
 python bench.py --height 6000 --width 8000 --scale 3 --frames 20 --steps 5 --warmup 2 --no-cpu-baseline > $OUT/bench_c5.json 2> /dev/null
 python bench.py --frames 8 --steps 10 --warmup 3 --no-cpu-baseline > $OUT/bench_c2.json 2> /dev/null
 bash tools/kernel_trace.sh $NAME/kt 5 > /dev/null 2>&1
 bash tools/pmc_all.sh $NAME/pmc_all > /dev/null 2>&1
 tools/ubench/valu_rate > $OUT/valu_rate.txt
+bash tools/traffic_calib.sh $NAME > /dev/null 2>&1
 (cd /tmp && export TMPDIR=/tmp && rocprofv3 --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_LDS --output-format csv -d /tmp/ldsp -o lds -- $GRAFT_REPO_ROOT/tools/ubench/lds_patterns > /dev/null 2>&1; python $GRAFT_REPO_ROOT/tools/ubench/pmc_lds.py /tmp/ldsp > $GRAFT_REPO_ROOT/$OUT/lds_patterns.txt)
 find $OUT -name "*agent_info*" -delete
 cut -c1-600 $OUT/bench_n1.json

@@ -555,7 +555,97 @@ def stage_grey_mode():
     save("grey_mode", **out)
 
 
+def stage_frontend():
+    """The step before the hot path: the reference's own `load_dng_burst` (utils_dng.py:50-164) executed
+    on a synthetic burst.  No .dng decoder exists offline, so `rawpy.imread` / `exifread.process_file` are replaced by
+    stand-ins that hand the loader what a decoder would: integer sensor counts, black levels, white level, camera white
+    balance, CFA pattern (rawpy's: second green = 3), the EXIF tags it reads.  Everything after that — the loader's
+    frame ordering, its integer -> float32 normalisation and white balance arithmetic (:149-160), the ISO clipping, the
+    CFA relabelling, the colour-matrix read — is upstream code.  Three sensors: RGGB 10 bit, BGGR 14 bit with unequal
+    black levels, GRBG 12 bit with an ISO below the clip."""
+    import fractions
+    import tempfile
+    import types
+
+    import rawpy as rp_stub
+    import exifread as er_stub
+    from handheld_super_resolution import utils_dng
+
+    rng = np.random.default_rng(321)
+    sensors = [
+        dict(tag="rggb10", pattern=[[0, 1], [3, 2]], black=[64, 64, 64, 64], white=1023, wb=[1.91, 1.0, 1.57, 0.0], iso=100,
+             shape=(4, 36, 52)),
+        dict(tag="bggr14", pattern=[[2, 3], [1, 0]], black=[1020, 1024, 1030, 1024], white=16383, wb=[2.2031, 1.0, 1.4297, 1.0],
+             iso=800, shape=(3, 30, 44)),
+        dict(tag="grbg12", pattern=[[1, 0], [2, 3]], black=[256, 257, 255, 257], white=4095, wb=[1.5, 1.0, 2.0, 1.0], iso=50,
+             shape=(2, 24, 40)),
+    ]
+    out = {}
+    for sns in sensors:
+        n, H, W = sns["shape"]
+        counts = rng.integers(0, sns["white"] + 1, (n, H, W)).astype(np.uint16)
+        counts[0, :2, :4] = [[0, sns["white"], sns["black"][0], sns["black"][1]], [1, sns["white"] - 1, 5, 7]]
+        ccm = [fractions.Fraction(int(v), 10000) for v in rng.integers(-9000, 18000, 9)]
+        with tempfile.TemporaryDirectory() as d:
+            paths = []
+            for i in range(n):
+                pth = os.path.join(d, f"im_{i:02d}.dng")
+                open(pth, "wb").write(b"not a real dng: the decoder is a stand-in")
+                paths.append(pth)
+            order = {os.path.realpath(p_): i for i, p_ in enumerate(paths)}
+
+            class FakeRaw:
+                def __init__(self, path):
+                    self.raw_image = counts[order[os.path.realpath(path)]]
+                    self.white_level = sns["white"]
+                    self.black_level_per_channel = list(sns["black"])
+                    self.camera_whitebalance = list(sns["wb"])
+                    self.raw_pattern = np.array(sns["pattern"], dtype=np.uint8)
+
+                def __enter__(self):
+                    return self
+
+                def __exit__(self, *a):
+                    return False
+
+            class Tag:
+                def __init__(self, values):
+                    self.values = values
+
+                def __str__(self):
+                    return str(self.values[0])
+
+            class Ratio:
+                def __init__(self, f):
+                    self.f = f
+
+                def decimal(self):
+                    return float(self.f)
+
+            tags = {"Image PhotometricInterpretation": Tag([32803]), "EXIF ISOSpeedRatings": Tag([sns["iso"]]),
+                    "Image Tag 0xC621": Tag([Ratio(f) for f in ccm]), "Image Orientation": Tag([1])}
+            rp_stub.imread = lambda path: FakeRaw(path)
+            er_stub.process_file = lambda f, **kw: dict(tags)
+            # the loader takes the files in glob order; make that order the sorted one on every file system
+            import glob as _glob
+            real_glob = _glob.glob
+            _glob.glob = lambda pat, **kw: sorted(real_glob(pat, **kw))
+            try:
+                ref_raw, raw_comp, iso, _, cfa, xyz2cam, wb, ref_path = utils_dng.load_dng_burst(d)
+            finally:
+                _glob.glob = real_glob
+        t = sns["tag"]
+        assert os.path.basename(ref_path) == "im_00.dng" and ref_raw.dtype == np.float32
+        out.update({f"{t}_counts": counts, f"{t}_black": np.array(sns["black"]), f"{t}_white": np.array(sns["white"]),
+                    f"{t}_wb": np.array(sns["wb"], np.float64), f"{t}_pattern": np.array(sns["pattern"]),
+                    f"{t}_iso_in": np.array(sns["iso"]), f"{t}_ref": ref_raw, f"{t}_comp": raw_comp, f"{t}_iso": np.array(iso),
+                    f"{t}_cfa": np.asarray(cfa), f"{t}_xyz2cam": xyz2cam,
+                    f"{t}_ccm_in": np.array([float(f) for f in ccm], np.float64)})
+    save("frontend", **out)
+
+
 STAGES = {
+    "frontend": stage_frontend,
     "grey_mode": stage_grey_mode,
     "post": stage_post,
     "grey": stage_grey, "downsample": stage_downsample, "hessian": stage_hessian, "bm_l2": stage_bm_l2,
