@@ -803,7 +803,11 @@ constexpr int QT = 16;  // LR workgroup edge
 
 // Body of the first-generation x2 kernel: general per-pixel geometry, any window position.  s_raw: >= RWIN * RPITCH
 // floats, s_cov: >= CWIN * CWIN float4, s_R: >= (QT + 4) * (QT + 5) floats (LMIN).
-template <bool ISO, bool LMIN>
+// MONO (`mode: grey`, merge.py:349-354): one covariance per PIXEL, so the staged covariance window has the raw
+// window's extent (19 x 19 cells at pitch CWM) instead of the Bayer grid's 11 x 11; the all-zero CFA pattern of a
+// monochrome launch routes the four parity classes into channel 0 (classes_to_rgb).
+constexpr int CWM = 20;  // covariance window pitch of the monochrome variant (float4 cells)
+template <bool ISO, bool LMIN, bool MONO = false>
 __device__ __forceinline__ void quad_tile_body(const BurstArgs& a, const Geo& g, const Cfa4 cfa, float* __restrict__ num,
                                                float* __restrict__ den, float* __restrict__ s_raw,
                                                float4* __restrict__ s_cov, float* __restrict__ s_Rf) {
@@ -834,12 +838,14 @@ __device__ __forceinline__ void quad_tile_body(const BurstArgs& a, const Geo& g,
     }
     float racc = 0.f;
 
-    constexpr int rwin = QT + 3, cwin = QT / 2 + 3;  // 19 raw pixels, 11 covariance cells
-    static_assert(rwin <= RWIN && cwin <= CWIN, "window buffers");
+    constexpr int rwin = QT + 3, cwin = MONO ? QT + 3 : QT / 2 + 3;  // 19 raw pixels, 11 (monochrome: 19) covariance cells
+    constexpr int CP = MONO ? CWM : CWIN;                             // pitch of the staged covariance window
+    static_assert(rwin <= RWIN && cwin <= CP, "window buffers");
     const int e0 = threadIdx.x, e1 = threadIdx.x + 256;
     const int e0y = e0 / rwin, e0x = e0 - e0y * rwin, e1y = e1 / rwin, e1x = e1 - e1y * rwin;
     const int cey = threadIdx.x / cwin, cex = threadIdx.x - cey * cwin;
-    const bool has1 = e1 < rwin * rwin, hasc = threadIdx.x < cwin * cwin;
+    const int ce1 = threadIdx.x + 256, ce1y = ce1 / cwin, ce1x = ce1 - ce1y * cwin;  // (monochrome: 361 cells)
+    const bool has1 = e1 < rwin * rwin, hasc = threadIdx.x < cwin * cwin, hasc1 = MONO && ce1 < cwin * cwin;
 
     // LMIN: the frames carry the thresholded map R; r = its 5x5 clamp-border minimum (robustness.py:641-686) is
     // taken here from a (QT+4)^2 window — the separate local-minimum pass and its 8 B/pixel disappear
@@ -850,7 +856,7 @@ __device__ __forceinline__ void quad_tile_body(const BurstArgs& a, const Geo& g,
     const int moff0 = clampi(ly0 - 2 + m0y, 0, g.H - 1) * g.W + clampi(lx0 - 2 + m0x, 0, g.W - 1);
     const int moff1 = clampi(ly0 - 2 + m1y, 0, g.H - 1) * g.W + clampi(lx0 - 2 + m1x, 0, g.W - 1);
     float pr0 = 0.f, pr1 = 0.f, plr = 0.f, plr1 = 0.f;
-    float4 pc = make_float4(0.f, 0.f, 0.f, 0.f);
+    float4 pc = make_float4(0.f, 0.f, 0.f, 0.f), pc1 = pc;
     float2 pfl = make_float2(0.f, 0.f);
     TileWin pw{0, 0, 0, 0};
     auto prefetch = [&](int n) {
@@ -858,8 +864,13 @@ __device__ __forceinline__ void quad_tile_body(const BurstArgs& a, const Geo& g,
         pfl = f.flow[tile];
         const FrameGeo qc = frame_geom<GEOM_P2, ISO>(pfl, g, p0);
         pw.rx0 = qc.cj - 1; pw.ry0 = qc.ci - 1;
-        pw.cx0 = qc.cj >= 1 ? (qc.cj - 1) >> 1 : 0;
-        pw.cy0 = qc.ci >= 1 ? (qc.ci - 1) >> 1 : 0;
+        if (MONO) {  // cells c - 1 .. c + 1 of every centre c of the tile (frame_geom's monochrome branch)
+            pw.cx0 = max(qc.cj - 1, 0);
+            pw.cy0 = max(qc.ci - 1, 0);
+        } else {
+            pw.cx0 = qc.cj >= 1 ? (qc.cj - 1) >> 1 : 0;
+            pw.cy0 = qc.ci >= 1 ? (qc.ci - 1) >> 1 : 0;
+        }
         {
             const int y = pw.ry0 + e0y, x = pw.rx0 + e0x;
             pr0 = (y >= 0 && y < g.H && x >= 0 && x < g.W) ? f.raw[(size_t)y * g.pitch + x] : 0.f;
@@ -871,6 +882,10 @@ __device__ __forceinline__ void quad_tile_body(const BurstArgs& a, const Geo& g,
         if (!ISO && hasc) {
             const int y = min(max(pw.cy0 + cey, 0), g.gh - 1), x = min(max(pw.cx0 + cex, 0), g.gw - 1);
             pc = f.cov[(size_t)y * g.gw + x];
+        }
+        if (!ISO && hasc1) {
+            const int y = min(max(pw.cy0 + ce1y, 0), g.gh - 1), x = min(max(pw.cx0 + ce1x, 0), g.gw - 1);
+            pc1 = f.cov[(size_t)y * g.gw + x];
         }
         if (LMIN) {
             plr = f.r[moff0];
@@ -885,7 +900,8 @@ __device__ __forceinline__ void quad_tile_body(const BurstArgs& a, const Geo& g,
         __syncthreads();  // the previous frame's taps are done with the LDS windows
         s_raw[e0y * RPITCH + e0x] = pr0;
         if (has1) s_raw[e1y * RPITCH + e1x] = pr1;
-        if (!ISO && hasc) s_cov[cey * CWIN + cex] = pc;
+        if (!ISO && hasc) s_cov[cey * CP + cex] = pc;
+        if (!ISO && hasc1) s_cov[ce1y * CP + ce1x] = pc1;
         if (LMIN) {
             s_R[m0y][m0x] = plr;
             if (hasm1) s_R[m1y][m1x] = plr1;
@@ -915,7 +931,7 @@ __device__ __forceinline__ void quad_tile_body(const BurstArgs& a, const Geo& g,
                         const int cx1 = min(q.x0 + 1, g.gw - 1) - w.cx0, cy1 = min(q.y0 + 1, g.gh - 1) - w.cy0;
                         taps_accum<ISO, false>(
                             q, g, local_r, [=](int di, int dj) { return rc[di * RPITCH + dj]; },
-                            [=](int k) { return s_cov[(k & 2 ? cy1 : cy0) * CWIN + (k & 1 ? cx1 : cx0)]; },
+                            [=](int k) { return s_cov[(k & 2 ? cy1 : cy0) * CP + (k & 1 ? cx1 : cx0)]; },
                             n4[sa][sb], d4[sa][sb]);
                     }
                 }
@@ -948,13 +964,13 @@ __device__ __forceinline__ void quad_tile_body(const BurstArgs& a, const Geo& g,
         }
 }
 
-template <bool ISO, bool LMIN>
+template <bool ISO, bool LMIN, bool MONO = false>
 __global__ void __launch_bounds__(256) k_merge_burst_quad(BurstArgs a, Geo g, Cfa4 cfa, float* __restrict__ num,
                                                            float* __restrict__ den) {
     __shared__ float s_raw[RWIN * RPITCH];
-    __shared__ float4 s_cov[CWIN * CWIN];
+    __shared__ float4 s_cov[MONO ? (QT + 3) * CWM : CWIN * CWIN];
     __shared__ float s_R[LMIN ? (QT + 4) * (QT + 4 + 1) : 1];  // LMIN: un-filtered robustness of the tile + 2-pixel border
-    quad_tile_body<ISO, LMIN>(a, g, cfa, num, den, s_raw, s_cov, s_R);
+    quad_tile_body<ISO, LMIN, MONO>(a, g, cfa, num, den, s_raw, s_cov, s_R);
 }
 
 // ---- x2, second generation: one WAVE per Bayer parity class --------------------------------------------------------
@@ -1906,11 +1922,12 @@ extern "C" int hhsr_merge_burst(const float* const* raws, const float* const* fl
     static const int env_force = (getenv("HHSR_MERGE_NO_LDS") ? HHSR_MERGE_FORCE_GENERIC : 0) |
                                  (getenv("HHSR_MERGE_NO_QUAD") ? HHSR_MERGE_FORCE_TILE : 0) |
                                  (getenv("HHSR_MERGE_X2_V1") ? HHSR_MERGE_FORCE_X2V1 : 0);
-    // monochrome sensors: the generic kernels only (the LDS-staged ones are laid out for the Bayer covariance grid)
-    const int force = kflags | env_force | (mono ? HHSR_MERGE_FORCE_GENERIC : 0);
+    // monochrome sensors: the x2 tile kernel with a per-pixel covariance window (k_merge_burst_quad<.., MONO>); every other
+    // scale takes the generic kernel (the tile / wave-per-class kernels are laid out for the Bayer covariance grid)
+    const int force = kflags | env_force;
     const int iscale = (int)scale;
     const bool tiled = !f64 && (double)iscale == scale && iscale >= 1 && ((int64_t)ts * iscale) % MT == 0 &&
-                       n_frames > 0 && row0 % MT == 0 && !(force & HHSR_MERGE_FORCE_GENERIC);
+                       n_frames > 0 && row0 % MT == 0 && !(force & HHSR_MERGE_FORCE_GENERIC) && !(mono && iscale != 2);
     const bool lmin = (flags & HHSR_MERGE_LOCAL_MIN) != 0;
     const bool quad = tiled && p2 && iscale == 2 && ts % QT == 0 && sW == 2 * W && sH == 2 * H && row0 % (2 * QT) == 0 &&
                       nrows % 2 == 0 && !(force & HHSR_MERGE_FORCE_TILE);
@@ -1923,7 +1940,25 @@ extern "C" int hhsr_merge_burst(const float* const* raws, const float* const* fl
                        "sH = 2 H, sW = 2 W, row0 %% 32 == 0, float32 weights)");
         return -3;
     }
-    if (quad && !x2_v1 && aligned16) {
+    if (mono && !quad) {  // (tiled is false for monochrome launches unless the x2 conditions hold)
+        if (lmin) {
+            hhsr_set_error("hhsr_merge_burst: HHSR_MERGE_LOCAL_MIN is not available with HHSR_SENSOR_MONO");
+            return -3;
+        }
+#define HHSR_MB(WT, GEOM, ISO) hipLaunchKernelGGL((k_merge_burst<WT, GEOM, ISO>), grid, block, 0, s, a, g, c, num, den)
+        if (f64) { if (iso) HHSR_MB(double, GEOM_F64, true); else HHSR_MB(double, GEOM_F64, false); }
+        else if (p2) { if (iso) HHSR_MB(float, GEOM_P2, true); else HHSR_MB(float, GEOM_P2, false); }
+        else { if (iso) HHSR_MB(float, GEOM_F64, true); else HHSR_MB(float, GEOM_F64, false); }
+#undef HHSR_MB
+    } else if (mono) {
+        if (lmin) {
+            hhsr_set_error("hhsr_merge_burst: HHSR_MERGE_LOCAL_MIN is not available with HHSR_SENSOR_MONO");
+            return -3;
+        }
+        const dim3 qgrid(hhsr_cdiv(W, QT), hhsr_cdiv(nrows / 2, QT));
+        if (iso) hipLaunchKernelGGL((k_merge_burst_quad<true, false, true>), qgrid, block, 0, s, a, g, c, num, den);
+        else hipLaunchKernelGGL((k_merge_burst_quad<false, false, true>), qgrid, block, 0, s, a, g, c, num, den);
+    } else if (quad && !x2_v1 && aligned16) {
         const dim3 qgrid(hhsr_cdiv(W, QT), hhsr_cdiv(nrows / 2, QT));
         if (lmin) {
             if (iso) hipLaunchKernelGGL((k_merge_x2<true, true>), qgrid, block, 0, s, a, g, c, num, den);

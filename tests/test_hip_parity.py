@@ -1584,6 +1584,43 @@ def test_mono_stages_golden(golden):
     assert_close(N(den), g["m_den_denref"], 2e-5, 1e-6, "mono denoiser denref")
 
 
+def test_mono_burst_merge_tile_kernel_vs_generic():
+    """`mode: grey`, x2: hhsr_merge_burst takes the LDS-staged tile kernel with a per-pixel covariance window
+    (k_merge_burst_quad<.., MONO>); it must agree with the generic per-pixel kernel (config.hip.merge_kernel: generic)
+    on flows large enough to push windows over the image border, NaN covariances included."""
+    rng = np.random.default_rng(5)
+    H, W, n = 208, 272, 3
+    cfa = [[0, 1], [1, 2]]
+    frames = []
+    for k in range(n):
+        raw = smooth(rng, H, W)
+        flow = (rng.standard_normal((H // 16, W // 16, 2)) * (1.5 + 4 * k)).astype(np.float32)
+        flow[0, 0] = (-9.0, 7.5)  # windows over the top-left corner
+        cov = np.zeros((H, W, 2, 2), np.float32)
+        a, b, c = 0.3 + rng.random((H, W)), 0.2 * rng.standard_normal((H, W)), 0.3 + rng.random((H, W))
+        cov[..., 0, 0], cov[..., 0, 1], cov[..., 1, 0], cov[..., 1, 1] = a, b, b, c
+        cov[40:44, 60:70] = np.nan  # flat regions (D10)
+        r = rng.random((H, W)).astype(np.float32)
+        r[100:120, 30:50] = 0
+        frames.append((T(raw), T(flow), T(cov), T(r)))
+    ref, ref_cov = T(smooth(rng, H, W)), frames[0][2].clone()
+    outs = {}
+    for kern in ("auto", "generic"):
+        for iso in (False, True):
+            cfg = base_config(ts=16, scale=2, mode="grey")
+            cfg.hip = {"merge_kernel": kern}
+            if iso:
+                cfg.merging.kernel = "iso"
+            num = torch.empty((2 * H, 2 * W, 3), dtype=torch.float32, device=DEV)
+            merge.merge_burst(frames, ref, ref_cov, num, None, cfa, cfg, do_ref=True, divide=True)
+            outs[kern, iso] = N(num)
+    for iso in (False, True):
+        a, b = outs["auto", iso], outs["generic", iso]
+        assert np.isnan(a[..., 1:]).all() and np.isnan(b[..., 1:]).all()  # 0 / 0: the accumulators have three channels
+        assert_close(a[..., 0], b[..., 0], 2e-5, 1e-6, f"mono x2 tile kernel vs generic, iso={iso}")
+    assert not np.array_equal(outs["auto", False][..., 0], outs["auto", True][..., 0], equal_nan=True)
+
+
 def test_e2e_mono_golden(golden):
     """main() with `mode: grey` against the reference's own result on the same 128x128 x3 monochrome burst: channel 0
     is the image, channels 1 and 2 are NaN (0/0: the accumulators always have three channels)."""
