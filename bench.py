@@ -65,6 +65,7 @@ def parse_args():
     ap.add_argument("--no-h2d", action="store_true", help="skip the host-resident (H2D-inclusive) leg")
     ap.add_argument("--cpu-crop", type=int, default=1024, help="edge of the crop the CPU baseline / parity leg runs on")
     ap.add_argument("--streams", type=int, default=None, help="HIP streams of the frame pipeline (default: config, 3)")
+    ap.add_argument("--chunk", type=int, default=None, help="frames per front-end chunk = per batched launch (default 4)")
     ap.add_argument("--gather", action="store_true", help="N > 1: gather the finished row slabs to rank 0")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo for plumbing tests)")
     ap.add_argument("--no-graph", action="store_true", help="launch every kernel from Python instead of replaying the "
@@ -153,6 +154,8 @@ def main():
     cfg.hip = {"graph": not args.no_graph}
     if args.streams is not None:
         cfg.hip["streams"] = args.streams
+    if args.chunk is not None:
+        cfg.hip["chunk"] = args.chunk
     hsr.prepare_config(cfg, np.full((H, W), float(ref.mean()), np.float32), synth.ALPHA_ISO100, synth.BETA_ISO100,
                        [[0, 1], [1, 2]], [1.0, 1.0, 1.0])
     engine_cls = hdist.HipEngine if on_gpu else load_engine(args.engine)
