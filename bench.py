@@ -348,7 +348,7 @@ def main():
         c -= c % 32
         # as many disjoint crops of the same burst as the host has cores for (one worker process per comp frame and crop),
         # all processed at the same time; crop 0 (the centre) doubles as the parity sample
-        cores = args.cpu_cores or os.cpu_count() or 1
+        cores = args.cpu_cores or oracle.available_cores()  # (affinity mask capped by the cgroup CPU quota)
         k_crops = max(1, min(cores // max(1, NF - 1), (H // c) * (W // c)))
         y0, x0 = ((H - c) // 64) * 32, ((W - c) // 64) * 32
         origins = [(y0, x0)] + [(gy * c, gx * c) for gy in range(H // c) for gx in range(W // c)][:k_crops - 1]
@@ -357,10 +357,11 @@ def main():
         cap = {}
         want, _, tc, cores_used = oracle.throughput_all_cores(crops, cfg, cores=cores, capture=cap)
         cpu = {"value": round(len(crops) * round(scale * c) ** 2 / tc / 1e6, 4), "unit": "output Mpix/s", "cores": cores_used,
-               "host_cores": os.cpu_count(), "kind": "port",
-               "sample": f"{len(crops)} crops of {c}x{c} of the same burst processed concurrently, all {NF} frames each, "
-                         f"x{scale}, NumPy oracle (golden-pinned port; the reference has no CPU path), one worker process "
-                         f"per comp frame and crop = {cores_used} processes, {tc:.1f} s wall"}
+               "host_cores": os.cpu_count(), "usable_cores": oracle.available_cores(), "kind": "port",
+               "sample": f"{len(crops)} crop(s) of {c}x{c} of the same burst processed concurrently, all {NF} frames each, "
+                         f"x{scale}, NumPy oracle (golden-pinned port; the reference has no CPU path), {cores_used} worker "
+                         f"processes = every core the container may use (logical CPUs capped by the cgroup CPU quota; "
+                         f"{os.cpu_count()} logical CPUs visible), {tc:.1f} s wall"}
 
         def diff(cfg_run):
             got = hsr.main(ref_c, comp_c, cfg_run)

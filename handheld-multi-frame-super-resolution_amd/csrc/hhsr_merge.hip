@@ -503,6 +503,8 @@ struct BurstArgs {
     int flags;
     float* acc_r;  // optional [H][W]: sum of the frames' robustness (integer scales only)
     int iscale;    // (int)scale (integer scales: accumulated robustness ownership, tile window sizes)
+    float* cls;    // chained x2 launches (HHSR_MERGE_STORE_CLASSES / _LOAD_CLASSES): per tile 33 x 256 floats
+    int first;     // HHSR_MERGE_LOAD_CLASSES: frames [0, first) are already in `cls` for the wave-uniform tiles
 };
 
 // The HR pixels with hi % s == 0 and hj % s == 0 map one-to-one onto the LR pixels (integer scale s): they
@@ -1102,8 +1104,19 @@ __global__ void __launch_bounds__(256, HHSR_X2_OCC) k_merge_x2(BurstArgs a, Geo 
     const int tile = (ly0 / g.ts) * g.nx + lx0 / g.ts;
 
     // ---- can the whole tile take the uniform path?  every window of every frame inside the image -------------------
+    // Chained launches (bursts whose last frames arrive late: graph.HostBurstRunner).  A STORE_CLASSES launch merges the
+    // frames it has into the parity-class accumulators and parks them in a.cls; a LOAD_CLASSES launch gets all frames so
+    // far, restores the accumulators and continues with frames [a.first, a.n) — a middle link parks them again, the final
+    // link adds the reference frame and runs the epilogue.  The register contents carry over exactly, so the result is
+    // bit-identical to ONE launch over all frames — provided a tile runs the same code in every link: the storing links
+    // apply the reference frame's border rule too and simply skip the tiles they would send down the per-pixel path
+    // (once a frame's window leaves the image the tile stays skipped: the set of frames only grows); the final link decides
+    // over ALL frames (like the single launch) and recomputes its per-pixel tiles from the first frame on (2 % of the
+    // tiles at 12 MP).
+    const bool chain_store = (a.flags & HHSR_MERGE_STORE_CLASSES) != 0, chain_load = (a.flags & HHSR_MERGE_LOAD_CLASSES) != 0;
     bool ok = lx0 + QT <= g.W && ly0 + QT <= lrow1;
-    if ((a.flags & HHSR_MERGE_DO_REF) && !(lx0 >= 1 && lx0 + QT + 2 <= g.W && ly0 >= 1 && ly0 + QT + 2 <= g.H)) ok = false;
+    if (((a.flags & HHSR_MERGE_DO_REF) || chain_store) &&
+        !(lx0 >= 1 && lx0 + QT + 2 <= g.W && ly0 >= 1 && ly0 + QT + 2 <= g.H)) ok = false;
     if (ok && lane < a.n) {
         const float2 fl = a.f[lane].flow[tile];
         const int ox = x2_comp_org(fl.x, lx0), oy = x2_comp_org(fl.y, ly0);
@@ -1111,9 +1124,12 @@ __global__ void __launch_bounds__(256, HHSR_X2_OCC) k_merge_x2(BurstArgs a, Geo 
         ok = ok && fl.x == fl.x && fl.y == fl.y;
     }
     if (!__all(ok)) {  // wave-uniform, identical in the four waves
+        if (chain_store) return;  // (the final link recomputes this tile over all frames)
         quad_tile_body<ISO, LMIN>(a, g, cfa, num, den, s_rawA, s_cov, s_R);
         return;
     }
+    float* __restrict__ cls = a.cls ? a.cls + (size_t)bid * (33 * 256) + tid : nullptr;
+    const int nfirst = chain_load ? a.first : 0;
 
 #if HHSR_X2_GEO
     // Per-frame geometry once per WORKGROUP: it only depends on the frame's flow vector and the parity class, so
@@ -1142,12 +1158,21 @@ __global__ void __launch_bounds__(256, HHSR_X2_OCC) k_merge_x2(BurstArgs a, Geo 
     const int ty = 2 * li + py, tx = 2 * lj + px;                   // LR pixel inside the tile
     const int ridx = (ly0 + ty) * g.W + lx0 + tx;
     float n4[2][2][2][2], d4[2][2][2][2];
-#pragma unroll
-    for (int k = 0; k < 16; ++k) {
-        (&n4[0][0][0][0])[k] = 0.f;
-        (&d4[0][0][0][0])[k] = 0.f;
-    }
     float racc = 0.f;
+    if (chain_load) {  // (coalesced: 256 consecutive floats per accumulator and tile)
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+            (&n4[0][0][0][0])[k] = cls[k * 256];
+            (&d4[0][0][0][0])[k] = cls[(16 + k) * 256];
+        }
+        racc = cls[32 * 256];
+    } else {
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+            (&n4[0][0][0][0])[k] = 0.f;
+            (&d4[0][0][0][0])[k] = 0.f;
+        }
+    }
 
     // staging slots (by thread id, independent of the pixel mapping)
     constexpr int rwin = X2_WIN, cwin = QT / 2 + 3;  // 19 raw pixels, 11 covariance cells
@@ -1368,8 +1393,8 @@ __global__ void __launch_bounds__(256, HHSR_X2_OCC) k_merge_x2(BurstArgs a, Geo 
         if (n + 2 < nloop) prefetch(n + 2);
     }
 #else
-    if (nloop > 0) prefetch(0);
-    for (int n = 0; n < nloop; ++n) {
+    if (nloop > nfirst) prefetch(nfirst);
+    for (int n = nfirst; n < nloop; ++n) {
         __syncthreads();  // the previous frame's taps are done with the LDS windows
         stage(n, 0);
         const float2 fl = sfl;
@@ -1379,6 +1404,15 @@ __global__ void __launch_bounds__(256, HHSR_X2_OCC) k_merge_x2(BurstArgs a, Geo 
         frame_n(n, fl, lr, 0);
     }
 #endif
+    if (chain_store) {  // park the accumulators for the final link
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+            cls[k * 256] = (&n4[0][0][0][0])[k];
+            cls[(16 + k) * 256] = (&d4[0][0][0][0])[k];
+        }
+        cls[32 * 256] = racc;
+        return;
+    }
     if (a.acc_r) a.acc_r[ridx] = ((a.flags & HHSR_MERGE_LOAD_ACC) ? a.acc_r[ridx] : 0.f) + racc;
     // ---- epilogue: CFA classes -> RGB, normalise, store -----------------------------------------------------------------
     const int ly = ly0 + ty, lx = lx0 + tx;
@@ -1872,11 +1906,48 @@ extern "C" int hhsr_accumulate_ref(const float* raw, int H, int W, int pitch, co
     HHSR_LAUNCHED();
 }
 
+static int merge_burst_impl(const float* const* raws, const float* const* flows, const float* const* covs,
+                            const float* const* rs, int n_frames, int H, int W, int pitch, int ny, int nx,
+                            int ts, const float* ref_raw, const float* ref_covs, const uint8_t cfa[4],
+                            double scale, int kflags, int flags, float* num, float* den, float* acc_r, int sH,
+                            int sW, int row0, int nrows, int lr_row_offset, float* class_acc, int n_done, void* stream);
+
 extern "C" int hhsr_merge_burst(const float* const* raws, const float* const* flows, const float* const* covs,
                                 const float* const* rs, int n_frames, int H, int W, int pitch, int ny, int nx,
                                 int ts, const float* ref_raw, const float* ref_covs, const uint8_t cfa[4],
                                 double scale, int kflags, int flags, float* num, float* den, float* acc_r, int sH,
                                 int sW, int row0, int nrows, int lr_row_offset, void* stream) {
+    if (flags & (HHSR_MERGE_STORE_CLASSES | HHSR_MERGE_LOAD_CLASSES)) {
+        hhsr_set_error("hhsr_merge_burst: chained launches go through hhsr_merge_burst_chain");
+        return -1;
+    }
+    return merge_burst_impl(raws, flows, covs, rs, n_frames, H, W, pitch, ny, nx, ts, ref_raw, ref_covs, cfa, scale, kflags,
+                            flags, num, den, acc_r, sH, sW, row0, nrows, lr_row_offset, nullptr, 0, stream);
+}
+
+extern "C" size_t hhsr_merge_chain_bytes(int H, int W) {
+    return (size_t)hhsr_cdiv(W, QT) * (size_t)hhsr_cdiv(H, QT) * 33 * 256 * sizeof(float);
+}
+
+extern "C" int hhsr_merge_burst_chain(const float* const* raws, const float* const* flows, const float* const* covs,
+                                      const float* const* rs, int n_frames, int H, int W, int pitch, int ny, int nx,
+                                      int ts, const float* ref_raw, const float* ref_covs, const uint8_t cfa[4],
+                                      double scale, int kflags, int flags, float* num, float* den, float* acc_r, int sH,
+                                      int sW, float* class_acc, int n_done, void* stream) {
+    const int st = flags & HHSR_MERGE_STORE_CLASSES, ld = flags & HHSR_MERGE_LOAD_CLASSES;
+    HHSR_ARG(class_acc && ((uintptr_t)class_acc & 3) == 0 && (st || ld));  // (both: a middle link)
+    HHSR_ARG(!st || !(flags & (HHSR_MERGE_DO_REF | HHSR_MERGE_DIVIDE | HHSR_MERGE_LOAD_ACC | HHSR_MERGE_STORE_DEN)));
+    HHSR_ARG(!ld || (n_done > 0 && n_done <= n_frames && !(flags & HHSR_MERGE_LOAD_ACC)));
+    HHSR_ARG(!(kflags & (HHSR_SENSOR_MONO | HHSR_WEIGHT_F64 | HHSR_MERGE_FORCE_GENERIC | HHSR_MERGE_FORCE_TILE | HHSR_MERGE_FORCE_X2V1)));
+    return merge_burst_impl(raws, flows, covs, rs, n_frames, H, W, pitch, ny, nx, ts, ref_raw, ref_covs, cfa, scale, kflags,
+                            flags, num, den, acc_r, sH, sW, 0, sH, 0, class_acc, ld ? n_done : 0, stream);
+}
+
+static int merge_burst_impl(const float* const* raws, const float* const* flows, const float* const* covs,
+                            const float* const* rs, int n_frames, int H, int W, int pitch, int ny, int nx,
+                            int ts, const float* ref_raw, const float* ref_covs, const uint8_t cfa[4],
+                            double scale, int kflags, int flags, float* num, float* den, float* acc_r, int sH,
+                            int sW, int row0, int nrows, int lr_row_offset, float* class_acc, int n_done, void* stream) {
     const int iso = kflags & HHSR_KERNEL_ISO, f64 = kflags & HHSR_WEIGHT_F64;
     const bool mono = (kflags & HHSR_SENSOR_MONO) != 0;
     HHSR_ARG(n_frames >= 0 && n_frames <= HHSR_MAX_FRAMES && (cfa || mono) && num);
@@ -1901,6 +1972,8 @@ extern "C" int hhsr_merge_burst(const float* const* raws, const float* const* fl
     a.ref_raw = ref_raw;
     a.ref_cov = reinterpret_cast<const float4*>(ref_covs);
     a.flags = flags;
+    a.cls = class_acc;
+    a.first = n_done;
     Geo g;
     fill_geo(g, H, W, pitch, ny, nx, ts, scale, sH, sW, mono);
     HHSR_ARG(row0 >= 0 && nrows > 0 && row0 + nrows <= sH);
@@ -1935,6 +2008,12 @@ extern "C" int hhsr_merge_burst(const float* const* raws, const float* const* fl
     const bool aligned16 = ((uintptr_t)num % 16 == 0) && (!(flags & HHSR_MERGE_STORE_DEN) || (uintptr_t)den % 16 == 0);
     const bool x3 = aligned16 && tiled && iscale == 3 && ts % QT == 0 && sW == 3 * W && sH == 3 * H && row0 % (3 * QT) == 0 && nrows % 3 == 0 &&
                     W % 4 == 0 && !(force & HHSR_MERGE_FORCE_TILE);
+    const bool chained = (flags & (HHSR_MERGE_STORE_CLASSES | HHSR_MERGE_LOAD_CLASSES)) != 0;
+    if (chained && !(quad && !x2_v1 && aligned16 && !mono)) {
+        hhsr_set_error("hhsr_merge_burst_chain: needs the wave-per-class x2 kernel (scale 2, ts %% 16 == 0, sH = 2 H, "
+                       "sW = 2 W, 16-byte aligned output, float32 weights, Bayer)");
+        return -3;
+    }
     if (lmin && !quad && !x3) {
         hhsr_set_error("hhsr_merge_burst: HHSR_MERGE_LOCAL_MIN needs the x2 kernel (scale 2, ts %% 16 == 0, "
                        "sH = 2 H, sW = 2 W, row0 %% 32 == 0, float32 weights)");
@@ -1999,7 +2078,7 @@ extern "C" int hhsr_merge_burst(const float* const* raws, const float* const* fl
         else { if (iso) HHSR_MB(float, GEOM_F64, true); else HHSR_MB(float, GEOM_F64, false); }
 #undef HHSR_MB
     }
-    if (!f64) {  // the border bands the float32 kernels skipped, with the reference's float64 weight chain
+    if (!f64 && !(flags & HHSR_MERGE_STORE_CLASSES)) {  // the border bands the float32 kernels skipped, with the reference's float64 weight chain
         const int nf = n_frames + ((flags & HHSR_MERGE_DO_REF) ? 1 : 0);
         static const bool border_v1 = getenv("HHSR_MERGE_BORDER_V1") != nullptr;  // A/B switch, read once
         if (nf >= 2 && nf <= 64 && !border_v1) {  // lane = (pixel, frame)

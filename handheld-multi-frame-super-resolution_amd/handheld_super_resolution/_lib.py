@@ -61,9 +61,11 @@ _SIGS = {
     "hhsr_postprocess": [P, P, P, I, I, FP, I, D, P, I, I, I, I, P],
     "hhsr_orient_plane": [P, P, I, I, I, P],
     "hhsr_merge_burst": [PP, PP, PP, PP, I, I, I, I, I, I, I, P, P, U8P, D, I, I, P, P, P, I, I, I, I, I, P],
+    "hhsr_merge_burst_chain": [PP, PP, PP, PP, I, I, I, I, I, I, I, P, P, U8P, D, I, I, P, P, P, I, I, P, I, P],
 }
 
 MERGE_LOAD_ACC, MERGE_DO_REF, MERGE_DIVIDE, MERGE_STORE_DEN = 1, 2, 4, 8
+MERGE_LOCAL_MIN, MERGE_STORE_CLASSES, MERGE_LOAD_CLASSES = 16, 32, 64
 MAX_FRAMES = 64
 MAX_BATCH = 8  # HHSR_MAX_BATCH: frames per launch of the batched front-end entry points
 
@@ -72,7 +74,7 @@ _lib = None
 
 def exported_symbols():
     """Every entry point include/hhsr.h declares (used by the symbol-export test)."""
-    return ["hhsr_version", "hhsr_last_error", *_SIGS]
+    return ["hhsr_version", "hhsr_last_error", "hhsr_merge_chain_bytes", *_SIGS]
 
 
 def load():
@@ -87,6 +89,8 @@ def load():
     lib = C.CDLL(LIB_PATH)
     lib.hhsr_version.restype = C.c_char_p
     lib.hhsr_last_error.restype = C.c_char_p
+    lib.hhsr_merge_chain_bytes.argtypes = [I, I]
+    lib.hhsr_merge_chain_bytes.restype = C.c_size_t
     for name, argtypes in _SIGS.items():
         fn = getattr(lib, name)
         fn.argtypes = argtypes

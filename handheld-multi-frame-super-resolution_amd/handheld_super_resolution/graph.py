@@ -16,6 +16,30 @@ pool: valid until the next call with the same inputs.
 import torch
 
 
+_shared = {}  # device index -> (main stream, high-priority upload stream) shared by every runner of the process
+
+
+def shared_streams(device):
+    """The ONE main stream and the ONE upload stream of a device, plus the frame pipeline's side streams, created together.
+    HIP streams share a few hardware queues (GPU_MAX_HW_QUEUES, default 4 per priority level, assigned round-robin as the
+    streams come into being): every runner that brought its own stream moved the mapping on, until a main stream shared
+    its queue with a side stream or with pending copies (measured: the same host-resident burst at 21.5 ms or 26-28 ms
+    depending on how many engines the process had created before).  Four normal-priority streams — main + three side
+    streams — fit the four queues; the upload stream lives in the high-priority set."""
+    from .super_resolution import DEFAULT_STREAMS, _stream_pool
+
+    idx = device.index if device.index is not None else torch.cuda.current_device()
+    hit = _shared.get(idx)
+    if hit is None:
+        dev = torch.device("cuda", idx)
+        main = torch.cuda.Stream(dev)
+        pool = _stream_pool.setdefault(idx, [])
+        while len(pool) < DEFAULT_STREAMS:
+            pool.append(torch.cuda.Stream(dev))
+        hit = _shared[idx] = (main, torch.cuda.Stream(dev, priority=-1))
+    return hit
+
+
 def _key(tensors):
     return tuple((t.data_ptr(), tuple(t.shape), t.dtype) for t in tensors)
 
@@ -31,7 +55,7 @@ class GraphRunner:
     def __init__(self, fn, device):
         self.fn = fn
         self.device = device
-        self.stream = torch.cuda.Stream(device)  # eager warm-up and capture run here: one set of per-stream plans
+        self.stream = shared_streams(device)[0]  # eager warm-up and capture run here: one set of per-stream plans
         self.seen = {}     # key -> number of eager calls
         self.graphs = {}   # key -> (graph, outputs, inputs kept alive)
         self.disabled = False
@@ -96,7 +120,8 @@ class HostBurstRunner:
         uploads (eager hipMemcpyAsync, back to back on one upload stream, one event per frame)
         g_ref            reference-frame state                       after the reference frame's copy
         g_chunk[c]       front end + robustness of a chunk of frames after the copies of ITS frames, on side stream c % S
-        g_merge          fused merge of the burst + normalisation    after all chunks
+        g_links[k]       (float frames) links of the chained merge   after every chunk of >= 2 frames
+        g_merge          (last link of the) fused merge + normalisation   after all chunks
 
     so the front end of the first chunks runs while later frames are still crossing PCIe, and the host enqueues
     ~20 copies + ~8 graph launches per burst.  Per key (shapes, dtype, frame count): first call eager (creates the
@@ -107,7 +132,7 @@ class HostBurstRunner:
     The call returns when the host buffers may be refilled (all uploads done); the result tensor is produced
     asynchronously on the current stream as usual and belongs to the runner: valid until its next call."""
 
-    COPY_THREADS = 16
+    COPY_THREADS = 12  # (the MI355X boxes of this project give a container 16 CPUs' worth of quota: more threads get throttled)
 
     def __init__(self, config, device):
         self.config, self.device = config, device
@@ -115,12 +140,12 @@ class HostBurstRunner:
         self.disabled = False
         # the eager calls run on the stream the graphs are captured on and replayed on later: the per-stream FFT plans
         # (which allocate: not capturable) then exist when the capture needs them
-        self.main = torch.cuda.Stream(device)
-        # HIGH priority: HIP streams share a few hardware queues (GPU_MAX_HW_QUEUES, default 4) per priority level.  A
-        # stream with 20 copies queued holds its queue with one barrier packet per copy, and every compute stream mapped
-        # to the same queue starts after the LAST copy (tools/debug/hwqueue_probe.py: 7 of 8 compute streams blocked for
-        # 8.7 ms; with the upload stream in the high-priority queue set: none)
-        self.up = torch.cuda.Stream(device, priority=-1)
+        # The upload stream has HIGH priority: HIP streams share a few hardware queues (GPU_MAX_HW_QUEUES, default 4) per
+        # priority level.  A stream with 20 copies queued holds its queue with one barrier packet per copy, and every compute
+        # stream mapped to the same queue starts after the LAST copy (tools/debug/hwqueue_probe.py: 7 of 8 compute streams
+        # blocked for 8.7 ms; with the upload stream in the high-priority queue set: none).  Both streams are shared by
+        # all runners of the process (shared_streams).
+        self.main, self.up = shared_streams(device)
 
     def _eager(self, ref_img, comp_imgs):
         from .super_resolution import main
@@ -251,11 +276,48 @@ class HostBurstRunner:
                     results.append(pipe._robustness(fronts, None, fuse_min))
                 st.g_chunks.append(g)
             st.frames = [f for chunk in results for f in chunk]
+            # The merge needs the LAST frame, and everything after the last upload is on the critical path.  Bursts whose
+            # uploads take longer than their kernels (float frames: 0.87 ms of PCIe per 12 MP frame against 0.46 ms of GPU
+            # work; uint16 counts are the other way round) leave the GPU idle between chunks: there the merge is CHAINED
+            # (merge.merge_burst_chain, bit-identical to the single launch) — after every chunk of >= 2 frames a link adds
+            # that chunk's frames to the parked class accumulators while later frames are crossing PCIe, and the last link
+            # only has the final single-frame chunks, the reference frame and the normalisation left (12 MP x 20: 1.4 ms
+            # instead of 4.0 after the last frame's front end).  Each link moves the 1.6 GB of accumulators twice (~0.7 ms
+            # of otherwise idle GPU time): not for GPU-bound bursts.
+            from .merge import can_chain, chain_buffer, merge_burst_chain
+
+            hip = cfg.get("hip", None) if hasattr(cfg, "get") else None
+            want_chain = (frames[0].dtype.itemsize >= 4) if hip is None or hip.get("merge_chain", None) is None \
+                else bool(hip.get("merge_chain"))
+            st.links = []  # (index of the chunk after which the link runs, frames merged once it has run)
+            if want_chain and fuse_min and can_chain(cfg, (H, W)) and len(st.chunks) > 2:
+                done = 0
+                for c, idx in enumerate(st.chunks[:-1]):
+                    done = idx[-1] + 1
+                    if len(idx) >= 2:
+                        st.links.append((c, done))
+            st.chain = bool(st.links)
+            st.g_links = []
+            st.num = torch.empty((sH, sW, 3), dtype=torch.float32, device=dev)
+            if st.chain:
+                st.cls = chain_buffer((H, W), dev)
+                prev = 0
+                for c, done in st.links:
+                    g = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(g, stream=st.main, capture_error_mode="thread_local"):
+                        merge_burst_chain(st.frames[:done], prev, pipe.ref, pipe.ref_covs, st.num, pipe.cfa, cfg, st.cls, False,
+                                          local_min=fuse_min)
+                    st.g_links.append(g)
+                    prev = done
             st.g_merge = torch.cuda.CUDAGraph()
             with torch.cuda.graph(st.g_merge, stream=st.main, capture_error_mode="thread_local"):
-                st.num = torch.empty((sH, sW, 3), dtype=torch.float32, device=dev)
-                merge_burst(st.frames, pipe.ref, pipe.ref_covs, st.num, None, pipe.cfa, cfg, do_ref=True, divide=True,
-                            acc_r=acc_r, local_min=fuse_min)
+                if st.chain:
+                    merge_burst_chain(st.frames, st.links[-1][1], pipe.ref, pipe.ref_covs, st.num, pipe.cfa, cfg, st.cls, True,
+                                      acc_r=acc_r, local_min=fuse_min)
+                else:
+                    merge_burst(st.frames, pipe.ref, pipe.ref_covs, st.num, None, pipe.cfa, cfg, do_ref=True, divide=True,
+                                acc_r=acc_r, local_min=fuse_min)
+            st.e_chunk = [torch.cuda.Event() for _ in st.chunks]
             st.acc_r = acc_r
             st.e_up = [torch.cuda.Event() for _ in range(n + 1)]
             st.e_ref = torch.cuda.Event()
@@ -320,7 +382,7 @@ class HostBurstRunner:
             with torch.cuda.stream(st.main):
                 st.g_ref.replay()
                 st.e_ref.record(st.main)
-            for idx, s, g in zip(st.chunks, st.streams, st.g_chunks):
+            for c, (idx, s, g) in enumerate(zip(st.chunks, st.streams, st.g_chunks)):
                 if futs is not None:
                     for i in idx:
                         upload(1 + i)
@@ -328,9 +390,16 @@ class HostBurstRunner:
                 with torch.cuda.stream(s):
                     s.wait_event(st.e_ref)
                     g.replay()
+                    st.e_chunk[c].record(s)
+                for (lc, _), gl in zip(st.links, st.g_links):
+                    if lc == c:  # the link after this chunk: everything it waits for is launched (short waits only)
+                        with torch.cuda.stream(st.main):
+                            for k in range(c + 1):
+                                st.main.wait_event(st.e_chunk[k])
+                            gl.replay()
             with torch.cuda.stream(st.main):
-                for s in set(st.streams):
-                    st.main.wait_stream(s)
+                for e in st.e_chunk:
+                    st.main.wait_event(e)
                 st.g_merge.replay()
             cur.wait_stream(st.main)
         debug = {"robustness": [], "flow": []}

@@ -119,3 +119,41 @@ def merge_burst(frames, ref_img, ref_kernels, num, den, cfa_pattern, config, loa
                   H, W, W, ny, nx, int(ts), _lib.ptr(ref_img if (f & 2) else None),
                   _lib.ptr(ref_kernels if (f & 2) else None), cfa, scale, kflags, f, _lib.ptr(num), _lib.ptr(den),
                   _lib.ptr(acc_r if chunk else None), sH, sW, int(row0), int(nrows), int(lr_row_offset), _lib.stream())
+
+
+def can_chain(config, shape):
+    """merge_burst_chain applies: the wave-per-class x2 kernel (same conditions as can_fuse_local_min at scale 2)."""
+    scale, _ = _common(config)
+    return scale == 2.0 and can_fuse_local_min(config, shape)
+
+
+def chain_buffer(shape, device):
+    """Parking space of the parity-class accumulators between the two launches of merge_burst_chain (1.6 GB at 12 MP)."""
+    H, W = shape
+    return torch.empty((_lib.load().hhsr_merge_chain_bytes(int(H), int(W)) // 4,), dtype=torch.float32, device=device)
+
+
+def merge_burst_chain(frames, n_done, ref_img, ref_kernels, num, cfa_pattern, config, class_acc, last, acc_r=None,
+                      local_min=False):
+    """One link of the fused x2 merge as a chain of launches, bit-identical to merge_burst(all frames, ..., do_ref=True,
+    divide=True) (include/hhsr.h, hhsr_merge_burst_chain).  `frames`: the frames that have arrived so far, of which the
+    first `n_done` were merged by earlier links; this link adds frames[n_done:] to the parity-class accumulators parked in
+    `class_acc` (chain_buffer).  `last`: also add the reference frame, normalise and write `num` (and `acc_r`) — the
+    earlier links can run while the remaining frames are still on their way."""
+    scale, kflags = _common(config)
+    assert 0 <= n_done <= len(frames) <= _lib.MAX_FRAMES and (n_done < len(frames) or last)
+    H, W = frames[0][0].shape
+    ny, nx, _ = frames[0][1].shape
+    sH, sW, _ = num.shape
+    flags = (_lib.MERGE_LOAD_CLASSES if n_done else 0) | \
+            ((_lib.MERGE_DO_REF | _lib.MERGE_DIVIDE) if last else _lib.MERGE_STORE_CLASSES)
+    if local_min:
+        flags |= _lib.MERGE_LOCAL_MIN
+    if last and not n_done:
+        raise ValueError("a chain of one link is merge_burst()")
+    ts = config.block_matching.tuning.tile_size
+    _lib.call("hhsr_merge_burst_chain", _lib.ptr_array([c[0] for c in frames]), _lib.ptr_array([c[1] for c in frames]),
+              _lib.ptr_array([c[2] for c in frames]), _lib.ptr_array([c[3] for c in frames]), len(frames), H, W, W, ny, nx,
+              int(ts), _lib.ptr(ref_img if last else None), _lib.ptr(ref_kernels if last else None),
+              _lib.cfa_bytes(cfa_pattern), scale, kflags, flags, _lib.ptr(num), _lib.ptr(None),
+              _lib.ptr(acc_r if last else None), sH, sW, _lib.ptr(class_acc), int(n_done), _lib.stream())

@@ -146,7 +146,9 @@ class BurstPipeline:
                 stream = _upload_streams.get(self.device.index)
                 if stream is None:
                     # (high priority = its own hardware queue: see graph.HostBurstRunner)
-                    stream = _upload_streams[self.device.index] = torch.cuda.Stream(self.device, priority=-1)
+                    from .graph import shared_streams
+
+                    stream = _upload_streams[self.device.index] = shared_streams(self.device)[1]
             if t.dtype == torch.float64:  # (half the PCIe bytes: the kernels work on float32 frames anyway)
                 t = t.to(torch.float32).pin_memory()
             with torch.cuda.stream(stream):

@@ -24,6 +24,7 @@
 #ifndef HHSR_H
 #define HHSR_H
 
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
@@ -276,6 +277,29 @@ int hhsr_merge_burst(const float* const* raws, const float* const* flows, const 
                      const uint8_t cfa[4], double scale, int kflags, int flags,
                      float* num, float* den, float* acc_r, int sH, int sW, int row0, int nrows,
                      int lr_row_offset, void* stream);
+
+/* The fused x2 merge as a CHAIN of launches for bursts whose last frames arrive late (frames crossing PCIe: the early links
+ * run while the late frames upload), bit-identical to ONE hhsr_merge_burst over all frames.  Every link gets the frames
+ * that have arrived so far, raws[0 .. n_frames), of which the first n_done were merged by the links before it:
+ *   first link   flags = HHSR_MERGE_STORE_CLASSES, n_done = 0: frames [0, n_frames) are merged into the kernel's
+ *                parity-class accumulators, which are parked in class_acc (hhsr_merge_chain_bytes(H, W) bytes);
+ *   middle link  flags = HHSR_MERGE_LOAD_CLASSES | HHSR_MERGE_STORE_CLASSES: restore, add frames [n_done, n_frames), park;
+ *   last link    flags = HHSR_MERGE_LOAD_CLASSES | the flags of the single launch (DO_REF, DIVIDE, ...): restore, add the
+ *                remaining frames, the reference frame, normalise, write the image (and acc_r).
+ * (+ HHSR_MERGE_LOCAL_MIN in every link if the single launch had it.)  Tiles in which a window of ANY frame leaves the
+ * image (they run a per-pixel code path: ~2 % at 12 MP) are skipped by the storing links and computed from the first
+ * frame on by the last link, so every tile runs exactly the instruction sequence of the single launch.
+ * Only with the wave-per-class x2 kernel (scale 2, ts % 16 == 0, sH = 2 H, sW = 2 W, float32 weights, Bayer, whole image);
+ * error -3 otherwise. */
+#define HHSR_MERGE_STORE_CLASSES 32
+#define HHSR_MERGE_LOAD_CLASSES 64
+size_t hhsr_merge_chain_bytes(int H, int W);
+int hhsr_merge_burst_chain(const float* const* raws, const float* const* flows, const float* const* covs,
+                           const float* const* rs, int n_frames, int H, int W, int pitch,
+                           int ny, int nx, int ts, const float* ref_raw, const float* ref_covs,
+                           const uint8_t cfa[4], double scale, int kflags, int flags,
+                           float* num, float* den, float* acc_r, int sH, int sW,
+                           float* class_acc, int n_done, void* stream);
 
 /* ---- burst front end (utils_dng.py:149-160) ------------------------------------------------
  * Sensor counts uint16 [n_frames][H][pitch] -> normalised, white-balanced float32 [n_frames][H][W]:

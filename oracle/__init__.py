@@ -37,6 +37,6 @@ from .robustness import (init_robustness, compute_robustness, guide_image, local
                          upscale_warp_stats, compute_s, local_min)
 from .merge import merge, merge_ref, divide  # noqa: F401
 from .pipeline import main  # noqa: F401
-from .parallel import main_parallel, throughput_all_cores  # noqa: F401
+from .parallel import main_parallel, throughput_all_cores, available_cores  # noqa: F401
 from . import frontend  # noqa: F401
 from . import post  # noqa: F401

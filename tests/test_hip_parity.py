@@ -1867,6 +1867,49 @@ def test_batched_front_end_equals_per_frame(hip):
     assert torch.equal(got[0], want[0]) and torch.equal(got[1], want[1])
 
 
+def test_merge_burst_chain_equals_single_launch():
+    """merge_burst_chain (a chain of launches: the frames that have arrived are merged into parked parity-class
+    accumulators, the last link adds the rest, the reference frame and the normalisation) == merge_burst (one launch), bit
+    for bit — also for tiles that the early links run wave-uniform but a LATER frame's flow sends down the per-pixel path
+    (the last link recomputes them), for tiles at the image border, with the fused 5 x 5 minimum and the fused accumulated
+    robustness, for 2 to 5 links."""
+    ref, comp, _ = synth.make_burst_torch(512, 640, 10, torch.device(DEV), seed=3, max_shift=3.0)
+    for lmin, accr in ((True, True), (False, False)):
+        cfg = base_config(ts=16, scale=2, metrics=("L1", "L2", "L2", "L2"))
+        pipe = hsr.BurstPipeline(cfg).init_ref(ref)
+        frames = pipe.process_frames([comp[i] for i in range(9)], None, fuse_local_min=lmin)
+        # frame 7 (a late link) gets a huge flow in an interior tile and one that pushes a window over the border; frame 2
+        # (an early link) another
+        fl = frames[7][1].clone()
+        fl[10, 12] = torch.tensor([140.0, -95.0], device=DEV)
+        fl[3, 37] = torch.tensor([60.0, 2.0], device=DEV)
+        frames[7] = (frames[7][0], fl, frames[7][2], frames[7][3])
+        fl = frames[2][1].clone()
+        fl[20, 5] = torch.tensor([-90.0, 30.0], device=DEV)
+        frames[2] = (frames[2][0], fl, frames[2][2], frames[2][3])
+        H, W = ref.shape
+        want = torch.empty((2 * H, 2 * W, 3), dtype=torch.float32, device=DEV)
+        acc_w = torch.zeros((H, W), dtype=torch.float32, device=DEV) if accr else None
+        merge.merge_burst(frames, pipe.ref, pipe.ref_covs, want, None, pipe.cfa, cfg, acc_r=acc_w, local_min=lmin)
+        assert merge.can_chain(cfg, (H, W))
+        cls = merge.chain_buffer((H, W), torch.device(DEV))
+        for cuts in ((1,), (5,), (8,), (9,), (4, 6), (2, 3, 7, 8), (3, 9)):
+            got = torch.full_like(want, -7.0)
+            acc_g = torch.full((H, W), -7.0, dtype=torch.float32, device=DEV) if accr else None
+            cls.fill_(float("nan"))
+            done = 0
+            for k in cuts:
+                merge.merge_burst_chain(frames[:k], done, pipe.ref, pipe.ref_covs, got, pipe.cfa, cfg, cls, False, local_min=lmin)
+                done = k
+            merge.merge_burst_chain(frames, done, pipe.ref, pipe.ref_covs, got, pipe.cfa, cfg, cls, True, acc_r=acc_g,
+                                    local_min=lmin)
+            assert torch.equal(torch.nan_to_num(got, nan=-1.0), torch.nan_to_num(want, nan=-1.0)), f"cuts={cuts} lmin={lmin}"
+            if accr:
+                assert torch.equal(acc_g, acc_w)
+    cfg3 = base_config(ts=16, scale=3)
+    assert not merge.can_chain(cfg3, (512, 640))
+
+
 # ------------------------------------------------------------------------------------------ host-resident bursts
 @pytest.mark.parametrize("kind", ["f32_pinned", "f32_numpy", "u16_pinned", "u16_numpy"])
 def test_host_burst_runner_equals_eager(kind):
@@ -1911,6 +1954,10 @@ def test_host_burst_runner_equals_eager(kind):
         assert torch.equal(dbg["accumulated robustness"], wdbg["accumulated robustness"])
     st = eng._host.states[next(iter(eng._host.states))]
     assert not eng._host.disabled and st != "seen" and len(st.g_chunks) >= 2, getattr(eng._host, "error", None)
+    if kind.startswith("f32"):  # upload-bound bursts chain the merge: 8 comp frames = chunks 4, 2, 1, 1 -> links after 4 and 6
+        assert st.chain and [k for _, k in st.links] == [4, 6]
+    else:
+        assert not st.chain and not st.links
 
 
 def test_main_numpy_serving_loop():
