@@ -162,7 +162,8 @@ class HostBurstRunner:
     def close(self):
         """Drop the captured states in a defined order: device idle first, then graphs, staging, copy threads."""
         try:
-            torch.cuda.synchronize(self.device)
+            if not torch.cuda.is_current_stream_capturing():  # (a finaliser may run in the middle of someone's capture)
+                torch.cuda.synchronize(self.device)
         except Exception:
             pass
         for st in list(self.states.values()):
