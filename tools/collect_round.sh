@@ -25,5 +25,17 @@ bash tools/pmc_all.sh $NAME/pmc_all > /dev/null 2>&1
 tools/ubench/valu_rate > $OUT/valu_rate.txt
 bash tools/traffic_calib.sh $NAME > /dev/null 2>&1
 (cd /tmp && export TMPDIR=/tmp && rocprofv3 --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_LDS --output-format csv -d /tmp/ldsp -o lds -- $GRAFT_REPO_ROOT/tools/ubench/lds_patterns > /dev/null 2>&1; python $GRAFT_REPO_ROOT/tools/ubench/pmc_lds.py /tmp/ldsp > $GRAFT_REPO_ROOT/$OUT/lds_patterns.txt)
+# host-resident legs, the copy / kernel timelines of one host-resident step, measured bounds
+python tools/debug/host_leg_timing.py 2>&1 | grep -v amdgpu.ids > $OUT/host_legs.txt
+bash tools/debug/h2d_trace.sh f32 2>&1 | grep -v "^\[" | grep -v "^\['id'" > $OUT/h2d_trace_f32.txt
+bash tools/debug/h2d_trace.sh u16 2>&1 | grep -v "^\[" | grep -v "^\['id'" > $OUT/h2d_trace_u16.txt
+python tools/debug/cov_inline_bound.py 2>&1 | grep -v amdgpu.ids > $OUT/cov_inline_bound.txt
+python tools/debug/mono_timing.py 2>&1 | grep -v amdgpu.ids > $OUT/mono_timing.txt
+python tools/debug/hwqueue_probe.py 2>&1 | grep -v amdgpu.ids > $OUT/hwqueue_probe.txt
+python tools/debug/copy_contention_probe.py 2>&1 | grep -v amdgpu.ids >> $OUT/hwqueue_probe.txt
+# the randomised sweep in report mode (the asserting run is part of the test suite above)
+rm -f $OUT/fuzz_report.txt
+HHSR_FUZZ_REPORT=$PWD/$OUT/fuzz_report.txt python -m pytest tests/test_fuzz_parity.py -m gpu -q > /dev/null 2>&1
+python tools/fuzz_report.py $OUT/fuzz_report.txt >> $OUT/PARITY.md
 find $OUT -name "*agent_info*" -delete
 cut -c1-600 $OUT/bench_n1.json
