@@ -10,18 +10,22 @@ in HBM.  Default workload = the configuration BASELINE.json's metric is quoted o
 
 N > 1: one process per GPU over RCCL (backend "nccl").  The driver launches the ranks with torch.distributed.run; run
 by hand (`python bench.py --gpus 4`) the script re-executes itself under torch.distributed.run.  Every rank count —
-N = 1 included — goes through handheld_super_resolution.distributed.main_sharded: alignment frame-parallel, ONE
-all-gather of the flow fields, kernels / robustness / merge row-parallel; the output stays sharded by rows
+N = 1 included — goes through handheld_super_resolution.distributed.main_sharded.  --strategy rows (default): alignment
+frame-parallel, ONE all-gather of the flow fields, kernels / robustness / merge row-parallel; --strategy reduce (the north
+star's): frames one per rank, ONE reduce-scatter of the float32 accumulators.  The output stays sharded by rows
 (`--gather` adds the gather to rank 0).  Total work is fixed, so scaling is "strong".
 
 Rank 0 prints ONE JSON line: metric "output Mpix/s" (scale^2 * H * W / time per burst), plus
-  value_incl_h2d  the same with the frames starting as pinned host float32 arrays, uploaded on the frame pipeline's
-                  side streams (the reference's timer spans its uploads: super_resolution.py:103-195); h2d.*_u16: the
-                  frames as uint16 sensor counts, normalised on the device (half the PCIe bytes);
+  value_incl_h2d  the same with the frames starting in HOST memory (the reference's timer spans its uploads:
+                  super_resolution.py:103-195): page-locked float32 arrays (with pcie_floor_ms / pcie_floor_frac),
+                  h2d.*_u16: uint16 sensor counts normalised on the device (half the PCIe bytes), h2d.value_numpy_pageable:
+                  plain NumPy float32 arrays through main() itself — eager uploads into static staging, per-chunk HIP
+                  graphs, chained fused merge (handheld_super_resolution/graph.py: HostBurstRunner);
   roofline        dominant kernel (hhsr_merge_burst): VALU issue and algorithmic bytes per launch / launch duration
                   measured with HIP events on the launch stream;
   cpu_baseline    the NumPy oracle (a golden-pinned port of the reference's algorithm; the reference itself has no CPU
-                  path) on ALL host cores (one process per frame) on a bounded crop of the same burst;
+                  path) on every core the container may use (logical CPUs capped by the cgroup CPU quota; one worker
+                  process per comp frame, several crops side by side when the cores allow) on a bounded crop of the burst;
   parity          max-abs difference of the GPU result to the oracle on that crop, with the residual attributed:
                   tiles whose block-matching decision differs (float32 near-ties), and the difference that remains
                   when the oracle's flow fields are injected into the GPU path.

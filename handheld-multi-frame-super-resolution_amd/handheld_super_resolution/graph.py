@@ -216,7 +216,7 @@ class HostBurstRunner:
             return main(ref_img, comp_imgs, self.config, _no_runner=True)
         if st is None:
             self.states[key] = "seen"
-            while len(self.states) > 4:
+            while len(self.states) > 2:  # (a captured state holds a burst's staging and intermediates: ~6 GB at 12 MP x 20)
                 self.states.pop(next(iter(self.states)))
             return self._eager(ref_img, comp_imgs)
         if st == "seen":
