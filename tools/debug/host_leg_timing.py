@@ -27,6 +27,22 @@ def config(u16):
     return cfg
 
 
+if os.environ.get("HHSR_PRELUDE"):  # what bench.py does before its host-resident legs: device-resident graph replays + eager steps
+    cfg0 = config(False)
+    e0 = hdist.HipEngine(cfg0)
+    for _ in range(8):
+        hdist.main_sharded(ref, comp, cfg0, engine=e0)
+    import copy
+    cfg1 = copy.deepcopy(cfg0)
+    cfg1.hip = dict(cfg1.hip, graph=False)
+    e1 = hdist.HipEngine(cfg1)
+    for _ in range(4):
+        hdist.main_sharded(ref, comp, cfg1, engine=e1)
+    torch.cuda.synchronize()
+    print("prelude done (resident graph engine kept alive:", os.environ["HHSR_PRELUDE"] == "keep", ")")
+    if os.environ["HHSR_PRELUDE"] != "keep":
+        del e0, e1
+
 c16 = lambda t: torch.from_numpy(np.clip(np.rint(t.cpu().numpy() * (white - black) + black), 0, white).astype(np.uint16))
 legs = {
     "pinned f32": (False, ref.cpu().pin_memory(), [comp[i].cpu().pin_memory() for i in range(NF - 1)]),
