@@ -36,7 +36,7 @@ def shared_streams(device):
         pool = _stream_pool.setdefault(idx, [])
         while len(pool) < DEFAULT_STREAMS:
             pool.append(torch.cuda.Stream(dev))
-        hit = _shared[idx] = (main, torch.cuda.Stream(dev, priority=-1))
+        hit = _shared[idx] = (main, torch.cuda.Stream(dev, priority=-1), torch.cuda.Stream(dev, priority=-1))
     return hit
 
 
@@ -145,7 +145,16 @@ class HostBurstRunner:
         # stream mapped to the same queue starts after the LAST copy (tools/debug/hwqueue_probe.py: 7 of 8 compute streams
         # blocked for 8.7 ms; with the upload stream in the high-priority queue set: none).  Both streams are shared by
         # all runners of the process (shared_streams).
-        self.main, self.up = shared_streams(device)
+        self.main, self.up, self.up2 = shared_streams(device)
+        import os
+
+        self.two_up = os.environ.get("HHSR_TWO_UPLOAD_STREAMS") == "1"  # (experiment: copies alternate between two streams)
+        # A chunk's copies are queued when the previous chunk's are done, not all 20 up front: with many copies pending on
+        # the stream the copy engine sometimes settles at HALF rate (1.6 instead of 0.85 ms per 48 MB for whole bursts,
+        # rocprofv3 --memory-copy-trace; seen after compute-only phases of the process, tools/debug/host_leg_timing.py with
+        # HHSR_PRELUDE) — queued a chunk at a time it stays at full rate in every state measured, at the price of a 20 us
+        # gap per chunk (17.3 -> 17.7 ms for 960 MB).  HHSR_PACED_UPLOADS=0: everything up front.
+        self.paced_uploads = os.environ.get("HHSR_PACED_UPLOADS", "1") != "0"
 
     def _eager(self, ref_img, comp_imgs):
         from .super_resolution import main
@@ -240,7 +249,7 @@ class HostBurstRunner:
         with torch.cuda.device(dev):
             st.stage = torch.empty((n + 1, H, W), dtype=frames[0].dtype, device=dev)
             st.pin = None
-            st.main, st.up = self.main, self.up
+            st.main, st.up, st.up2 = self.main, self.up, self.up2
             for i, f in enumerate(frames):  # valid content for the capture-time launches' validation paths
                 st.stage[i].copy_(f)
             torch.cuda.synchronize(dev)
@@ -358,6 +367,8 @@ class HostBurstRunner:
                 futs.append([st.pool.submit(np.copyto, st.pin_np[i, a:b], src[a:b]) for a, b in zip(cuts[:-1], cuts[1:]) if b > a])
         with torch.cuda.device(dev):
             st.up.wait_stream(st.main)   # the previous burst's kernels are done with the device staging buffers
+            if self.two_up:
+                st.up2.wait_stream(st.main)
             st.main.wait_stream(cur)
 
             def upload(i):
@@ -366,12 +377,14 @@ class HostBurstRunner:
                     for f in futs[i]:
                         f.result()
                     src = st.pin[i]
-                with torch.cuda.stream(st.up):
+                up = st.up2 if (self.two_up and i % 2) else st.up
+                with torch.cuda.stream(up):
                     st.stage[i].copy_(src, non_blocking=True)
-                    st.e_up[i].record(st.up)
+                    st.e_up[i].record(up)
 
             upload(0)
-            if futs is None:  # page-locked frames: all copies queued up front, back to back
+            paced = futs is not None or self.paced_uploads
+            if not paced:  # (page-locked frames, HHSR_PACED_UPLOADS=0: all copies queued up front, back to back)
                 for i in range(1, n + 1):
                     upload(i)
             # The graphs are launched HOST-PACED: the host waits for a chunk's last copy, then launches its graph.  Queued
@@ -384,10 +397,11 @@ class HostBurstRunner:
                 st.g_ref.replay()
                 st.e_ref.record(st.main)
             for c, (idx, s, g) in enumerate(zip(st.chunks, st.streams, st.g_chunks)):
-                if futs is not None:
+                if paced:
                     for i in idx:
                         upload(1 + i)
-                st.e_up[1 + idx[-1]].synchronize()  # copies complete in order: the chunk's frames are all there
+                for i in (idx if self.two_up else idx[-1:]):
+                    st.e_up[1 + i].synchronize()  # (one upload stream: copies complete in order)
                 with torch.cuda.stream(s):
                     s.wait_event(st.e_ref)
                     g.replay()

@@ -50,6 +50,32 @@ legs = {
     "pageable f32 (numpy)": (False, ref.cpu().numpy(), comp.cpu().numpy()),
     "pageable u16 (numpy)": (True, c16(ref).numpy(), np.stack([c16(comp[i]).numpy() for i in range(NF - 1)])),
 }
+def arena(r, c):  # the same frames as views of ONE page-locked allocation
+    a = torch.empty((len(c) + 1, *r.shape), dtype=r.dtype, pin_memory=True)
+    a[0].copy_(r)
+    for i, f in enumerate(c):
+        a[i + 1].copy_(f)
+    return a[0], list(a[1:].unbind(0))
+
+
+legs["pinned f32, ONE arena"] = (False, *arena(legs["pinned f32"][1], legs["pinned f32"][2]))
+legs["pinned u16, ONE arena"] = (True, *arena(legs["pinned u16"][1], legs["pinned u16"][2]))
+import threading
+
+_stop = threading.Event()
+
+
+def _busy():  # host memory traffic: keeps the host's data fabric out of its idle power state
+    a, b = np.zeros(8 << 20, np.float32), np.zeros(8 << 20, np.float32)
+    while not _stop.is_set():
+        np.copyto(a, b)
+
+
+if os.environ.get("HHSR_HOST_BUSY"):
+    for _ in range(int(os.environ["HHSR_HOST_BUSY"])):
+        threading.Thread(target=_busy, daemon=True).start()
+    print("host busy threads:", os.environ["HHSR_HOST_BUSY"])
+
 for name, (u16, r, c) in legs.items():
     cfg = config(u16)
     eng = hdist.HipEngine(cfg)
