@@ -170,7 +170,9 @@ def oracle_jobs():
     """All 64 oracle runs are submitted at once to a fork pool (NumPy-only children: they never touch the GPU) and the
     batches consume them as they finish: the sweep takes about as long as the slowest oracle case."""
     all_cases = [c for gs, n in BATCHES for c in cases(gs, n)]
-    workers = max(1, min(len(all_cases), (os.cpu_count() or 2) // 2))
+    # every core the container may use (cgroup quota: 16 of the GPU boxes' 256 logical CPUs) minus two for this process:
+    # with one worker per case the workers starved the checking thread (the sweep took 290 s instead of ~2 min)
+    workers = max(1, min(len(all_cases), oracle.available_cores() - 2))
     pool = mp.get_context("fork").Pool(workers)
     jobs = {c["id"]: pool.apply_async(_oracle_case, (c,)) for c in all_cases}
     yield jobs

@@ -1332,13 +1332,14 @@ def test_full_size_properties():
 
 @pytest.mark.parametrize("metric0", ["L1", "L1_ref_effective"])
 def test_c2_full_size_against_oracle(metric0):
-    """BASELINE config C2 geometry at FULL size — 3000x4000, x2 -> 48 MP — against the oracle (2 comp frames: ~1 min of
-    NumPy on two host cores), every difference attributed to a flipped block-matching tile.  Both readings of the
+    """BASELINE config C2 at FULL size — 3000x4000, 8 frames, x2 -> 48 MP — against the oracle (one worker process per
+    comp frame), every difference attributed to a flipped block-matching tile.  Both readings of the
     headline configuration's level-0 metric (configs/default.yaml:17 `L1`; upstream's L1 kernels are undefined
     behaviour): the intended SAD argmin, and `L1_ref_effective` = what the hardware most likely
     does with the uninitialised shift (flow <- round(flow))."""
     H, W = 3000, 4000
-    ref, comp, _ = synth.make_burst(H, W, 3, seed=1234)
+    # the intended-L1 reading with the configuration's own 8 frames (7 oracle workers, ~1.5 min); the other with 3
+    ref, comp, _ = synth.make_burst(H, W, 8 if metric0 == "L1" else 3, seed=1234)
     _e2e_vs_oracle(ref, comp, lambda: base_config(ts=16, scale=2, metrics=(metric0, "L2", "L2", "L2")), 16,
                    f"C2 full size {metric0}",
                    max_flipped=FLIP_BUDGET["c2_full" if metric0 == "L1" else "c2_full_eff"], parallel=True,
