@@ -292,7 +292,12 @@ constexpr int TB = HHSR_FFT_TB;
 __device__ __forceinline__ size_t t_index(int kx, int y, int H) { return ((size_t)(kx / TB) * H + y) * TB + (kx % TB); }
 
 constexpr int FFT_NT = 512;          // threads per workgroup
-constexpr int FFT_ROWS_WPE = 6;     // row kernels: 48 KB of LDS -> three workgroups per CU need <= 85 VGPRs
+#ifndef HHSR_FFT_TWG
+#define HHSR_FFT_TWG 0  // 1 (A/B, round 3): row kernels read their pass twiddles from global memory (L1 / L2) instead of an LDS
+                        // copy: 32 KB of LDS per workgroup -> four workgroups per CU (<= 64 VGPRs).  Measured: 248 / 221 us
+                        // per 3-4 frame launch instead of 118 / 116 — the twiddle loads sit on every pass's critical path
+#endif
+constexpr int FFT_ROWS_WPE = HHSR_FFT_TWG ? 8 : 6;  // row kernels: 48 KB of LDS -> three workgroups per CU need <= 85 VGPRs
 constexpr int FFT_COLS_WPE = 4;     // column kernel: 72 KB of LDS -> two workgroups per CU (<= 128 VGPRs)
 
 // n elements global -> LDS (or any load / store pair) with the loads of a 4-iteration batch all in flight before the first
@@ -353,9 +358,14 @@ __global__ void __launch_bounds__(FFT_NT, FFT_ROWS_WPE) k_rows_fwd(FftFrames fr,
                                                                         const float2* __restrict__ twW) {
     extern __shared__ __attribute__((aligned(16))) float2 fl[];
     const int M = W / 2, tid = threadIdx.x;
+#if HHSR_FFT_TWG
+    const float2* __restrict__ tw = twM;
+    float2* buf = fl;
+#else
     float2* tw = fl;
     float2* buf = tw + ((twlen + 1) & ~1);  // 16-byte aligned
     batched_for<float2>(twlen, tid, [&](int k) { return twM[k]; }, [&](int k, float2 v) { tw[k] = v; });
+#endif
     // persistent workgroups: the grid is one resident round (HHSR_FFT_PERSIST), every workgroup walks the row blocks
     // (row_block): one twiddle copy and one dispatch per workgroup slot instead of per block
     const int nb = (H + RB - 1) / RB;
@@ -455,9 +465,14 @@ __global__ void __launch_bounds__(FFT_NT, FFT_ROWS_WPE) k_rows_inv(const float2*
                                                                         const float2* __restrict__ twW) {
     extern __shared__ __attribute__((aligned(16))) float2 fl[];
     const int M = W / 2, tid = threadIdx.x;
+#if HHSR_FFT_TWG
+    const float2* __restrict__ tw = twM;
+    float2* buf = fl;
+#else
     float2* tw = fl;
     float2* buf = tw + ((twlen + 1) & ~1);  // 16-byte aligned
     batched_for<float2>(twlen, tid, [&](int k) { return twM[k]; }, [&](int k, float2 v) { tw[k] = v; });
+#endif
     const int nb = (H + RB - 1) / RB;
     for (int it = 0, vblk; (vblk = row_block<RB>(it, nb * fr.n)) >= 0; ++it) {  // persistent workgroups, see k_rows_fwd
     if (it) __syncthreads();
@@ -637,7 +652,7 @@ bool hhsr_fft_create(HhsrFft& f, int H, int W, int batch) {
     const std::vector<float2> hM = pass_twiddles(f.radM), hH = pass_twiddles(f.radH);
     f.twlenM = (int)hM.size();
     f.twlenH = (int)hH.size();
-    f.lds_rows = sizeof(float2) * ((size_t)((f.twlenM + 1) & ~1) + (size_t)f.rb * M);
+    f.lds_rows = sizeof(float2) * ((HHSR_FFT_TWG ? 0 : (size_t)((f.twlenM + 1) & ~1)) + (size_t)f.rb * M);
     f.lds_cols = sizeof(float2) * ((size_t)((f.twlenH + 1) & ~1) + (size_t)f.nc * H);
     if (f.lds_cols > 150 * 1024 || f.lds_rows > 150 * 1024) return false;
     const void* kf = f.rb == 4 ? (const void*)k_rows_fwd<4> : f.rb == 2 ? (const void*)k_rows_fwd<2> : (const void*)k_rows_fwd<1>;
@@ -673,7 +688,7 @@ void hhsr_fft_destroy(HhsrFft& f) {
 
 int hhsr_fft_lowpass(const HhsrFft& f, const float* const* srcs, float* const* dsts, int n, hipStream_t s) {
     // row kernels: at most one resident round of workgroups (3 per CU by their 48 kB of LDS), each walking several blocks
-    static const int persist = getenv("HHSR_FFT_PERSIST") ? atoi(getenv("HHSR_FFT_PERSIST")) : 768;
+    static const int persist = getenv("HHSR_FFT_PERSIST") ? atoi(getenv("HHSR_FFT_PERSIST")) : (HHSR_FFT_TWG ? 1024 : 768);
     // unnormalised inverse transforms multiply by (W/2) and H
     const float norm = (float)(1.0 / ((double)(f.W / 2) * (double)f.H));
     for (int n0 = 0; n0 < n; n0 += f.batch) {  // the plan holds f.batch spectra: longer lists run in rounds
