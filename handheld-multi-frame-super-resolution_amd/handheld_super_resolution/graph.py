@@ -147,6 +147,9 @@ class HostBurstRunner:
         # all runners of the process (shared_streams).
         self.main, self.up, self.up2 = shared_streams(device)
         import os
+        import threading
+
+        self._lock = threading.Lock()  # one burst at a time per runner (static staging, shared streams)
 
         self.two_up = os.environ.get("HHSR_TWO_UPLOAD_STREAMS") == "1"  # (experiment: copies alternate between two streams)
         # A chunk's copies are queued when the previous chunk's are done, not all 20 up front: with many copies pending on
@@ -215,6 +218,10 @@ class HostBurstRunner:
         return all(tuple(f.shape) == tuple(t0.shape) and f.dtype == t0.dtype for f in frames) and len(t0.shape) == 2
 
     def __call__(self, ref_img, comp_imgs):
+        with self._lock:
+            return self._call(ref_img, comp_imgs)
+
+    def _call(self, ref_img, comp_imgs):
         from .super_resolution import main
 
         frames = [torch.as_tensor(f) for f in (ref_img, *[comp_imgs[i] for i in range(len(comp_imgs))])]
