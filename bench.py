@@ -56,6 +56,18 @@ def merge_burst_bytes(n_comp, P, S):
     return float(n_comp * 12 * P + 8 * P + 12 * S * P)
 
 
+def step_bytes(n_comp, P, S):
+    """Algorithmic HBM bytes of one WHOLE step of the fused pipeline (fp32, Bayer; DESIGN.md §4 kernel table), per comp
+    frame: grey FFT 16 P (raw in, kept half spectrum out / in / out / in, grey out); pyramid 4 P + P + P/16 + P/256 read,
+    P/4 + P/64 + P/1024 written ~ 5.4 P; alignment reference + moving level read once per level, flow negligible:
+    8 P (1 + 1/4 + 1/64 + 1/1024) ~ 10.1 P; raw pass 4 P in, 3 P means + 4 P covariances out; robustness 3 P means + 4 P
+    R out + 20 P of reference planes per group of 4 frames = 12 P; merge 12 P.  Per burst: the merge's reference frame
+    and output (8 P + 12 S P), the reference frame's own precompute ~ 60 P.  (SURVEY.md §8d's 68.5 GB model priced the
+    reference's per-frame read-modify-write of the accumulators, which the fused merge does not do.)"""
+    per_frame = (16 + 5.4 + 10.1 + 11 + 12 + 12) * P
+    return float(n_comp * per_frame + (8 + 12 * S) * P + 60 * P)
+
+
 def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -431,7 +443,14 @@ def main():
             "rccl_ranks": dist.get_world_size() if world > 1 else 1,
             "backend": (args.backend if world > 1 else None),
             "engine": "HipEngine (libhhsr_hip.so)" if on_gpu else f"{args.engine} (launch-plumbing test, not a measurement)",
-            "roofline": roof, "cpu_baseline": cpu, "parity": parity,
+            "roofline": roof,
+            "step_roofline": {"algorithmic_bytes": step_bytes(NF - 1, P, S) / world,
+                              "achieved": round(step_bytes(NF - 1, P, S) / (ms_per_step * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS,
+                              "unit": "GB/s", "frac": round(step_bytes(NF - 1, P, S) / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                              "note": "whole step: algorithmic bytes of every kernel of the fused pipeline (bench.step_bytes) over "
+                                      "the step time; its kernels are VALU- or latency-bound (profiles/*_kernel_bottlenecks.md), "
+                                      "none is HBM-bound"},
+            "cpu_baseline": cpu, "parity": parity,
             "reference_published": "48 MP in < 4 s (>= 12 output Mpix/s) on an RTX 3090 for a 20-frame burst (README.md:10)",
         }
         if h2d:
