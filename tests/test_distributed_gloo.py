@@ -142,12 +142,13 @@ class SeamEngine(OracleEngine):
         return torch.from_numpy(fl)
 
 
-def _worker(rank, world, port, out_path, strategy="rows", seam=False):
+def _worker(rank, world, port, out_path, strategy="rows", seam=False, n_comp=3):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         ref, comp, cfg = _burst(seam)
+        comp = comp[:n_comp]
         eng = OracleEngine(cfg)
         if seam:  # frame 1 of the burst is aligned by rank 1 % world as its (1 // world)-th frame
             eng = SeamEngine(cfg)
@@ -254,6 +255,21 @@ def test_reduce_strategy_matches_sequential(tmp_path, world):
         d = np.abs(got["out"] - want)
     assert np.nanmax(d) < 2e-6  # measured 2.4e-7
     np.testing.assert_allclose(got["acc_r"], dbg["accumulated robustness"].astype(np.float32), rtol=0, atol=2e-6)
+
+
+@pytest.mark.timeout(300)
+@pytest.mark.parametrize("strategy", ["rows", "reduce"])
+def test_more_ranks_than_frames(tmp_path, strategy):
+    """3 ranks, 2 comp frames: one rank aligns / merges nothing (zero contribution to the all-gather / reduce-scatter)."""
+    out_path = str(tmp_path / "out.npz")
+    mp.spawn(_worker, args=(3, _free_port(), out_path, strategy, False, 2), nprocs=3, join=True)
+    got = np.load(out_path)
+    ref, comp, cfg = _burst()
+    want, _ = oracle.main(ref, comp[:2], cfg)
+    assert (np.isnan(got["out"]) == np.isnan(want)).all()
+    with np.errstate(all="ignore"):
+        d = np.nanmax(np.abs(got["out"] - want))
+    assert d == 0.0 if strategy == "rows" else d < 2e-6
 
 
 def test_single_process_path_is_main():

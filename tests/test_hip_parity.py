@@ -1961,6 +1961,22 @@ def test_host_burst_runner_equals_eager(kind):
         assert not st.chain and not st.links
 
 
+@pytest.mark.parametrize("n_comp", [1, 2, 3])
+def test_host_burst_runner_tiny_bursts(n_comp):
+    """Bursts of 2-4 frames through the runner (one chunk, no chain, single-frame chunks): eager, capture, replay."""
+    from handheld_super_resolution import distributed as hdist
+
+    ref, comp, _ = synth.make_burst(512, 640, n_comp + 1, seed=13, max_shift=2.0)
+    cfg = base_config(ts=16, scale=2)
+    want = hsr.main(T(ref), T(comp), base_config(ts=16, scale=2))[0]
+    eng = hdist.HipEngine(cfg)
+    for it in range(3):
+        got, _ = eng.single(ref, [comp[i] for i in range(n_comp)])
+        assert torch.equal(torch.nan_to_num(got, nan=-1.0), torch.nan_to_num(want, nan=-1.0)), f"call {it}"
+    st = next(iter(eng._host.states.values()))
+    assert not eng._host.disabled and st != "seen" and not st.chain
+
+
 def test_main_numpy_serving_loop():
     """main() itself, called again and again with NumPy arrays and the same configuration object (the reference's
     signature in a serving loop), goes through the runner from the third call on and still hands out fresh tensors."""
