@@ -2021,7 +2021,8 @@ static int merge_burst_impl(const float* const* raws, const float* const* flows,
     }
     if (mono && !quad) {  // (tiled is false for monochrome launches unless the x2 conditions hold)
         if (lmin) {
-            hhsr_set_error("hhsr_merge_burst: HHSR_MERGE_LOCAL_MIN is not available with HHSR_SENSOR_MONO");
+            hhsr_set_error("hhsr_merge_burst: HHSR_MERGE_LOCAL_MIN with HHSR_SENSOR_MONO needs the x2 tile kernel (scale 2, "
+                           "ts %% 16 == 0, sH = 2 H, sW = 2 W, row0 %% 32 == 0, float32 weights)");
             return -3;
         }
 #define HHSR_MB(WT, GEOM, ISO) hipLaunchKernelGGL((k_merge_burst<WT, GEOM, ISO>), grid, block, 0, s, a, g, c, num, den)
@@ -2030,13 +2031,14 @@ static int merge_burst_impl(const float* const* raws, const float* const* flows,
         else { if (iso) HHSR_MB(float, GEOM_F64, true); else HHSR_MB(float, GEOM_F64, false); }
 #undef HHSR_MB
     } else if (mono) {
-        if (lmin) {
-            hhsr_set_error("hhsr_merge_burst: HHSR_MERGE_LOCAL_MIN is not available with HHSR_SENSOR_MONO");
-            return -3;
-        }
         const dim3 qgrid(hhsr_cdiv(W, QT), hhsr_cdiv(nrows / 2, QT));
-        if (iso) hipLaunchKernelGGL((k_merge_burst_quad<true, false, true>), qgrid, block, 0, s, a, g, c, num, den);
-        else hipLaunchKernelGGL((k_merge_burst_quad<false, false, true>), qgrid, block, 0, s, a, g, c, num, den);
+        if (lmin) {
+            if (iso) hipLaunchKernelGGL((k_merge_burst_quad<true, true, true>), qgrid, block, 0, s, a, g, c, num, den);
+            else hipLaunchKernelGGL((k_merge_burst_quad<false, true, true>), qgrid, block, 0, s, a, g, c, num, den);
+        } else {
+            if (iso) hipLaunchKernelGGL((k_merge_burst_quad<true, false, true>), qgrid, block, 0, s, a, g, c, num, den);
+            else hipLaunchKernelGGL((k_merge_burst_quad<false, false, true>), qgrid, block, 0, s, a, g, c, num, den);
+        }
     } else if (quad && !x2_v1 && aligned16) {
         const dim3 qgrid(hhsr_cdiv(W, QT), hhsr_cdiv(nrows / 2, QT));
         if (lmin) {

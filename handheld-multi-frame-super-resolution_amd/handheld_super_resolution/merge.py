@@ -68,7 +68,9 @@ def can_fuse_local_min(config, shape):
     hhsr_merge_burst."""
     scale, kflags = _common(config)
     H, W = shape
-    ok = not (kflags & (WEIGHT_F64 | FORCE_GENERIC | FORCE_TILE | SENSOR_MONO)) and int(config.block_matching.tuning.tile_size) % 16 == 0
+    ok = not (kflags & (WEIGHT_F64 | FORCE_GENERIC | FORCE_TILE)) and int(config.block_matching.tuning.tile_size) % 16 == 0
+    if kflags & SENSOR_MONO:  # monochrome: the x2 tile kernel only
+        return ok and scale == 2.0 and not (kflags & FORCE_X2V1)
     return ok and ((scale == 2.0 and H % 2 == 0 and W % 2 == 0) or (scale == 3.0 and W % 4 == 0))
 
 
@@ -123,8 +125,8 @@ def merge_burst(frames, ref_img, ref_kernels, num, den, cfa_pattern, config, loa
 
 def can_chain(config, shape):
     """merge_burst_chain applies: the wave-per-class x2 kernel (same conditions as can_fuse_local_min at scale 2)."""
-    scale, _ = _common(config)
-    return scale == 2.0 and can_fuse_local_min(config, shape)
+    scale, kflags = _common(config)
+    return scale == 2.0 and not (kflags & SENSOR_MONO) and can_fuse_local_min(config, shape)
 
 
 def chain_buffer(shape, device):

@@ -155,7 +155,7 @@ def compute_robustness(comp_img, ref_local_means, ref_local_stds, flows, cfa_pat
     ny, nx, _ = flows.shape
     if config.mode != "bayer":
         return _compute_robustness_mono(comp_img, ref_local_means, ref_local_stds, flows, noise_model, config, return_R,
-                                        accumulate_into, ref_sigma_sq, comp_means)
+                                        accumulate_into, ref_sigma_sq, comp_means, fuse_local_min)
     if ref_sigma_sq is None:  # a BurstPipeline passes the per-burst map; stand-alone callers get it here
         ref_sigma_sq = noise_sigma_sq(ref_local_means, ref_local_stds, std_curve)
     cm = comp_means  # a BurstPipeline gets them from the fused per-frame pass (kernels.frame_stats)
@@ -184,7 +184,7 @@ def mono_sigma_sq(ref_local_means, ref_local_stds, std_curve):
 
 
 def _compute_robustness_mono(comp_img, ref_local_means, ref_local_stds, flows, noise_model, config, return_R,
-                             accumulate_into, ref_sigma_sq, comp_means):
+                             accumulate_into, ref_sigma_sq, comp_means, fuse_local_min=False):
     """`mode: grey` (robustness.py:79-170 with the one-channel branches): 3x3 means of the frame itself, fused
     warp / distance / noise model / threshold, 5x5 minimum."""
     from .kernels import mono_frame_stats
@@ -201,6 +201,9 @@ def _compute_robustness_mono(comp_img, ref_local_means, ref_local_stds, flows, n
     _lib.call("hhsr_mono_rob_frame", _lib.ptr(cm), H, W, _lib.ptr(ref_local_means), _lib.ptr(sigma_sq), _lib.ptr(flows),
               ny, nx, int(ts), _lib.ptr(S), _lib.ptr(diff_curve), int(diff_curve.numel()), float(t.t), _lib.ptr(R),
               _lib.stream())
+    if fuse_local_min:  # the caller's merge applies Alg. 9 itself (merge_burst(..., local_min=True))
+        assert accumulate_into is None and not return_R
+        return R
     r = local_min(R, accumulate_into)
     return (r, R) if return_R else r
 

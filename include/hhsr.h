@@ -234,8 +234,8 @@ int hhsr_mono_rob_frame(const float* comp_means, int H, int W, const float* ref_
 #define HHSR_SENSOR_MONO 32  /* `mode: grey`: every sample goes to channel 0 (channels 1, 2 of num / den are left as they
                                 are), covs is [H][W][2][2] read at the position itself, cfa is ignored (may be NULL);
                                 hhsr_merge_burst: scale 2 (ts % 16 == 0, even sizes) runs the LDS-staged x2 tile kernel
-                                with a per-pixel covariance window, other scales the generic kernel; no
-                                HHSR_MERGE_LOCAL_MIN                                                               */
+                                with a per-pixel covariance window (HHSR_MERGE_LOCAL_MIN available), other scales the
+                                generic kernel                                                                     */
 
 /* ---- merge, Alg. 4 / Alg. 11 (merge.py; utils.py:62-120) --------------------------------------
  * hhsr_accumulate: one comp frame, num/den += (merge.py:291-434).

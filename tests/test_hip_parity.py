@@ -1620,6 +1620,16 @@ def test_mono_burst_merge_tile_kernel_vs_generic():
         assert np.isnan(a[..., 1:]).all() and np.isnan(b[..., 1:]).all()  # 0 / 0: the accumulators have three channels
         assert_close(a[..., 0], b[..., 0], 2e-5, 1e-6, f"mono x2 tile kernel vs generic, iso={iso}")
     assert not np.array_equal(outs["auto", False][..., 0], outs["auto", True][..., 0], equal_nan=True)
+    # the 5 x 5 minimum of Alg. 9 taken inside the merge (HHSR_MERGE_LOCAL_MIN) == applied beforehand, bit for bit
+    cfg = base_config(ts=16, scale=2, mode="grey")
+    assert merge.can_fuse_local_min(cfg, (H, W)) and not merge.can_chain(cfg, (H, W))
+    pre = [(f[0], f[1], f[2], robustness.local_min(f[3])) for f in frames]
+    a = torch.empty((2 * H, 2 * W, 3), dtype=torch.float32, device=DEV)
+    b = torch.empty_like(a)
+    acc_a, acc_b = torch.zeros((H, W), device=DEV), torch.zeros((H, W), device=DEV)
+    merge.merge_burst(frames, ref, ref_cov, a, None, cfa, cfg, acc_r=acc_a, local_min=True)
+    merge.merge_burst(pre, ref, ref_cov, b, None, cfa, cfg, acc_r=acc_b, local_min=False)
+    assert torch.equal(torch.nan_to_num(a, nan=-1.0), torch.nan_to_num(b, nan=-1.0)) and torch.equal(acc_a, acc_b)
 
 
 def test_e2e_mono_golden(golden):
@@ -1669,7 +1679,8 @@ def test_mono_not_sharded():
 
     cfg = base_config(mode="grey")
     cfg.block_matching.tuning.factors = [1, 2, 2, 2]
-    assert merge.can_fuse_local_min(cfg, (128, 128)) is False
+    assert merge.can_fuse_local_min(cfg, (128, 128)) is True  # (x2 tile kernel; the generic kernels of other scales: no)
+    assert merge.can_fuse_local_min(base_config(mode="grey", scale=3), (128, 128)) is False
     ref, comp, _ = synth.make_burst(128, 128, 2, seed=1, cfa=MONO)
     out, _ = hdist.main_sharded(ref, comp, cfg)  # world size 1 is main()
     assert np.isfinite(N(out)[..., 0]).mean() > 0.99

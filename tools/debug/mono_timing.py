@@ -43,4 +43,8 @@ for kern in ("generic", "auto"):
     fr = pipe.process_frames([comp[i] for i in range(NF - 1)], None)
     num = torch.empty((2 * H, 2 * W, 3), dtype=torch.float32, device=dev)
     tm = timed(lambda: merge_burst(fr, pipe.ref, pipe.ref_covs, num, None, pipe.cfa, cfg))
-    print(f"merge kernel {kern}: main() {t:.2f} ms per burst (eager), fused merge alone {tm:.2f} ms")
+    from handheld_super_resolution import distributed as hdist
+
+    eng = hdist.HipEngine(cfg)
+    tg = timed(lambda: eng.single(ref, comp), 8)
+    print(f"merge kernel {kern}: main() {t:.2f} ms per burst (eager), {tg:.2f} ms replayed from a HIP graph, fused merge alone {tm:.2f} ms")
