@@ -1006,13 +1006,121 @@ __global__ void __launch_bounds__(256) k_mono_rob_frame(const float* __restrict_
     R[o] = (float)v;
 }
 
+// The same with the float32 arithmetic of the Bayer kernels (see k_rob_frame_tile: exact integer / predicate geometry,
+// float32 Dodgson weights, v_rcp_f32 / v_exp_f32 tail; |dR| <= 1e-4) and a thread per 4 horizontally adjacent pixels
+// (x0 % 4 == 0, ts % 4 == 0: one flow tile).  Pixels k and k + 2 lie one guide pixel apart with the same sub-pixel
+// phase and share the weights; the two phases' 3 x 4 windows overlap in a 3 x 5 window read once from L1 / L2 (the
+// guide positions of a 64 x 16 pixel workgroup cover 35 x 11 values).  The reference-frame planes and R move as
+// 16-byte vectors.  The float64 kernel above took 248 us per 12 MP frame (VALU: float64 Dodgson weights, two float64
+// divisions and an expf per pixel, 9 dword loads); it remains the fall-back for odd widths / tile sizes.
+__global__ void __launch_bounds__(256) k_mono_rob_frame4(const float* __restrict__ cm, const float* __restrict__ rmean,
+                                                          const float* __restrict__ ssq,
+                                                          const float2* __restrict__ flow, int nx, int ts,
+                                                          const float* __restrict__ S, const double* __restrict__ difc,
+                                                          int ncurve, float tf, float* __restrict__ R, int H, int W) {
+    const int x0 = (blockIdx.x * 16 + (threadIdx.x & 15)) * 4, y = blockIdx.y * 16 + (threadIdx.x >> 4);
+    if (x0 >= W || y >= H) return;
+    const int tix = x0 / ts, tiy = y / ts;
+    const float2 f = flow[(size_t)tiy * nx + tix];
+    const float Sv = S[(size_t)tiy * nx + tix];
+    const RobAxis ay = rob_axis(f.y), ax = rob_axis(f.x);
+    const size_t o = (size_t)y * W + x0;
+    const float4 rb4 = *reinterpret_cast<const float4*>(rmean + o);
+    const float4 ss4 = *reinterpret_cast<const float4*>(ssq + o);
+    const float rbk[4] = {rb4.x, rb4.y, rb4.z, rb4.w}, ssk[4] = {ss4.x, ss4.y, ss4.z, ss4.w};
+    int cy, cx[4];
+    float ry, rx[4], wyv[3];
+    bool inx[4];
+    const bool iny = rob_centre(ay, y, H, cy, ry);
+    dodgson3(ry, cy, H, wyv);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) inx[k] = rob_centre(ax, x0 + k, W, cx[k], rx[k]);
+    const float* row[3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) row[i] = cm + (size_t)clampi(cy - 1 + i, 0, H - 1) * W;
+    float cmu[4] = {INFINITY, INFINITY, INFINITY, INFINITY};
+    // no clamped tap in x for any of the 4 pixels, and no round-half-even tie (there pixel k + 2 rounds the other way)
+    if (iny && inx[0] && inx[1] && !ax.eq && cx[0] >= 1 && cx[1] + 2 <= W - 1) {
+        const int c0 = cx[0] - 1;
+        const bool d = cx[1] != cx[0];  // phase 1 starts at c0 or c0 + 1
+        float g[3][5];
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+#pragma unroll
+            for (int j = 0; j < 5; ++j) g[i][j] = row[i][min(c0 + j, W - 1)];
+#pragma unroll
+        for (int ph = 0; ph < 2; ++ph) {
+            float wxv[3], w[3][3], wacc = 0.f;
+            dodgson3(rx[ph], cx[ph], W, wxv);
+#pragma unroll
+            for (int i = 0; i < 3; ++i)
+#pragma unroll
+                for (int j = 0; j < 3; ++j) {
+                    w[i][j] = wyv[i] * wxv[j];
+                    wacc += w[i][j];
+                }
+            const float iw = __builtin_amdgcn_rcpf(wacc);
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                float b = 0.f;
+#pragma unroll
+                for (int i = 0; i < 3; ++i)
+#pragma unroll
+                    for (int j = 0; j < 3; ++j) {
+                        const float t_ = (ph && d) ? g[i][j + q + 1] : g[i][j + q];
+                        b = fmaf(t_, w[i][j], b);
+                    }
+                cmu[ph + 2 * q] = b * iw;
+            }
+        }
+    } else {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            if (!(iny && inx[k])) continue;
+            float wxv[3], b = 0.f, wacc = 0.f;
+            dodgson3(rx[k], cx[k], W, wxv);
+#pragma unroll
+            for (int i = 0; i < 3; ++i)
+#pragma unroll
+                for (int j = 0; j < 3; ++j) {
+                    const float w = wyv[i] * wxv[j];
+                    b = fmaf(row[i][clampi(cx[k] - 1 + j, 0, W - 1)], w, b);
+                    wacc += w;
+                }
+            cmu[k] = b * __builtin_amdgcn_rcpf(wacc);
+        }
+    }
+    float out[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        int id = 0;
+        const double bb = 1000.0 * (double)rbk[k];  // the curve index in float64 like the reference (robustness.py:517)
+        if (isfinite(bb)) id = clampi((int)rint(bb), 0, ncurve - 1);
+        const float d_t = (float)difc[id];
+        const float dp = fabsf(rbk[k] - cmu[k]);
+        const float dp2 = dp * dp;
+        const float shrink = dp2 * __builtin_amdgcn_rcpf(dp2 + d_t * d_t);
+        const float d_sq = dp2 * shrink * shrink;
+        const float e = __builtin_amdgcn_exp2f((-d_sq * __builtin_amdgcn_rcpf(ssk[k])) * 1.44269504088896341f);
+        out[k] = __builtin_amdgcn_fmed3f(Sv * e - tf, 0.f, 1.f);  // NaN -> 0 like the reference's clamp
+    }
+    *reinterpret_cast<float4*>(R + o) = make_float4(out[0], out[1], out[2], out[3]);
+}
+
 extern "C" int hhsr_mono_rob_frame(const float* comp_means, int H, int W, const float* ref_means,
                                    const float* sigma_sq, const float* flow, int ny, int nx, int ts, const float* S,
                                    const double* diff_curve, int ncurve, double t, float* R, void* stream) {
     HHSR_ARG(comp_means && ref_means && sigma_sq && flow && S && diff_curve && R);
     HHSR_ARG(H > 0 && W > 0 && ts > 0 && ncurve > 0 && (int64_t)ny * ts >= H && (int64_t)nx * ts >= W);
-    hipLaunchKernelGGL(k_mono_rob_frame, dim3(hhsr_cdiv(W, 64), hhsr_cdiv(H, 4)), dim3(256), 0, (hipStream_t)stream,
-                       comp_means, ref_means, sigma_sq, reinterpret_cast<const float2*>(flow), nx, ts, S, diff_curve,
-                       ncurve, t, R, H, W);
+    const bool vec = W % 4 == 0 && ts % 4 == 0 &&
+                     (((uintptr_t)ref_means | (uintptr_t)sigma_sq | (uintptr_t)R) & 15) == 0;
+    if (vec)
+        hipLaunchKernelGGL(k_mono_rob_frame4, dim3(hhsr_cdiv(W, 64), hhsr_cdiv(H, 16)), dim3(256), 0,
+                           (hipStream_t)stream, comp_means, ref_means, sigma_sq,
+                           reinterpret_cast<const float2*>(flow), nx, ts, S, diff_curve, ncurve, (float)t, R, H, W);
+    else
+        hipLaunchKernelGGL(k_mono_rob_frame, dim3(hhsr_cdiv(W, 64), hhsr_cdiv(H, 4)), dim3(256), 0,
+                           (hipStream_t)stream, comp_means, ref_means, sigma_sq,
+                           reinterpret_cast<const float2*>(flow), nx, ts, S, diff_curve, ncurve, t, R, H, W);
     HHSR_LAUNCHED();
 }

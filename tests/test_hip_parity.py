@@ -1585,6 +1585,54 @@ def test_mono_stages_golden(golden):
     assert_close(N(den), g["m_den_denref"], 2e-5, 1e-6, "mono denoiser denref")
 
 
+def test_mono_rob_frame_vector_kernel_vs_float64_kernel():
+    """hhsr_mono_rob_frame: the 4-pixels-per-thread float32 kernel (W % 4 == 0, 16-byte aligned planes) against the
+    reference-typed float64 kernel the library falls back to for an unaligned R, on flows that leave the image, sit on
+    round-half-even ties (x.5), are NaN / huge, and on non-finite reference means; R within 1e-4, same zeros at the
+    out-of-image pixels."""
+    from handheld_super_resolution import _lib
+    rng = np.random.default_rng(77)
+    H, W, ts = 208, 336, 16
+    ny, nx = -(-H // ts), -(-W // ts)
+    cfg = base_config(mode="grey")
+    ref = rng.random((H, W), dtype=np.float32)
+    comp = np.clip(ref + 0.03 * rng.standard_normal((H, W)).astype(np.float32), 0, 1)
+    comp[40:90, 100:180] = rng.random((50, 80), dtype=np.float32)  # an occluder: R spans 0 .. 1
+    flow = (rng.standard_normal((ny, nx, 2)) * 6).astype(np.float32)
+    flow[0, :, 1] = -30.0          # above the image
+    flow[:, 0, 0] = -2.5           # tie + left border
+    flow[3, 3] = (0.5, 1.5)        # ties on both axes
+    flow[4, 4] = (np.nan, 0.0)
+    flow[5, 5] = (1e30, -1e30)
+    flow[-1, :, 1] = 25.0          # below
+    flow[:, -1, 0] = 3.0           # right border / outside
+    flow[6, 6] = (0.0, 0.0)
+    cfa, wb = [[0, 1], [1, 2]], [1.0, 1.0, 1.0]
+    rm, rv = robustness.init_robustness(T(ref), cfa, wb, cfg)
+    rm[0, 120:124, 200:204] = float("nan")
+    rm[0, 130, 210] = float("inf")
+    curves = robustness.noise_curves_to_device(np.array(cfg.noise_model.std_curve), np.array(cfg.noise_model.diff_curve), DEV)
+    std_curve, diff_curve = curves
+    sig = robustness.mono_sigma_sq(rm, rv, std_curve)
+    cm = kernels.mono_frame_stats(T(comp), cfg, covs=False)[0]
+    t = cfg.robustness.tuning
+    fl = T(flow)
+    S = robustness.compute_s(fl, t.Mt, t.s1, t.s2)
+    outs = []
+    for off in (0, 1):  # off = 1: R starts 4 bytes past a 16-byte boundary -> the float64 kernel
+        buf = torch.full((H * W + 4,), -1.0, dtype=torch.float32, device=DEV)
+        R = buf[off:off + H * W].view(H, W)
+        _lib.call("hhsr_mono_rob_frame", _lib.ptr(cm), H, W, _lib.ptr(rm), _lib.ptr(sig), _lib.ptr(fl), ny, nx, ts,
+                  _lib.ptr(S), _lib.ptr(diff_curve), int(diff_curve.numel()), float(t.t), _lib.ptr(R), _lib.stream())
+        outs.append(N(R))
+        assert float(buf[off + H * W:].min()) == -1.0 and (off == 0 or float(buf[0]) == -1.0)
+    a, b = outs
+    assert np.isfinite(a).all() and np.isfinite(b).all() and a.min() >= 0 and a.max() <= 1
+    assert 0.05 < (b > 0.5).mean() < 0.95 and ((b > 0) & (b < 1)).mean() > 0.05, "inputs do not exercise R"
+    assert_close(a, b, 0, 1e-4, "mono R: float32 vector kernel vs float64 kernel")
+    assert (a[:ts] == 0).all() and (b[:ts] == 0).all()  # first tile row: warped outside the image
+
+
 def test_mono_burst_merge_tile_kernel_vs_generic():
     """`mode: grey`, x2: hhsr_merge_burst takes the LDS-staged tile kernel with a per-pixel covariance window
     (k_merge_burst_quad<.., MONO>); it must agree with the generic per-pixel kernel (config.hip.merge_kernel: generic)
