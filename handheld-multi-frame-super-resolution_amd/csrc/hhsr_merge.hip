@@ -1009,6 +1009,9 @@ __global__ void __launch_bounds__(256) k_merge_burst_quad(BurstArgs a, Geo g, Cf
 #ifndef HHSR_XS_OCC
 #define HHSR_XS_OCC 2  // k_merge_xs<3>: 72 accumulators per thread; 3 waves per SIMD (168 VGPRs) spills 50 dwords
 #endif
+#ifndef HHSR_XS_PIPE
+#define HHSR_XS_PIPE 1  // k_merge_xs: LDS reads of sub-pixel q + 1 issued before the taps of sub-pixel q
+#endif
 #ifndef HHSR_X2_OCC
 #define HHSR_X2_OCC 4  // waves per SIMD the register allocation of k_merge_x2 is held to (125 VGPRs; A/B: 3 = 4; 5 spills: 6.9 ms)
 #endif
@@ -1706,7 +1709,7 @@ __global__ void __launch_bounds__(256, HHSR_XS_OCC) k_merge_xs(BurstArgs a, Geo 
         for (int q = 0; q < S * S; ++q) {
             const int sa = q / S, sb = q % S;
             Sub nxt = cur;
-            if (q + 1 < S * S) nxt = load_sub((q + 1) / S, (q + 1) % S);
+            if (HHSR_XS_PIPE && q + 1 < S * S) nxt = load_sub((q + 1) / S, (q + 1) % S);
             float ixx = 2.f * X2_KEXP, ixy = 0.f, iyy = 2.f * X2_KEXP;
             bool finite = true;
             if (!ISO) {
@@ -1770,7 +1773,8 @@ __global__ void __launch_bounds__(256, HHSR_XS_OCC) k_merge_xs(BurstArgs a, Geo 
                 else { asm volatile("; xs fold 00"); HHSR_FOLD(0, 0) asm volatile("; xs end 00"); }
             }
 #undef HHSR_FOLD
-            cur = nxt;
+            if (HHSR_XS_PIPE) cur = nxt;
+            else if (q + 1 < S * S) cur = load_sub((q + 1) / S, (q + 1) % S);
         }
     }
     if (a.acc_r) a.acc_r[ridx] = ((a.flags & HHSR_MERGE_LOAD_ACC) ? a.acc_r[ridx] : 0.f) + racc;

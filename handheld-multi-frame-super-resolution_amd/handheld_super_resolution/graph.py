@@ -309,9 +309,10 @@ class HostBurstRunner:
             st.links = []  # (index of the chunk after which the link runs, frames merged once it has run)
             if want_chain and fuse_min and can_chain(cfg, (H, W)) and len(st.chunks) > 2:
                 done = 0
+                after = None if hip is None else hip.get("merge_link_after", None)  # explicit chunk indices (tuning)
                 for c, idx in enumerate(st.chunks[:-1]):
                     done = idx[-1] + 1
-                    if len(idx) >= 2:
+                    if (len(idx) >= 2) if after is None else (c in after):
                         st.links.append((c, done))
             st.chain = bool(st.links)
             st.g_links = []

@@ -31,6 +31,8 @@ bash tools/debug/h2d_trace.sh f32 2>&1 | grep -v "^\[" | grep -v "^\['id'" > $OU
 bash tools/debug/h2d_trace.sh u16 2>&1 | grep -v "^\[" | grep -v "^\['id'" > $OUT/h2d_trace_u16.txt
 python tools/debug/cov_inline_bound.py 2>&1 | grep -v amdgpu.ids > $OUT/cov_inline_bound.txt
 python tools/debug/mono_timing.py 2>&1 | grep -v amdgpu.ids > $OUT/mono_timing.txt
+bash tools/debug/kt_mono.sh 2>&1 | grep -v amdgpu.ids > $OUT/kernel_trace_mono.md
+bash tools/debug/kt_c5.sh 2>&1 | grep -v amdgpu.ids > $OUT/kernel_trace_c5.md
 python tools/debug/hwqueue_probe.py 2>&1 | grep -v amdgpu.ids > $OUT/hwqueue_probe.txt
 python tools/debug/copy_contention_probe.py 2>&1 | grep -v amdgpu.ids >> $OUT/hwqueue_probe.txt
 # the randomised sweep in report mode (the asserting run is part of the test suite above)

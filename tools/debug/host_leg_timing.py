@@ -22,6 +22,10 @@ def config(u16):
     for k in ("HHSR_CHUNK", "HHSR_STREAMS"):
         if os.environ.get(k):
             cfg.hip[k[5:].lower()] = int(os.environ[k])
+    if os.environ.get("HHSR_MERGE_CHAIN"):
+        cfg.hip["merge_chain"] = os.environ["HHSR_MERGE_CHAIN"] == "1"
+    if os.environ.get("HHSR_LINK_AFTER"):
+        cfg.hip["merge_link_after"] = [int(v) for v in os.environ["HHSR_LINK_AFTER"].split(",")]
     hsr.prepare_config(cfg, np.full((H, W), float(ref.mean()), np.float32), synth.ALPHA_ISO100, synth.BETA_ISO100,
                        [[0, 1], [1, 2]], [1.0, 1.0, 1.0])
     return cfg
@@ -76,7 +80,10 @@ if os.environ.get("HHSR_HOST_BUSY"):
         threading.Thread(target=_busy, daemon=True).start()
     print("host busy threads:", os.environ["HHSR_HOST_BUSY"])
 
+only = os.environ.get("HHSR_LEGS")  # substring filter, e.g. "pinned u16"
 for name, (u16, r, c) in legs.items():
+    if only and only not in name:
+        continue
     cfg = config(u16)
     eng = hdist.HipEngine(cfg)
     for _ in range(3):

@@ -34,8 +34,8 @@ def main(root, steps):
     print("|---|---:|---:|---:|---:|---:|---:|---:|---:|---:|---:|---:|")
     rows = []
     for k, (c, tot) in dur.items():
-        if k not in cnt:
-            continue
+        if k not in cnt or not k.startswith("k_"):  # the include regex also matches library GEMMs ("Cijk_...": the
+            continue                                 # synthetic burst generator of bench.py, outside the step)
         per = {n: v / max(1, len(disp[k][n])) for n, v in cnt[k].items()}
         us = tot / c
         cyc = per.get("GRBM_GUI_ACTIVE", 0) / XCDS  # cycles of the launch
