@@ -210,7 +210,9 @@ int hhsr_local_min5(const float* R, int H, int W, float* r, float* acc_r, void* 
  * hhsr_mono_rob_upscale: robustness.py:296-421 on a one-channel map, which keeps its size while the kernel keeps its
  *   hard-coded s = 2 — the top-left quadrant stretched over the frame (+inf outside), reproduced as it is;
  *   flow NULL = the reference frame.
- * hhsr_mono_rob_sigma / hhsr_mono_rob_frame: robustness.py:505-528 / the fused per-frame pass -> R, one channel. */
+ * hhsr_mono_rob_sigma / hhsr_mono_rob_frame: robustness.py:505-528 / the fused per-frame pass -> R, one channel.
+ *   hhsr_mono_rob_frame: with W % 4 == 0, ts % 4 == 0 and 16-byte aligned ref_means / sigma_sq / R the float32
+ *   4-pixels-per-thread kernel runs (|dR| <= 1e-4 like the Bayer kernels), otherwise the float64 one-pixel kernel. */
 int hhsr_mono_frame_stats(const float* raw, int H, int W, int pitch, float* means, float* vars, float* covs,
                           double alpha, double beta, double k_detail, double k_denoise, double D_th, double D_tr,
                           double k_stretch, double k_shrink, int law, void* stream);
