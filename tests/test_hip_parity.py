@@ -834,6 +834,27 @@ def test_e2e_golden_x1_denoiser(golden):
     assert_close(N(out2), o, 0, 0, "debug path == fast path")
 
 
+@pytest.mark.parametrize("tag", ["s15", "s3", "s2iso"])
+def test_e2e_golden_scales(golden, tag):
+    """The reference's own main() at x1.5 (GRBG sensor, white balance: the any-scale kernel), x3 with 4 frames (the x3
+    class kernel) and x2 with isotropic kernels on a GBRG sensor (tools/refsim stage e2e_scales); debug and fast paths."""
+    from helpers import e2e_scales_case
+
+    g = golden("e2e_scales")
+    ref, comp, _, cfg_fn = e2e_scales_case(tag)
+    cfg = cfg_fn()
+    cfg.debug = True
+    out, dbg = hsr.main(ref, comp, cfg)
+    assert_close(np.stack(dbg["flow"]), g[f"{tag}_flow"], 0, 5e-5, "flow")
+    assert_close(np.stack(dbg["robustness"]), g[f"{tag}_r"], 0, 1e-4, "r")
+    assert_close(N(dbg["accumulated robustness"]), g[f"{tag}_acc_r"], 0, 1e-4, "acc r")
+    o = N(out)
+    assert_close(o, g[f"{tag}_out"], 0, 5e-5, "output")
+    out2, _ = hsr.main(ref, comp, cfg_fn())  # non-debug (chunk-batched, graph-replayed) path
+    assert_close(N(out2), g[f"{tag}_out"], 0, 5e-5, "output, fast path")
+    assert_close(N(out2), o, 2e-5, 1e-6, "debug path vs fast path")
+
+
 def _e2e_vs_oracle(ref, comp, cfg_fn, ts, what, max_flipped, out_atol=1e-4, flow_atol=1e-4, r_atol=1e-4, acc_atol=3e-4,
                    parallel=False, stray=(0, 0.0)):
     """HIP main() against the oracle on one burst, every difference accounted for (tolerances ~10x the measured

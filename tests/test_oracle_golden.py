@@ -203,6 +203,23 @@ def test_e2e_x1_denoiser(golden):
     assert_close(out, g["out"], 0, 5e-5, "output")
 
 
+@pytest.mark.parametrize("tag", ["s15", "s3", "s2iso"])
+def test_e2e_scales(golden, tag):
+    """main() as the reference itself computed it at x1.5 (GRBG, white balance), x3 (4 frames) and x2 with isotropic
+    kernels (GBRG, white balance): tools/refsim stage e2e_scales."""
+    from helpers import e2e_scales_case
+
+    g = golden("e2e_scales")
+    ref, comp, shifts, cfg_fn = e2e_scales_case(tag)
+    np.testing.assert_array_equal(shifts, g[f"{tag}_shifts"])
+    cap = {}
+    out, dbg = oracle.main(ref, comp, cfg_fn(), capture=cap)
+    assert_close(np.stack(cap["flow"]), g[f"{tag}_flow"], 0, 5e-5, "flow")
+    assert_close(np.stack(cap["r"]), g[f"{tag}_r"], 0, 5e-5, "r")
+    assert_close(dbg["accumulated robustness"], g[f"{tag}_acc_r"], 0, 5e-5, "acc r")
+    assert_close(out, g[f"{tag}_out"], 0, 5e-5, "output")
+
+
 def test_post_path_golden(golden):
     """The step after the path: orientation, median frame-count denoiser and raw2rgb.postprocess
     without sharpening against outputs of the reference's own functions (tools/refsim stage "post")."""

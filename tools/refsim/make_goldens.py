@@ -418,6 +418,59 @@ def stage_e2e_x1():
          out=npy(out), acc_r=np.asarray(dbg["accumulated robustness"], dtype=np.float32))
 
 
+E2E_SCALES = {  # name: (H, W, frames, seed, scale, cfa, white balance, kernel)
+    "s15": (128, 160, 3, 5, 1.5, ((1, 0), (2, 1)), (2.1, 1.0, 1.4), "steerable"),   # GRBG
+    "s3": (128, 128, 4, 9, 3, ((0, 1), (1, 2)), (1.0, 1.0, 1.0), "steerable"),       # RGGB, 3 compared frames
+    "s2iso": (128, 144, 3, 21, 2, ((1, 2), (0, 1)), (1.7, 1.0, 2.2), "iso"),         # GBRG, isotropic kernels
+}
+
+
+def e2e_scales_config(scale, cfa, wb, kernel):
+    cfg = base_config(ts=16, scale=scale)
+    cfg.block_matching.tuning.factors = [1, 2, 2, 2]
+    cfg.exif = {"cfa_pattern": [list(r) for r in cfa], "iso": 100, "white_balance": list(wb)}
+    cfg.merging.kernel = kernel
+    return cfg
+
+
+def stage_e2e_scales():
+    """main() end to end at the scales / CFA layouts the two other end-to-end goldens do not cover: x1.5 on a GRBG sensor
+    with white balance, x3 with three compared frames, x2 with isotropic kernels on a GBRG sensor (Ts=16, factors
+    [1,2,2,2], all-L2)."""
+    sr = loader.ref("super_resolution")
+    out = {}
+    for tag, (H, W, n, seed, scale, cfa, wb, kernel) in E2E_SCALES.items():
+        ref, comp, shifts = synth.make_burst(H, W, n, seed=seed, max_shift=2.0, occluder=True, cfa=cfa, wb=wb)
+        cfg = e2e_scales_config(scale, cfa, wb, kernel)
+        cap = {"flow": [], "r": []}
+        orig = {}
+
+        def wrap(name, key):
+            f = orig[name] = getattr(sr, name)
+
+            def g(*a, **k):
+                o = f(*a, **k)
+                cap[key].append(npy(o))
+                return o
+
+            setattr(sr, name, g)
+
+        wrap("align", "flow")
+        wrap("compute_robustness", "r")
+        t0 = time.time()
+        try:
+            with np.errstate(all="ignore"):
+                res, dbg = sr.main(ref, comp, cfg)
+        finally:
+            for name, f in orig.items():
+                setattr(sr, name, f)
+        print(f"    {tag}: main() {time.time() - t0:.1f}s")
+        out.update({f"{tag}_shifts": shifts, f"{tag}_flow": np.stack(cap["flow"]), f"{tag}_r": np.stack(cap["r"]),
+                    f"{tag}_out": npy(res),
+                    f"{tag}_acc_r": np.asarray(dbg["accumulated robustness"], dtype=np.float32)})
+    save("e2e_scales", **out)
+
+
 def stage_post():
     """The step after the hot path: apply_orientation, the median frame-count denoiser, and
     raw2rgb.postprocess without sharpening (colour matrix, devignetting, gamma) — all executed upstream code.
@@ -651,6 +704,7 @@ STAGES = {
     "grey": stage_grey, "downsample": stage_downsample, "hessian": stage_hessian, "bm_l2": stage_bm_l2,
     "ica": stage_ica, "upscale": stage_upscale, "kernels": stage_kernels, "robustness": stage_robustness,
     "merge": stage_merge, "params": stage_params, "e2e": stage_e2e, "e2e_x1": stage_e2e_x1,
+    "e2e_scales": stage_e2e_scales,
 }
 
 
