@@ -29,20 +29,21 @@ def base_config(ts=16, scale=2, snr=30.0, metrics=("L2", "L2", "L2", "L2"), **kw
 
 
 # the bursts of tests/golden/e2e_scales.npz (tools/refsim/make_goldens.py, stage e2e_scales: the reference's own main())
-E2E_SCALES = {  # name: (H, W, frames, seed, scale, cfa, white balance, kernel)
-    "s15": (128, 160, 3, 5, 1.5, ((1, 0), (2, 1)), (2.1, 1.0, 1.4), "steerable"),
-    "s3": (128, 128, 4, 9, 3, ((0, 1), (1, 2)), (1.0, 1.0, 1.0), "steerable"),
-    "s2iso": (128, 144, 3, 21, 2, ((1, 2), (0, 1)), (1.7, 1.0, 2.2), "iso"),
+E2E_SCALES = {  # name: (H, W, frames, seed, scale, cfa, white balance, kernel, tile size)
+    "s15": (128, 160, 3, 5, 1.5, ((1, 0), (2, 1)), (2.1, 1.0, 1.4), "steerable", 16),
+    "s3": (128, 128, 4, 9, 3, ((0, 1), (1, 2)), (1.0, 1.0, 1.0), "steerable", 16),
+    "s2iso": (128, 144, 3, 21, 2, ((1, 2), (0, 1)), (1.7, 1.0, 2.2), "iso", 16),
+    "ts32": (192, 256, 3, 33, 2, ((2, 1), (1, 0)), (1.0, 1.0, 1.0), "steerable", 32),
 }
 
 
 def e2e_scales_case(tag):
     """(ref, comp, shifts, config factory) of one burst of the e2e_scales golden."""
-    H, W, n, seed, scale, cfa, wb, kernel = E2E_SCALES[tag]
+    H, W, n, seed, scale, cfa, wb, kernel, ts = E2E_SCALES[tag]
     ref, comp, shifts = synth.make_burst(H, W, n, seed=seed, max_shift=2.0, occluder=True, cfa=cfa, wb=wb)
 
     def cfg_fn():
-        cfg = base_config(ts=16, scale=scale)
+        cfg = base_config(ts=ts, scale=scale)
         cfg.block_matching.tuning.factors = [1, 2, 2, 2]
         cfg.exif = {"cfa_pattern": [list(r) for r in cfa], "iso": 100, "white_balance": list(wb)}
         cfg.merging.kernel = kernel

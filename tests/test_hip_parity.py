@@ -834,7 +834,7 @@ def test_e2e_golden_x1_denoiser(golden):
     assert_close(N(out2), o, 0, 0, "debug path == fast path")
 
 
-@pytest.mark.parametrize("tag", ["s15", "s3", "s2iso"])
+@pytest.mark.parametrize("tag", ["s15", "s3", "s2iso", "ts32"])
 def test_e2e_golden_scales(golden, tag):
     """The reference's own main() at x1.5 (GRBG sensor, white balance: the any-scale kernel), x3 with 4 frames (the x3
     class kernel) and x2 with isotropic kernels on a GBRG sensor (tools/refsim stage e2e_scales); debug and fast paths."""

@@ -203,7 +203,7 @@ def test_e2e_x1_denoiser(golden):
     assert_close(out, g["out"], 0, 5e-5, "output")
 
 
-@pytest.mark.parametrize("tag", ["s15", "s3", "s2iso"])
+@pytest.mark.parametrize("tag", ["s15", "s3", "s2iso", "ts32"])
 def test_e2e_scales(golden, tag):
     """main() as the reference itself computed it at x1.5 (GRBG, white balance), x3 (4 frames) and x2 with isotropic
     kernels (GBRG, white balance): tools/refsim stage e2e_scales."""

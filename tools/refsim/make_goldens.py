@@ -418,15 +418,16 @@ def stage_e2e_x1():
          out=npy(out), acc_r=np.asarray(dbg["accumulated robustness"], dtype=np.float32))
 
 
-E2E_SCALES = {  # name: (H, W, frames, seed, scale, cfa, white balance, kernel)
-    "s15": (128, 160, 3, 5, 1.5, ((1, 0), (2, 1)), (2.1, 1.0, 1.4), "steerable"),   # GRBG
-    "s3": (128, 128, 4, 9, 3, ((0, 1), (1, 2)), (1.0, 1.0, 1.0), "steerable"),       # RGGB, 3 compared frames
-    "s2iso": (128, 144, 3, 21, 2, ((1, 2), (0, 1)), (1.7, 1.0, 2.2), "iso"),         # GBRG, isotropic kernels
+E2E_SCALES = {  # name: (H, W, frames, seed, scale, cfa, white balance, kernel, tile size)
+    "s15": (128, 160, 3, 5, 1.5, ((1, 0), (2, 1)), (2.1, 1.0, 1.4), "steerable", 16),   # GRBG
+    "s3": (128, 128, 4, 9, 3, ((0, 1), (1, 2)), (1.0, 1.0, 1.0), "steerable", 16),       # RGGB, 3 compared frames
+    "s2iso": (128, 144, 3, 21, 2, ((1, 2), (0, 1)), (1.7, 1.0, 2.2), "iso", 16),         # GBRG, isotropic kernels
+    "ts32": (192, 256, 3, 33, 2, ((2, 1), (1, 0)), (1.0, 1.0, 1.0), "steerable", 32),   # BGGR, 32-pixel tiles
 }
 
 
-def e2e_scales_config(scale, cfa, wb, kernel):
-    cfg = base_config(ts=16, scale=scale)
+def e2e_scales_config(scale, cfa, wb, kernel, ts):
+    cfg = base_config(ts=ts, scale=scale)
     cfg.block_matching.tuning.factors = [1, 2, 2, 2]
     cfg.exif = {"cfa_pattern": [list(r) for r in cfa], "iso": 100, "white_balance": list(wb)}
     cfg.merging.kernel = kernel
@@ -439,9 +440,9 @@ def stage_e2e_scales():
     [1,2,2,2], all-L2)."""
     sr = loader.ref("super_resolution")
     out = {}
-    for tag, (H, W, n, seed, scale, cfa, wb, kernel) in E2E_SCALES.items():
+    for tag, (H, W, n, seed, scale, cfa, wb, kernel, ts) in E2E_SCALES.items():
         ref, comp, shifts = synth.make_burst(H, W, n, seed=seed, max_shift=2.0, occluder=True, cfa=cfa, wb=wb)
-        cfg = e2e_scales_config(scale, cfa, wb, kernel)
+        cfg = e2e_scales_config(scale, cfa, wb, kernel, ts)
         cap = {"flow": [], "r": []}
         orig = {}
 
