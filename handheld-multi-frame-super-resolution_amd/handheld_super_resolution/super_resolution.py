@@ -104,8 +104,8 @@ class BurstPipeline:
         # (before, after): the flow fields handed to this pipeline are row slices (views) of larger fields with that many
         # tile rows around them — the sub-image pipelines of distributed.py; see robustness.compute_s
         self.flow_rows = (0, 0)
-        self._batch = (True if hip is None else bool(hip.get("batch", True))) and not self.mono \
-            and self.grey_method == "FFT" and config.verbose < 2
+        self._batch = (True if hip is None else bool(hip.get("batch", True))) \
+            and (self.mono or self.grey_method == "FFT") and config.verbose < 2
 
     def _ingest(self, img):
         """One frame -> float32 device tensor, on the current stream.  Float frames are the reference's call signature
@@ -243,8 +243,8 @@ class BurstPipeline:
         if len(imgs) < 2 or not self._batch or not can_align_batch(cfg):
             return [self.align_frame(img, wait_ref) for img in imgs]
         raws = [self._ingest(img) for img in imgs]
-        pyramids = build_gaussian_pyramids(compute_grey_images_batch(raws, self.grey_method),
-                                           cfg.block_matching.tuning.factors)
+        greys = raws if self.mono else compute_grey_images_batch(raws, self.grey_method)
+        pyramids = build_gaussian_pyramids(greys, cfg.block_matching.tuning.factors)
         if wait_ref is not None:
             torch.cuda.current_stream(self.device).wait_event(self._align_ready)
         return align_batch(self.align_state[0], self.align_state[5], pyramids, cfg)
@@ -271,13 +271,14 @@ class BurstPipeline:
         if len(imgs) < 2 or not self._batch or not can_align_batch(cfg) or any(f is not None for f in inj):
             return [self._front(img, wait_ref, i, f) for img, i, f in zip(imgs, indices, inj)]
         raws = [self._ingest(img) for img in imgs]
-        pyramids = build_gaussian_pyramids(compute_grey_images_batch(raws, self.grey_method),
-                                           cfg.block_matching.tuning.factors)
+        greys = raws if self.mono else compute_grey_images_batch(raws, self.grey_method)  # mono: the frame itself
+        pyramids = build_gaussian_pyramids(greys, cfg.block_matching.tuning.factors)
         if wait_ref is not None:
             torch.cuda.current_stream(self.device).wait_event(self._align_ready)
         fl = align_batch(self.align_state[0], self.align_state[5], pyramids, cfg)
         if cfg.robustness.enabled:
-            stats = frame_stats_batch(raws, self.cfa, self.wb, cfg)
+            stats = ([frame_stats(raw, self.cfa, self.wb, cfg) for raw in raws] if self.mono  # (per-pixel covariances)
+                     else frame_stats_batch(raws, self.cfa, self.wb, cfg))
             return [(raw, f, st[2], st[0]) for raw, f, st in zip(raws, fl, stats)]
         return [(raw, f, estimate_kernels(raw, cfg), None) for raw, f in zip(raws, fl)]
 

@@ -1948,6 +1948,23 @@ def test_batched_front_end_equals_per_frame(hip):
     assert torch.equal(got[0], want[0]) and torch.equal(got[1], want[1])
 
 
+def test_batched_front_end_equals_per_frame_mono():
+    """The same for a monochrome burst (`mode: grey`: the frames are their own grey images — pyramid and alignment
+    levels one launch per chunk, per-pixel statistics per frame), graph replay included."""
+    ref, comp, _ = synth.make_burst_torch(512, 640, 7, torch.device(DEV), seed=45, max_shift=3.0, cfa=MONO)
+
+    def run(**h):
+        cfg = base_config(ts=16, scale=2, mode="grey")
+        cfg.robustness.save_mask = True
+        cfg.hip = h
+        outs = [hsr.main(ref, comp, cfg) for _ in range(3)]  # third call: replayed from the HIP graph
+        return [(torch.nan_to_num(o, nan=-1.0), d["accumulated robustness"]) for o, d in outs]
+
+    want = run(batch=False, graph=False)[0]
+    for got in run() + run(chunk=3, streams=2):
+        assert torch.equal(got[0], want[0]) and torch.equal(got[1], want[1])
+
+
 def test_merge_burst_chain_equals_single_launch():
     """merge_burst_chain (a chain of launches: the frames that have arrived are merged into parked parity-class
     accumulators, the last link adds the rest, the reference frame and the normalisation) == merge_burst (one launch), bit
