@@ -158,6 +158,9 @@ class HostBurstRunner:
         # HHSR_PRELUDE) — queued a chunk at a time it stays at full rate in every state measured, at the price of a 20 us
         # gap per chunk (17.3 -> 17.7 ms for 960 MB).  HHSR_PACED_UPLOADS=0: everything up front.
         self.paced_uploads = os.environ.get("HHSR_PACED_UPLOADS", "1") != "0"
+        # chunks whose copies are queued AHEAD of the chunk the host is waiting for (paced uploads): with 0 the copy engine
+        # idles from a chunk's last copy until the host has woken up, launched the chunk's graph and queued the next copies
+        self.upload_ahead = int(os.environ.get("HHSR_UPLOAD_AHEAD", "1"))
 
     def _eager(self, ref_img, comp_imgs):
         from .super_resolution import main
@@ -404,10 +407,12 @@ class HostBurstRunner:
             with torch.cuda.stream(st.main):
                 st.g_ref.replay()
                 st.e_ref.record(st.main)
+            queued = 0  # chunks whose copies are queued
             for c, (idx, s, g) in enumerate(zip(st.chunks, st.streams, st.g_chunks)):
-                if paced:
-                    for i in idx:
+                while paced and queued < len(st.chunks) and queued <= c + (self.upload_ahead if futs is None else 0):
+                    for i in st.chunks[queued]:
                         upload(1 + i)
+                    queued += 1
                 for i in (idx if self.two_up else idx[-1:]):
                     st.e_up[1 + i].synchronize()  # (one upload stream: copies complete in order)
                 with torch.cuda.stream(s):

@@ -82,7 +82,7 @@ if os.environ.get("HHSR_HOST_BUSY"):
 
 only = os.environ.get("HHSR_LEGS")  # substring filter, e.g. "pinned u16"
 for name, (u16, r, c) in legs.items():
-    if only and only not in name:
+    if only and only not in name + ":":
         continue
     cfg = config(u16)
     eng = hdist.HipEngine(cfg)
