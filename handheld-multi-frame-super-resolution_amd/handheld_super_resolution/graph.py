@@ -280,6 +280,13 @@ class HostBurstRunner:
             if len(pool) < ns:
                 pool += [torch.cuda.Stream(dev) for _ in range(ns - len(pool))]
             st.chunks = host_chunks(n, pipe._chunk_size())
+            hip_ = cfg.get("hip", None) if hasattr(cfg, "get") else None
+            sizes = None if hip_ is None else hip_.get("host_chunk_sizes", None)  # explicit chunk sizes (tuning)
+            if sizes is not None and sum(sizes) == n and all(1 <= k <= pipe._chunk_size() for k in sizes):
+                st.chunks, i0 = [], 0
+                for k in sizes:
+                    st.chunks.append(list(range(i0, i0 + int(k))))
+                    i0 += int(k)
             st.streams = [pool[c % ns] for c in range(len(st.chunks))]  # (FFT plans exist per pool stream: eager call)
             if cfg.grey_method == "FFT":  # plans allocate: they have to exist before their stream is captured
                 from . import _lib

@@ -24,6 +24,8 @@ def config(u16):
             cfg.hip[k[5:].lower()] = int(os.environ[k])
     if os.environ.get("HHSR_MERGE_CHAIN"):
         cfg.hip["merge_chain"] = os.environ["HHSR_MERGE_CHAIN"] == "1"
+    if os.environ.get("HHSR_HOST_CHUNKS"):
+        cfg.hip["host_chunk_sizes"] = [int(v) for v in os.environ["HHSR_HOST_CHUNKS"].split(",")]
     if os.environ.get("HHSR_LINK_AFTER"):
         cfg.hip["merge_link_after"] = [int(v) for v in os.environ["HHSR_LINK_AFTER"].split(",")]
     hsr.prepare_config(cfg, np.full((H, W), float(ref.mean()), np.float32), synth.ALPHA_ISO100, synth.BETA_ISO100,
