@@ -1,0 +1,29 @@
+"""Dissect ONE case of tests/test_fuzz_parity.py with the oracle's flows injected: where the values above 1e-4 are, the
+flows, the robustness of every frame (oracle / HIP) and the accumulated weights there.
+   python tools/debug/fuzz_case.py <generator seed> <case index>"""
+import sys
+import numpy as np
+sys.path.insert(0, "handheld-multi-frame-super-resolution_amd"); sys.path.insert(0, "."); sys.path.insert(0, "tests")
+import test_fuzz_parity as fz
+import handheld_super_resolution as hsr
+
+gs, k = int(sys.argv[1]), int(sys.argv[2])
+c = fz.cases(gs, k + 1)[k]
+print("case", c)
+ref, comp, want, oflow, o_r = fz._oracle_case(c)
+cfg = fz.config(c, inject_flows=[f for f in oflow])
+cfg.debug = True
+out, dbg = hsr.main(ref, comp, cfg)
+o = out.cpu().numpy()
+d = np.where(np.isnan(want), 0.0, np.abs(o.astype(np.float64) - want))
+ts, s = c["ts"], c["scale"]
+hr = np.stack(dbg["robustness"])
+print("max |r_hip - r_oracle| =", float(np.abs(hr - o_r).max()))
+for (y, x, ch) in np.argwhere(d > 1e-4)[:8]:
+    ly, lx = int((y + 0.5) / s), int((x + 0.5) / s)
+    ty, tx = min(ly // ts, oflow.shape[1] - 1), min(lx // ts, oflow.shape[2] - 1)
+    print(f"HR ({y}, {x}) ch {ch}: hip {o[y, x, ch]:.6f} oracle {want[y, x, ch]:.6f} diff {d[y, x, ch]:.2e}; LR ({ly}, {lx}) tile ({ty}, {tx})")
+    for n in range(oflow.shape[0]):
+        win = (slice(max(ly - 2, 0), ly + 3), slice(max(lx - 2, 0), lx + 3))
+        print(f"   frame {n}: flow {oflow[n, ty, tx]}, r oracle 5x5 around: min {o_r[n][win].min():.3e} max {o_r[n][win].max():.3e}; "
+              f"hip min {hr[n][win].min():.3e} max {hr[n][win].max():.3e}; max |dr| {np.abs(hr[n][win] - o_r[n][win]).max():.2e}")
