@@ -4,27 +4,31 @@ sizes (also odd multiples of 2), 2-4 frames, scales 1 / 1.5 / 2 / 3, the four Ba
 
 Asserted per case (every case also runs with the oracle's flow fields injected, config.hip.inject_flows — that run
 exercises kernels + robustness + merge on identical geometry, the flow comparison exercises the alignment):
-  * identical NaN pattern; at most one tile whose flow differs by > 0.05 px (a float32 near-tie of ONE block-matching
-    decision somewhere in the pyramid; measured: 1 tile in the 64 cases) and at most FLIPPED_PER_BATCH per batch;
+  * identical NaN pattern (and equal infinities); the tiles whose flow differs by > FLIP_PX = 1e-3 px form at most ONE
+    cluster per case — one frame, a bounding box of at most CLUSTER x CLUSTER tiles: a float32 near-tie of ONE block-matching
+    decision somewhere in the pyramid, which all finest-level tiles under that coarser tile inherit (measured: one single
+    tile at 0.099 px in the 64 cases; held-out batches 20-22: one 2 x 2 block at 0.04 - 0.11 px, the children of one
+    level-1 tile) — and at most FLIPPED_PER_BATCH clusters per batch;
   * everywhere else flow <= 1e-4 px and robustness r <= 1e-4;
-  * oracle flows injected: image <= 1.05e-4 everywhere outside tiles with a diverged alignment (|flow| > DIVERGED_PX: the
-    moving occluder) and their neighbours (measured: 1.01e-4 at two values of case 1.12, every other case <= 9.6e-5);
-    inside them at most MAX_INJ_OUTLIERS isolated values per case, each <=
-    MAX_OUTLIER (measured over the 64 cases: 61 cases <= 9.6e-5, one case with 2 values at 1.01e-4; round 2's batches:
-    one case at 1.6e-4; the held-out batches HHSR_FUZZ_BATCHES=10:22,11:22,12:20: 63 cases <= 5.4e-5, one 2-frame case
-    with 2 values, 1.5e-4 and 6.3e-4, in a tile displaced by (-50, -18) px — mechanism (a) below, which does not depend
-    on whose flows are used);
+  * oracle flows injected: image <= 1e-4 wherever every frame is fully accepted (r = 1 in the 5 x 5 raw-pixel
+    neighbourhood; with the robustness off: everywhere); where some frame is being rejected at most MAX_INJ_OUTLIERS
+    isolated values per case, each <= MAX_OUTLIER — mechanism (a) below.  Measured: the 64 cases: 63 <= 9.6e-5, one with
+    2 values at 1.01e-4; three held-out sets of 64 (HHSR_FUZZ_BATCHES=10:22,11:22,12:20 / 20:.. / 30:..): 186 of 192 <=
+    1e-4, six cases with 1-2 values each between 1.1e-4 and 6.3e-4.  (Two earlier forms of this assertion — each value <=
+    3e-4; values > 1.05e-4 only in tiles displaced by > 30 px — were calibrated on the 64 fixed cases and FAILED on the
+    held-out sets: r in its transition band is what the exceptions have in common, not a diverged alignment.)
   * own flows: image <= 1e-4 outside the footprint of a flipped tile EXCEPT
-      (a) isolated pixels in diverged tiles: at most MAX_OUTLIERS values per case, each <= MAX_OUTLIER;
+      (a) isolated pixels where some frame is being rejected: at most MAX_OUTLIERS values per case, each <= MAX_OUTLIER;
       (b) flow-sensitive pixels — pixels that agree (<= 1e-4) once the oracle's flows are injected, i.e. whose whole
           difference comes from the <= 1e-4 px by which the flows differ: at most two tiles' worth per case.
 
 Why those pixels exist — conditioning of the reference algorithm, not arithmetic differences:
-(a) under a diverged flow the merged content is wrong in both implementations; with robustness off the image
-derivative with respect to the flow is large there (8e-5 px of float32 ICA noise become 3e-4), with robustness on r sits
-in its transition band (~1e-5) where R = S e - t cancels to 1e-4 of its operands while the comp sample outweighs the
-reference sample ~100x: a relative 1e-6 in e becomes 1e-3 in the image — the reference's own float32 buffers carry the
-same rounding noise.  (b) the 3 x 3 tap window is centred on round(position) (merge.py:343-361): the output is
+(a) where a frame is being rejected, r sits in its transition band (1e-5 ... 1e-3) at some taps: R = S e - t cancels to
+1e-4 of its operands, and where the frame's sample and the reference sample weigh about the same the normalised value
+(a w_ref + b r w) / (w_ref + r w) moves by (b - a) / 4r per unit of r — HIP and oracle r differing by 8e-7 around r =
+5.9e-4 is 1.5e-4 in the image (case 32.7, no occluder, two frames); under a moving occluder or a diverged alignment the
+same happens with larger (b - a) (6.3e-4, case 10.0).  The reference's own float32 buffers carry the same rounding noise.
+(b) the 3 x 3 tap window is centred on round(position) (merge.py:343-361): the output is
 DISCONTINUOUS in the flow where a tile's position (h + 0.5) / s + flow crosses a rounding boundary — a 1e-5 px flow
 difference then swaps a row of taps for the opposite one for every pixel of the tile with that sub-pixel phase (measured:
 one tile of one case, 6.9e-2 with own flows, 1.8e-7 with the oracle's flows).
@@ -48,12 +52,13 @@ CFAS = [((0, 1), (1, 2)), ((2, 1), (1, 0)), ((1, 0), (2, 1)), ((1, 2), (0, 1))]
 BATCHES = [(0, 22), (1, 22), (2, 20)]  # (generator seed, cases): the 64 cases
 if os.environ.get("HHSR_FUZZ_BATCHES"):  # held-out batches, e.g. "10:22,11:22,12:20" (same assertions on other bursts)
     BATCHES = [tuple(int(v) for v in b.split(":")) for b in os.environ["HHSR_FUZZ_BATCHES"].split(",")]
-FLIPPED_PER_BATCH = 2   # tiles with a flipped block-matching decision                (measured: 0, 0, 1)
-MAX_OUTLIERS = 64       # own flows, diverged tiles: values (pixel x channel) > 1e-4   (measured: 3 and 2 in two cases)
+FLIPPED_PER_BATCH = 2   # flipped block-matching decisions (clusters of tiles)        (measured: 0, 0, 1)
+FLIP_PX = 1e-3          # flow difference that marks a tile as following another decision (everything else: <= 8e-5 px)
+CLUSTER = 8             # tiles per side of the finest-level tiles under one level-2 tile of the default pyramid
+MAX_OUTLIERS = 64       # own flows, where a frame is being rejected: values (pixel x channel) > 1e-4 (measured: <= 3 per case)
 MAX_OUTLIER = 5e-3      # ... the largest of them                                      (measured: 2.8e-3)
-DIVERGED_PX = 30.0      # |flow| beyond which a tile's alignment counts as diverged (the pyramid's honest range is ~10 px here)
-MAX_INJ_OUTLIERS = 16   # oracle flows injected: values > 1e-4, all inside diverged tiles (measured: 2 per case, at most
-                        # 1.01e-4 in the 64 cases, 1.6e-4 in round 2's batches, 6.3e-4 in the held-out batches)
+MAX_INJ_OUTLIERS = 16   # oracle flows injected: values > 1e-4, all where a frame is being rejected (measured: <= 2 per case,
+                        # at most 1.01e-4 in the 64 cases, 1.6e-4 in round 2's batches, 6.3e-4 in the held-out sets)
 
 
 def cases(gen_seed, n):
@@ -109,7 +114,7 @@ def _oracle_case(c):
 
 
 def check(c, ref, comp, want, oflow, o_r, report=None):
-    """Returns the number of flipped tiles of the case."""
+    """Returns the number of flipped block-matching decisions (clusters of tiles) of the case: 0 or 1."""
     from helpers import footprint
 
     cfg = config(c)
@@ -123,8 +128,12 @@ def check(c, ref, comp, want, oflow, o_r, report=None):
     H, W, ts, scale = c["H"], c["W"], c["ts"], c["scale"]
     tag = f"case {c['id']} ({H}x{W} x{c['nf']} s={scale} ts={ts} {c['metric0']} rob={c['rob']} den={c['den']} occ={c['occ']})"
     gflow = np.stack(dbg["flow"])
-    flipped = flipped_tiles(gflow, oflow)
+    flipped = flipped_tiles(gflow, oflow, FLIP_PX)
     nflip = int(flipped.sum())
+    one_cluster = True
+    if nflip:
+        fn, fy, fx = np.nonzero(flipped)
+        one_cluster = len(set(fn.tolist())) == 1 and np.ptp(fy) < CLUSTER and np.ptp(fx) < CLUSTER
     nan_mis = int((np.isnan(o) != np.isnan(want)).sum()) + int((np.isnan(oi) != np.isnan(want)).sum())
     dflow = float(np.abs(gflow - oflow).max(-1)[~flipped].max())
     dr = dr_i = 0.0
@@ -132,40 +141,48 @@ def check(c, ref, comp, want, oflow, o_r, report=None):
         m1 = np.stack([footprint(f, ts, (H, W), 1.0, ts + 3) for f in flipped])  # (+ the neighbour tiles: their S)
         dr = float(np.where(m1, 0, np.abs(np.stack(dbg["robustness"]) - o_r)).max())
         dr_i = float(np.abs(np.stack(dbg_i["robustness"]) - o_r).max())
-    with np.errstate(all="ignore"):
-        d = np.where(np.isnan(want), 0.0, np.abs(o.astype(np.float64) - want))
-        di = np.where(np.isnan(want), 0.0, np.abs(oi.astype(np.float64) - want))
+    with np.errstate(all="ignore"):  # NaN == NaN (the pattern is compared above), inf == inf; inf vs finite stays inf
+        d = np.where(np.isnan(want) | (o == want), 0.0, np.abs(o.astype(np.float64) - want))
+        di = np.where(np.isnan(want) | (oi == want), 0.0, np.abs(oi.astype(np.float64) - want))
     d = np.where(footprint(flipped, ts, (H, W), scale, ts + 3)[..., None], 0.0, d)
-    # tiles with a diverged alignment in some frame, grown by one tile (a sample's kernel reaches into the neighbour)
-    big = np.abs(oflow).max(-1).max(0) > DIVERGED_PX
-    grown = np.zeros_like(big)
-    for dy in (-1, 0, 1):
-        for dx in (-1, 0, 1):
-            grown |= np.roll(np.roll(big, dy, 0), dx, 1)
-    yy = np.minimum(((np.arange(o.shape[0]) + 0.5) / scale).astype(int) // ts, big.shape[0] - 1)
-    xx = np.minimum(((np.arange(o.shape[1]) + 0.5) / scale).astype(int) // ts, big.shape[1] - 1)
-    div = grown[np.ix_(yy, xx)][..., None]
+    # where some frame is NOT fully accepted: r < 1 somewhere in the 5 x 5 raw-pixel neighbourhood (the merge reads r at
+    # its 3 x 3 taps) — the only places where the r-sensitivity of the normalisation (mechanism (a)) can act
+    rej = np.zeros(o.shape[:2], bool)
+    if c["rob"]:
+        from scipy.ndimage import minimum_filter
+
+        low = minimum_filter(o_r.min(0), size=5, mode="nearest") < 0.999
+        yy = np.minimum(((np.arange(o.shape[0]) + 0.5) / scale).astype(int), H - 1)
+        xx = np.minimum(((np.arange(o.shape[1]) + 0.5) / scale).astype(int), W - 1)
+        rej = low[np.ix_(yy, xx)]
+    div = rej[..., None]
     bad_i = di > 1e-4
     n_inj, inj_max, inj_outside = int(bad_i.sum()), float(di.max()), int((bad_i & ~div).sum())
     bad = d > 1e-4
     sens = bad & ~bad_i                      # (b) agree once the flows agree
-    rest = bad & bad_i                       # (a) must be diverged-tile outliers
+    rest = bad & bad_i                       # (a) only where a frame is being rejected
     n_sens, sens_max = int(sens.sum()), float(np.where(sens, d, 0).max())
     n_rest, rest_max, rest_outside = int(rest.sum()), float(np.where(rest, d, 0).max()), int((rest & ~div).sum())
+    failed = []  # the assertions of the case (report mode lists them next to the numbers instead of stopping)
+    if not (nan_mis == 0 and one_cluster):
+        failed.append(f"{nflip} flipped tiles (one cluster: {one_cluster}), {nan_mis} NaN mismatches")
+    if not (dflow <= 1e-4 and dr <= 1e-4 and dr_i <= 1e-4):
+        failed.append(f"flow {dflow:.2e} px, r {dr:.2e} / {dr_i:.2e}")
+    if not (n_inj <= MAX_INJ_OUTLIERS and inj_max <= MAX_OUTLIER and inj_outside == 0):
+        failed.append(f"oracle flows injected: {n_inj} values above 1e-4 (max {inj_max:.2e}), {inj_outside} where every frame "
+                      f"is accepted")
+    if not (n_rest <= MAX_OUTLIERS and rest_max <= MAX_OUTLIER and rest_outside == 0):
+        failed.append(f"{n_rest} values above 1e-4 (max {rest_max:.2e}), {rest_outside} where every frame is accepted")
+    if not n_sens <= 2 * 3 * int(round(ts * scale)) ** 2:
+        failed.append(f"{n_sens} flow-sensitive values (max {sens_max:.2e})")
     if report is not None:
-        report.append(f"{tag}: flipped {nflip}, nan {nan_mis}, flow {dflow:.1e}, r {dr:.1e} / injected {dr_i:.1e}; injected "
-                      f"image max {inj_max:.2e} ({n_inj} > 1e-4, {inj_outside} outside diverged tiles); own flows: flow-"
+        report.append(f"{tag}: flipped {nflip}{'' if one_cluster else ' (NOT one cluster)'}, nan {nan_mis}, flow {dflow:.1e}, r {dr:.1e} / injected {dr_i:.1e}; injected "
+                      f"image max {inj_max:.2e} ({n_inj} > 1e-4, {inj_outside} outside rejecting regions); own flows: flow-"
                       f"sensitive {n_sens} (max {sens_max:.1e}), other {n_rest} (max {rest_max:.1e}, {rest_outside} outside "
-                      f"diverged tiles)")
-        return nflip
-    assert nan_mis == 0 and nflip <= 1, f"{tag}: {nflip} flipped tiles, {nan_mis} NaN mismatches"
-    assert dflow <= 1e-4 and dr <= 1e-4 and dr_i <= 1e-4, f"{tag}: flow {dflow:.2e} px, r {dr:.2e} / {dr_i:.2e}"
-    assert n_inj <= MAX_INJ_OUTLIERS and inj_max <= MAX_OUTLIER and (inj_outside == 0 or inj_max <= 1.05e-4), \
-        f"{tag}: oracle flows injected: {n_inj} values above 1e-4 (max {inj_max:.2e}), {inj_outside} outside diverged tiles"
-    assert n_rest <= MAX_OUTLIERS and rest_max <= MAX_OUTLIER and rest_outside == 0, \
-        f"{tag}: {n_rest} values above 1e-4 (max {rest_max:.2e}), {rest_outside} outside diverged tiles"
-    assert n_sens <= 2 * 3 * int(round(ts * scale)) ** 2, f"{tag}: {n_sens} flow-sensitive values (max {sens_max:.2e})"
-    return nflip
+                      f"rejecting regions)" + (f"  ASSERTIONS FAILED: {'; '.join(failed)}" if failed else ""))
+        return int(nflip > 0)
+    assert not failed, f"{tag}: " + "; ".join(failed)
+    return int(nflip > 0)
 
 
 _pool, _jobs = None, {}
@@ -197,4 +214,4 @@ def test_fuzz_sweep(oracle_jobs, gen_seed, n):
         with open(os.environ["HHSR_FUZZ_REPORT"], "a") as f:
             f.write("\n".join(report) + "\n")
     else:
-        assert flipped <= FLIPPED_PER_BATCH, f"batch {gen_seed}: {flipped} flipped tiles"
+        assert flipped <= FLIPPED_PER_BATCH, f"batch {gen_seed}: {flipped} flipped decisions"

@@ -27,3 +27,13 @@ for (y, x, ch) in np.argwhere(d > 1e-4)[:8]:
         win = (slice(max(ly - 2, 0), ly + 3), slice(max(lx - 2, 0), lx + 3))
         print(f"   frame {n}: flow {oflow[n, ty, tx]}, r oracle 5x5 around: min {o_r[n][win].min():.3e} max {o_r[n][win].max():.3e}; "
               f"hip min {hr[n][win].min():.3e} max {hr[n][win].max():.3e}; max |dr| {np.abs(hr[n][win] - o_r[n][win]).max():.2e}")
+
+# own flows: the tiles whose flow differs from the oracle's by more than the ICA noise
+cfg = fz.config(c)
+cfg.debug = True
+_, dbg2 = hsr.main(ref, comp, cfg)
+g = np.stack(dbg2["flow"])
+df = np.abs(g - oflow).max(-1)
+print("own flows: tiles with |flow - oracle flow| > 1e-4 px:")
+for (n, ty, tx) in np.argwhere(df > 1e-4):
+    print(f"   frame {n} tile ({ty}, {tx}): hip {g[n, ty, tx]} oracle {oflow[n, ty, tx]} diff {df[n, ty, tx]:.3e}")

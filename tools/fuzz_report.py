@@ -6,8 +6,8 @@ import sys
 
 rows = []
 for line in open(sys.argv[1]):
-    m = re.match(r"case (\S+) \((.*?)\): flipped (\d+), nan (\d+), flow (\S+), r (\S+) / injected (\S+); injected image max (\S+) "
-                 r"\((\d+) > 1e-4, (\d+) outside diverged tiles\); own flows: flow-sensitive (\d+) \(max (\S+)\), other (\d+) "
+    m = re.match(r"case (\S+) \((.*?)\): flipped (\d+)(?: \(NOT one cluster\))?, nan (\d+), flow (\S+), r (\S+) / injected (\S+); injected image max (\S+) "
+                 r"\((\d+) > 1e-4, (\d+) outside rejecting regions\); own flows: flow-sensitive (\d+) \(max (\S+)\), other (\d+) "
                  r"\(max (\S+), (\d+) outside", line)
     if m:
         g = m.groups()
@@ -16,7 +16,7 @@ for line in open(sys.argv[1]):
                          other=int(g[12]), other_max=float(g[13])))
 n = len(rows)
 print(f"\n## Randomised end-to-end sweep (tests/test_fuzz_parity.py, {n} cases, HIP main() vs oracle.main())\n")
-print(f"* NaN pattern mismatches: {sum(r['nan'] for r in rows)}; tiles with a flipped block-matching decision (> 0.05 px): "
+print(f"* NaN pattern mismatches: {sum(r['nan'] for r in rows)}; tiles that follow another block-matching decision (flow differs by > 1e-3 px): "
       f"{sum(r['flipped'] for r in rows)} (in case{'s' if sum(1 for r in rows if r['flipped']) != 1 else ''} "
       f"{', '.join(r['id'] for r in rows if r['flipped']) or '-'})")
 print(f"* flow, all other tiles: max {max(r['flow'] for r in rows):.1e} px (asserted 1e-4); robustness r: max "
@@ -29,3 +29,5 @@ print("* image, own flows, outside the footprint of the flipped tile: "
       "flows are the oracle's): "
       + "; ".join(f"case {r['id']} ({r['desc']}): {r['sens']} values, max {r['sens_max']:.1e}" for r in rows if r["sens"])
       + "; other values > 1e-4: " + ("; ".join(f"case {r['id']}: {r['other']}, max {r['other_max']:.1e}" for r in rows if r["other"]) or "none"))
+nfail = sum(1 for line in open(sys.argv[1]) if "ASSERTIONS FAILED" in line)
+print(f"* cases violating an assertion of the test: {nfail}")
