@@ -17,7 +17,7 @@ bash tools/pmc_merge.sh "k_merge_xs" $NAME/pmc_x3 --no-h2d --steps 1 --warmup 0 
 python tools/pmc_report.py $OUT/pmc_x3 k_merge_xs profiles/${NAME}_pmc_merge_x3.json $MSRC "6000x8000x20 x3" \
   "tools/pmc_merge.sh k_merge_xs (bench.py --no-cpu-baseline --no-h2d --steps 1 --warmup 0 --height 6000 --width 8000 --scale 3), profiles/${NAME}_pmc_merge_x3.md" > $OUT/pmc_x3.md
 cp profiles/${NAME}_pmc_merge_x3.json $OUT/pmc_merge_x3.json
-/usr/bin/time -f "bench.py default run: %e s wall" -o $OUT/bench_n1.time python bench.py > $OUT/bench_n1.json 2> $OUT/bench_n1.err
+T0=$(date +%s); python bench.py > $OUT/bench_n1.json 2> $OUT/bench_n1.err; echo "bench.py default run: $(( $(date +%s) - T0 )) s wall" > $OUT/bench_n1.time
 python bench.py --height 6000 --width 8000 --scale 3 --frames 20 --steps 5 --warmup 2 --no-cpu-baseline > $OUT/bench_c5.json 2> /dev/null
 python bench.py --frames 8 --steps 10 --warmup 3 --no-cpu-baseline > $OUT/bench_c2.json 2> /dev/null
 bash tools/kernel_trace.sh $NAME/kt 5 > /dev/null 2>&1
