@@ -249,7 +249,8 @@ def main():
         ev_steps = max(3, min(10, args.steps))
         fn_e = lambda: hdist.main_sharded(ref, comp, cfg_e, engine=eng_e, gather=args.gather, strategy=args.strategy,  # noqa: E731
                                           max_flow=args.max_flow)[0]
-        fn_e()
+        for _ in range(2):  # (the second call still grows the caching allocator at 48 MP frames: 86 vs 68 ms per step)
+            fn_e()
         barrier()
         timed_call.on = True
         ms_eager = timed(fn_e, ev_steps, 0)
