@@ -241,6 +241,8 @@ class HostBurstRunner:
         if st == "seen":
             try:
                 st = self.states[key] = self._capture(frames)
+            except _ConfigError:    # a tuning knob of config.hip that cannot be honoured: the caller's mistake
+                raise
             except Exception as e:  # not capturable after all: stay eager
                 self.disabled, self.error = True, e
                 torch.cuda.synchronize(self.device)
@@ -282,7 +284,12 @@ class HostBurstRunner:
             st.chunks = host_chunks(n, pipe._chunk_size())
             hip_ = cfg.get("hip", None) if hasattr(cfg, "get") else None
             sizes = None if hip_ is None else hip_.get("host_chunk_sizes", None)  # explicit chunk sizes (tuning)
-            if sizes is not None and sum(sizes) == n and all(1 <= k <= pipe._chunk_size() for k in sizes):
+            if sizes is not None:
+                from ._lib import MAX_BATCH
+
+                if sum(sizes) != n or not all(1 <= int(k) <= MAX_BATCH for k in sizes):
+                    raise _ConfigError(f"config.hip.host_chunk_sizes {list(sizes)}: sizes in 1..{MAX_BATCH} that sum to "
+                                       f"the {n} compared frames")
                 st.chunks, i0 = [], 0
                 for k in sizes:
                     st.chunks.append(list(range(i0, i0 + int(k))))
@@ -441,6 +448,10 @@ class HostBurstRunner:
         if st.acc_r is not None:
             debug["accumulated robustness"] = st.acc_r
         return st.num, debug
+
+
+class _ConfigError(ValueError):
+    pass
 
 
 def host_chunks(n, size):

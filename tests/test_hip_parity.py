@@ -2009,6 +2009,32 @@ def test_merge_burst_chain_equals_single_launch():
 
 
 # ------------------------------------------------------------------------------------------ host-resident bursts
+def test_host_burst_runner_tuning_knobs():
+    """config.hip.host_chunk_sizes / merge_link_after (explicit chunks and chained-merge links of a host-resident burst)
+    give the eager path's bits; chunk sizes that do not cover the burst are the caller's error, not a silent fall-back."""
+    from handheld_super_resolution import distributed as hdist
+
+    ref, comp, _ = synth.make_burst(512, 640, 9, seed=15, max_shift=2.5)
+    ref_h, comp_h = torch.from_numpy(ref).pin_memory(), [torch.from_numpy(comp[i]).pin_memory() for i in range(8)]
+
+    def cfg_fn(**hip):
+        cfg = base_config(ts=16, scale=2, metrics=("L1", "L2", "L2", "L2"))
+        cfg.hip = hip
+        return cfg
+
+    want, _ = hsr.main(ref, comp, cfg_fn(graph=False))
+    eng = hdist.HipEngine(cfg_fn(host_chunk_sizes=[1, 3, 2, 1, 1], merge_link_after=[1, 2]))
+    for it in range(3):
+        got, _ = eng.single(ref_h, comp_h)
+        assert torch.equal(torch.nan_to_num(got, nan=-1.0), torch.nan_to_num(want, nan=-1.0)), it
+    st = eng._host.states[next(iter(eng._host.states))]
+    assert not eng._host.disabled and [len(c) for c in st.chunks] == [1, 3, 2, 1, 1] and [k for _, k in st.links] == [4, 6]
+    bad = hdist.HipEngine(cfg_fn(host_chunk_sizes=[4, 3]))
+    bad.single(ref_h, comp_h)  # (the first call of a shape runs eagerly)
+    with pytest.raises(ValueError, match="host_chunk_sizes"):
+        bad.single(ref_h, comp_h)
+
+
 @pytest.mark.parametrize("kind", ["f32_pinned", "f32_numpy", "u16_pinned", "u16_numpy"])
 def test_host_burst_runner_equals_eager(kind):
     """Bursts that start in host memory (the reference's signature / timer scope): graph.HostBurstRunner — eager uploads
