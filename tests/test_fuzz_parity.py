@@ -5,7 +5,7 @@ sizes (also odd multiples of 2), 2-4 frames, scales 1 / 1.5 / 2 / 3, the four Ba
 Asserted per case (every case also runs with the oracle's flow fields injected, config.hip.inject_flows — that run
 exercises kernels + robustness + merge on identical geometry, the flow comparison exercises the alignment):
   * identical NaN pattern (and equal infinities);
-  * flow <= 1e-4 px (measured <= 7.8e-5) on every tile EXCEPT
+  * flow <= 1e-4 px (measured <= 9.9e-5) on every tile EXCEPT
       - the tiles under ONE flipped block-matching decision per case: a float32 near-tie somewhere in the pyramid, which
         all finest-level tiles under that coarser tile inherit — the tiles whose flow differs by > FLIP_PX = 1e-3 px
         (measured 0.04 - 0.11 px) must lie in one frame inside a bounding box of CLUSTER x CLUSTER tiles (measured: a
@@ -17,12 +17,12 @@ exercises kernels + robustness + merge on identical geometry, the flow compariso
   * oracle flows injected: image <= 1e-4 wherever every frame is fully accepted (r = 1 in the 5 x 5 raw-pixel
     neighbourhood; with the robustness off: everywhere); where some frame is being rejected at most two raw
     pixels' worth of isolated values per case (2 x 3 x ceil(scale)^2: one raw pixel is scale^2 output pixels x 3
-    channels), each <= MAX_OUTLIER — mechanism (a) below.  Measured: the 64 cases: 63 <= 9.6e-5, one with
-    2 values at 1.01e-4; three held-out sets of 64 (HHSR_FUZZ_BATCHES=10:22,11:22,12:20 / 20:.. / 30:..): 186 of 192 <=
-    1e-4, six cases with 1-2 values each between 1.1e-4 and 6.3e-4; six more sets (40.. - 90..): up to 4 values at
-    scales <= 2 (<= 2.3e-3), 18 and 22 values (one raw pixel, <= 1.6e-3) in two cases at scale 3.  (Two earlier forms of this assertion — each value <=
-    3e-4; values > 1.05e-4 only in tiles displaced by > 30 px — were calibrated on the 64 fixed cases and FAILED on the
-    held-out sets: r in its transition band is what the exceptions have in common, not a diverged alignment.)
+    channels), each <= MAX_OUTLIER — mechanism (a) below.  Measured: the 64 cases: 63 <= 9.6e-5, one with 2 values at
+    1.01e-4; nine held-out sets of 64 (HHSR_FUZZ_BATCHES=10:22,11:22,12:20 ... 90:22,91:22,92:20): 546 of 576 <= 1e-4,
+    30 cases with 1 - 4 values each (18 and 22 — one raw pixel — in two cases at scale 3) between 1.1e-4 and 2.3e-3.
+    (Earlier forms of this assertion — each value <= 3e-4; values above 1.05e-4 only in tiles displaced by > 30 px; <= 16
+    values per case — were calibrated on the 64 fixed cases and FAILED on held-out sets: r in its transition band is
+    what the exceptions have in common, not a diverged alignment.)
   * own flows: image <= 1e-4 outside the footprint of a flipped tile EXCEPT
       (a) isolated pixels where some frame is being rejected: at most MAX_OUTLIERS values per case, each <= MAX_OUTLIER;
       (b) flow-sensitive pixels — pixels that agree (<= 1e-4) once the oracle's flows are injected, i.e. whose whole
