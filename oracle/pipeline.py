@@ -54,6 +54,8 @@ def main(ref_img, comp_imgs, config, capture=None):
     if capture is not None:
         capture["covs"].append(covs)
     merge_ref(ref, covs, num, den, cfa, config, acc_r if accumulate_r else None)
+    if capture is not None:
+        capture["den"] = den.copy()  # accumulated weights before the normalisation (conditioning of num / den)
     divide(num, den)
     if accumulate_r:
         debug["accumulated robustness"] = acc_r

@@ -17,7 +17,9 @@ exercises kernels + robustness + merge on identical geometry, the flow compariso
   * oracle flows injected: image <= 1e-4 wherever every frame is fully accepted (r = 1 in the 5 x 5 raw-pixel
     neighbourhood; with the robustness off: everywhere); where some frame is being rejected at most two raw
     pixels' worth of isolated values per case (2 x 3 x ceil(scale)^2: one raw pixel is scale^2 output pixels x 3
-    channels), each <= MAX_OUTLIER — mechanism (a) below.  Measured: the 64 cases: 63 <= 9.6e-5, one with 2 values at
+    channels), each <= MAX_OUTLIER or, where the value's accumulated weight den is smaller than NUM_ERR / MAX_OUTLIER,
+    <= NUM_ERR / den (case 101.9: 0.104 at den = 3.4e-7 — every outlier of set 100 has |d out| x den <= 8.9e-8, float32
+    rounding of num and den themselves) — mechanism (a) below.  Measured: the 64 cases: 63 <= 9.6e-5, one with 2 values at
     1.01e-4; nine held-out sets of 64 (HHSR_FUZZ_BATCHES=10:22,11:22,12:20 ... 90:22,91:22,92:20): 546 of 576 <= 1e-4,
     30 cases with 1 - 4 values each (18 and 22 — one raw pixel — in two cases at scale 3) between 1.1e-4 and 2.3e-3.
     (Earlier forms of this assertion — each value <= 3e-4; values above 1.05e-4 only in tiles displaced by > 30 px; <= 16
@@ -63,7 +65,8 @@ FLIP_PX = 1e-3          # flow difference that marks a tile as following another
 MAX_ICA_TILES = 16      # tiles per case with a flow difference between 1e-4 and FLIP_PX (measured: <= 10, in 3 of 640 cases)
 CLUSTER = 8             # tiles per side of the finest-level tiles under one level-2 tile of the default pyramid
 MAX_OUTLIERS = 64       # own flows, where a frame is being rejected: values (pixel x channel) > 1e-4 (measured: <= 3 per case)
-MAX_OUTLIER = 5e-3      # ... the largest of them                                      (measured: 2.8e-3)
+MAX_OUTLIER = 5e-3      # ... the largest of them (measured: 2.8e-3) — unless the accumulated weight den of the value is so
+NUM_ERR = 1e-6          # small that NUM_ERR / den exceeds it: then |d out| x den <= NUM_ERR (measured <= 8.9e-8: set 100)
 
 
 def max_inj_outliers(scale):
@@ -121,10 +124,10 @@ def _oracle_case(c):
     ref, comp = burst(c)
     cap = {}
     want, _ = oracle.main(ref, comp, config(c), capture=cap)
-    return ref, comp, want, np.stack(cap["flow"]), (np.stack(cap["r"]) if c["rob"] else None)
+    return ref, comp, want, np.stack(cap["flow"]), (np.stack(cap["r"]) if c["rob"] else None), cap["den"]
 
 
-def check(c, ref, comp, want, oflow, o_r, report=None):
+def check(c, ref, comp, want, oflow, o_r, den_o, report=None):
     """Returns the number of flipped block-matching decisions (clusters of tiles) of the case: 0 or 1."""
     from helpers import footprint
 
@@ -170,21 +173,26 @@ def check(c, ref, comp, want, oflow, o_r, report=None):
     div = rej[..., None]
     bad_i = di > 1e-4
     n_inj, inj_max, inj_outside = int(bad_i.sum()), float(di.max()), int((bad_i & ~div).sum())
+    # the same differences referred to the numerator: |d out| x den — what an absolute error of num (or of out x den) of
+    # that size produces; large image differences at tiny den are the normalisation's conditioning, not arithmetic
+    inj_q = float(np.where(bad_i, di * den_o, 0.0).max())
+    inj_over = int((bad_i & (di > np.maximum(MAX_OUTLIER, NUM_ERR / np.maximum(den_o, 1e-30)))).sum())
     bad = d > 1e-4
     sens = bad & ~bad_i                      # (b) agree once the flows agree
     rest = bad & bad_i                       # (a) only where a frame is being rejected
     n_sens, sens_max = int(sens.sum()), float(np.where(sens, d, 0).max())
     n_rest, rest_max, rest_outside = int(rest.sum()), float(np.where(rest, d, 0).max()), int((rest & ~div).sum())
+    rest_over = int((rest & (d > np.maximum(MAX_OUTLIER, NUM_ERR / np.maximum(den_o, 1e-30)))).sum())
     failed = []  # the assertions of the case (report mode lists them next to the numbers instead of stopping)
     if not (nan_mis == 0 and one_cluster and n_ica <= MAX_ICA_TILES):
         failed.append(f"{nflip} flipped tiles (one cluster: {one_cluster}), {n_ica} tiles between 1e-4 and {FLIP_PX:g} px, "
                       f"{nan_mis} NaN mismatches")
     if not (dflow <= 1e-4 and dr <= 1e-4 and dr_i <= 1e-4):
         failed.append(f"flow {dflow:.2e} px, r {dr:.2e} / {dr_i:.2e}")
-    if not (n_inj <= max_inj_outliers(scale) and inj_max <= MAX_OUTLIER and inj_outside == 0):
+    if not (n_inj <= max_inj_outliers(scale) and inj_over == 0 and inj_outside == 0):
         failed.append(f"oracle flows injected: {n_inj} values above 1e-4 (max {inj_max:.2e}), {inj_outside} where every frame "
                       f"is accepted")
-    if not (n_rest <= MAX_OUTLIERS and rest_max <= MAX_OUTLIER and rest_outside == 0):
+    if not (n_rest <= MAX_OUTLIERS and rest_over == 0 and rest_outside == 0):
         failed.append(f"{n_rest} values above 1e-4 (max {rest_max:.2e}), {rest_outside} where every frame is accepted")
     if not n_sens <= 2 * 3 * int(round(ts * scale)) ** 2:
         failed.append(f"{n_sens} flow-sensitive values (max {sens_max:.2e})")
@@ -192,7 +200,7 @@ def check(c, ref, comp, want, oflow, o_r, report=None):
         report.append(f"{tag}: flipped {nflip}{'' if one_cluster else ' (NOT one cluster)'}, ica {n_ica}, nan {nan_mis}, flow {dflow:.1e}, r {dr:.1e} / injected {dr_i:.1e}; injected "
                       f"image max {inj_max:.2e} ({n_inj} > 1e-4, {inj_outside} outside rejecting regions); own flows: flow-"
                       f"sensitive {n_sens} (max {sens_max:.1e}), other {n_rest} (max {rest_max:.1e}, {rest_outside} outside "
-                      f"rejecting regions)" + (f"  ASSERTIONS FAILED: {'; '.join(failed)}" if failed else ""))
+                      f"rejecting regions); injected outliers x den max {inj_q:.2e}" + (f"  ASSERTIONS FAILED: {'; '.join(failed)}" if failed else ""))
         return int(nflip > 0)
     assert not failed, f"{tag}: " + "; ".join(failed)
     return int(nflip > 0)

@@ -37,3 +37,11 @@ df = np.abs(g - oflow).max(-1)
 print("own flows: tiles with |flow - oracle flow| > 1e-4 px:")
 for (n, ty, tx) in np.argwhere(df > 1e-4):
     print(f"   frame {n} tile ({ty}, {tx}): hip {g[n, ty, tx]} oracle {oflow[n, ty, tx]} diff {df[n, ty, tx]:.3e}")
+
+# taps where exactly one of the two implementations has r == 0 (R = S e - t within rounding of the clamp)
+for n in range(oflow.shape[0]):
+    z = (hr[n] == 0) != (o_r[n] == 0)
+    print(f"frame {n}: {int(z.sum())} raw pixels where exactly one of HIP / oracle has r == 0; there max r = "
+          f"{float(np.maximum(hr[n], o_r[n])[z].max()) if z.any() else 0.0:.2e}")
+    for (y, x) in np.argwhere(z)[:12]:
+        print(f"      raw ({y}, {x}): hip {hr[n, y, x]:.3e} oracle {o_r[n, y, x]:.3e}")
