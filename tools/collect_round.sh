@@ -39,11 +39,12 @@ python tools/debug/copy_contention_probe.py 2>&1 | grep -v amdgpu.ids >> $OUT/hw
 rm -f $OUT/fuzz_report.txt
 HHSR_FUZZ_REPORT=$PWD/$OUT/fuzz_report.txt python -m pytest tests/test_fuzz_parity.py -m gpu -q > /dev/null 2>&1
 python tools/fuzz_report.py $OUT/fuzz_report.txt >> $OUT/PARITY.md
-# ... and the same assertions on held-out generator seeds (nine more sets of 64; ~23 GPU-minutes)
+# ... and the same assertions on held-out generator seeds (eleven more sets of 64; ~28 GPU-minutes)
 bash tools/debug/fuzz_sets.sh > $OUT/fuzz_sets.log 2>&1
-bash tools/debug/fuzz_more_sets.sh 50 60 70 80 90 >> $OUT/fuzz_sets.log 2>&1
+bash tools/debug/fuzz_more_sets.sh 50 60 70 80 90 100 110 >> $OUT/fuzz_sets.log 2>&1
 cat gpurun_out/fuzz/set1.txt gpurun_out/fuzz/set2.txt gpurun_out/fuzz/set3.txt gpurun_out/fuzz/set4.txt gpurun_out/fuzz/set50.txt \
-    gpurun_out/fuzz/set60.txt gpurun_out/fuzz/set70.txt gpurun_out/fuzz/set80.txt gpurun_out/fuzz/set90.txt > $OUT/fuzz_heldout.txt
-python tools/fuzz_report.py $OUT/fuzz_heldout.txt | sed 's/576 cases, HIP main/576 HELD-OUT cases (nine sets of 64 from other generator seeds; same assertions), HIP main/' >> $OUT/PARITY.md
+    gpurun_out/fuzz/set60.txt gpurun_out/fuzz/set70.txt gpurun_out/fuzz/set80.txt gpurun_out/fuzz/set90.txt gpurun_out/fuzz/set100.txt \
+    gpurun_out/fuzz/set110.txt > $OUT/fuzz_heldout.txt
+python tools/fuzz_report.py $OUT/fuzz_heldout.txt | sed 's/704 cases, HIP main/704 HELD-OUT cases (eleven sets of 64 from other generator seeds; same assertions), HIP main/' >> $OUT/PARITY.md
 find $OUT -name "*agent_info*" -delete
 cut -c1-600 $OUT/bench_n1.json
