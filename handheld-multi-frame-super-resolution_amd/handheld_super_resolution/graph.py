@@ -155,11 +155,12 @@ class HostBurstRunner:
         # A chunk's copies are queued when the previous chunk's are done, not all 20 up front: with many copies pending on
         # the stream the copy engine sometimes settles at HALF rate (1.6 instead of 0.85 ms per 48 MB for whole bursts,
         # rocprofv3 --memory-copy-trace; seen after compute-only phases of the process, tools/debug/host_leg_timing.py with
-        # HHSR_PRELUDE) — queued a chunk at a time it stays at full rate in every state measured, at the price of a 20 us
-        # gap per chunk (17.3 -> 17.7 ms for 960 MB).  HHSR_PACED_UPLOADS=0: everything up front.
+        # HHSR_PRELUDE) — queued a chunk at a time it stays at full rate in every state measured, at the price of a gap
+        # per chunk (17.3 -> 17.7 ms for 960 MB; 17.3 again with upload_ahead below).  HHSR_PACED_UPLOADS=0: everything up front.
         self.paced_uploads = os.environ.get("HHSR_PACED_UPLOADS", "1") != "0"
         # chunks whose copies are queued AHEAD of the chunk the host is waiting for (paced uploads): with 0 the copy engine
         # idles from a chunk's last copy until the host has woken up, launched the chunk's graph and queued the next copies
+        # (~130 us per chunk, 19.3 -> 19.1 ms per float32 burst); 1 and 2 measure the same, "all" is the half-rate mode above
         self.upload_ahead = int(os.environ.get("HHSR_UPLOAD_AHEAD", "1"))
 
     def _eager(self, ref_img, comp_imgs):
