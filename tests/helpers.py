@@ -158,3 +158,86 @@ def assert_explained(got, want, atol, flipped, ts, shape, scale, what, max_flipp
         k = np.unravel_index(np.nanargmax(err), err.shape)
         raise AssertionError(f"{what}: {int(unexplained.sum())} differences above {atol} outside the footprint of the "
                              f"{nf} flipped tiles; worst at {k}: {got[k]} vs {want[k]}")
+
+
+# ---- the per-case rules of tests/test_fuzz_parity.py (pure NumPy: unit-tested on the CPU in test_host_logic.py) -------------
+FLIP_PX = 1e-3          # flow difference that marks a tile as following another block-matching decision
+MAX_ICA_TILES = 16      # tiles per case with a flow difference between 1e-4 and FLIP_PX (measured: <= 10, in 3 of 768 cases)
+CLUSTER = 8             # tiles per side of the finest-level tiles under one level-2 tile of the default pyramid
+MAX_OUTLIERS = 64       # own flows, where a frame is being rejected: values (pixel x channel) > 1e-4 (measured: <= 22 per case)
+MAX_OUTLIER = 5e-3      # ... the largest of them (measured: 2.8e-3) — unless the accumulated weight den of the value is so
+NUM_ERR = 1e-6          # small that NUM_ERR / den exceeds it: then |d out| x den <= NUM_ERR (measured <= 8.9e-8: set 100)
+
+
+def max_inj_outliers(scale):
+    """Oracle flows injected: values > 1e-4 allowed per case (all where a frame is being rejected): two raw pixels' worth.
+    Measured per case: <= 4 at scales 1 - 2, 18 and 22 at scale 3 (one raw pixel = 27 values), each <= 2.3e-3."""
+    return 2 * 3 * int(np.ceil(scale)) ** 2
+
+
+def fuzz_verdict(shape, ts, scale, o, oi, want, gflow, oflow, hr, hr_i, o_r, den_o):
+    """One case of the fuzz sweep, judged: HIP outputs with own flows `o` / with the oracle's flows injected `oi` against the
+    oracle's `want`; flows [n, ny, nx, 2]; robustness maps [n, H, W] of the two HIP runs (`hr`, `hr_i`) and of the oracle
+    (`o_r`), None with the robustness off; `den_o` the oracle's accumulated weights.  Returns (numbers, failed rules) —
+    the rules are spelled out in the docstring of tests/test_fuzz_parity.py."""
+    H, W = shape
+    rob = o_r is not None
+    gflow = np.asarray(gflow)
+    big = flipped_tiles(gflow, oflow, FLIP_PX)
+    flipped = flipped_tiles(gflow, oflow, 1e-4)  # every tile whose flow deviates: their footprint is not compared below
+    nflip, n_ica = int(big.sum()), int((flipped & ~big).sum())
+    one_cluster = True
+    if nflip:
+        fn, fy, fx = np.nonzero(big)
+        one_cluster = len(set(fn.tolist())) == 1 and np.ptp(fy) < CLUSTER and np.ptp(fx) < CLUSTER
+    nan_mis = int((np.isnan(o) != np.isnan(want)).sum()) + int((np.isnan(oi) != np.isnan(want)).sum())
+    dflow = float(np.abs(gflow - oflow).max(-1)[~flipped].max())
+    dr = dr_i = 0.0
+    if rob:
+        m1 = np.stack([footprint(f, ts, (H, W), 1.0, ts + 3) for f in flipped])  # (+ the neighbour tiles: their S)
+        dr = float(np.where(m1, 0, np.abs(hr - o_r)).max())
+        dr_i = float(np.abs(hr_i - o_r).max())
+    with np.errstate(all="ignore"):  # NaN == NaN (the pattern is compared above), inf == inf; inf vs finite stays inf
+        d = np.where(np.isnan(want) | (o == want), 0.0, np.abs(o.astype(np.float64) - want))
+        di = np.where(np.isnan(want) | (oi == want), 0.0, np.abs(oi.astype(np.float64) - want))
+    d = np.where(footprint(flipped, ts, (H, W), scale, ts + 3)[..., None], 0.0, d)
+    # where some frame is NOT fully accepted: r < 1 somewhere in the 5 x 5 raw-pixel neighbourhood (the merge reads r at
+    # its 3 x 3 taps) — the only places where the r-sensitivity of the normalisation (mechanism (a)) can act
+    rej = np.zeros(o.shape[:2], bool)
+    if rob:
+        from scipy.ndimage import minimum_filter
+
+        low = minimum_filter(o_r.min(0), size=5, mode="nearest") < 0.999
+        yy = np.minimum(((np.arange(o.shape[0]) + 0.5) / scale).astype(int), H - 1)
+        xx = np.minimum(((np.arange(o.shape[1]) + 0.5) / scale).astype(int), W - 1)
+        rej = low[np.ix_(yy, xx)]
+    div = rej[..., None]
+    bad_i = di > 1e-4
+    n_inj, inj_max, inj_outside = int(bad_i.sum()), float(di.max()), int((bad_i & ~div).sum())
+    # the same differences referred to the numerator: |d out| x den — what an absolute error of num (or of out x den) of
+    # that size produces; large image differences at tiny den are the normalisation's conditioning, not arithmetic
+    inj_q = float(np.where(bad_i, di * den_o, 0.0).max())
+    inj_over = int((bad_i & (di > np.maximum(MAX_OUTLIER, NUM_ERR / np.maximum(den_o, 1e-30)))).sum())
+    bad = d > 1e-4
+    sens = bad & ~bad_i                      # (b) agree once the flows agree
+    rest = bad & bad_i                       # (a) only where a frame is being rejected
+    n_sens, sens_max = int(sens.sum()), float(np.where(sens, d, 0).max())
+    n_rest, rest_max, rest_outside = int(rest.sum()), float(np.where(rest, d, 0).max()), int((rest & ~div).sum())
+    rest_over = int((rest & (d > np.maximum(MAX_OUTLIER, NUM_ERR / np.maximum(den_o, 1e-30)))).sum())
+    failed = []  # the assertions of the case (report mode lists them next to the numbers instead of stopping)
+    if not (nan_mis == 0 and one_cluster and n_ica <= MAX_ICA_TILES):
+        failed.append(f"{nflip} flipped tiles (one cluster: {one_cluster}), {n_ica} tiles between 1e-4 and {FLIP_PX:g} px, "
+                      f"{nan_mis} NaN mismatches")
+    if not (dflow <= 1e-4 and dr <= 1e-4 and dr_i <= 1e-4):
+        failed.append(f"flow {dflow:.2e} px, r {dr:.2e} / {dr_i:.2e}")
+    if not (n_inj <= max_inj_outliers(scale) and inj_over == 0 and inj_outside == 0):
+        failed.append(f"oracle flows injected: {n_inj} values above 1e-4 (max {inj_max:.2e}), {inj_outside} where every frame "
+                      f"is accepted")
+    if not (n_rest <= MAX_OUTLIERS and rest_over == 0 and rest_outside == 0):
+        failed.append(f"{n_rest} values above 1e-4 (max {rest_max:.2e}), {rest_outside} where every frame is accepted")
+    if not n_sens <= 2 * 3 * int(round(ts * scale)) ** 2:
+        failed.append(f"{n_sens} flow-sensitive values (max {sens_max:.2e})")
+    v = dict(nflip=nflip, one_cluster=one_cluster, n_ica=n_ica, nan_mis=nan_mis, dflow=dflow, dr=dr, dr_i=dr_i, inj_max=inj_max,
+             n_inj=n_inj, inj_outside=inj_outside, inj_q=inj_q, n_sens=n_sens, sens_max=sens_max, n_rest=n_rest,
+             rest_max=rest_max, rest_outside=rest_outside)
+    return v, failed

@@ -164,3 +164,78 @@ def test_config_watch_sees_every_in_place_edit():
     w = ConfigWatch()
     w.changed(a)
     assert not w.changed(b)  # another object: a first look again
+
+
+def test_fuzz_verdict_rules():
+    """The per-case rules of the randomised parity sweep (helpers.fuzz_verdict, used by tests/test_fuzz_parity.py on the GPU)
+    on hand-made arrays: what passes, and that each rule trips on the violation it exists for."""
+    from helpers import fuzz_verdict, max_inj_outliers
+
+    H, W, ts, scale, n = 64, 96, 16, 2, 2
+    ny, nx = H // ts, W // ts
+    rng = np.random.default_rng(0)
+    want = rng.random((2 * H, 2 * W, 3)).astype(np.float32)
+    want[0, 0, 1] = np.nan
+    want[1, 1, 2] = np.inf
+    oflow = rng.standard_normal((n, ny, nx, 2)).astype(np.float32)
+    o_r = np.ones((n, H, W), np.float32)
+    o_r[0, 20:30, 40:50] = 0.3          # a region where frame 0 is being rejected
+    den = np.full_like(want, 2.0)
+
+    def run(o=None, oi=None, gflow=None, hr=None, hr_i=None, den_o=None, rob=True):
+        o = want.copy() if o is None else o
+        oi = want.copy() if oi is None else oi
+        return fuzz_verdict((H, W), ts, scale, o, oi, want, oflow if gflow is None else gflow, oflow,
+                            (o_r if hr is None else hr) if rob else None, (o_r if hr_i is None else hr_i) if rob else None,
+                            o_r if rob else None, den if den_o is None else den_o)
+
+    v, failed = run()
+    assert not failed and v["n_inj"] == 0 and v["nflip"] == 0 and v["nan_mis"] == 0  # NaN == NaN, inf == inf
+    assert not run(rob=False)[1]
+    # arithmetic noise below 1e-4 everywhere
+    assert not run(o=want + 5e-5, oi=want - 5e-5)[1]
+    # an outlier where every frame is accepted: fails, with own and with injected flows
+    bad = want.copy()
+    bad[100, 20, 0] += 3e-4
+    assert run(oi=bad)[1] and run(o=bad, oi=bad)[1]
+    # ... inside the rejecting region (HR rows 40-60, cols 80-100): tolerated up to MAX_OUTLIER, counted
+    ok = want.copy()
+    ok[50, 90, 0] += 3e-3
+    v, failed = run(oi=ok)
+    assert not failed and v["n_inj"] == 1 and v["inj_outside"] == 0
+    ok[50, 90, 0] += 0.1                 # too large for a normal accumulated weight ...
+    assert run(oi=ok)[1]
+    tiny = den.copy()
+    tiny[50, 90, 0] = 1e-6               # ... but not where the accumulated weight vanishes: 0.103 x 1e-6 <= NUM_ERR
+    assert not run(oi=ok, den_o=tiny)[1]
+    many = want.copy()
+    many[44:48, 84:88, :] += 2e-4        # 48 values > two raw pixels' worth at scale 2 (24)
+    assert max_inj_outliers(scale) == 24 and run(oi=many)[1]
+    # flow-sensitive values: differ with own flows, agree once the flows are the oracle's
+    v, failed = run(o=bad)
+    assert not failed and v["n_sens"] == 1 and v["n_rest"] == 0
+    # flows: one flipped 2 x 2 block is one decision; its footprint is not compared
+    g = oflow.copy()
+    g[1, 1:3, 2:4] += 0.08
+    o2 = want.copy()
+    o2[2 * ts * 1: 2 * ts * 3, 2 * ts * 2: 2 * ts * 4] += 0.05
+    v, failed = run(gflow=g, o=o2)
+    assert not failed and v["nflip"] == 4 and v["one_cluster"]
+    g[0, 0, 0] += 0.08                   # a second decision in another frame
+    assert run(gflow=g, o=o2)[1]
+    g = oflow.copy()
+    g[0, 2, 3] += 3e-4                   # an ill-conditioned ICA tile: counted, tolerated
+    v, failed = run(gflow=g)
+    assert not failed and v["n_ica"] == 1 and v["nflip"] == 0
+    g[0] += 3e-4                         # ... not a whole frame of them
+    assert run(gflow=g)[1]
+    # robustness beyond 1e-4 outside any deviating tile; NaN pattern; inf vs finite
+    hr = o_r.copy()
+    hr[1, 5, 5] -= 2e-4
+    assert run(hr=hr)[1] and run(hr_i=hr)[1]
+    nanned = want.copy()
+    nanned[3, 3, 0] = np.nan
+    assert run(o=nanned)[1]
+    finite = want.copy()
+    finite[1, 1, 2] = 1.0
+    assert run(oi=finite)[1]

@@ -10,7 +10,7 @@ import handheld_super_resolution as hsr
 gs, k = int(sys.argv[1]), int(sys.argv[2])
 c = fz.cases(gs, k + 1)[k]
 print("case", c)
-ref, comp, want, oflow, o_r = fz._oracle_case(c)
+ref, comp, want, oflow, o_r, den_o = fz._oracle_case(c)
 cfg = fz.config(c, inject_flows=[f for f in oflow])
 cfg.debug = True
 out, dbg = hsr.main(ref, comp, cfg)
