@@ -231,6 +231,32 @@ def main():
     timed_call.on = False
     out_pix = round(scale * H) * round(scale * W)
     value = out_pix / (ms_per_step * 1e-3) / 1e6
+    P, S = H * W, float(scale) ** 2
+    headline = NF == 20 and H * W == 12_000_000 and scale == 2
+    # ---- the measurement exists from here on: the line is built NOW and printed exactly once — at the end of the optional
+    # legs below (each guarded: a failing leg leaves its error string in line["errors"]), or by the exit hook if anything
+    # else ends the process first.  N > 1 runs none of the host-resident / CPU legs (they are N = 1 figures).
+    errors = {}
+    line = {
+        "metric": "output Mpix/s for 12MP x 20-frame x2 SR burst; max-abs diff vs reference" if headline else
+                  f"output Mpix/s for {H * W / 1e6:.0f}MP x {NF}-frame x{scale} SR burst; max-abs diff vs reference",
+        "value": round(value, 2), "unit": "Mpix/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "strong",
+        "vs_baseline": round(value / 12.0, 2) if headline else None,
+        "dtype": "f32", "data": "synthetic",
+    }
+    printed = []
+
+    def emit():
+        if rank == 0 and not printed:
+            printed.append(1)
+            if errors:
+                line["errors"] = errors
+            print(json.dumps(line), flush=True)
+
+    import atexit
+
+    atexit.register(emit)
     graphed = bool(on_gpu and any(getattr(getattr(engine, r, None), "graphs", None)
                                   for r in ("_runner", "_runner_a", "_runner_p")))
     if world > 1:  # the eager section below runs collectives: every rank takes it when any rank replayed a graph
@@ -243,30 +269,118 @@ def main():
         # duration comes from a few eager steps of the same workload right after (same kernel, same inputs)
         import copy
 
-        cfg_e = copy.deepcopy(cfg)
-        cfg_e.hip = dict(cfg_e.hip, graph=False)
-        eng_e = engine_cls(cfg_e)
-        ev_steps = max(3, min(10, args.steps))
-        fn_e = lambda: hdist.main_sharded(ref, comp, cfg_e, engine=eng_e, gather=args.gather, strategy=args.strategy,  # noqa: E731
-                                          max_flow=args.max_flow)[0]
-        for _ in range(2):  # (the second call still grows the caching allocator at 48 MP frames: 86 vs 68 ms per step)
-            fn_e()
-        barrier()
-        timed_call.on = True
-        ms_eager = timed(fn_e, ev_steps, 0)
+        try:
+            cfg_e = copy.deepcopy(cfg)
+            cfg_e.hip = dict(cfg_e.hip, graph=False)
+            eng_e = engine_cls(cfg_e)
+            ev_steps = max(3, min(10, args.steps))
+            fn_e = lambda: hdist.main_sharded(ref, comp, cfg_e, engine=eng_e, gather=args.gather, strategy=args.strategy,  # noqa: E731
+                                              max_flow=args.max_flow)[0]
+            for _ in range(2):  # (the second call still grows the caching allocator at 48 MP frames: 86 vs 68 ms per step)
+                fn_e()
+            barrier()
+            timed_call.on = True
+            ms_eager = timed(fn_e, ev_steps, 0)
+            del eng_e
+        except Exception as e:  # noqa: BLE001
+            errors["eager_leg"] = f"{type(e).__name__}: {e}"
+            ev.clear()
         timed_call.on = False
 
-    # ---- H2D-inclusive leg: the reference's scope (frames are host arrays when the timer starts) ---------------------
+    # ---- descriptive fields + the whole-step roofline (nothing below this block can lose the measurement) -----------
+    sb = step_bytes(NF - 1, P, S) / world  # per rank: every rank's kernels cover 1 / world of the burst's work
+    line.update({
+        "config": {"workload": f"{H}x{W} Bayer burst, {NF} frames, x{scale} SR, Ts={cfg.block_matching.tuning.tile_size}, "
+                               f"metrics={cfg.block_matching.tuning.metrics}, robustness on, frames resident in HBM "
+                               f"(`value`, `vs_baseline`: device-resident scope; `value_reference_scope`, "
+                               f"`vs_baseline_reference_scope`: the reference's timer scope, frames start as host float32 "
+                               f"arrays, super_resolution.py:103-195)",
+                   "l1_semantics": "intended (SAD argmin; the reference's level-0 L1 kernel is undefined behaviour "
+                                   "upstream, SURVEY.md App. A D1: block_matching.py:168-180; oracle-defined, unpinned)",
+                   "parallelism": ((f"{world} ranks, strategy rows: alignment frame-parallel, all-gather of flows, merge "
+                                    f"row-parallel" if args.strategy == "rows" else
+                                    f"{world} ranks, strategy reduce: frames one per rank, reduce-scatter of the float32 "
+                                    f"accumulators over row slabs") +
+                                   f", output {'gathered to rank 0' if args.gather else 'sharded by rows'}")
+                   if world > 1 else "single GPU"},
+        "strategy": args.strategy if world > 1 else None,
+        "launch": (("HIP graph replay: the step is captured once (stream capture incl. the frame pipeline's side "
+                    "streams) and replayed with one launch per burst; every kernel runs on every step" if world == 1
+                    else ("HIP graph replay of the per-rank steps (alignment of the rank's frames; robustness + "
+                          "kernels + merge of its rows), the all-gather of the flow fields between them"
+                          if args.strategy == "rows" else
+                          "HIP graph replay of the two per-rank steps (the rank's frames through the whole chain into "
+                          "accumulators; reference frame + normalisation of its slab), the reduce-scatter between them"))
+                   if graphed else "one launch per kernel from Python"),
+        "ms_per_step_eager": round(ms_eager, 3) if ms_eager else None,
+        "rccl_ranks": dist.get_world_size() if world > 1 else 1,
+        "backend": (args.backend if world > 1 else None),
+        "engine": "HipEngine (libhhsr_hip.so)" if on_gpu else f"{args.engine} (launch-plumbing test, not a measurement)",
+        "step_roofline": {"algorithmic_bytes": sb, "achieved": round(sb / (ms_per_step * 1e-3) / 1e9, 1),
+                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(sb / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                          "note": "whole step, PER RANK: algorithmic bytes of every kernel of the fused pipeline "
+                                  "(bench.step_bytes) / ranks over the step time against ONE GPU's HBM peak; its kernels are "
+                                  "VALU- or latency-bound (profiles/*_kernel_bottlenecks.md), none is HBM-bound"},
+        "reference_published": "48 MP in < 4 s (>= 12 output Mpix/s) on an RTX 3090 for a 20-frame burst (README.md:10)",
+    })
+
+    # ---- dominant-kernel roofline -------------------------------------------------------------------------------------
+    roof = None
+    try:
+        step_ms = [e0.elapsed_time(e1) for e0, e1, nfr in ev if nfr > 0]
+        if step_ms:
+            avg_ms = float(np.sum(step_ms)) / ev_steps
+            # whole-image launch on one GPU; on N ranks each launch covers 1/N of the output rows (+ halo rows of input)
+            nbytes = merge_burst_bytes(NF - 1, P, S) / world
+            achieved = nbytes / (avg_ms * 1e-3) / 1e9
+            # the kernel hhsr_merge_burst picks for this scale (csrc/hhsr_merge.hip: x2 and x3 have wave-per-parity-class
+            # kernels, other integer scales the tile kernel, non-integer scales the generic one)
+            kernel = ("k_merge_x2" if float(scale) == 2.0 else "k_merge_xs<3>" if float(scale) == 3.0 and W % 4 == 0
+                      else "k_merge_burst_tile" if float(scale).is_integer() else "k_merge_burst")
+            traffic, valu, pmc_note = None, None, None
+            try:  # HBM bytes / VALU instructions per launch from the committed rocprofv3 --pmc passes of this exact kernel
+                pmc_file = "r03_pmc_merge_x3.json" if float(scale) == 3.0 else "r03_pmc_merge.json"
+                with open(os.path.join(ROOT, "profiles", pmc_file)) as f:
+                    pm = json.load(f)
+                sha = hashlib.sha256(open(MERGE_SRC, "rb").read()).hexdigest()[:16]
+                if pm.get("workload") == f"{H}x{W}x{NF} x{scale}" and world == 1:
+                    if pm.get("source_sha16") == sha:
+                        traffic = pm["traffic_bytes_per_launch"]
+                        insts = pm["valu_wave_insts_per_launch"]
+                        lane_ops = insts * 64 / (avg_ms * 1e-3)
+                        valu = {"wave_insts_per_launch": insts, "achieved_Tlaneops": round(lane_ops / 1e12, 2),
+                                "peak_Tlaneops": VALU_PEAK_TLANEOPS, "frac": round(lane_ops / 1e12 / VALU_PEAK_TLANEOPS, 3)}
+                    else:
+                        pmc_note = (f"profiles/{pmc_file} was collected for kernel source {pm.get('source_sha16')}, "
+                                    f"the source is now {sha}: counters not reported (re-run tools/pmc_merge.sh)")
+            except Exception as e:  # noqa: BLE001
+                pmc_note = f"no PMC record: {e}"
+            roof = {"kernel": f"{kernel} (hhsr_merge_burst)", "bound": "valu", "achieved": round(achieved, 1),
+                    "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+                    "avg_launch_ms": round(avg_ms, 4), "bytes_per_launch": nbytes, "valu_issue": valu,
+                    "frac_valu": valu["frac"] if valu else None, "frac_hbm": round(achieved / HBM_PEAK_GBS, 4),
+                    "note": "the fused burst merge keeps the accumulators in registers: ~100 flop per byte, bound by VALU "
+                            "issue (frac_valu), not by HBM; achieved / peak / frac are the HBM figures the contract asks for"
+                            + ("; launch duration from HIP events around the launch in eager steps of the same workload "
+                               "right after the timed graph replays" if graphed else "")
+                            + ("; " + pmc_note if pmc_note else "")}
+
+    except Exception as e:  # noqa: BLE001
+        errors["roofline"] = f"{type(e).__name__}: {e}"
+    line["roofline"] = roof
+
+    # ---- H2D-inclusive legs: the reference's scope (frames are host arrays when the timer starts); N = 1 only --------
     h2d = None
-    if on_gpu and not args.no_h2d:
+    if on_gpu and not args.no_h2d and world == 1:
         import copy
 
         steps_h = max(3, args.steps // 2)
-        nbytes = 4.0 * H * W * NF
+        nbytes_h = 4.0 * H * W * NF
         PCIE_GBS = 63.0  # PCIe Gen5 x16 spec, one direction
+        floor = nbytes_h / (PCIE_GBS * 1e9) * 1e3
 
-        def host_leg(r_h, c_h, cfg_h, what):
-            """`what` starting in host memory: one engine kept across the bursts (graph.HostBurstRunner: eager uploads
+        def host_leg(r_h, c_h, cfg_h):
+            """A burst starting in host memory: one engine kept across the bursts (graph.HostBurstRunner: eager uploads
             into static staging, per-chunk HIP graphs of the front end, one merge graph)."""
             eng_h = engine_cls(cfg_h)
             fn = lambda: hdist.main_sharded(r_h, c_h, cfg_h, engine=eng_h, gather=args.gather, strategy=args.strategy,  # noqa: E731
@@ -280,183 +394,119 @@ def main():
             del eng_h
             return ms, graphs
 
-        ref_h = ref.cpu().pin_memory()
-        comp_h = [comp[i].cpu().pin_memory() for i in range(NF - 1)]  # one pinned float32 array per frame
-        ms_h, g_h = host_leg(ref_h, comp_h, cfg, "pinned float32 frames")
-        floor = nbytes / (PCIE_GBS * 1e9) * 1e3
-        h2d = {"value_incl_h2d": round(out_pix / (ms_h * 1e-3) / 1e6, 2), "ms_per_step_incl_h2d": round(ms_h, 3),
-               "steps": steps_h, "host_bytes_per_step": nbytes, "pcie_floor_ms": round(floor, 2),
-               "pcie_floor_frac": round(floor / ms_h, 3), "graphs": g_h,
-               "note": "frames start as pinned host float32 (the reference's timer scope, super_resolution.py:103-195): "
-                       "uploads are eager hipMemcpyAsync calls back to back on one upload stream into static staging "
-                       "buffers, the kernels replay as per-chunk HIP graphs that wait for their frames' copies "
-                       "(graph.HostBurstRunner); pcie_floor = bytes / 63 GB/s (PCIe Gen5 x16 spec)"}
-        if world == 1:
-            # the same scope with the frames as the sensor's uint16 counts (what a DNG holds; the reference converts them
-            # to float32 on the host, utils_dng.py:149-160): half the PCIe bytes, normalised on the device per frame
-            black, white = 64.0, 1023.0
-            to_counts = lambda t: torch.from_numpy(np.clip(np.rint(t.numpy() * (white - black) + black), 0, white)  # noqa: E731
-                                                   .astype(np.uint16)).pin_memory()
-            ref16, comp16 = to_counts(ref_h), [to_counts(c) for c in comp_h]
-            cfg16 = copy.deepcopy(cfg)
-            cfg16.hip = dict(cfg16.get("hip", None) or {}, raw_norm={"black_levels": [black] * 3, "white_level": white})
-            ms_16, g_16 = host_leg(ref16, comp16, cfg16, "pinned uint16 counts")
-            h2d.update(value_incl_h2d_u16=round(out_pix / (ms_16 * 1e-3) / 1e6, 2), ms_per_step_incl_h2d_u16=round(ms_16, 3),
-                       pcie_floor_ms_u16=round(floor / 2, 2), pcie_floor_frac_u16=round(floor / 2 / ms_16, 3), graphs_u16=g_16,
-                       note_u16="frames start as pinned host uint16 sensor counts (10-bit, black 64): uploaded as "
-                                "counts, normalised on the device frame by frame (hhsr_normalize_raw_u16)")
-            del ref16, comp16
-            # the reference's literal call: main(ref, comp, config) with plain (pageable) NumPy float32 arrays
-            ref_np, comp_np = ref_h.numpy().copy(), np.stack([c.numpy() for c in comp_h])
-            cfg_np = copy.deepcopy(cfg)
-            fn_np = lambda: hsr.main(ref_np, comp_np, cfg_np)[0]  # noqa: E731
-            ms_np = timed(fn_np, steps_h, 10)
-            h2d.update(value_numpy_pageable=round(out_pix / (ms_np * 1e-3) / 1e6, 2), ms_per_step_numpy_pageable=round(ms_np, 3),
-                       note_numpy="hsr.main(ref, comp, config) on pageable NumPy float32 arrays, the same config object "
-                                  "call after call: 8 host threads copy the frames into page-locked staging while "
-                                  "earlier frames cross PCIe; fresh result tensor per call (one device copy)")
-            del ref_np, comp_np
-        del ref_h, comp_h
-
-    # ---- dominant-kernel roofline -------------------------------------------------------------------------------------
-    P, S = H * W, float(scale) ** 2
-    roof = None
-    step_ms = [e0.elapsed_time(e1) for e0, e1, nfr in ev if nfr > 0]
-    if step_ms:
-        avg_ms = float(np.sum(step_ms)) / ev_steps
-        # whole-image launch on one GPU; on N ranks each launch covers 1/N of the output rows (+ halo rows of input)
-        nbytes = merge_burst_bytes(NF - 1, P, S) / world
-        achieved = nbytes / (avg_ms * 1e-3) / 1e9
-        # the kernel hhsr_merge_burst picks for this scale (csrc/hhsr_merge.hip: x2 and x3 have wave-per-parity-class
-        # kernels, other integer scales the tile kernel, non-integer scales the generic one)
-        kernel = ("k_merge_x2" if float(scale) == 2.0 else "k_merge_xs<3>" if float(scale) == 3.0 and W % 4 == 0
-                  else "k_merge_burst_tile" if float(scale).is_integer() else "k_merge_burst")
-        traffic, valu, pmc_note = None, None, None
-        try:  # HBM bytes / VALU instructions per launch from the committed rocprofv3 --pmc passes of this exact kernel
-            pmc_file = "r03_pmc_merge_x3.json" if float(scale) == 3.0 else "r03_pmc_merge.json"
-            with open(os.path.join(ROOT, "profiles", pmc_file)) as f:
-                pm = json.load(f)
-            sha = hashlib.sha256(open(MERGE_SRC, "rb").read()).hexdigest()[:16]
-            if pm.get("workload") == f"{H}x{W}x{NF} x{scale}" and world == 1:
-                if pm.get("source_sha16") == sha:
-                    traffic = pm["traffic_bytes_per_launch"]
-                    insts = pm["valu_wave_insts_per_launch"]
-                    lane_ops = insts * 64 / (avg_ms * 1e-3)
-                    valu = {"wave_insts_per_launch": insts, "achieved_Tlaneops": round(lane_ops / 1e12, 2),
-                            "peak_Tlaneops": VALU_PEAK_TLANEOPS, "frac": round(lane_ops / 1e12 / VALU_PEAK_TLANEOPS, 3)}
-                else:
-                    pmc_note = (f"profiles/{pmc_file} was collected for kernel source {pm.get('source_sha16')}, "
-                                f"the source is now {sha}: counters not reported (re-run tools/pmc_merge.sh)")
+        ref_h = comp_h = None
+        try:
+            ref_h = ref.cpu().pin_memory()
+            comp_h = [comp[i].cpu().pin_memory() for i in range(NF - 1)]  # one pinned float32 array per frame
+            ms_h, g_h = host_leg(ref_h, comp_h, cfg)
+            h2d = {"value_incl_h2d": round(out_pix / (ms_h * 1e-3) / 1e6, 2), "ms_per_step_incl_h2d": round(ms_h, 3),
+                   "steps": steps_h, "host_bytes_per_step": nbytes_h, "pcie_floor_ms": round(floor, 2),
+                   "pcie_floor_frac": round(floor / ms_h, 3), "graphs": g_h,
+                   "note": "frames start as pinned host float32 (the reference's timer scope, super_resolution.py:103-195): "
+                           "uploads are eager hipMemcpyAsync calls back to back on one upload stream into static staging "
+                           "buffers, the kernels replay as per-chunk HIP graphs that wait for their frames' copies "
+                           "(graph.HostBurstRunner); pcie_floor = bytes / 63 GB/s (PCIe Gen5 x16 spec)"}
+            # the reference-scope figure leads the line next to `value`
+            line.update(value_reference_scope=h2d["value_incl_h2d"], ms_per_step_reference_scope=h2d["ms_per_step_incl_h2d"],
+                        vs_baseline_reference_scope=round(h2d["value_incl_h2d"] / 12.0, 2) if headline else None,
+                        value_incl_h2d=h2d["value_incl_h2d"], ms_per_step_incl_h2d=h2d["ms_per_step_incl_h2d"],
+                        vs_baseline_incl_h2d=round(h2d["value_incl_h2d"] / 12.0, 2) if headline else None, h2d=h2d)
         except Exception as e:  # noqa: BLE001
-            pmc_note = f"no PMC record: {e}"
-        roof = {"kernel": f"{kernel} (hhsr_merge_burst)", "bound": "valu", "achieved": round(achieved, 1),
-                "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
-                "avg_launch_ms": round(avg_ms, 4), "bytes_per_launch": nbytes, "valu_issue": valu,
-                "frac_valu": valu["frac"] if valu else None, "frac_hbm": round(achieved / HBM_PEAK_GBS, 4),
-                "note": "the fused burst merge keeps the accumulators in registers: ~100 flop per byte, bound by VALU "
-                        "issue (frac_valu), not by HBM; achieved / peak / frac are the HBM figures the contract asks for"
-                        + ("; launch duration from HIP events around the launch in eager steps of the same workload "
-                           "right after the timed graph replays" if graphed else "")
-                        + ("; " + pmc_note if pmc_note else "")}
+            errors["h2d_f32_leg"] = f"{type(e).__name__}: {e}"
+        if h2d is not None:
+            try:
+                # the same scope with the frames as the sensor's uint16 counts (what a DNG holds; the reference converts them
+                # to float32 on the host, utils_dng.py:149-160): half the PCIe bytes, normalised on the device per frame
+                black, white = 64.0, 1023.0
+                to_counts = lambda t: torch.from_numpy(np.clip(np.rint(t.numpy() * (white - black) + black), 0, white)  # noqa: E731
+                                                       .astype(np.uint16)).pin_memory()
+                ref16, comp16 = to_counts(ref_h), [to_counts(c) for c in comp_h]
+                cfg16 = copy.deepcopy(cfg)
+                cfg16.hip = dict(cfg16.get("hip", None) or {}, raw_norm={"black_levels": [black] * 3, "white_level": white})
+                ms_16, g_16 = host_leg(ref16, comp16, cfg16)
+                h2d.update(value_incl_h2d_u16=round(out_pix / (ms_16 * 1e-3) / 1e6, 2), ms_per_step_incl_h2d_u16=round(ms_16, 3),
+                           pcie_floor_ms_u16=round(floor / 2, 2), pcie_floor_frac_u16=round(floor / 2 / ms_16, 3), graphs_u16=g_16,
+                           note_u16="frames start as pinned host uint16 sensor counts (10-bit, black 64): uploaded as "
+                                    "counts, normalised on the device frame by frame (hhsr_normalize_raw_u16)")
+                del ref16, comp16
+            except Exception as e:  # noqa: BLE001
+                errors["h2d_u16_leg"] = f"{type(e).__name__}: {e}"
+            try:
+                # the reference's literal call: main(ref, comp, config) with plain (pageable) NumPy float32 arrays
+                from handheld_super_resolution.graph import HostBurstRunner
+
+                ref_np, comp_np = ref_h.numpy().copy(), np.stack([c.numpy() for c in comp_h])
+                cfg_np = copy.deepcopy(cfg)
+                fn_np = lambda: hsr.main(ref_np, comp_np, cfg_np)[0]  # noqa: E731
+                ms_np = timed(fn_np, steps_h, 10)
+                h2d.update(value_numpy_pageable=round(out_pix / (ms_np * 1e-3) / 1e6, 2), ms_per_step_numpy_pageable=round(ms_np, 3),
+                           note_numpy=f"hsr.main(ref, comp, config) on pageable NumPy float32 arrays, the same config object "
+                                      f"call after call: {HostBurstRunner.COPY_THREADS} host threads copy the frames into "
+                                      f"page-locked staging while earlier frames cross PCIe; fresh result tensor per call "
+                                      f"(one device copy)")
+                del ref_np, comp_np
+            except Exception as e:  # noqa: BLE001
+                errors["h2d_numpy_leg"] = f"{type(e).__name__}: {e}"
+        del ref_h, comp_h
 
     # ---- CPU baseline (all host cores) + parity with attribution, on a crop of the same burst ----------------------
     cpu, parity = None, None
     if rank == 0 and world == 1 and on_gpu and not args.no_cpu_baseline:
-        import oracle
+        try:
+            import oracle
 
-        c = min(args.cpu_crop, H, W)
-        c -= c % 32
-        # as many disjoint crops of the same burst as the host has cores for (one worker process per comp frame and crop),
-        # all processed at the same time; crop 0 (the centre) doubles as the parity sample
-        cores = args.cpu_cores or oracle.available_cores()  # (affinity mask capped by the cgroup CPU quota)
-        k_crops = max(1, min(cores // max(1, NF - 1), (H // c) * (W // c)))
-        y0, x0 = ((H - c) // 64) * 32, ((W - c) // 64) * 32
-        origins = [(y0, x0)] + [(gy * c, gx * c) for gy in range(H // c) for gx in range(W // c)][:k_crops - 1]
-        crops = [(ref[y:y + c, x:x + c].cpu().numpy(), comp[:, y:y + c, x:x + c].cpu().numpy()) for y, x in origins]
-        ref_c, comp_c = crops[0]
-        cap = {}
-        want, _, tc, cores_used = oracle.throughput_all_cores(crops, cfg, cores=cores, capture=cap)
-        cpu = {"value": round(len(crops) * round(scale * c) ** 2 / tc / 1e6, 4), "unit": "output Mpix/s", "cores": cores_used,
-               "host_cores": os.cpu_count(), "usable_cores": oracle.available_cores(), "kind": "port",
-               "sample": f"{len(crops)} crop(s) of {c}x{c} of the same burst processed concurrently, all {NF} frames each, "
-                         f"x{scale}, NumPy oracle (golden-pinned port; the reference has no CPU path), {cores_used} worker "
-                         f"processes = every core the container may use (logical CPUs capped by the cgroup CPU quota; "
-                         f"{os.cpu_count()} logical CPUs visible), {tc:.1f} s wall"}
+            c = min(args.cpu_crop, H, W)
+            c -= c % 32
+            # as many disjoint crops of the same burst as the host has cores for (one worker process per comp frame and crop),
+            # all processed at the same time; crop 0 (the centre) doubles as the parity sample
+            cores = args.cpu_cores or oracle.available_cores()  # (affinity mask capped by the cgroup CPU quota)
+            k_crops = max(1, min(cores // max(1, NF - 1), (H // c) * (W // c)))
+            y0, x0 = ((H - c) // 64) * 32, ((W - c) // 64) * 32
+            origins = [(y0, x0)] + [(gy * c, gx * c) for gy in range(H // c) for gx in range(W // c)][:k_crops - 1]
+            crops = [(ref[y:y + c, x:x + c].cpu().numpy(), comp[:, y:y + c, x:x + c].cpu().numpy()) for y, x in origins]
+            ref_c, comp_c = crops[0]
+            cap = {}
+            want, _, tc, cores_used = oracle.throughput_all_cores(crops, cfg, cores=cores, capture=cap)
+            cpu = {"value": round(len(crops) * round(scale * c) ** 2 / tc / 1e6, 4), "unit": "output Mpix/s", "cores": cores_used,
+                   "host_cores": os.cpu_count(), "usable_cores": oracle.available_cores(), "kind": "port",
+                   "sample": f"{len(crops)} crop(s) of {c}x{c} of the same burst processed concurrently, all {NF} frames each, "
+                             f"x{scale}, NumPy oracle (golden-pinned port; the reference has no CPU path), {cores_used} worker "
+                             f"processes = every core the container may use (logical CPUs capped by the cgroup CPU quota; "
+                             f"{os.cpu_count()} logical CPUs visible), {tc:.1f} s wall"}
 
-        def diff(cfg_run):
-            got = hsr.main(ref_c, comp_c, cfg_run)
-            o = got[0].cpu().numpy()
-            with np.errstate(all="ignore"):
-                d = np.abs(o.astype(np.float64) - want.astype(np.float64))
-            return o, d, got[1]
+            def diff(cfg_run):
+                got = hsr.main(ref_c, comp_c, cfg_run)
+                o = got[0].cpu().numpy()
+                with np.errstate(all="ignore"):
+                    d = np.abs(o.astype(np.float64) - want.astype(np.float64))
+                return o, d, got[1]
 
-        cfg_d = cfg.copy()
-        cfg_d.debug = True
-        got, dabs, dbg = diff(cfg_d)
-        fin = np.isfinite(dabs)
-        # tiles whose flow differs by more than ICA noise: a block-matching decision flipped (float32 near-tie)
-        gflow, oflow = np.stack(dbg["flow"]), np.stack(cap["flow"])
-        flipped = np.abs(gflow - oflow).max(-1) > 0.05
-        cfg_i = cfg.copy()
-        cfg_i.hip = dict(cfg.get("hip", None) or {}, inject_flows=[f for f in cap["flow"]])
-        _, dinj, _ = diff(cfg_i)
-        fin_i = np.isfinite(dinj)
-        parity = {"max_abs_diff": float(dabs[fin].max()), "p999_abs_diff": float(np.percentile(dabs[fin], 99.9)),
-                  "frac_above_1e-4": float((dabs[fin] > 1e-4).mean()),
-                  "nan_mismatch": int((np.isnan(got) != np.isnan(want)).sum()),
-                  "flipped_tiles": int(flipped.sum()), "tiles": int(flipped.size),
-                  "max_flow_diff_unflipped_px": float(np.abs(gflow - oflow).max(-1)[~flipped].max()),
-                  "max_abs_diff_oracle_flows_injected": float(dinj[fin_i].max()),
-                  "vs": "oracle (golden-pinned port)", "sample": f"{c}x{c} crop, {NF} frames, x{scale}",
-                  "note": "flipped_tiles = tiles (over all comp frames) whose flow differs from the oracle's by > 0.05 px: "
-                          "float32 near-ties of one block-matching decision; with the oracle's flow fields injected "
-                          "(config.hip.inject_flows) the remaining difference is the arithmetic of robustness + kernels + merge"}
+            cfg_d = cfg.copy()
+            cfg_d.debug = True
+            got, dabs, dbg = diff(cfg_d)
+            fin = np.isfinite(dabs)
+            # tiles whose flow differs by more than ICA noise: a block-matching decision flipped (float32 near-tie)
+            gflow, oflow = np.stack(dbg["flow"]), np.stack(cap["flow"])
+            flipped = np.abs(gflow - oflow).max(-1) > 0.05
+            cfg_i = cfg.copy()
+            cfg_i.hip = dict(cfg.get("hip", None) or {}, inject_flows=[f for f in cap["flow"]])
+            _, dinj, _ = diff(cfg_i)
+            fin_i = np.isfinite(dinj)
+            parity = {"max_abs_diff": float(dabs[fin].max()), "p999_abs_diff": float(np.percentile(dabs[fin], 99.9)),
+                      "frac_above_1e-4": float((dabs[fin] > 1e-4).mean()),
+                      "nan_mismatch": int((np.isnan(got) != np.isnan(want)).sum()),
+                      "flipped_tiles": int(flipped.sum()), "tiles": int(flipped.size),
+                      "max_flow_diff_unflipped_px": float(np.abs(gflow - oflow).max(-1)[~flipped].max()),
+                      "max_abs_diff_oracle_flows_injected": float(dinj[fin_i].max()),
+                      "vs": "oracle (golden-pinned port)", "sample": f"{c}x{c} crop, {NF} frames, x{scale}",
+                      "note": "flipped_tiles = tiles (over all comp frames) whose flow differs from the oracle's by > 0.05 px: "
+                              "float32 near-ties of one block-matching decision; with the oracle's flow fields injected "
+                              "(config.hip.inject_flows) the remaining difference is the arithmetic of robustness + kernels + merge"}
 
-    if rank == 0:
-        headline = NF == 20 and H * W == 12_000_000 and scale == 2
-        line = {
-            "metric": "output Mpix/s for 12MP x 20-frame x2 SR burst; max-abs diff vs reference" if headline else
-                      f"output Mpix/s for {H * W / 1e6:.0f}MP x {NF}-frame x{scale} SR burst; max-abs diff vs reference",
-            "value": round(value, 2), "unit": "Mpix/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "strong",
-            "vs_baseline": round(value / 12.0, 2) if headline else None,
-            "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"{H}x{W} Bayer burst, {NF} frames, x{scale} SR, Ts={cfg.block_matching.tuning.tile_size}, "
-                                   f"metrics={cfg.block_matching.tuning.metrics}, robustness on, frames resident in HBM",
-                       "l1_semantics": "intended (SAD argmin; the reference's level-0 L1 kernel is undefined behaviour "
-                                       "upstream, SURVEY.md App. A D1: block_matching.py:168-180; oracle-defined, unpinned)",
-                       "parallelism": ((f"{world} ranks, strategy rows: alignment frame-parallel, all-gather of flows, merge "
-                                        f"row-parallel" if args.strategy == "rows" else
-                                        f"{world} ranks, strategy reduce: frames one per rank, reduce-scatter of the float32 "
-                                        f"accumulators over row slabs") +
-                                       f", output {'gathered to rank 0' if args.gather else 'sharded by rows'}")
-                       if world > 1 else "single GPU"},
-            "strategy": args.strategy if world > 1 else None,
-            "launch": (("HIP graph replay: the step is captured once (stream capture incl. the frame pipeline's side "
-                        "streams) and replayed with one launch per burst; every kernel runs on every step" if world == 1
-                        else ("HIP graph replay of the two per-rank steps (alignment of the rank's frames; robustness + "
-                              "kernels + merge of its rows), the all-gather of the flow fields between them"
-                              if args.strategy == "rows" else
-                              "HIP graph replay of the two per-rank steps (the rank's frames through the whole chain into "
-                              "accumulators; reference frame + normalisation of its slab), the reduce-scatter between them"))
-                       if graphed else "one launch per kernel from Python"),
-            "ms_per_step_eager": round(ms_eager, 3) if ms_eager else None,
-            "rccl_ranks": dist.get_world_size() if world > 1 else 1,
-            "backend": (args.backend if world > 1 else None),
-            "engine": "HipEngine (libhhsr_hip.so)" if on_gpu else f"{args.engine} (launch-plumbing test, not a measurement)",
-            "roofline": roof,
-            "step_roofline": {"algorithmic_bytes": step_bytes(NF - 1, P, S) / world,
-                              "achieved": round(step_bytes(NF - 1, P, S) / (ms_per_step * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS,
-                              "unit": "GB/s", "frac": round(step_bytes(NF - 1, P, S) / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
-                              "note": "whole step: algorithmic bytes of every kernel of the fused pipeline (bench.step_bytes) over "
-                                      "the step time; its kernels are VALU- or latency-bound (profiles/*_kernel_bottlenecks.md), "
-                                      "none is HBM-bound"},
-            "cpu_baseline": cpu, "parity": parity,
-            "reference_published": "48 MP in < 4 s (>= 12 output Mpix/s) on an RTX 3090 for a 20-frame burst (README.md:10)",
-        }
-        if h2d:
-            line.update(value_incl_h2d=h2d["value_incl_h2d"], ms_per_step_incl_h2d=h2d["ms_per_step_incl_h2d"], h2d=h2d)
-        print(json.dumps(line), flush=True)
+        except Exception as e:  # noqa: BLE001
+            errors["cpu_parity_leg"] = f"{type(e).__name__}: {e}"
+    line.update(cpu_baseline=cpu, parity=parity)
+    emit()
     if world > 1:
         dist.destroy_process_group()
 

@@ -2013,6 +2013,10 @@ static int merge_burst_impl(const float* const* raws, const float* const* flows,
     const bool x3 = aligned16 && tiled && iscale == 3 && ts % QT == 0 && sW == 3 * W && sH == 3 * H && row0 % (3 * QT) == 0 && nrows % 3 == 0 &&
                     W % 4 == 0 && !(force & HHSR_MERGE_FORCE_TILE);
     const bool chained = (flags & (HHSR_MERGE_STORE_CLASSES | HHSR_MERGE_LOAD_CLASSES)) != 0;
+    if (chained && HHSR_X2_DB) {  // (the double-buffered A/B variant's frame loop starts at frame 0: it would count the
+        hhsr_set_error("hhsr_merge_burst_chain: not available in the HHSR_X2_DB variant build");  // parked frames twice)
+        return -3;
+    }
     if (chained && !(quad && !x2_v1 && aligned16 && !mono)) {
         hhsr_set_error("hhsr_merge_burst_chain: needs the wave-per-class x2 kernel (scale 2, ts %% 16 == 0, sH = 2 H, "
                        "sW = 2 W, 16-byte aligned output, float32 weights, Bayer)");

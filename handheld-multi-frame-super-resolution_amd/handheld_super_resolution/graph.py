@@ -225,6 +225,19 @@ class HostBurstRunner:
         with self._lock:
             return self._call(ref_img, comp_imgs)
 
+    def call_cloned(self, ref_img, comp_imgs):
+        """__call__ for callers that may run concurrently (plain main() from several threads): the result is cloned
+        INSIDE the runner's lock — the static result tensor is overwritten by the next replay — and the next replay is
+        ordered behind that clone even when it is issued from a thread with another current stream."""
+        with self._lock:
+            out, dbg = self._call(ref_img, comp_imgs)
+            if dbg.get("accumulated robustness", None) is not None:
+                dbg = dict(dbg, **{"accumulated robustness": dbg["accumulated robustness"].clone()})
+            out = out.clone()
+            self._consumed = torch.cuda.Event()
+            self._consumed.record(torch.cuda.current_stream(self.device))
+            return out, dbg
+
     def _call(self, ref_img, comp_imgs):
         from .super_resolution import main
 
@@ -396,6 +409,10 @@ class HostBurstRunner:
             if self.two_up:
                 st.up2.wait_stream(st.main)
             st.main.wait_stream(cur)
+            consumed = getattr(self, "_consumed", None)
+            if consumed is not None:  # the previous call's clone of the static result (call_cloned), on whatever stream
+                st.main.wait_event(consumed)
+                self._consumed = None
 
             def upload(i):
                 src = frames[i]

@@ -70,11 +70,28 @@ def init_robustness(ref_img, cfa_pattern, white_balance, config):
     return upscale_warp_stats(m), upscale_warp_stats(v)
 
 
+def _check_flow_view(flows, flow_rows):
+    """`flow_rows` != (0, 0) makes the kernels read `before` / `after` tile rows OUTSIDE the tensor they are handed: that
+    is only memory-safe for a true row-slice VIEW of a larger float32 field (a silent copy — dtype, device or contiguity
+    conversion — would be read out of bounds)."""
+    before, after = int(flow_rows[0]), int(flow_rows[1])
+    if before == 0 and after == 0:
+        return
+    ny, nx, two = flows.shape
+    if not (flows.is_cuda and flows.dtype == torch.float32 and flows.is_contiguous() and two == 2):
+        raise ValueError("flow_rows needs a contiguous float32 device VIEW of the full flow field")
+    off = flows.storage_offset()
+    total = flows.untyped_storage().nbytes() // 4
+    if before < 0 or after < 0 or off < before * nx * 2 or off + (ny + after) * nx * 2 > total:
+        raise ValueError(f"flow_rows {tuple(flow_rows)}: the tile rows around the view are not inside its storage")
+
+
 def compute_s(flows, M_th, s1, s2, flow_rows=(0, 0)):
     """Per-tile flow-irregularity weight (robustness.py:530-612).  `flow_rows` = (before, after): `flows` is a row
     slice (a VIEW) of a larger field with that many tile rows around it in memory — the multi-GPU row slabs — and the
     3 x 3 tile neighbourhood reads them, so the slice's first and last rows get the full field's weights."""
     ny, nx, _ = flows.shape
+    _check_flow_view(flows, flow_rows)
     S = torch.empty((ny, nx), dtype=torch.float32, device=flows.device)
     _lib.call("hhsr_rob_s", _lib.ptr(flows), ny, nx, float(M_th), float(s1), float(s2), _lib.ptr(S),
               int(flow_rows[0]), int(flow_rows[1]), _lib.stream())
@@ -225,6 +242,8 @@ def compute_robustness_group(comp_imgs, ref_local_means, flows, noise_model, con
     # per-frame fall-back kernels of hhsr_rob_frames need the S maps — same test as in the library
     inline_s = (int(ts) % 16 == 0 and W % 4 == 0 and curve_index is not None and diff_curve.numel() <= 1024
                 and not _NO_GROUP)
+    for f in flows:
+        _check_flow_view(f, flow_rows)
     S = None if inline_s else [compute_s(f, t.Mt, t.s1, t.s2, flow_rows) for f in flows]
     R = [torch.empty((H, W), dtype=torch.float32, device=comp_imgs[0].device) for _ in flows]
     _lib.call("hhsr_rob_frames", _lib.ptr_array(comp_means), len(flows), H // 2, W // 2, _lib.ptr(ref_local_means),

@@ -420,6 +420,7 @@ class BurstPipeline:
 
 
 _main_runners = []  # [(config, ConfigWatch, HostBurstRunner)], most recently used last
+_main_runners_lock = __import__("threading").Lock()  # main() may be called from several threads
 
 
 def _drop_host_runners():
@@ -440,20 +441,21 @@ def _host_runner(config, device):
     configuration edited in place gets a new one.  At most two are kept (each holds a burst's intermediates)."""
     from .graph import ConfigWatch, HostBurstRunner
 
-    for k, (cfg, watch, runner) in enumerate(_main_runners):
-        if cfg is config and runner.device == device:
-            _main_runners.append(_main_runners.pop(k))
-            if watch.changed(config):
-                _main_runners.pop()
-                break
-            return runner
-    watch = ConfigWatch()
-    watch.changed(config)
-    runner = HostBurstRunner(config, device)
-    _main_runners.append((config, watch, runner))
-    while len(_main_runners) > 2:
-        _main_runners.pop(0)[2].close()
-    return runner
+    with _main_runners_lock:
+        for k, (cfg, watch, runner) in enumerate(_main_runners):
+            if cfg is config and runner.device == device:
+                _main_runners.append(_main_runners.pop(k))
+                if watch.changed(config):
+                    _main_runners.pop()
+                    break
+                return runner
+        watch = ConfigWatch()
+        watch.changed(config)
+        runner = HostBurstRunner(config, device)
+        _main_runners.append((config, watch, runner))
+        while len(_main_runners) > 2:
+            _main_runners.pop(0)[2].close()
+        return runner
 
 
 def main(ref_img, comp_imgs, config, *, _no_runner=False):
@@ -472,11 +474,12 @@ def main(ref_img, comp_imgs, config, *, _no_runner=False):
     if not _no_runner and torch.cuda.is_available():
         from .graph import HostBurstRunner
 
+        denoiser_enabled(config)  # derives den.enabled in place NOW: the runner's ConfigWatch snapshot then already has it
         if HostBurstRunner.usable(config, ref_img, comp_imgs):
-            out, dbg = _host_runner(config, _device())(ref_img, comp_imgs)
-            if "accumulated robustness" in dbg and dbg["accumulated robustness"] is not None:
-                dbg = dict(dbg, **{"accumulated robustness": dbg["accumulated robustness"].clone()})
-            return out.clone(), dbg
+            # (the runner keeps a burst's staging and intermediates on the device — ~6 GB at 12 MP x 20, plus 1.6 GB for the
+            # chained merge of float bursts — until the configuration object is dropped or edited; config.hip.graph: false
+            # opts out.)  The result is cloned inside the runner's lock: concurrent callers never see each other's pixels
+            return _host_runner(config, _device()).call_cloned(ref_img, comp_imgs)
     verbose = config.verbose >= 1
     debug_mode = bool(config.debug)
     debug_dict = {"robustness": [], "flow": []}

@@ -233,8 +233,10 @@ int hhsr_mono_rob_frame(const float* comp_means, int H, int W, const float* ref_
 #define HHSR_MERGE_FORCE_TILE 8     /* no x2 kernel: the 16 x 16 HR tile kernel                                  */
 #define HHSR_MERGE_FORCE_X2V1 16    /* x2: first-generation kernel (per-pixel geometry) instead of k_merge_x2    */
 /* all three merge entry points: */
-#define HHSR_SENSOR_MONO 32  /* `mode: grey`: every sample goes to channel 0 (channels 1, 2 of num / den are left as they
-                                are), covs is [H][W][2][2] read at the position itself, cfa is ignored (may be NULL);
+#define HHSR_SENSOR_MONO 32  /* `mode: grey`: every sample goes to channel 0; the per-frame entry points and the generic
+                                burst kernel leave channels 1, 2 of num / den as they are, the x2 tile kernel of
+                                hhsr_merge_burst WRITES them (0, or 0 / 0 = NaN with HHSR_MERGE_DIVIDE — what the reference's
+                                three-channel accumulators hold for a monochrome burst); covs is [H][W][2][2] read at the position itself, cfa is ignored (may be NULL);
                                 hhsr_merge_burst: scale 2 (ts % 16 == 0, even sizes) runs the LDS-staged x2 tile kernel
                                 with a per-pixel covariance window (HHSR_MERGE_LOCAL_MIN available), other scales the
                                 generic kernel                                                                     */

@@ -214,6 +214,14 @@ def test_fuzz_verdict_rules():
     # flow-sensitive values: differ with own flows, agree once the flows are the oracle's
     v, failed = run(o=bad)
     assert not failed and v["n_sens"] == 1 and v["n_rest"] == 0
+    wild = want.copy()
+    wild[100, 20, 0] += 0.3              # ... but not of any size (MAX_SENS)
+    assert run(o=wild)[1]
+    # the den floor: just above it the image bound applies, just below it the numerator bound
+    from helpers import DEN_FLOOR, MAX_OUTLIER, NUM_ERR, outlier_over
+    assert abs(DEN_FLOOR * MAX_OUTLIER - NUM_ERR) < 1e-12
+    assert outlier_over(np.array([6e-3]), np.array([1.0]))[0] and not outlier_over(np.array([4e-3]), np.array([1.0]))[0]
+    assert outlier_over(np.array([0.2]), np.array([1e-5]))[0] and not outlier_over(np.array([0.05]), np.array([1e-5]))[0]
     # flows: one flipped 2 x 2 block is one decision; its footprint is not compared
     g = oflow.copy()
     g[1, 1:3, 2:4] += 0.08
@@ -223,6 +231,11 @@ def test_fuzz_verdict_rules():
     assert not failed and v["nflip"] == 4 and v["one_cluster"]
     g[0, 0, 0] += 0.08                   # a second decision in another frame
     assert run(gflow=g, o=o2)[1]
+    g = oflow.copy()
+    g[1, 0:4, 0:6] += 0.08               # one cluster, but 24 tiles (MAX_FLIP_TILES = 16)
+    o3 = want.copy()
+    o3[: 2 * ts * 4, : 2 * ts * 6] += 0.05
+    assert run(gflow=g, o=o3)[1]
     g = oflow.copy()
     g[0, 2, 3] += 3e-4                   # an ill-conditioned ICA tile: counted, tolerated
     v, failed = run(gflow=g)
