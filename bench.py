@@ -257,8 +257,8 @@ def main():
     import atexit
 
     atexit.register(emit)
-    graphed = bool(on_gpu and any(getattr(getattr(engine, r, None), "graphs", None)
-                                  for r in ("_runner", "_runner_a", "_runner_p")))
+    graphed = bool(on_gpu and (any(getattr(getattr(engine, r, None), "graphs", None) for r in ("_runner", "_runner_p"))
+                               or getattr(engine, "_plans", None)))
     if world > 1:  # the eager section below runs collectives: every rank takes it when any rank replayed a graph
         g_any = torch.tensor([int(graphed)], dtype=torch.int32, device=dev)
         dist.all_reduce(g_any, op=dist.ReduceOp.MAX)

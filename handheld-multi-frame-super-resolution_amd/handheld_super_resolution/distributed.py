@@ -8,13 +8,22 @@ One process per GPU, two selectable strategies (`main_sharded(..., strategy=)`, 
   B. kernel estimation, robustness and the merge are local in the image plane (a few pixels of halo plus the flow)
      -> row-parallel: the output is cut into G row slabs and rank j runs steps B for ALL frames on the raw rows its
      slab needs (slab + |flow| + HALO rows), finishing its slab completely: reference frame, normalisation.
-  The only data-path exchange is ONE all-gather of the flow fields (ny x nx x 2 floats per frame: 376 kB at 12 MP, 7 MB
-  per 20-frame burst).  Host-resident frames: a rank uploads its own N/G frames whole (step A) and rows [S0, S1) of every
-  frame (step B): (N/G + N (1/G + 2 halo/H)) frames' worth of bytes instead of N.
+  The only data-path exchange is the all-gather of the flow fields (ny x nx x 2 floats per frame: 376 kB at 12 MP, 7 MB
+  per 20-frame burst).  It is PIPELINED (round 4): the burst is cut into STAGES of whole rounds (round r = frames r G ..
+  r G + G - 1, one per rank; a stage holds >= 4 frames: stage_plan) and stage s's flows are gathered and its frames'
+  step B (raw pass, robustness on the slab) runs while stage s + 1 is being aligned — step A on one HIP stream, step B
+  on another, the RCCL all-gather between them, every piece a HIP graph on replay (RowsPlan).  The sub-image extent
+  needs a bound on |flow_y| BEFORE the flows exist: the plan is captured with the bound its first (eager) burst measured
+  plus a margin, every burst checks its gathered flows against it on the device, the host reads that flag when the last
+  stage's step B has been queued (the merge is still running: nothing waits for the read) and a burst that exceeds the
+  bound is recomputed eagerly with its own measured bound, which the next capture takes over.  Slabs are UNEVEN: ranks
+  that align one frame fewer take more rows (slab_bounds with `align_cost`).
+  Host-resident frames: a rank uploads its own N/G frames whole (step A) and rows [S0, S1) of every frame (step B):
+  (N/G + N (1/G + 2 halo/H)) frames' worth of bytes instead of N.
 
 "reduce" (the north star's formulation).  Frames shard one per GPU round-robin; every rank runs the WHOLE single-GPU
   chain on its frames and merges them into float32 accumulators num / den [sH, sW, 3] (reference merge.py:432-434);
-  ONE reduce-scatter (sum) over row slabs — issued as two RCCL calls, num and den — leaves rank j with the summed
+  ONE reduce-scatter (sum) over row slabs — one RCCL call on the packed [world, 2, rows, sW, 3] buffer — leaves rank j with the summed
   accumulators of slab j, to which it adds the reference frame and normalises.  1.15 GB of accumulators per rank at
   12 MP x2 cross xGMI (per-link bound for a ring: modelled 8-10 ms against 1.1 ms of compute per rank at G = 8), so
   this strategy only pays for very long bursts; it exists so that both can be measured.  Results differ from the
@@ -57,16 +66,51 @@ def shard_indices(n_frames, rank, world):
 
 
 def slab_rows(sH, world):
-    """Rows per slab: ceil(sH / world) rounded up to SLAB_ALIGN.  All slabs have this (padded) size so that
+    """Rows per EQUAL slab: ceil(sH / world) rounded up to SLAB_ALIGN.  All slabs have this (padded) size so that
     every collective moves equal chunks; slab j covers output rows [j*rows, min((j+1)*rows, sH))."""
     rows = -(-sH // world)
     return -(-rows // SLAB_ALIGN) * SLAB_ALIGN
 
 
-def slab_bounds(sH, world):
-    """Valid (un-padded) row range [b[j], b[j+1]) of every slab."""
-    rows = slab_rows(sH, world)
-    return [min(j * rows, sH) for j in range(world + 1)]
+ALIGN_COST = 0.9  # step A of one frame costs about as much as step B of one frame over this fraction of the image
+                  # (12 MP x2, profiles/r03_kernel_trace_1stream.md: 0.24 ms against 5.1 ms / 19 frames); config.hip.align_cost
+
+
+def slab_bounds(sH, world, n_frames=0, align_cost=0.0):
+    """Valid (un-padded) row range [b[j], b[j+1]) of every slab, boundaries on multiples of SLAB_ALIGN.
+    align_cost = 0: equal slabs (strategy "reduce": the reduce-scatter moves equal chunks).  Strategy "rows" passes the
+    frame count and align_cost = rho: rank j aligns a_j = |{j, j+G, ...}| frames, and its slab is sized so that
+    a_j rho sH + rows_j n is the same for every rank — rows_j = sH ((1 + rho) / G - a_j rho / n): with 19 frames on 8 ranks
+    the three ranks that align 3 frames get 576 rows, the five that align 2 get 864 (x2 of 12 MP)."""
+    if not n_frames or align_cost <= 0.0 or world == 1:
+        rows = slab_rows(sH, world)
+        return [min(j * rows, sH) for j in range(world + 1)]
+    want = [max(0.0, sH * ((1.0 + align_cost) / world - len(range(j, n_frames, world)) * align_cost / n_frames))
+            for j in range(world)]
+    total = sum(want) or 1.0
+    b, acc = [0], 0.0
+    for j in range(world - 1):
+        acc += want[j] * sH / total
+        b.append(min(sH, max(b[-1], int(round(acc / SLAB_ALIGN)) * SLAB_ALIGN)))
+    b.append(sH)
+    return b
+
+
+def stage_plan(n_frames, world, min_frames=4):
+    """Stages of the pipelined "rows" strategy: [(first round, rounds)], whole rounds each (round r = frames r G ..
+    r G + G - 1, frame i aligned by rank i % G), at least `min_frames` frames per full stage (the robustness kernel
+    shares its pass over the reference planes among 4 frames; the batched front end wants several frames per launch).
+    min_frames >= n_frames: ONE stage = step A of every frame, one all-gather, step B (the un-pipelined form)."""
+    rounds = -(-n_frames // world) if n_frames else 0
+    per = max(1, -(-int(min_frames) // world))
+    return [(r, min(per, rounds - r)) for r in range(0, rounds, per)]
+
+
+def stage_frames(stage, n_frames, world, rank=None):
+    """Frame indices of a stage (all of them, or the ones `rank` aligns), in frame order."""
+    r0, k = stage
+    idx = range(r0 * world, min(n_frames, (r0 + k) * world))
+    return [i for i in idx if rank is None or i % world == rank]
 
 
 def sub_image_rows(r0, r1, scale, H, ts, max_flow_y, from_top=False):
@@ -95,7 +139,7 @@ class HipEngine:
         self.accumulate_r = self.denoiser_on or bool(config.robustness.save_mask)
         self.pipe = None
         self._runner = None  # HIP-graph replay of main() for device-resident bursts (graph.py)
-        self._runner_a, self._runners_b, self._flows_static = None, {}, None  # ... and of the two multi-GPU steps
+        self._plans, self._plan_seen, self._bounds = {}, {}, {}  # strategy "rows": RowsPlan per input set, measured flow bounds
         self._runner_p, self._runners_f = None, {}  # strategy "reduce": partial merge of the rank's frames / slab finish
         self._host = None  # graph.HostBurstRunner: host-resident bursts on one GPU
         self._buffers = {}  # static exchange buffers (a graph is bound to the addresses of its inputs)
@@ -139,7 +183,7 @@ class HipEngine:
         if getattr(self, "_watch", None) is None:
             self._watch = ConfigWatch()
         if self._watch.changed(self.config):
-            self._runner, self._runner_a, self._runners_b, self._flows_static = None, None, {}, None
+            self._runner, self._plans, self._plan_seen = None, {}, {}
             self._runner_p, self._runners_f = None, {}
             self._host = None
 
@@ -151,25 +195,6 @@ class HipEngine:
         self.device = self.pipe.device
         self.pipe.init_ref(ref_img, robustness=False)
         return self
-
-    def step_a(self, ref_img, my_frames):
-        """init_ref + align_frames; replayed from a HIP graph when an engine sees the same device tensors again.
-        Returns (flows [n, ny, nx, 2], the device-resident reference frame)."""
-        from .graph import GraphRunner, capturable
-
-        def fn(ref, *frames):
-            self.init_ref(ref)
-            return self.align_frames(list(frames)), self.pipe.ref
-
-        tensors = (ref_img, *my_frames)
-        if not capturable(self.config, tensors):
-            return fn(*tensors)
-        self._check_config()
-        if self._runner_a is None:
-            self._runner_a = GraphRunner(fn, ref_img.device)
-        out = self._runner_a(*tensors)
-        self.device = ref_img.device
-        return out
 
     def shape(self):
         return tuple(self.pipe.ref.shape)
@@ -189,94 +214,66 @@ class HipEngine:
         return torch.stack(flows)
 
     def merge_rows(self, comp_imgs, flows, r0, r1, max_flow_y, ref_dev=None):
-        """Step B: output rows [r0, r1) from ALL frames (flows: [N-1, ny, nx, 2]).  Returns (slab float32
-        [r1 - r0, sW, 3], accumulated robustness of the raw rows [ceil(r0 / scale), ceil(r1 / scale)) — the rows whose
-        first output row lies in the slab: a disjoint cover over the slabs — or None).  With the device-resident
-        reference frame of step_a (`ref_dev`) and device-resident frames the step is replayed from a HIP graph: the
-        gathered flows are copied into a static buffer, the flow bound is rounded up to a multiple of 8 rows (the result
-        does not depend on the halo, only the sub-image's extent does) and one graph is kept per (r0, r1, bound)."""
-        from .graph import GraphRunner, capturable
+        """Step B in one piece (eager): output rows [r0, r1) from ALL frames (flows: [N-1, ny, nx, 2]).  Returns (slab
+        float32 [r1 - r0, sW, 3], accumulated robustness of the raw rows [ceil(r0 / scale), ceil(r1 / scale)) — the rows
+        whose first output row lies in the slab: a disjoint cover over the slabs — or None)."""
+        return self._merge_rows(comp_imgs, flows, r0, r1, max_flow_y, self.pipe.ref if ref_dev is None else ref_dev)
+
+    def rows_open(self, ref_img, comp_imgs, stages, rank, world, rows, max_flow):
+        """Strategy "rows": the per-rank context main_sharded drives stage by stage (align / gather buffer / front /
+        finish).  Device-resident float32 bursts that an engine sees again are replayed from HIP graphs, pipelined over
+        two streams (RowsPlan: first call eager — it measures the flow bound —, second call captures); everything else
+        runs eagerly (EagerRows: step A per stage, the bound measured from all flows, then step B in one piece)."""
+        from .graph import capturable, _key
 
         packed = torch.is_tensor(comp_imgs)
-        tensors = (comp_imgs,) if packed else tuple(comp_imgs)
-        if ref_dev is None or flows is None or not capturable(self.config, (ref_dev, flows, *tensors)):
-            return self._merge_rows(comp_imgs, flows, r0, r1, max_flow_y, self.pipe.ref if ref_dev is None else ref_dev)
-        bound = float(math.ceil(max_flow_y / 8.0) * 8)
-        if self._flows_static is None or self._flows_static.shape != flows.shape:
-            self._flows_static = torch.empty_like(flows)
-            self._runners_b = {}
-        self._flows_static.copy_(flows)
-        key = (int(r0), int(r1), bound, packed)
-        runner = self._runners_b.get(key)
-        if runner is None:
-            if len(self._runners_b) >= 4:
-                self._runners_b.pop(next(iter(self._runners_b)))
-            runner = self._runners_b[key] = GraphRunner(
-                lambda ref, fl, *comp: self._merge_rows(comp[0] if packed else list(comp), fl, r0, r1, bound, ref),
-                ref_dev.device)
-        return runner(ref_dev, self._flows_static, *tensors)
+        tensors = (ref_img, comp_imgs) if packed else (ref_img, *comp_imgs)
+        ok = capturable(self.config, tensors) and all(t.dtype == torch.float32 and t.is_contiguous() for t in tensors) \
+            and len(comp_imgs) > 0 and rows[1] > rows[0]
+        if not ok:
+            return EagerRows(self, ref_img, comp_imgs, stages, rank, world, rows, max_flow)
+        self._check_config()
+        key = (_key(tensors), tuple(stages), rank, world, tuple(rows), None if max_flow is None else float(max_flow))
+        plan = self._plans.get(key)
+        if plan is not None:
+            return plan.open()
+        if key not in self._plan_seen:  # first burst of this input set: eager; remembers the bound it measured
+            self._plan_seen[key] = True
+            return EagerRows(self, ref_img, comp_imgs, stages, rank, world, rows, max_flow, remember=key)
+        bound = float(max_flow) if max_flow is not None else self._bounds.get(key)
+        if bound is None:  # (cannot happen: the eager call stored it)
+            return EagerRows(self, ref_img, comp_imgs, stages, rank, world, rows, max_flow, remember=key)
+        try:
+            plan = RowsPlan(self, ref_img, comp_imgs, stages, rank, world, rows, bound, check=max_flow is None, key=key)
+        except Exception as e:  # not capturable after all: stay eager for this input set
+            self._plan_error = e
+            torch.cuda.synchronize(ref_img.device)
+            self._plan_seen[key] = "failed"
+            return EagerRows(self, ref_img, comp_imgs, stages, rank, world, rows, max_flow)
+        if self._plan_seen.get(key) == "failed":
+            return EagerRows(self, ref_img, comp_imgs, stages, rank, world, rows, max_flow)
+        while len(self._plans) >= 2:  # (a plan holds a burst's intermediates of this rank)
+            self._plans.pop(next(iter(self._plans)))
+        self._plans[key] = plan
+        return plan.open()
 
     def _merge_rows(self, comp_imgs, flows, r0, r1, max_flow_y, ref_dev):
-        from .super_resolution import BurstPipeline
-        from .merge import merge, merge_ref, merge_burst, can_fuse_acc_r
-        from .utils import divide
-
-        cfg = self.config
-        H, W = self.shape()
-        sH, sW, _ = self.output_shape()
-        scale, ts = cfg.scale, self.tile_size()
-        pow2 = float(scale) in (1.0, 2.0, 4.0, 8.0)
-        # (the per-frame operator path of the denoiser has no row offset: for scales whose positions idx / scale are
-        # not exact in float32 its sub-image starts at the top of the frame, where sub-image = full-frame coordinates)
-        S0, S1, row0 = sub_image_rows(r0, r1, scale, H, ts, max_flow_y, from_top=self.denoiser_on and not pow2)
-        Hs = S1 - S0
-        sHs = int(round(scale * Hs))
-        nrows = r1 - r0
-        t0, t1 = S0 // ts, -(-S1 // ts)
-        sub = BurstPipeline(cfg, self.device)
-        sub.init_ref(ref_dev[S0:S1], alignment=False)  # device-resident rows of the replicated reference frame
-        n = len(comp_imgs)
-        # row slices = VIEWS of the full fields + the tile rows around them: the flow-irregularity weight S of the
-        # sub-image's first / last tile row is evaluated on the full field (module docstring)
         flows = flows.contiguous()
-        sub_flows = [flows[i, t0:t1] for i in range(n)]
-        sub.flow_rows = (t0, int(flows.shape[1]) - t1)
-        out = torch.empty((nrows, sW, 3), dtype=torch.float32, device=self.device)
-        acc_r = torch.zeros((Hs, W), dtype=torch.float32, device=self.device) if self.accumulate_r else None
-        L0 = int(math.ceil(r0 / scale)) - S0
-        L1 = min(Hs, int(math.ceil(r1 / scale)) - S0)
-        if self.denoiser_on:
-            # the accumulated-robustness denoiser (merge.py:223-228) needs sum_n r_n before the reference frame is
-            # merged: sequential operator path on the sub-image
-            num = torch.zeros((sHs, sW, 3), dtype=torch.float32, device=self.device)
-            den = torch.zeros_like(num)
-            for i in range(n):
-                raw, flow, covs, r = sub.process_frame(comp_imgs[i][S0:S1], acc_r, flow=sub_flows[i])
-                merge(raw, flow, covs, r, num, den, sub.cfa, cfg)
-            merge_ref(sub.ref, sub.ref_covs, num, den, sub.cfa, cfg, acc_r)
-            divide(num, den)
-            out.copy_(num[row0:row0 + nrows])
-        else:
-            fuse_acc = acc_r is not None and can_fuse_acc_r(cfg) and n > 0
-            fuse_min = sub.fuses_local_min() and (fuse_acc or acc_r is None) and row0 % SLAB_ALIGN == 0
-            frames = sub.process_frames([img[S0:S1] for img in comp_imgs], None if fuse_acc else acc_r,
-                                        fuse_local_min=fuse_min, flows=sub_flows)
-            merge_burst(frames, sub.ref, sub.ref_covs, out, None, sub.cfa, cfg, do_ref=True, divide=True,
-                        acc_r=acc_r if fuse_acc else None, rows=(row0, nrows), out_height=sHs, local_min=fuse_min,
-                        lr_row_offset=S0)
-        return out, (acc_r[L0:L1] if acc_r is not None else None)
+        b = SlabWork(self, ref_dev, r0, r1, max_flow_y, int(flows.shape[1]))
+        n = len(comp_imgs)
+        b.front([comp_imgs[i] for i in range(n)], [flows[i] for i in range(n)])
+        return b.finish()
 
     # ---- strategy "reduce": frame-sharded merge + one reduce-scatter of the accumulators ---------------------------------
-    def partial(self, ref_img, my_frames, padded_rows):
+    def partial(self, ref_img, my_frames, bounds, rows):
         """This rank's frames through the whole single-GPU chain and into raw accumulators (no reference frame, no
-        normalisation): (num, den) float32 [padded_rows, sW, 3] — the first sH rows are the image, the padding rows
-        (equal slabs for the reduce-scatter) are zero — and the rank's accumulated robustness [H, W] or None.
-        Replayed from a HIP graph for device-resident inputs like step_a."""
+        normalisation), laid out for ONE reduce-scatter: acc float32 [world, 2, rows, sW, 3] — acc[j, 0] / acc[j, 1] are
+        num / den of output rows [bounds[j], bounds[j + 1]) (one merge launch per slab; the padding rows of the equal
+        chunks stay zero) — and the rank's accumulated robustness [H, W] or None.  Replayed from a HIP graph for
+        device-resident inputs."""
         from .graph import GraphRunner, capturable
 
-        if self.denoiser_on:
-            raise NotImplementedError("strategy 'reduce' does not apply the accumulated-robustness denoiser "
-                                      "(merge.py:223-228 needs the reduced robustness before the reference frame): use 'rows'")
+        world = len(bounds) - 1
 
         def fn(ref, *frames):
             from .super_resolution import BurstPipeline
@@ -287,14 +284,18 @@ class HipEngine:
             self.device = pipe.device
             H, W = pipe.ref.shape
             sH, sW = pipe.output_size()
-            acc = torch.zeros((2, padded_rows, sW, 3), dtype=torch.float32, device=self.device)
+            acc = torch.zeros((world, 2, rows, sW, 3), dtype=torch.float32, device=self.device)
             acc_r = torch.zeros((H, W), dtype=torch.float32, device=self.device) if self.accumulate_r else None
             if frames:
                 fuse_acc = acc_r is not None and can_fuse_acc_r(cfg)
                 fuse_min = pipe.fuses_local_min() and (fuse_acc or acc_r is None)
                 fr = pipe.process_frames(list(frames), None if fuse_acc else acc_r, fuse_local_min=fuse_min)
-                merge_burst(fr, None, None, acc[0, :sH], acc[1, :sH], pipe.cfa, cfg, do_ref=False, divide=False,
-                            store_den=True, acc_r=acc_r if fuse_acc else None, local_min=fuse_min)
+                for j in range(world):
+                    b0, b1 = bounds[j], bounds[j + 1]
+                    if b1 > b0:
+                        merge_burst(fr, None, None, acc[j, 0, : b1 - b0], acc[j, 1, : b1 - b0], pipe.cfa, cfg, do_ref=False,
+                                    divide=False, store_den=True, acc_r=acc_r if fuse_acc else None, rows=(b0, b1 - b0),
+                                    out_height=sH, local_min=fuse_min)
             return acc, acc_r, pipe.ref, pipe.ref_covs
 
         tensors = (ref_img, *my_frames)
@@ -307,29 +308,303 @@ class HipEngine:
         self.device = ref_img.device
         return out
 
-    def finish_rows(self, acc_slab, r0, r1, ref_dev, ref_covs):
+    def finish_rows(self, acc_slab, r0, r1, ref_dev, ref_covs, acc_r=None):
         """Reference frame + normalisation of output rows [r0, r1) on top of the reduced accumulators
-        acc_slab [2, rows, sW, 3] (merge.py:83-233, utils.py:85): slab float32 [r1 - r0, sW, 3]."""
+        acc_slab [2, rows, sW, 3] (merge.py:83-233, utils.py:85): slab float32 [r1 - r0, sW, 3].  With the
+        accumulated-robustness denoiser (merge.py:223-228) `acc_r` is the REDUCED robustness [H, W] and the reference
+        frame goes through the sequential operator on the sub-image of the slab (like SlabWork)."""
         from .graph import GraphRunner, capturable
-        from .merge import merge_burst
+        from .merge import merge_burst, merge_ref
+        from .utils import divide
 
         cfg = self.config
         H, W = ref_dev.shape
         sH = round(cfg.scale * H)
+        n = r1 - r0
 
-        def fn(acc, ref, covs):
-            num, den = acc[0, : r1 - r0], acc[1, : r1 - r0]
+        def fn(acc, ref, covs, *rob):
+            if self.denoiser_on:
+                scale, ts = cfg.scale, self.tile_size()
+                pow2 = float(scale) in (1.0, 2.0, 4.0, 8.0)
+                S0, S1, row0 = sub_image_rows(r0, r1, scale, H, ts, 0.0, from_top=not pow2)
+                q = 1 if self.pipe.mono else 2  # covariances: one per Bayer quad (monochrome: per pixel)
+                num = torch.zeros((int(round(scale * (S1 - S0))), acc.shape[2], 3), dtype=torch.float32, device=acc.device)
+                den = torch.zeros_like(num)
+                num[row0:row0 + n] = acc[0, :n]
+                den[row0:row0 + n] = acc[1, :n]
+                merge_ref(ref[S0:S1], covs[S0 // q:S1 // q], num, den, self.pipe.cfa, cfg, rob[0][S0:S1])
+                divide(num, den)
+                return num[row0:row0 + n].contiguous()
+            num, den = acc[0, :n], acc[1, :n]
             merge_burst([], ref, covs, num, den, self.pipe.cfa, cfg, load_acc=True, do_ref=True, divide=True,
-                        rows=(r0, r1 - r0), out_height=sH)
+                        rows=(r0, n), out_height=sH)
             return num
 
-        if not capturable(cfg, (acc_slab, ref_dev, ref_covs)):
-            return fn(acc_slab, ref_dev, ref_covs)
+        tensors = (acc_slab, ref_dev, ref_covs) + ((acc_r,) if self.denoiser_on else ())
+        if not capturable(cfg, tensors):
+            return fn(*tensors)
         key = (int(r0), int(r1))
         runner = self._runners_f.get(key)
         if runner is None:
             runner = self._runners_f[key] = GraphRunner(fn, ref_dev.device)
-        return runner(acc_slab, ref_dev, ref_covs)
+        return runner(*tensors)
+
+
+class SlabWork:
+    """Step B of one rank as pieces: sub-image setup (reference-frame state of the raw rows [S0, S1) the slab depends on),
+    front(frames, flows) for any subset of the frames — raw pass + robustness on the sub-image, or with the denoiser the
+    sequential per-frame merge — and finish(): fused merge + reference frame + normalisation of the slab.  The eager path
+    calls front() once with every frame; RowsPlan captures setup / one front() per stage / finish() as separate graphs."""
+
+    def __init__(self, eng, ref_dev, r0, r1, max_flow_y, ny_full, ref_wait=True):
+        from .super_resolution import BurstPipeline
+        from .merge import can_fuse_acc_r
+
+        cfg = self.cfg = eng.config
+        self.eng = eng
+        H, W = ref_dev.shape
+        scale, ts = cfg.scale, eng.tile_size()
+        sW = round(scale * W)
+        pow2 = float(scale) in (1.0, 2.0, 4.0, 8.0)
+        # (the per-frame operator path of the denoiser has no row offset: for scales whose positions idx / scale are
+        # not exact in float32 its sub-image starts at the top of the frame, where sub-image = full-frame coordinates)
+        S0, S1, row0 = sub_image_rows(r0, r1, scale, H, ts, max_flow_y, from_top=eng.denoiser_on and not pow2)
+        self.S0, self.S1, self.row0, self.nrows = S0, S1, row0, r1 - r0
+        Hs = S1 - S0
+        self.sHs = int(round(scale * Hs))
+        self.t0, self.t1 = S0 // ts, -(-S1 // ts)
+        dev = ref_dev.device
+        sub = self.sub = BurstPipeline(cfg, dev)
+        sub.ref_wait = ref_wait
+        sub.init_ref(ref_dev[S0:S1], alignment=False)  # device-resident rows of the replicated reference frame
+        # row slices = VIEWS of the full fields + the tile rows around them: the flow-irregularity weight S of the
+        # sub-image's first / last tile row is evaluated on the full field (module docstring)
+        sub.flow_rows = (self.t0, int(ny_full) - self.t1)
+        self.out = torch.empty((self.nrows, sW, 3), dtype=torch.float32, device=dev)
+        self.acc_r = torch.zeros((Hs, W), dtype=torch.float32, device=dev) if eng.accumulate_r else None
+        self.L0 = int(math.ceil(r0 / scale)) - S0
+        self.L1 = min(Hs, int(math.ceil(r1 / scale)) - S0)
+        self.frames = []
+        if eng.denoiser_on:
+            # the accumulated-robustness denoiser (merge.py:223-228) needs sum_n r_n before the reference frame is
+            # merged: sequential operator path on the sub-image
+            self.num = torch.zeros((self.sHs, sW, 3), dtype=torch.float32, device=dev)
+            self.den = torch.zeros_like(self.num)
+        else:
+            self.fuse_acc = self.acc_r is not None and can_fuse_acc_r(cfg)
+            self.fuse_min = sub.fuses_local_min() and (self.fuse_acc or self.acc_r is None) and row0 % SLAB_ALIGN == 0
+
+    def front(self, imgs, flows):
+        """`imgs`: full frames (their rows [S0, S1) are used); `flows`: their FULL flow fields [ny, nx, 2] (views welcome)."""
+        from .merge import merge
+
+        sub, S0, S1 = self.sub, self.S0, self.S1
+        sub_flows = [f[self.t0:self.t1] for f in flows]
+        if self.eng.denoiser_on:
+            for img, fl in zip(imgs, sub_flows):
+                raw, flow, covs, r = sub.process_frame(img[S0:S1], self.acc_r, flow=fl)
+                merge(raw, flow, covs, r, self.num, self.den, sub.cfa, self.cfg)
+        elif imgs:
+            self.frames += sub.process_frames([img[S0:S1] for img in imgs], None if self.fuse_acc else self.acc_r,
+                                              fuse_local_min=self.fuse_min, flows=sub_flows)
+
+    def finish(self):
+        from .merge import merge_ref, merge_burst
+        from .utils import divide
+
+        sub, cfg = self.sub, self.cfg
+        if self.eng.denoiser_on:
+            merge_ref(sub.ref, sub.ref_covs, self.num, self.den, sub.cfa, cfg, self.acc_r)
+            divide(self.num, self.den)
+            self.out.copy_(self.num[self.row0:self.row0 + self.nrows])
+        else:
+            merge_burst(self.frames, sub.ref, sub.ref_covs, self.out, None, sub.cfa, cfg, do_ref=True, divide=True,
+                        acc_r=self.acc_r if (self.fuse_acc and self.frames) else None, rows=(self.row0, self.nrows),
+                        out_height=self.sHs, local_min=self.fuse_min, lr_row_offset=self.S0)
+        return self.out, (self.acc_r[self.L0:self.L1] if self.acc_r is not None else None)
+
+
+class EagerRows:
+    """Strategy "rows" without graphs, for any engine with init_ref / align_frames / merge_rows (HipEngine on host frames,
+    first bursts, timers, debug; the NumPy engine of the CPU tests): step A stage by stage, then — the flow bound is
+    MEASURED here, so every flow has to be known — step B in one piece."""
+
+    streams = None  # collectives on the current stream
+
+    def __init__(self, eng, ref_img, comp_imgs, stages, rank, world, rows, max_flow, remember=None):
+        self.eng, self.ref_img, self.comp_imgs = eng, ref_img, comp_imgs
+        self.stages, self.rank, self.world, self.rows, self.max_flow = stages, rank, world, rows, max_flow
+        self.remember = remember
+        self.gathered = []
+        self.ready = False
+
+    def _ensure_ref(self):
+        if not self.ready:
+            self.eng.init_ref(self.ref_img)
+            self.ready = True
+
+    def align(self, s):
+        self._ensure_ref()
+        mine = stage_frames(self.stages[s], len(self.comp_imgs), self.world, self.rank)
+        local = self.eng.align_frames([self.comp_imgs[i] for i in mine])  # [len(mine), ny, nx, 2]
+        padded = torch.zeros((self.stages[s][1], *local.shape[1:]), dtype=local.dtype, device=local.device)
+        padded[: local.shape[0]] = local
+        return padded
+
+    def gather_buffer(self, s, like):
+        return torch.empty((self.world, *like.shape), dtype=like.dtype, device=like.device)
+
+    def front(self, s, gathered):
+        self.gathered.append(gathered)
+
+    def finish(self):
+        self._ensure_ref()
+        eng, n = self.eng, len(self.comp_imgs)
+        H, W = eng.shape()
+        r0, r1 = self.rows
+        flows, extra, max_flow = None, {}, self.max_flow
+        if n:
+            # frame i was aligned by rank i % world in round i // world: slot (i // world - first round) of its stage
+            flows = torch.cat([g.transpose(0, 1).reshape(-1, *g.shape[2:]) for g in self.gathered])[:n].contiguous()
+            if max_flow is None:
+                max_flow = float(flows[..., 1].abs().max())                     # the one host read of the eager step
+                if not math.isfinite(max_flow):
+                    max_flow = float(H)
+                if self.remember is not None:  # the bound the captured plan of this input set will use
+                    eng._bounds[self.remember] = min(float(H), 1.25 * max_flow + 2.0)
+            else:  # caller's bound: no host read; the check stays on the device
+                extra["flow_bound_exceeded"] = ~(flows[..., 1].abs().amax() <= float(max_flow))
+        max_flow = 0.0 if max_flow is None else float(max_flow)
+        slab, acc_r = (eng.merge_rows(self.comp_imgs, flows, r0, r1, max_flow) if r1 > r0 else (None, None))
+        self.device = flows.device if flows is not None else (slab.device if slab is not None else torch.device("cpu"))
+        return slab, acc_r, extra, False
+
+
+_plan_streams = {}  # device index -> the step-A stream of every RowsPlan of the process (step B: graph.shared_streams()[0])
+
+
+class RowsPlan:
+    """Strategy "rows" of one rank for one set of device-resident float32 inputs as HIP graphs on TWO streams:
+
+        s_a:  g_ref_a (reference alignment state)   g_a[0]   g_a[1]   g_a[2] ...          (step A of the rank's frames)
+        RCCL:                                          all-gather 0  all-gather 1 ...       (flows of a stage: G x k x 376 kB)
+        s_b:  g_ref_b (reference state of the slab's rows)      g_b[0]    g_b[1] ...  g_fin (raw pass + robustness of a
+                                                                                           stage's frames on the slab; merge)
+
+    so the latency-bound step-A kernels of stage s + 1 (barrier-bound FFT phases, coarse pyramid levels) run next to the
+    VALU-bound step-B kernels of stage s, and no stream ever waits for the host.  The sub-image extent is fixed at capture
+    (`bound` on |flow_y|, rounded up to 8 rows); every g_b checks its gathered flows against it on the device and
+    finish() reads the flag once the merge has been queued — exceeded: the caller recomputes the burst eagerly."""
+
+    def __init__(self, eng, ref, comp_imgs, stages, rank, world, rows, bound, check, key):
+        from . import _lib
+        from .graph import shared_streams
+        from .super_resolution import BurstPipeline, _stream_pool
+        from .utils_image import _grey_plan, _grey_plans
+
+        cfg, dev = eng.config, ref.device
+        self.eng, self.key, self.check, self.stages, self.world, self.rank = eng, key, check, stages, world, rank
+        n, G = len(comp_imgs), world
+        comps = [comp_imgs[i] for i in range(n)]
+        self.keep = (ref, comp_imgs)
+        self.bound = float(math.ceil(float(bound) / 8.0) * 8)
+        self.device = dev
+        idx = dev.index if dev.index is not None else torch.cuda.current_device()
+        self.s_b = shared_streams(dev)[0]
+        if idx not in _plan_streams:
+            _plan_streams[idx] = torch.cuda.Stream(dev)
+        self.s_a = _plan_streams[idx]
+        r0, r1 = rows
+        H, W = ref.shape
+        with torch.cuda.device(dev):
+            pipe = self.pipe = BurstPipeline(cfg, dev)
+            pipe.ref_wait = False  # the pieces are separate captures: their order is the order of the replays on s_a / s_b
+            ns = pipe._n_streams(None)
+            pool = _stream_pool.setdefault(idx, [])
+            if len(pool) < ns:
+                pool += [torch.cuda.Stream(dev) for _ in range(ns - len(pool))]
+            if cfg.grey_method == "FFT" and not pipe.mono:  # plans allocate: they have to exist before their stream is captured
+                for st in (self.s_a, *pool[:ns]):
+                    with torch.cuda.stream(st):
+                        _grey_plan(H, W, dev, _lib.MAX_BATCH)
+            torch.cuda.synchronize(dev)
+            mode = dict(capture_error_mode="thread_local")
+            self.g_ref_a = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self.g_ref_a, stream=self.s_a, **mode):
+                pipe.init_ref(ref, robustness=False)
+            eng.pipe, eng.device = pipe, dev
+            ny, nx = pipe.flow_grid()
+            self.local, self.gath, self.g_a = [], [], []
+            for st in stages:
+                mine = stage_frames(st, n, G, rank)
+                loc = torch.zeros((st[1], ny, nx, 2), dtype=torch.float32, device=dev)
+                self.local.append(loc)
+                self.gath.append(torch.zeros((G, st[1], ny, nx, 2), dtype=torch.float32, device=dev))
+                g = None
+                if mine:
+                    g = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(g, stream=self.s_a, **mode):
+                        loc[: len(mine)].copy_(eng.align_frames([comps[i] for i in mine]))
+                self.g_a.append(g)
+            self.flag = torch.zeros((1,), dtype=torch.bool, device=dev)
+            self.flag_host = torch.zeros((1,), dtype=torch.bool).pin_memory()
+            self.g_ref_b = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self.g_ref_b, stream=self.s_b, **mode):
+                self.flag.zero_()
+                work = self.work = SlabWork(eng, ref, r0, r1, self.bound, ny, ref_wait=False)
+            self.g_b = []
+            for st, gat in zip(stages, self.gath):
+                fr = stage_frames(st, n, G)
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g, stream=self.s_b, **mode):
+                    self.flag.logical_or_(~(gat[..., 1].abs().amax() <= self.bound))
+                    work.front([comps[i] for i in fr], [gat[i % G, i // G - st[0]] for i in fr])
+                self.g_b.append(g)
+            self.g_fin = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self.g_fin, stream=self.s_b, **mode):
+                self.out, self.acc_r = work.finish()
+            self.e_flag = torch.cuda.Event()
+            self.plans = list(_grey_plans.values())  # the graphs hold the FFT plans' spectrum buffers: keep them alive
+        self.streams = (self.s_a, self.s_b)
+
+    def open(self):
+        self.cur = cur = torch.cuda.current_stream(self.device)
+        self.s_a.wait_stream(cur)
+        self.s_b.wait_stream(cur)
+        with torch.cuda.stream(self.s_a):
+            self.g_ref_a.replay()
+        with torch.cuda.stream(self.s_b):
+            self.g_ref_b.replay()
+        self.eng.pipe, self.eng.device = self.pipe, self.device
+        return self
+
+    def align(self, s):
+        if self.g_a[s] is not None:
+            with torch.cuda.stream(self.s_a):
+                self.g_a[s].replay()
+        return self.local[s]
+
+    def gather_buffer(self, s, like):
+        return self.gath[s]
+
+    def front(self, s, gathered):
+        with torch.cuda.stream(self.s_b):
+            self.g_b[s].replay()
+
+    def finish(self):
+        with torch.cuda.stream(self.s_b):
+            if self.check:
+                self.flag_host.copy_(self.flag, non_blocking=True)
+                self.e_flag.record(self.s_b)
+            self.g_fin.replay()
+        self.cur.wait_stream(self.s_a)
+        self.cur.wait_stream(self.s_b)
+        if self.check:
+            self.e_flag.synchronize()  # (the flag is known when the last stage's flows are there: the merge is still running)
+            if bool(self.flag_host[0]):
+                return None, None, {}, True
+            return self.out, self.acc_r, {}, False
+        return self.out, self.acc_r, {"flow_bound_exceeded": self.flag[0]}, False
 
 
 def _staged(t, group):
@@ -345,8 +620,41 @@ def _all_gather(t, world, group):
     return out.to(t.device)
 
 
+def _all_gather_stage(out, src, world, group, streams=None):
+    """out [world, *src.shape] <- every rank's src (one stage's flow fields).  `streams` = (producer, consumer) HIP
+    streams of a RowsPlan: RCCL reads `src` once the producer stream has written it and only the CONSUMER stream waits
+    for the collective — the producer goes on aligning the next stage.  None: everything on the current stream.
+    Host-only backends (gloo: CPU tests, ranks sharing one GPU) stage through host memory."""
+    if world == 1 and not (dist.is_available() and dist.is_initialized()):
+        out.copy_(src.unsqueeze(0))
+        return
+    if src.is_cuda and dist.get_backend(group) == "nccl":
+        if streams is None:
+            dist.all_gather_into_tensor(out, src, group=group)
+            return
+        with torch.cuda.stream(streams[0]):
+            work = dist.all_gather_into_tensor(out, src, group=group, async_op=True)
+        with torch.cuda.stream(streams[1]):
+            work.wait()  # (a stream-level wait: the host does not block)
+        return
+    if src.is_cuda and streams is not None:
+        with torch.cuda.stream(streams[0]):
+            host = src.cpu()
+    else:
+        host = src.cpu() if src.is_cuda else src
+    parts = torch.empty((world, *host.shape), dtype=host.dtype)
+    dist.all_gather(list(parts.unbind(0)), host.contiguous(), group=group)
+    if out.is_cuda and streams is not None:
+        with torch.cuda.stream(streams[1]):
+            out.copy_(parts)
+    else:
+        out.copy_(parts)
+
+
 def _gather(t, dst, world, group):
     """Equal-size gather of `t` to global rank `dst`; returns the stacked tensor there, None elsewhere."""
+    if not (dist.is_available() and dist.is_initialized()):
+        return t.unsqueeze(0)
     me = dist.get_rank()
     staged = _staged(t, group)
     src = t.cpu() if staged else t.contiguous()
@@ -358,27 +666,29 @@ def _gather(t, dst, world, group):
 
 
 def _reduce_scatter_rows(acc, world, group, buffers=None):
-    """acc [2, world * rows, sW, 3] -> this rank's summed slab [2, rows, sW, 3].  RCCL: reduce-scatter over xGMI (two
-    calls: num, den) into a buffer that is kept across bursts (`buffers`: the engine's dict — the finishing step is a HIP
-    graph bound to its address); host backends (gloo, CPU tests) have no reduce-scatter: all-reduce + slice."""
-    rows = acc.shape[1] // world
-    rank = dist.get_rank(group)
+    """acc [world, 2, rows, sW, 3] (chunk j = num / den of slab j) -> this rank's summed slab [2, rows, sW, 3].  RCCL: ONE
+    reduce-scatter over xGMI into a buffer that is kept across bursts (`buffers`: the engine's dict — the finishing step
+    is a HIP graph bound to its address); host backends (gloo, CPU tests) have no reduce-scatter: all-reduce + slice."""
+    rank = dist.get_rank(group) if dist.is_available() and dist.is_initialized() else 0
+    if not (dist.is_available() and dist.is_initialized()):
+        return acc[0]
     if acc.is_cuda and dist.get_backend(group) == "nccl":
-        shape = (2, rows, *acc.shape[2:])
+        shape = tuple(acc.shape[1:])
         out = buffers.get("rs_out") if buffers is not None else None
         if out is None or tuple(out.shape) != shape or out.device != acc.device:
             out = torch.empty(shape, dtype=acc.dtype, device=acc.device)
             if buffers is not None:
                 buffers["rs_out"] = out
-        for k in range(2):
-            dist.reduce_scatter_tensor(out[k], acc[k], op=dist.ReduceOp.SUM, group=group)
+        dist.reduce_scatter_tensor(out, acc, op=dist.ReduceOp.SUM, group=group)
         return out
     host = acc.cpu() if acc.is_cuda else acc.clone()
     dist.all_reduce(host, op=dist.ReduceOp.SUM, group=group)
-    return host[:, rank * rows:(rank + 1) * rows].contiguous().to(acc.device)
+    return host[rank].contiguous().to(acc.device)
 
 
 def _all_reduce(t, group):
+    if not (dist.is_available() and dist.is_initialized()):
+        return t
     if t.is_cuda and dist.get_backend(group) != "nccl":
         h = t.cpu()
         dist.all_reduce(h, op=dist.ReduceOp.SUM, group=group)
@@ -396,7 +706,8 @@ def _strategy(config, strategy):
     return strategy
 
 
-def main_sharded(ref_img, comp_imgs, config, group=None, engine=None, gather=True, max_flow=None, strategy=None):
+def main_sharded(ref_img, comp_imgs, config, group=None, engine=None, gather=True, max_flow=None, strategy=None,
+                 force_sharded=False):
     """Multi-GPU equivalent of main() (see the module docstring).
 
     gather=True : returns (output [sH, sW, 3], debug_dict) on rank 0 and (None, {}) on the other ranks;
@@ -407,22 +718,25 @@ def main_sharded(ref_img, comp_imgs, config, group=None, engine=None, gather=Tru
     inspect later: True = some flow left the halo, rows near slab seams are then not the single-GPU result); default:
     measured from the gathered flow fields — the one device-to-host read of a scalar of the step, after which the
     sub-image extent is rounded up to multiples of 8 rows so that the captured step-B graph is reused from burst to
-    burst.  Works un-initialised / with world_size 1 (then it IS main())."""
+    burst.  Works un-initialised / with world_size 1 (then it IS main(), unless `force_sharded` sends the one rank through
+    the sharded code path — stages, collectives, slab finish — e.g. to run the RCCL call sites on a one-GPU box)."""
     world = dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
     rank = dist.get_rank(group) if world > 1 else 0
     eng = engine if engine is not None else HipEngine(config)
     n = len(comp_imgs)
-    if world == 1:
+    if world == 1 and not force_sharded:
         out, debug = eng.single(ref_img, comp_imgs)
         if not gather:
             debug = dict(debug, rows=(0, int(out.shape[0])))
         return out, debug
-    if config.mode != "bayer":
-        # the reference's one-channel robustness reads the statistics of row y / 2 for row y (robustness.py:358 with the
-        # same-size map of :337-343): a row slab is not self-contained there, so monochrome bursts run on one GPU
-        raise NotImplementedError("mode 'grey' is not sharded over GPUs (its robustness is not row-local); use main()")
     root = dist.get_global_rank(group, 0) if group is not None else 0
     strategy = _strategy(config, strategy)
+    if config.mode != "bayer":
+        # the reference's one-channel robustness reads the statistics of row y / 2 for row y (robustness.py:358 with the
+        # same-size map of :337-343): a row slab is not self-contained there.  Monochrome bursts therefore always shard by
+        # FRAMES ("reduce": every rank runs whole frames; only the reference frame's merge and the normalisation, which
+        # are row-local in this mode too, are done per slab)
+        strategy = "reduce"
     mine = shard_indices(n, rank, world)
     want_acc = bool(getattr(eng, "accumulate_r", False))
     debug = {"robustness": [], "flow": []}
@@ -435,51 +749,56 @@ def main_sharded(ref_img, comp_imgs, config, group=None, engine=None, gather=Tru
         rows = slab_rows(sH, world)
         bounds = slab_bounds(sH, world)
         r0, r1 = bounds[rank], bounds[rank + 1]
-        acc, acc_r_part, ref_dev, ref_covs = eng.partial(ref_img, [comp_imgs[i] for i in mine], world * rows)
-        red = _reduce_scatter_rows(acc, world, group, getattr(eng, "_buffers", None))                   # [2, rows, sW, 3]: this rank's slab, summed
-        if r1 > r0:
-            slab = eng.finish_rows(red, r0, r1, ref_dev, ref_covs)
+        acc, acc_r_part, ref_dev, ref_covs = eng.partial(ref_img, [comp_imgs[i] for i in mine], bounds, rows)
+        red = _reduce_scatter_rows(acc, world, group, getattr(eng, "_buffers", None))   # [2, rows, sW, 3]: this rank's slab, summed
         if want_acc:
             acc_full = _all_reduce(acc_r_part, group)                       # [H, W], 48 MB at 12 MP
+        if r1 > r0:
+            # (the accumulated-robustness denoiser reads the REDUCED robustness when it merges the reference frame)
+            slab = (eng.finish_rows(red, r0, r1, ref_dev, ref_covs, acc_full) if getattr(eng, "denoiser_on", False)
+                    else eng.finish_rows(red, r0, r1, ref_dev, ref_covs))
+        if want_acc:
             a0, a1 = int(math.ceil(r0 / config.scale)), min(H, int(math.ceil(r1 / config.scale)))
             acc_r = acc_full[a0:a1] if r1 > r0 else None
         dev = acc.device
     else:
-        # ---- A: frame-parallel alignment, then ONE all-gather of the flow fields -----------------------------------
-        per_rank = -(-n // world) if n else 0
-        flows, ref_dev = None, None
-        if hasattr(eng, "step_a"):  # reference-frame state + alignment of this rank's frames (a HIP graph on replay)
-            local, ref_dev = eng.step_a(ref_img, [comp_imgs[i] for i in mine])
-        else:
-            eng.init_ref(ref_img)
-            local = eng.align_frames([comp_imgs[i] for i in mine]) if n else None  # [len(mine), ny, nx, 2]
-        sH, sW, _ = eng.output_shape()
-        H, W = eng.shape()
-        if max_flow is None:
-            hip = config.get("hip", None) if hasattr(config, "get") else None
-            max_flow = hip.get("max_flow", None) if hip is not None else None
-        if n:
-            padded = torch.zeros((per_rank, *local.shape[1:]), dtype=local.dtype, device=local.device)
-            padded[: local.shape[0]] = local
-            allf = _all_gather(padded, world, group)                            # [world, per_rank, ny, nx, 2]
-            # frame i was aligned by rank i % world as its (i // world)-th frame
-            flows = allf.transpose(0, 1).reshape(per_rank * world, *local.shape[1:])[:n]
-            if max_flow is None:
-                max_flow = float(flows[..., 1].abs().max())                     # the one host read of the step
-                if not math.isfinite(max_flow):
-                    max_flow = float(H)
-            else:  # caller's bound: no host read; the check stays on the device
-                debug["flow_bound_exceeded"] = ~(flows[..., 1].abs().amax() <= float(max_flow))
-        max_flow = 0.0 if max_flow is None else float(max_flow)
-
-        # ---- B: row-parallel kernels + robustness + merge + reference frame + normalisation ------------------------
-        rows = slab_rows(sH, world)
-        bounds = slab_bounds(sH, world)
+        # ---- A: frame-parallel alignment, stage by stage, each stage's flows all-gathered; B: row-parallel kernels +
+        # robustness of the stage's frames on this rank's slab as soon as they are there; then merge + reference frame +
+        # normalisation of the slab (HipEngine on device-resident bursts: RowsPlan, pipelined over two streams)
+        H, W = tuple(ref_img.shape)
+        sH, sW = round(config.scale * H), round(config.scale * W)
+        hip = config.get("hip", None) if hasattr(config, "get") else None
+        if max_flow is None and hip is not None:
+            max_flow = hip.get("max_flow", None)
+        cost = float(hip.get("align_cost", ALIGN_COST)) if hip is not None else ALIGN_COST
+        stages = stage_plan(n, world, int(hip.get("stage_frames", 4)) if hip is not None else 4)
+        bounds = slab_bounds(sH, world, n, cost)
+        rows = max(b1 - b0 for b0, b1 in zip(bounds[:-1], bounds[1:]))  # (padded chunk of the optional gather)
         r0, r1 = bounds[rank], bounds[rank + 1]
-        if r1 > r0:
-            slab, acc_r = (eng.merge_rows(comp_imgs, flows, r0, r1, max_flow, ref_dev=ref_dev) if ref_dev is not None
-                           else eng.merge_rows(comp_imgs, flows, r0, r1, max_flow))
-        dev = flows.device if flows is not None else (slab.device if slab is not None else torch.device("cpu"))
+
+        def run(ctx):
+            for st in range(len(stages)):
+                local = ctx.align(st)
+                out_buf = ctx.gather_buffer(st, local)
+                _all_gather_stage(out_buf, local, world, group, ctx.streams)
+                ctx.front(st, out_buf)
+            return ctx.finish()
+
+        open_ = getattr(eng, "rows_open", None)
+        ctx = open_(ref_img, comp_imgs, stages, rank, world, (r0, r1), max_flow) if open_ is not None else \
+            EagerRows(eng, ref_img, comp_imgs, stages, rank, world, (r0, r1), max_flow)
+        slab, acc_r, extra, retry = run(ctx)
+        if retry:
+            # some flow of this burst left the halo the captured plan was sized for (every rank sees the same gathered
+            # flows, so every rank gets here): recompute eagerly with the measured bound; the next capture takes it over
+            key = ctx.key
+            eng._plans.pop(key, None)
+            eng._plan_seen[key] = True
+            ctx = EagerRows(eng, ref_img, comp_imgs, stages, rank, world, (r0, r1), None, remember=key)
+            slab, acc_r, extra, _ = run(ctx)
+            extra = dict(extra, flow_bound_recomputed=True)
+        debug.update(extra)
+        dev = getattr(ctx, "device", None) or (slab.device if slab is not None else torch.device("cpu"))
     debug["rows"] = (r0, r1)
     if not gather:
         if acc_r is not None:
@@ -500,7 +819,10 @@ def main_sharded(ref_img, comp_imgs, config, group=None, engine=None, gather=Tru
         acc_all = _gather(a_send, root, world, group)
     if rank != 0:
         return None, {}
-    out = gathered.view(world * rows, sW, 3)[:sH]
+    if all(bounds[j + 1] - bounds[j] == rows for j in range(world - 1)):  # equal slabs: the padded chunks are the image
+        out = gathered.view(world * rows, sW, 3)[:sH]
+    else:
+        out = torch.cat([gathered[j, : bounds[j + 1] - bounds[j]] for j in range(world)])
     debug = {"robustness": [], "flow": []}
     if want_acc and acc_full is not None:
         debug["accumulated robustness"] = acc_full

@@ -104,6 +104,10 @@ class BurstPipeline:
         # (before, after): the flow fields handed to this pipeline are row slices (views) of larger fields with that many
         # tile rows around them — the sub-image pipelines of distributed.py; see robustness.compute_s
         self.flow_rows = (0, 0)
+        # False: the side streams do not wait for the reference-frame events — the caller orders the reference precompute
+        # before the frames itself (distributed.RowsPlan captures them as separate graphs: an event recorded in one
+        # capture cannot be waited for in another)
+        self.ref_wait = True
         self._batch = (True if hip is None else bool(hip.get("batch", True))) \
             and (self.mono or self.grey_method == "FFT") and config.verbose < 2
 
@@ -404,7 +408,7 @@ class BurstPipeline:
         for i in range(n):
             s = pool[i % n_streams]
             with torch.cuda.stream(s):
-                f = work(i, self._ref_ready)
+                f = work(i, self._ref_ready if self.ref_wait else None)
             for t in _tensors(f):
                 t.record_stream(main)  # consumed by the merge on the caller's stream (raw too: it is allocated on
                 # the side stream when the frame was uploaded / converted there)

@@ -89,23 +89,29 @@ class OracleEngine:
 
 
     # ---- strategy "reduce" --------------------------------------------------------------------------------------------
-    def partial(self, ref, my_frames, padded_rows):
+    def partial(self, ref, my_frames, bounds, rows):
         cfg = self.cfg
         self.init_ref(ref)
         H, W = self.ref.shape
         sH, sW, _ = self.output_shape()
         stats = oracle.init_robustness(self.ref, self.cfa, self.wb, cfg)
-        acc = np.zeros((2, padded_rows, sW, 3), np.float32)
+        num = np.zeros((sH, sW, 3), np.float32)
+        den = np.zeros_like(num)
         acc_r = np.zeros((H, W), np.float32)
         for img in my_frames:
             img = np.asarray(img, np.float32)
             flow = oracle.align(*self.al, oracle.compute_grey_images(img, "FFT"), cfg)
             r = oracle.compute_robustness(img, *stats, flow, self.cfa, self.wb, self.curves, cfg)
             acc_r += r
-            oracle.merge(img, flow, oracle.estimate_kernels(img, cfg), r, acc[0, :sH], acc[1, :sH], self.cfa, cfg)
+            oracle.merge(img, flow, oracle.estimate_kernels(img, cfg), r, num, den, self.cfa, cfg)
+        world = len(bounds) - 1
+        acc = np.zeros((world, 2, rows, sW, 3), np.float32)  # chunk j = num / den of slab j (one reduce-scatter)
+        for j in range(world):
+            b0, b1 = bounds[j], bounds[j + 1]
+            acc[j, 0, : b1 - b0], acc[j, 1, : b1 - b0] = num[b0:b1], den[b0:b1]
         return torch.from_numpy(acc), torch.from_numpy(acc_r), self.ref, oracle.estimate_kernels(self.ref, cfg)
 
-    def finish_rows(self, acc_slab, r0, r1, ref, ref_covs):
+    def finish_rows(self, acc_slab, r0, r1, ref, ref_covs, acc_r=None):
         cfg = self.cfg
         sH, sW, _ = self.output_shape()
         num = np.zeros((sH, sW, 3), np.float32)
@@ -142,13 +148,15 @@ class SeamEngine(OracleEngine):
         return torch.from_numpy(fl)
 
 
-def _worker(rank, world, port, out_path, strategy="rows", seam=False, n_comp=3):
+def _worker(rank, world, port, out_path, strategy="rows", seam=False, n_comp=3, hip=None):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         ref, comp, cfg = _burst(seam)
         comp = comp[:n_comp]
+        if hip:
+            cfg.hip = hip
         eng = OracleEngine(cfg)
         if seam:  # frame 1 of the burst is aligned by rank 1 % world as its (1 // world)-th frame
             eng = SeamEngine(cfg)
@@ -175,6 +183,27 @@ def test_slab_bounds():
     assert hdist.slab_bounds(100, 8) == [0, 96, 100, 100, 100, 100, 100, 100, 100]  # trailing slabs may be empty
 
 
+def test_uneven_slabs_and_stages():
+    """Strategy "rows": ranks that align one frame fewer take more rows; stages are whole rounds of >= 4 frames."""
+    b = hdist.slab_bounds(6000, 8, 19, 0.9)
+    assert b[0] == 0 and b[-1] == 6000 and all(x % 96 == 0 for x in b[:-1]) and b == sorted(b)
+    sizes = [b1 - b0 for b0, b1 in zip(b[:-1], b[1:])]
+    assert max(sizes[:3]) < min(sizes[3:])          # ranks 0-2 align 3 frames, ranks 3-7 two
+    # the modelled per-rank cost a_j rho sH + rows_j n is level to within one slab-alignment step
+    cost = [len(range(j, 19, 8)) * 0.9 * 6000 + sizes[j] * 19 for j in range(8)]
+    assert max(cost) - min(cost) <= 2 * 96 * 19
+    assert hdist.slab_bounds(6000, 8, 19, 0.0) == hdist.slab_bounds(6000, 8)
+    assert hdist.slab_bounds(6000, 1, 19, 0.9) == [0, 6000]
+    assert hdist.stage_plan(19, 8) == [(0, 1), (1, 1), (2, 1)]
+    assert hdist.stage_plan(19, 2) == [(0, 2), (2, 2), (4, 2), (6, 2), (8, 2)]
+    assert hdist.stage_plan(19, 8, 100) == [(0, 3)] and hdist.stage_plan(0, 4) == []
+    assert hdist.stage_frames((2, 1), 19, 8) == [16, 17, 18] and hdist.stage_frames((0, 2), 19, 2, 1) == [1, 3]
+    for n, g in ((19, 8), (19, 3), (3, 8), (7, 2)):     # every frame in exactly one stage, aligned by exactly one rank
+        st = hdist.stage_plan(n, g)
+        assert sorted(i for s_ in st for i in hdist.stage_frames(s_, n, g)) == list(range(n))
+        assert sorted(i for s_ in st for r in range(g) for i in hdist.stage_frames(s_, n, g, r)) == list(range(n))
+
+
 def test_shard_indices():
     assert hdist.shard_indices(19, 0, 8) == [0, 8, 16]
     assert hdist.shard_indices(19, 7, 8) == [7, 15]
@@ -197,6 +226,20 @@ def test_sharded_equals_sequential(tmp_path, world):
     # every pixel a slab depends on lies >= 8 rows inside its sub-image: the row-sharded result is the sequential one,
     # bit for bit (no partial sums are exchanged, so there is no summation-order difference either)
     assert np.nanmax(d) == 0.0
+    assert np.array_equal(got["acc_r"], dbg["accumulated robustness"].astype(np.float32))
+
+
+@pytest.mark.timeout(300)
+def test_staged_gathers_equal_sequential(tmp_path):
+    """config.hip.stage_frames = 1: every round is its own stage (two all-gathers for 3 frames on 2 ranks, the second
+    one with a rank that has no frame left) — same bits as one gather of everything."""
+    out_path = str(tmp_path / "out.npz")
+    mp.spawn(_worker, args=(2, _free_port(), out_path, "rows", False, 3, {"stage_frames": 1, "align_cost": 0.0}),
+             nprocs=2, join=True)
+    got = np.load(out_path)
+    ref, comp, cfg = _burst()
+    want, dbg = oracle.main(ref, comp, cfg)
+    assert np.array_equal(got["out"], want, equal_nan=True)
     assert np.array_equal(got["acc_r"], dbg["accumulated robustness"].astype(np.float32))
 
 
