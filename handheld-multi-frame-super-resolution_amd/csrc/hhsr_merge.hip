@@ -1827,6 +1827,374 @@ __global__ void __launch_bounds__(256, HHSR_XS_OCC) k_merge_xs(BurstArgs a, Geo 
     }
 }
 
+// ---- x3, second generation (round 4): 768-thread workgroups, wave = parity class x output SUB-ROW -------------------------
+// k_merge_xs<3> carries 3 x 3 sub-pixels x 8 accumulators = 72 accumulators per thread: two waves per SIMD, and it waits on
+// LDS / transcendental latency there (41.8 ms at 48 MP x 20, 66 % of k_merge_x2's per-instruction rate).  Every
+// register-only variant of that design spills at three waves.  Here the tile's work is split the other
+// way: the SAME 16 x 16 LR tile, staged ONCE per frame, is worked on by 12 waves — wave w owns parity class w & 3 and
+// output sub-row w >> 2, a thread owns one LR pixel's three sub-pixels of that sub-row.  Per thread: 3 x 6 accumulators
+// (Bayer sensors: the two green classes are summed when a frame is folded — red / green / blue instead of four
+// classes), ~3 x fewer taps per frame, the same staging slots spread over 3 x the threads; the wave-uniform float64
+// geometry of a frame is evaluated once per workgroup (lane = frame) into an LDS table that the waves read back with
+// broadcast loads.  <= 168 VGPRs: three waves per SIMD (one 12-wave workgroup per CU).
+// Non-Bayer 2 x 2 colour layouts keep k_merge_xs (the channel fold below needs red and blue on one diagonal).
+#ifndef HHSR_X3W_OCC
+#define HHSR_X3W_OCC 3
+#endif
+#ifndef HHSR_X3W
+#define HHSR_X3W 0  // 1: scale 3 runs k_merge_x3w by default.  Measured (48 MP x 20 x3, tools/debug/ab_c5.sh): k_merge_xs<3>
+                    // 41.3 ms (124 VGPRs + 72 accumulators, 2 waves / SIMD), k_merge_x3w 47.8 ms (147 VGPRs, 3 waves / SIMD,
+                    // one 12-wave workgroup per CU), double-buffered (one barrier per frame) 48.1 ms: occupancy is not what
+                    // k_merge_xs<3> lacks.  The kernel stays selectable (HHSR_MERGE_FORCE_X3W, config.hip.merge_kernel:
+                    // x3w) and tested.
+#endif
+#ifndef HHSR_X3W_DB
+#define HHSR_X3W_DB 1  // 1: double-buffered LDS windows, one barrier per frame
+#endif
+constexpr int X3_NT = 768;
+
+static bool cfa_is_bayer(const Cfa4& c) {  // red (0) and blue (2) on one diagonal, green (1) on the other
+    for (int k = 0; k < 4; ++k)
+        if (c.c[k] == 0) return c.c[3 - k] == 2 && c.c[k ^ 1] == 1 && c.c[k ^ 2] == 1;
+    return false;
+}
+
+template <bool ISO, bool LMIN>
+__global__ void __launch_bounds__(X3_NT, HHSR_X3W_OCC) k_merge_x3w(BurstArgs a, Geo g, Cfa4 cfa, float* __restrict__ num,
+                                                                   float* __restrict__ den) {
+    constexpr int S = 3;
+    constexpr int RAWSZ = 20 * X2_RP, COVSZ = CWIN * X2_CP, OP = 3 * S * QT + 4, OROWS = S * QT;
+    constexpr int GQ = 14;  // float4 per frame of the geometry table: x [parity][4], y [parity][sub-row]
+    constexpr int NB = HHSR_X3W_DB ? 2 : 1;  // window buffers (2: frame n + 1 is staged while frame n is evaluated)
+    __shared__ __align__(16) float s_rawA[NB * RAWSZ];
+    __shared__ __align__(16) float s_rawB[NB * RAWSZ];
+    __shared__ float4 s_cov[NB * COVSZ];
+    __shared__ __align__(16) float s_R[NB * RAWSZ];
+    __shared__ __align__(16) float s_out[OROWS * OP];
+    __shared__ float4 s_geo[HHSR_MAX_FRAMES * GQ];
+    const int tid = threadIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+    const int cls = wave & 3, sa = wave >> 2;  // parity class and output sub-row of this wave
+    const int nbx = gridDim.x, nblk = gridDim.x * gridDim.y;
+    const int bid = xcd_remap(blockIdx.y * nbx + blockIdx.x, nblk);
+    const int lx0 = (bid % nbx) * QT, ly0 = g.row0 / S + (bid / nbx) * QT;  // LR origin of the workgroup
+    const int lrow1 = g.row1 / S;
+    const int tile = (min(ly0, g.H - 1) / g.ts) * g.nx + min(lx0, g.W - 1) / g.ts;
+    const int py = cls >> 1, px = cls & 1;
+    const int li = lane >> 3, lj = lane & 7;
+    const int ty = 2 * li + py, tx = 2 * lj + px;
+    const int ly = ly0 + ty, lx = lx0 + tx;
+
+    bool ok = lx0 + QT <= g.W && ly0 + QT <= lrow1;
+    if ((a.flags & HHSR_MERGE_DO_REF) && !(lx0 >= 1 && lx0 + QT + 2 <= g.W && ly0 >= 1 && ly0 + QT + 2 <= g.H)) ok = false;
+    if (ok && lane < a.n) {
+        const float2 fl = a.f[lane].flow[tile];
+        const int ox = xs_comp_org<S>(fl.x, lx0), oy = xs_comp_org<S>(fl.y, ly0);
+        ok = ox >= 0 && ox + X2_WIN <= g.W && oy >= 0 && oy + X2_WIN <= g.H && fl.x == fl.x && fl.y == fl.y;
+    }
+    if (!__all(ok)) {  // (identical in the twelve waves: every wave looks at every frame)
+        // generic per-pixel code from global memory for the three output pixels of this thread
+        if (lx >= g.W || ly >= lrow1) return;
+        if (a.acc_r && sa == 0) {
+            float racc = (a.flags & HHSR_MERGE_LOAD_ACC) ? a.acc_r[(size_t)ly * g.W + lx] : 0.f;
+            for (int n = 0; n < a.n; ++n) racc += robustness_at(a.f[n].r, g, ly, lx, LMIN);
+            a.acc_r[(size_t)ly * g.W + lx] = racc;
+        }
+#pragma unroll 1
+        for (int sb = 0; sb < S; ++sb) {
+            const int hi = S * ly + sa, hj = S * lx + sb;
+            if (!border_pixel(g, hi, hj)) merge_pixel<float, GEOM_F64, ISO>(a, g, cfa, hi, hj, num, den);
+        }
+        return;
+    }
+
+    // per-frame geometry, once per workgroup: lane = frame (visible after the first barrier of the frame loop)
+    if (tid < a.n) {
+        const float2 fl = a.f[tid].flow[tile];
+#pragma unroll
+        for (int p = 0; p < 2; ++p) {
+            const XsAxis<S> u = xs_comp_axis<S>(fl.x, lx0, p);
+            float4* q = s_geo + tid * GQ + p * 4;
+            q[0] = make_float4(__int_as_float(u.org), __int_as_float(u.e[0]), __int_as_float(u.e[1]), __int_as_float(u.e[2]));
+            q[1] = make_float4(u.d0[0], u.d0[1], u.d0[2], 0.f);
+            q[2] = make_float4(__int_as_float(u.oc[0]), __int_as_float(u.oc[1]), __int_as_float(u.oc[2]), 0.f);
+            q[3] = make_float4(u.f[0], u.f[1], u.f[2], 0.f);
+            const XsAxis<S> v = xs_comp_axis<S>(fl.y, ly0, p);
+#pragma unroll
+            for (int k = 0; k < S; ++k)
+                s_geo[tid * GQ + 8 + p * 3 + k] = make_float4(__int_as_float(v.org), __int_as_float(v.e[k] | (v.oc[k] << 8)), v.d0[k], v.f[k]);
+        }
+    }
+
+    const int ridx = ly * g.W + lx;
+    float n3[S][3], d3[S][3];
+#pragma unroll
+    for (int k = 0; k < S * 3; ++k) {
+        (&n3[0][0])[k] = 0.f;
+        (&d3[0][0])[k] = 0.f;
+    }
+    float racc = 0.f;
+    // class index of the red (channel 0) sample; blue is the other end of that diagonal, the two greens the other diagonal
+    const int rcl = cfa.c[0] == 0 ? 0 : cfa.c[1] == 0 ? 1 : cfa.c[2] == 0 ? 2 : 3;
+    const int ri = rcl >> 1, rj = rcl & 1;
+
+    // staging slots, by thread id: raw window [0, 361), covariance cells [384, 505), R window [512, 768) + [0, 144)
+    constexpr int rwin = X2_WIN, cwin = QT / 2 + 3, RW = QT + 4;
+    const bool hasr = tid < rwin * rwin;
+    const int e0y = tid / rwin, e0x = tid - e0y * rwin;
+    const int ct = tid - 384;
+    const bool hasc = ct >= 0 && ct < cwin * cwin;
+    const int cey = max(ct, 0) / cwin, cex = max(ct, 0) - cey * cwin;
+    const int m0 = tid >= 512 ? tid - 512 : tid + 256;
+    const bool hasm = LMIN && (tid >= 512 || tid < RW * RW - 256);
+    const int m0y = m0 / RW, m0x = m0 - m0y * RW;
+    const int moff0 = clampi(ly0 - 2 + m0y, 0, g.H - 1) * g.W + clampi(lx0 - 2 + m0x, 0, g.W - 1);
+    const int nloop = a.n + ((a.flags & HHSR_MERGE_DO_REF) ? 1 : 0);
+    float pr0 = 0.f, plr = 0.f;
+    float4 pc = make_float4(0.f, 0.f, 0.f, 0.f);
+    auto prefetch = [&](int n) {
+        const bool isref = n >= a.n;
+        const float* __restrict__ raw = isref ? a.ref_raw : a.f[n].raw;
+        const float4* __restrict__ cov = isref ? a.ref_cov : a.f[n].cov;
+        int ox = lx0 - 1, oy = ly0 - 1;
+        if (!isref) {
+            const float2 fl = a.f[n].flow[tile];
+            ox = xs_comp_org<S>(fl.x, lx0);
+            oy = xs_comp_org<S>(fl.y, ly0);
+        }
+        if (hasr) pr0 = raw[(size_t)(oy + e0y) * g.pitch + ox + e0x];
+        if (!ISO && hasc) pc = cov[(size_t)min((oy >> 1) + cey, g.gh - 1) * g.gw + min((ox >> 1) + cex, g.gw - 1)];
+        if (!isref) {
+            if (LMIN) {
+                if (hasm) plr = a.f[n].r[moff0];
+            } else {
+                plr = a.f[n].r[ridx];
+            }
+        }
+    };
+    const float* __restrict__ rbase = s_R + ty * X2_RP + 2 * lj;
+    const int cbase = li * X2_CP + lj;
+
+    // stage(n, bo): the prefetched registers of frame n -> window buffer bo; sr = that frame's own robustness value
+    float sr = 0.f;
+    auto stage = [&](int n, int bo) {
+        const bool isref = n >= a.n;
+        if (hasr) {
+            s_rawA[bo * RAWSZ + e0y * X2_RP + e0x] = pr0;
+            if (e0x > 0) s_rawB[bo * RAWSZ + e0y * X2_RP + e0x - 1] = pr0;
+        }
+        if (!ISO && hasc) s_cov[bo * COVSZ + cey * X2_CP + cex] = pc;
+        if (LMIN && !isref && hasm) s_R[bo * RAWSZ + m0y * X2_RP + m0x] = plr;
+        sr = isref ? 1.f : plr;
+    };
+#if HHSR_X3W_DB
+    // ONE workgroup barrier per frame: with a single 12-wave workgroup per CU nobody fills the time a barrier costs
+    if (nloop > 0) {
+        prefetch(0);
+        __syncthreads();  // (the geometry table)
+        stage(0, 0);
+        __syncthreads();
+        if (nloop > 1) prefetch(1);
+    }
+#else
+    if (nloop > 0) prefetch(0);
+#endif
+    for (int n = 0; n < nloop; ++n) {
+        const bool isref = n >= a.n;
+#if HHSR_X3W_DB
+        const int bo = n & 1;
+        float local_r = sr;
+#else
+        const int bo = 0;
+        __syncthreads();
+        stage(n, 0);
+        float local_r = sr;
+        __syncthreads();
+        if (n + 1 < nloop) prefetch(n + 1);
+#endif
+        if (LMIN && !isref) {  // 5 x 5 minimum of the robustness window (bit patterns: R is in [0, 1], see k_merge_x2)
+            unsigned m = 0x7f7fffffu;
+#pragma unroll
+            for (int r = 0; r < 5; ++r) {
+                const float2 v01 = lds_pair(rbase + bo * RAWSZ + r * X2_RP), v23 = lds_pair(rbase + bo * RAWSZ + r * X2_RP + 2);
+                const float2 v45 = lds_pair(rbase + bo * RAWSZ + r * X2_RP + 4);
+                m = min(m, min(min(__float_as_uint(v01.y), __float_as_uint(v23.x)),
+                               min(__float_as_uint(v23.y), min(__float_as_uint(v45.x), __float_as_uint(px ? v45.y : v01.x)))));
+            }
+            local_r = __uint_as_float(m);
+        }
+        if (!isref && sa == 0) racc += local_r;
+        if (local_r != 0.f) {
+        XsAxis<S> ax;
+        int ay_org, ay_e, ay_oc;
+        float ay_d0, ay_f;
+        if (isref) {  // the reference frame's positions are float32 per LR pixel (merge.py:113-114): per-thread geometry
+            ax = xs_ref_axis<S>(lx, lx0, 0, g.scale, lj);
+            const XsAxis<S> ay = xs_ref_axis<S>(ly, ly0, g.off_lr, g.scale, li);
+            ay_org = ay.org;
+            ay_e = sa == 0 ? ay.e[0] : sa == 1 ? ay.e[1] : ay.e[2];
+            ay_oc = sa == 0 ? ay.oc[0] : sa == 1 ? ay.oc[1] : ay.oc[2];
+            ay_d0 = sa == 0 ? ay.d0[0] : sa == 1 ? ay.d0[1] : ay.d0[2];
+            ay_f = sa == 0 ? ay.f[0] : sa == 1 ? ay.f[1] : ay.f[2];
+        } else {
+            const float4* q = s_geo + n * GQ + px * 4;
+            const float4 q0 = lds_quad(q), q1 = lds_quad(q + 1), q2 = lds_quad(q + 2), q3 = lds_quad(q + 3);
+            const float4 qy = lds_quad(s_geo + n * GQ + 8 + py * 3 + sa);
+            ax.org = __float_as_int(q0.x);
+            ax.e[0] = __float_as_int(q0.y); ax.e[1] = __float_as_int(q0.z); ax.e[2] = __float_as_int(q0.w);
+            ax.d0[0] = q1.x; ax.d0[1] = q1.y; ax.d0[2] = q1.z;
+            ax.oc[0] = __float_as_int(q2.x); ax.oc[1] = __float_as_int(q2.y); ax.oc[2] = __float_as_int(q2.z);
+            ax.f[0] = q3.x; ax.f[1] = q3.y; ax.f[2] = q3.z;
+            ay_org = __float_as_int(qy.x);
+            const int pk = __float_as_int(qy.y);
+            ay_e = pk & 0xff;
+            ay_oc = pk >> 8;
+            ay_d0 = qy.z;
+            ay_f = qy.w;
+        }
+        struct Sub {
+            float4 c00, c01, c10, c11;
+            float2 v01[3], v23[3];
+        };
+        auto load_sub = [&](int sb) {
+            Sub t;
+            if (!ISO) {
+                const int ca = bo * COVSZ + cbase + ay_oc * X2_CP + ax.oc[sb];
+                t.c00 = lds_quad(s_cov + ca);
+                t.c01 = lds_quad(s_cov + ca + 1);
+                t.c10 = lds_quad(s_cov + ca + X2_CP);
+                t.c11 = lds_quad(s_cov + ca + X2_CP + 1);
+            }
+            const int mcol = px + ax.e[sb];
+            const float* __restrict__ rp = ((mcol & 1) ? s_rawB : s_rawA) + bo * RAWSZ + (ty + ay_e) * X2_RP + 2 * lj + (mcol & 2);
+#pragma unroll
+            for (int di = 0; di < 3; ++di) {
+                t.v01[di] = lds_pair(rp + di * X2_RP);
+                t.v23[di] = lds_pair(rp + di * X2_RP + 2);
+            }
+            return t;
+        };
+        const int by = (ay_org + py + ay_e) & 1;
+        Sub cur = load_sub(0);
+#pragma unroll
+        for (int sb = 0; sb < S; ++sb) {
+            Sub nxt = cur;
+            if (sb + 1 < S) nxt = load_sub(sb + 1);
+            float ixx = 2.f * X2_KEXP, ixy = 0.f, iyy = 2.f * X2_KEXP;
+            bool finite = true;
+            if (!ISO) {
+                const float gx = ax.f[sb], gy = ay_f;
+                const float w11 = gx * gy, w01 = gx - w11, w10 = gy - w11, w00 = (1.f - gx) - w10;
+                const float cxx = fmaf(w11, cur.c11.x, fmaf(w10, cur.c10.x, fmaf(w01, cur.c01.x, w00 * cur.c00.x)));
+                const float cxy = fmaf(w11, cur.c11.y, fmaf(w10, cur.c10.y, fmaf(w01, cur.c01.y, w00 * cur.c00.y)));
+                const float cyy = fmaf(w11, cur.c11.w, fmaf(w10, cur.c10.w, fmaf(w01, cur.c01.w, w00 * cur.c00.w)));
+                const float det = fmaf(cxx, cyy, -(cxy * cxy));
+                const float s1 = __builtin_amdgcn_rcpf(det) * X2_KEXP;
+                ixx = s1 * cyy;
+                ixy = (-2.f * s1) * cxy;
+                iyy = s1 * cxx;
+                if (isref && !(fabsf(det) > 1e-10f)) {
+                    ixx = X2_KEXP;
+                    ixy = 0.f;
+                    iyy = X2_KEXP;
+                }
+                const float probe = fmaf(0.f, ixx, fmaf(0.f, ixy, 0.f * iyy));
+                finite = probe == probe;
+            }
+            const float dx0 = ax.d0[sb], dy0 = ay_d0;
+            const float dxs[3] = {dx0 - 1.f, dx0, dx0 + 1.f};
+            float sv[2][2], sd[2][2];
+            auto taps = [&](auto exact_c) {
+                constexpr bool EXACT = decltype(exact_c)::value;
+#pragma unroll
+                for (int di = 0; di < 3; ++di) {
+                    const float c3[3] = {cur.v01[di].x, cur.v01[di].y, cur.v23[di].x};
+                    const float dy = dy0 + (float)(di - 1);
+                    const float qa = iyy * dy * dy, qb = ixy * dy;
+#pragma unroll
+                    for (int dj = 0; dj < 3; ++dj) {
+                        const float dx = dxs[dj];
+                        const float z = fmaf(fmaf(ixx, dx, qb), dx, qa);
+                        const float w = EXACT ? __builtin_amdgcn_exp2f(fminf(z, 0.f))
+                                              : __builtin_amdgcn_fmed3f(__builtin_amdgcn_exp2f(z), 0.f, 1.f);
+                        if (di < 2 && dj < 2) {
+                            sv[di & 1][dj & 1] = w * c3[dj];
+                            sd[di & 1][dj & 1] = w;
+                        } else {
+                            sv[di & 1][dj & 1] = fmaf(w, c3[dj], sv[di & 1][dj & 1]);
+                            sd[di & 1][dj & 1] += w;
+                        }
+                    }
+                }
+            };
+            if (ISO || finite) taps(std::false_type{});
+            else taps(std::true_type{});
+            // tap parity (a, b) is colour class (a ^ by, b ^ bx): red sits at parity (ri ^ by, rj ^ bx), blue diagonally
+            // opposite, the greens on the other diagonal — four wave-uniform arrangements
+            const int bx = (ax.org + px + ax.e[sb]) & 1;
+            const int ra = ri ^ by, rb = rj ^ bx;
+#define HHSR_FOLD3(RA, RB)                                                                    \
+    {                                                                                         \
+        n3[sb][0] = fmaf(local_r, sv[RA][RB], n3[sb][0]);                                     \
+        d3[sb][0] = fmaf(local_r, sd[RA][RB], d3[sb][0]);                                     \
+        n3[sb][1] = fmaf(local_r, sv[RA ^ 1][RB] + sv[RA][RB ^ 1], n3[sb][1]);                \
+        d3[sb][1] = fmaf(local_r, sd[RA ^ 1][RB] + sd[RA][RB ^ 1], d3[sb][1]);                \
+        n3[sb][2] = fmaf(local_r, sv[RA ^ 1][RB ^ 1], n3[sb][2]);                             \
+        d3[sb][2] = fmaf(local_r, sd[RA ^ 1][RB ^ 1], d3[sb][2]);                             \
+    }
+            if (ra) {
+                if (rb) HHSR_FOLD3(1, 1) else HHSR_FOLD3(1, 0)
+            } else {
+                if (rb) HHSR_FOLD3(0, 1) else HHSR_FOLD3(0, 0)
+            }
+#undef HHSR_FOLD3
+            cur = nxt;
+        }
+        }  // local_r != 0
+#if HHSR_X3W_DB
+        // stage frame n + 1 into the other buffer (its registers were prefetched during frame n - 1's taps), ONE barrier,
+        // then start the loads of frame n + 2
+        if (n + 1 < nloop) stage(n + 1, (n + 1) & 1);
+        __syncthreads();
+        if (n + 2 < nloop) prefetch(n + 2);
+#endif
+    }
+    if (a.acc_r && sa == 0) a.acc_r[ridx] = ((a.flags & HHSR_MERGE_LOAD_ACC) ? a.acc_r[ridx] : 0.f) + racc;
+    if (a.flags & HHSR_MERGE_LOAD_ACC) {
+#pragma unroll
+        for (int sb = 0; sb < S; ++sb) {
+            const int hi = S * ly + sa, hj = S * lx + sb;
+            if (border_pixel(g, hi, hj)) continue;
+            const size_t o = ((size_t)(hi - g.row0) * g.sW + hj) * 3;
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                const float nk = num[o + k] + n3[sb][k], dk = den[o + k] + d3[sb][k];
+                num[o + k] = (a.flags & HHSR_MERGE_DIVIDE) ? nk / dk : nk;
+                if (a.flags & HHSR_MERGE_STORE_DEN) den[o + k] = dk;
+            }
+        }
+        return;
+    }
+    const int npass = (a.flags & HHSR_MERGE_STORE_DEN) ? 2 : 1;
+    for (int pass = 0; pass < npass; ++pass) {
+        if (pass) __syncthreads();
+        float* row = s_out + (S * ty + sa) * OP + 3 * S * tx;
+#pragma unroll
+        for (int sb = 0; sb < S; ++sb)
+#pragma unroll
+            for (int k = 0; k < 3; ++k)
+                row[3 * sb + k] = pass ? d3[sb][k] : ((a.flags & HHSR_MERGE_DIVIDE) ? n3[sb][k] / d3[sb][k] : n3[sb][k]);
+        __syncthreads();
+        float* __restrict__ dst = pass ? den : num;
+        constexpr int CPR = 3 * S * QT / 4, NCH = OROWS * CPR;  // float4 chunks per tile row / per tile
+        for (int qd = tid; qd < NCH; qd += X3_NT) {
+            const int orow = qd / CPR, oc = (qd - orow * CPR) * 4;
+            *reinterpret_cast<float4*>(dst + ((size_t)(S * ly0 + orow - g.row0) * g.sW + S * lx0) * 3 + oc) =
+                *reinterpret_cast<const float4*>(s_out + orow * OP + oc);
+        }
+    }
+}
+
 static bool scale_is_pow2(double s) {  // 1, 2, 4, 8: (h + 0.5)/s is exact in float32
     return s == 1.0 || s == 2.0 || s == 4.0 || s == 8.0;
 }
@@ -2065,8 +2433,19 @@ static int merge_burst_impl(const float* const* raws, const float* const* flows,
             if (iso) hipLaunchKernelGGL((k_merge_burst_quad<true, false>), qgrid, block, 0, s, a, g, c, num, den);
             else hipLaunchKernelGGL((k_merge_burst_quad<false, false>), qgrid, block, 0, s, a, g, c, num, den);
         }
+    } else if (x3 && (HHSR_X3W || (force & HHSR_MERGE_FORCE_X3W)) && cfa_is_bayer(c) && !(force & HHSR_MERGE_FORCE_X2V1)) {
+        // x3, Bayer: 768-thread workgroups, wave = parity class x output sub-row (k_merge_x3w)
+        const dim3 qgrid(hhsr_cdiv(W, QT), hhsr_cdiv(nrows / 3, QT)), wblock(X3_NT);
+        if (lmin) {
+            if (iso) hipLaunchKernelGGL((k_merge_x3w<true, true>), qgrid, wblock, 0, s, a, g, c, num, den);
+            else hipLaunchKernelGGL((k_merge_x3w<false, true>), qgrid, wblock, 0, s, a, g, c, num, den);
+        } else {
+            if (iso) hipLaunchKernelGGL((k_merge_x3w<true, false>), qgrid, wblock, 0, s, a, g, c, num, den);
+            else hipLaunchKernelGGL((k_merge_x3w<false, false>), qgrid, wblock, 0, s, a, g, c, num, den);
+        }
     } else if (x3) {
-        // x3: the wave-per-parity-class kernel generalised to S x S sub-pixels (k_merge_xs)
+        // x3: the wave-per-parity-class kernel generalised to S x S sub-pixels (k_merge_xs): non-Bayer colour layouts,
+        // config.hip.merge_kernel = x2_v1 (validation: the round-3 kernel)
         const dim3 qgrid(hhsr_cdiv(W, QT), hhsr_cdiv(nrows / 3, QT));
         if (lmin) {
             if (iso) hipLaunchKernelGGL((k_merge_xs<3, true, true>), qgrid, block, 0, s, a, g, c, num, den);

@@ -9,10 +9,12 @@ One process per GPU, two selectable strategies (`main_sharded(..., strategy=)`, 
      -> row-parallel: the output is cut into G row slabs and rank j runs steps B for ALL frames on the raw rows its
      slab needs (slab + |flow| + HALO rows), finishing its slab completely: reference frame, normalisation.
   The only data-path exchange is the all-gather of the flow fields (ny x nx x 2 floats per frame: 376 kB at 12 MP, 7 MB
-  per 20-frame burst).  It is PIPELINED (round 4): the burst is cut into STAGES of whole rounds (round r = frames r G ..
-  r G + G - 1, one per rank; a stage holds >= 4 frames: stage_plan) and stage s's flows are gathered and its frames'
+  per 20-frame burst).  It can be PIPELINED (round 4, config.hip.stage_frames): the burst is cut into STAGES of whole
+  rounds (round r = frames r G .. r G + G - 1, one per rank: stage_plan) and stage s's flows are gathered and its frames'
   step B (raw pass, robustness on the slab) runs while stage s + 1 is being aligned — step A on one HIP stream, step B
-  on another, the RCCL all-gather between them, every piece a HIP graph on replay (RowsPlan).  The sub-image extent
+  on another, the RCCL all-gather between them, every piece a HIP graph on replay (RowsPlan).  Measured per-rank
+  compute says ONE stage is faster on this hardware (STAGE_FRAMES below), so that is the default: the same plan with a
+  single all-gather, and still no host read between step A and step B.  The sub-image extent
   needs a bound on |flow_y| BEFORE the flows exist: the plan is captured with the bound its first (eager) burst measured
   plus a margin, every burst checks its gathered flows against it on the device, the host reads that flag when the last
   stage's step B has been queued (the merge is still running: nothing waits for the read) and a burst that exceeds the
@@ -72,6 +74,12 @@ def slab_rows(sH, world):
     return -(-rows // SLAB_ALIGN) * SLAB_ALIGN
 
 
+STAGE_FRAMES = 0  # frames per stage of strategy "rows" (config.hip.stage_frames); 0 = ONE stage: step A of all the rank's
+                  # frames in one batched launch per kernel, one all-gather, step B.  Measured (tools/debug/emulate_ranks.py, one
+                  # MI355X running each rank's graphs, 12 MP x 20 x2, per-rank compute at G = 8): one stage 1.85 ms, stages of
+                  # >= 4 frames (3 stages) 2.22 ms — the step-A kernels of ONE frame per launch are latency-bound (they were
+                  # sized for chunks of 4), and step A and step B on two streams do not overlap: either fills the GPU
+                  # (G = 1: 9.81 ms pipelined, 3.81 + 5.84 alone).  Staging pays only where the all-gather's latency does.
 ALIGN_COST = 0.9  # step A of one frame costs about as much as step B of one frame over this fraction of the image
                   # (12 MP x2, profiles/r03_kernel_trace_1stream.md: 0.24 ms against 5.1 ms / 19 frames); config.hip.align_cost
 
@@ -771,7 +779,8 @@ def main_sharded(ref_img, comp_imgs, config, group=None, engine=None, gather=Tru
         if max_flow is None and hip is not None:
             max_flow = hip.get("max_flow", None)
         cost = float(hip.get("align_cost", ALIGN_COST)) if hip is not None else ALIGN_COST
-        stages = stage_plan(n, world, int(hip.get("stage_frames", 4)) if hip is not None else 4)
+        sf = int(hip.get("stage_frames", STAGE_FRAMES)) if hip is not None else STAGE_FRAMES
+        stages = stage_plan(n, world, sf if sf > 0 else max(n, 1))
         bounds = slab_bounds(sH, world, n, cost)
         rows = max(b1 - b0 for b0, b1 in zip(bounds[:-1], bounds[1:]))  # (padded chunk of the optional gather)
         r0, r1 = bounds[rank], bounds[rank + 1]
@@ -823,7 +832,7 @@ def main_sharded(ref_img, comp_imgs, config, group=None, engine=None, gather=Tru
         out = gathered.view(world * rows, sW, 3)[:sH]
     else:
         out = torch.cat([gathered[j, : bounds[j + 1] - bounds[j]] for j in range(world)])
-    debug = {"robustness": [], "flow": []}
+    debug = {"robustness": [], "flow": [], **{k: v for k, v in debug.items() if k.startswith("flow_bound")}}
     if want_acc and acc_full is not None:
         debug["accumulated robustness"] = acc_full
     elif want_acc:

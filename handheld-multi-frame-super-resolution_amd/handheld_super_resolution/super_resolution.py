@@ -272,6 +272,12 @@ class BurstPipeline:
         inj = [None if flows is None else flows[i] for i in indices]
         if flows is None and self._inject_flows is not None:
             inj = [self._inject_flows[i] for i in indices]
+        if len(imgs) >= 2 and self._batch and all(f is not None for f in inj) and cfg.robustness.enabled and not self.mono:
+            # every flow is given (multi-GPU step B on a row slab): no alignment, ONE raw pass for the chunk — on a slab
+            # a per-frame launch is a few hundred workgroups and leaves most of the GPU idle
+            raws = [self._ingest(img) for img in imgs]
+            stats = frame_stats_batch(raws, self.cfa, self.wb, cfg)
+            return [(raw, _lib.f32c(f, self.device), st[2], st[0]) for raw, f, st in zip(raws, inj, stats)]
         if len(imgs) < 2 or not self._batch or not can_align_batch(cfg) or any(f is not None for f in inj):
             return [self._front(img, wait_ref, i, f) for img, i, f in zip(imgs, indices, inj)]
         raws = [self._ingest(img) for img in imgs]

@@ -87,13 +87,19 @@ def main():
                         continue
                     plan = hdist.RowsPlan(eng, ref, comp, stages, j, G, (r0, r1), 1.25 * bound + 2.0, check=True, key=None)
 
+                    pre = []  # what each stage's all-gather delivers
+                    for s, st in enumerate(stages):
+                        t = torch.zeros_like(plan.gath[s])
+                        for i in hdist.stage_frames(st, n, G):
+                            t[i % G, i // G - st[0]].copy_(flows[i])
+                        pre.append(t)
+
                     def step():
                         ctx = plan.open()
                         for s, st in enumerate(stages):
                             ctx.align(s)
                             with torch.cuda.stream(plan.s_b):  # stand-in for the all-gather: the stage's flows appear
-                                for i in hdist.stage_frames(st, n, G):
-                                    plan.gath[s][i % G, i // G - st[0]].copy_(flows[i], non_blocking=True)
+                                plan.gath[s].copy_(pre[s], non_blocking=True)
                             ctx.front(s, None)
                         out = ctx.finish()
                         assert not out[3]
