@@ -582,6 +582,9 @@ __device__ __forceinline__ float swap16_add(float a, float b) {
     return __uint_as_float(x) + __uint_as_float(y);
 }
 
+#ifndef HHSR_ALIGN_PERM
+#define HHSR_ALIGN_PERM 1  // level 0: conflict-free window pitch + row permutation (0: round 3's layout, A/B)
+#endif
 template <int N, int CW>
 struct Stage2D {  // N x N window, lane -> (row lane / CW + k * (64 / CW), column lane % CW)
     static constexpr int RPP = HHSR_WAVE / CW, NK = (N + RPP - 1) / RPP;
@@ -610,7 +613,12 @@ __global__ void __launch_bounds__(256) k_align_wave(const float* __restrict__ re
     constexpr int PPT = TS * TS / HHSR_WAVE > 0 ? TS * TS / HHSR_WAVE : 1;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x / HHSR_WAVE), lane = threadIdx.x & (HHSR_WAVE - 1);
     constexpr int n1 = 2 * r + 1, n = n1 * n1;
-    constexpr int WS = TS + 2 * r + 2 * M + 1, WP = WS | 1;  // moving window
+    // moving window.  Pitch: odd in general; level 0 (TS = 16, r = 1: 23 x 23) uses 24 together with the row
+    // permutation of `li` below — a half-wave then reads 16 + 16 consecutive floats of rows i and i + 2, 2 x 24 = 48 = 16
+    // (mod 32) banks apart: conflict-free (pitch 23, rows i and i + 1: 7 of the 32 banks are hit twice by EVERY
+    // bilinear tap / candidate read; 46 % of the kernel's LDS cycles were conflicts, profiles/r03_kernel_bottlenecks.md)
+    constexpr bool PERM = HHSR_ALIGN_PERM && TS == 16 && R == 1;
+    constexpr int WS = TS + 2 * r + 2 * M + 1, WP = PERM ? ((WS + 7) & ~15) + 8 : (WS | 1);
     constexpr int slice = (RS * RP + WS * WP + 3) & ~3;
     float* s_ref = lds + (size_t)wave * slice;
     float* s_win = s_ref + RS * RP;
@@ -697,7 +705,8 @@ __global__ void __launch_bounds__(256) k_align_wave(const float* __restrict__ re
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     // lane's pixels p = lane + 64k: row lane / TS + k * (64 / TS), column lane % TS
     constexpr int RSTEP = HHSR_WAVE / TS > 0 ? HHSR_WAVE / TS : 1;
-    const int li = lane / TS, lj = lane % TS;
+    // (PERM: the four 16-lane groups own rows 0, 2, 1, 3 (+ 4k) of the tile)
+    const int li = PERM ? (((lane >> 4) & 1) << 1) | (lane >> 5) : lane / TS, lj = lane % TS;
     // ---------------- block matching ----------------
     float nfx = f0, nfy = f1;  // flow after block matching
     if (L1 && mode == 1) {     // "L1_ref_effective": flow <- round(flow)
@@ -796,8 +805,7 @@ __global__ void __launch_bounds__(256) k_align_wave(const float* __restrict__ re
         float rc[PPT], lgx[PPT], lgy[PPT];
 #pragma unroll
         for (int k = 0; k < PPT; ++k) {
-            const int p = lane + k * HHSR_WAVE;
-            const float* c = s_ref + (p / TS + 1) * RP + p % TS + 1;
+            const float* c = s_ref + (li + k * RSTEP + 1) * RP + lj + 1;  // pixel (li + k RSTEP, lj): the lane's k-th pixel
             rc[k] = c[0];
             lgx[k] = c[1] - c[-1];
             lgy[k] = c[RP] - c[-RP];
@@ -816,8 +824,7 @@ __global__ void __launch_bounds__(256) k_align_wave(const float* __restrict__ re
             const float* wl = s_win + (li + sy) * WP + (lj + sx);
 #pragma unroll
             for (int k = 0; k < PPT; ++k) {
-                const int p = lane + k * HHSR_WAVE;
-                const int i = p / TS, j = p % TS;
+                const int i = li + k * RSTEP, j = lj;
                 float m00, m01, m10, m11;
                 if (in_lds) {
                     const float* w = TS * TS >= HHSR_WAVE ? wl + k * RSTEP * WP : s_win + (i + sy) * WP + (j + sx);
@@ -856,7 +863,8 @@ __global__ void __launch_bounds__(256) k_align_wave(const float* __restrict__ re
 }
 
 static size_t align_wave_lds(int ts, int r) {
-    const int RS = ts + 2, RP = RS | 1, WS = ts + 2 * r + 2 * ICA_M + 1, WP = WS | 1;
+    const int RS = ts + 2, RP = RS | 1, WS = ts + 2 * r + 2 * ICA_M + 1;
+    const int WP = (HHSR_ALIGN_PERM && ts == 16 && r == 1) ? ((WS + 7) & ~15) + 8 : (WS | 1);  // (k_align_wave's PERM pitch)
     return (size_t)4 * ((RS * RP + WS * WP + 3) & ~3) * sizeof(float);
 }
 

@@ -1009,6 +1009,12 @@ __global__ void __launch_bounds__(256) k_merge_burst_quad(BurstArgs a, Geo g, Cf
 #ifndef HHSR_XS_OCC
 #define HHSR_XS_OCC 2  // k_merge_xs<3>: 72 accumulators per thread; 3 waves per SIMD (168 VGPRs) spills 50 dwords
 #endif
+#ifndef HHSR_XS_EDGE
+#define HHSR_XS_EDGE 1  // k_merge_xs: frames whose window leaves the image run the uniform code with masks (0: per-pixel path)
+#endif
+#ifndef HHSR_XS_RGB
+#define HHSR_XS_RGB 1  // k_merge_xs: 3 + 3 channel accumulators per sub-pixel (Bayer) instead of 4 + 4 parity classes
+#endif
 #ifndef HHSR_XS_PIPE
 #define HHSR_XS_PIPE 1  // k_merge_xs: LDS reads of sub-pixel q + 1 issued before the taps of sub-pixel q
 #endif
@@ -1553,6 +1559,23 @@ __device__ __forceinline__ XsAxis<S> xs_ref_axis(int l, int l0, int off_lr, doub
     return u;
 }
 
+// the R, G, B sums of one sub-pixel from its NC accumulators (3: channels already; 4: parity classes -> channels)
+template <int NC>
+__device__ __forceinline__ void xs_rgb(const Cfa4 cfa, const float* nsub, const float* dsub, float n3[3], float d3[3]) {
+#pragma unroll
+    for (int k = 0; k < 3; ++k) n3[k] = d3[k] = 0.f;
+    if (NC == 3) {
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            n3[k] = nsub[k];
+            d3[k] = dsub[k];
+        }
+    } else {
+        const float n4[2][2] = {{nsub[0], nsub[1]}, {nsub[2], nsub[3]}}, d4[2][2] = {{dsub[0], dsub[1]}, {dsub[2], dsub[3]}};
+        classes_to_rgb(cfa, n4, d4, n3, d3);
+    }
+}
+
 template <int S, bool ISO, bool LMIN>
 __global__ void __launch_bounds__(256, HHSR_XS_OCC) k_merge_xs(BurstArgs a, Geo g, Cfa4 cfa, float* __restrict__ num,
                                                       float* __restrict__ den) {
@@ -1562,6 +1585,8 @@ __global__ void __launch_bounds__(256, HHSR_XS_OCC) k_merge_xs(BurstArgs a, Geo 
     __shared__ float4 s_cov[COVSZ];
     __shared__ __align__(16) float s_R[RAWSZ];
     __shared__ __align__(16) float s_out[OROWS * OP];
+    __shared__ __align__(16) float s_mskA[RAWSZ];  // EDGE frames: 1 where the window position lies inside the frame, else 0
+    __shared__ __align__(16) float s_mskB[RAWSZ];  // (the same shifted by one column, like s_rawB)
     const int tid = threadIdx.x;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
     const int nbx = gridDim.x, nblk = gridDim.x * gridDim.y;
@@ -1574,13 +1599,33 @@ __global__ void __launch_bounds__(256, HHSR_XS_OCC) k_merge_xs(BurstArgs a, Geo 
     const int ty = 2 * li + py, tx = 2 * lj + px;
     const int ly = ly0 + ty, lx = lx0 + tx;
 
+    // EDGE frames (round 4): a frame whose 19 x 19 window leaves the image — the image's perimeter tiles for the
+    // reference frame, tiles pushed over the border by their flow for the others — used to send the whole tile down the
+    // per-pixel path below (operands from global memory, float64 geometry per tap: ~40 x the time of a uniform tile;
+    // measured at 48 MP x 20: the top and bottom tile rows alone were 5.4 of the launch's 41.4 ms, the perimeter ~9 ms).
+    // Now such a frame is staged with clamped coordinates plus a 0 / 1 mask of the window positions inside the frame and
+    // evaluated by the SAME uniform code with the reference's border rules applied per lane: taps outside the frame get
+    // weight 0 (merge.py:404-405), a sub-pixel whose position lies outside the frame contributes nothing (:346-347), and
+    // a centre in column / row 0 takes covariance cells 0 and 1 with the negative fraction (D11, :349-361).  Only partial
+    // tiles and non-finite / absurd flows are left to the per-pixel path.
     bool ok = lx0 + QT <= g.W && ly0 + QT <= lrow1;
-    if ((a.flags & HHSR_MERGE_DO_REF) && !(lx0 >= 1 && lx0 + QT + 2 <= g.W && ly0 >= 1 && ly0 + QT + 2 <= g.H)) ok = false;
+    bool edge_f = false;
     if (ok && lane < a.n) {
         const float2 fl = a.f[lane].flow[tile];
-        const int ox = xs_comp_org<S>(fl.x, lx0), oy = xs_comp_org<S>(fl.y, ly0);
-        ok = ox >= 0 && ox + X2_WIN <= g.W && oy >= 0 && oy + X2_WIN <= g.H && fl.x == fl.x && fl.y == fl.y;
+        ok = fabsf(fl.x) < 1.0e6f && fabsf(fl.y) < 1.0e6f;  // (NaN fails)
+        if (ok) {
+            const int ox = xs_comp_org<S>(fl.x, lx0), oy = xs_comp_org<S>(fl.y, ly0);
+            edge_f = !(ox >= 0 && ox + X2_WIN <= g.W && oy >= 0 && oy + X2_WIN <= g.H);
+        }
     }
+#if !HHSR_XS_EDGE  // A/B: round 3's rule — any window outside the image sends the tile down the per-pixel path
+    if (edge_f || ((a.flags & HHSR_MERGE_DO_REF) && !(lx0 >= 1 && lx0 + QT + 2 <= g.W && ly0 >= 1 && ly0 + QT + 2 <= g.H))) ok = false;
+    const unsigned long long edge_mask = 0ull;
+    const bool edge_ref = false;
+#else
+    const unsigned long long edge_mask = __ballot(edge_f);  // bit n: frame n is an EDGE frame (identical in the four waves)
+    const bool edge_ref = !(lx0 >= 1 && lx0 + QT + 2 <= g.W && ly0 >= 1 && ly0 + QT + 2 <= g.H);
+#endif
     if (!__all(ok)) {
         // generic per-pixel code from global memory for the S x S output pixels of this thread's LR pixel
         if (lx >= g.W || ly >= lrow1) return;
@@ -1598,13 +1643,20 @@ __global__ void __launch_bounds__(256, HHSR_XS_OCC) k_merge_xs(BurstArgs a, Geo 
     }
 
     const int ridx = ly * g.W + lx;
-    float n4[S][S][2][2], d4[S][S][2][2];
+    // HHSR_XS_RGB (Bayer sensors: the only layouts this kernel is launched for, cfa_is_bayer): the two green parity
+    // classes are summed when a frame is folded, so a sub-pixel has 3 + 3 accumulators instead of 4 + 4 (54 instead of 72
+    // per thread); 0: the four parity classes of round 3, mapped to channels in the epilogue (A/B)
+    constexpr int NC = HHSR_XS_RGB ? 3 : 4;
+    float nacc[S][S][NC], dacc[S][S][NC];
 #pragma unroll
-    for (int k = 0; k < S * S * 4; ++k) {
-        (&n4[0][0][0][0])[k] = 0.f;
-        (&d4[0][0][0][0])[k] = 0.f;
+    for (int k = 0; k < S * S * NC; ++k) {
+        (&nacc[0][0][0])[k] = 0.f;
+        (&dacc[0][0][0])[k] = 0.f;
     }
     float racc = 0.f;
+    // class index of the red (channel 0) sample; blue is the other end of that diagonal, the two greens the other diagonal
+    const int rcl = cfa.c[0] == 0 ? 0 : cfa.c[1] == 0 ? 1 : cfa.c[2] == 0 ? 2 : 3;
+    const int ri = rcl >> 1, rj = rcl & 1;
 
     constexpr int rwin = X2_WIN, cwin = QT / 2 + 3;
     const int e0 = tid, e1 = tid + 256;
@@ -1621,7 +1673,8 @@ __global__ void __launch_bounds__(256, HHSR_XS_OCC) k_merge_xs(BurstArgs a, Geo 
     float pr0 = 0.f, pr1 = 0.f, plr = 0.f, plr1 = 0.f;
     float4 pc = make_float4(0.f, 0.f, 0.f, 0.f);
     float2 pfl = make_float2(0.f, 0.f);
-    auto prefetch = [&](int n) {
+    auto is_edge = [&](int n) { return n >= a.n ? edge_ref : (bool)((edge_mask >> n) & 1ull); };  // wave-uniform
+    auto prefetch = [&](int n, const bool edge_n) {
         const bool isref = n >= a.n;
         const float* __restrict__ raw = isref ? a.ref_raw : a.f[n].raw;
         const float4* __restrict__ cov = isref ? a.ref_cov : a.f[n].cov;
@@ -1631,9 +1684,17 @@ __global__ void __launch_bounds__(256, HHSR_XS_OCC) k_merge_xs(BurstArgs a, Geo 
             ox = xs_comp_org<S>(pfl.x, lx0);
             oy = xs_comp_org<S>(pfl.y, ly0);
         }
+        if (edge_n) {  // clamped coordinates; the mask says which window positions are real samples
+            const int y0 = oy + e0y, x0 = ox + e0x, y1 = oy + e1y, x1 = ox + e1x;
+            pr0 = raw[(size_t)clampi(y0, 0, g.H - 1) * g.pitch + clampi(x0, 0, g.W - 1)];
+            if (has1) pr1 = raw[(size_t)clampi(y1, 0, g.H - 1) * g.pitch + clampi(x1, 0, g.W - 1)];
+            if (!ISO && hasc)
+                pc = cov[(size_t)clampi((oy >> 1) + cey, 0, g.gh - 1) * g.gw + clampi((ox >> 1) + cex, 0, g.gw - 1)];
+        } else {
         pr0 = raw[(size_t)(oy + e0y) * g.pitch + ox + e0x];
         if (has1) pr1 = raw[(size_t)(oy + e1y) * g.pitch + ox + e1x];
         if (!ISO && hasc) pc = cov[(size_t)min((oy >> 1) + cey, g.gh - 1) * g.gw + min((ox >> 1) + cex, g.gw - 1)];
+        }
         if (!isref) {
             if (LMIN) {
                 plr = a.f[n].r[moff0];
@@ -1646,7 +1707,14 @@ __global__ void __launch_bounds__(256, HHSR_XS_OCC) k_merge_xs(BurstArgs a, Geo 
     const float* __restrict__ rbase = s_R + ty * X2_RP + 2 * lj;
     const int cbase = li * X2_CP + lj;
 
-    if (nloop > 0) prefetch(0);
+    // The WHOLE frame loop exists twice: tiles without a single EDGE frame (all but the image's perimeter and the tiles a
+    // large flow pushes over the border) run round 3's loop, in which nothing of the edge handling exists; the others run
+    // the copy with the per-frame (wave-uniform, run-time) edge branches.  One loop with the branches inside cost the
+    // common tiles 12 % (34.4 -> 38.8 ms over the interior rows of the 48 MP x 20 burst), two copies of only the
+    // sub-pixel loop behind one branch spill 140 VGPRs; two copies of the loop cost code size only.
+    auto run_frames = [&](auto edge_tile_c) __attribute__((always_inline)) {
+    constexpr bool EDGE_TILE = decltype(edge_tile_c)::value;
+    if (nloop > 0) prefetch(0, EDGE_TILE && is_edge(0));
     for (int n = 0; n < nloop; ++n) {
         const bool isref = n >= a.n;
         __syncthreads();
@@ -1661,10 +1729,27 @@ __global__ void __launch_bounds__(256, HHSR_XS_OCC) k_merge_xs(BurstArgs a, Geo 
             s_R[m0y * X2_RP + m0x] = plr;
             if (hasm1) s_R[m1y * X2_RP + m1x] = plr1;
         }
+        const bool edge = EDGE_TILE && is_edge(n);
+        if (edge) {
+            int ox = lx0 - 1, oy = ly0 - 1;
+            if (!isref) {
+                ox = xs_comp_org<S>(pfl.x, lx0);
+                oy = xs_comp_org<S>(pfl.y, ly0);
+            }
+            const int y0 = oy + e0y, x0 = ox + e0x, y1 = oy + e1y, x1 = ox + e1x;
+            const float pm0 = (y0 >= 0 && y0 < g.H && x0 >= 0 && x0 < g.W) ? 1.f : 0.f;
+            const float pm1 = (y1 >= 0 && y1 < g.H && x1 >= 0 && x1 < g.W) ? 1.f : 0.f;
+            s_mskA[e0y * X2_RP + e0x] = pm0;
+            if (e0x > 0) s_mskB[e0y * X2_RP + e0x - 1] = pm0;
+            if (has1) {
+                s_mskA[e1y * X2_RP + e1x] = pm1;
+                if (e1x > 0) s_mskB[e1y * X2_RP + e1x - 1] = pm1;
+            }
+        }
         const float2 fl = pfl;
         float local_r = isref ? 1.f : plr;
         __syncthreads();
-        if (n + 1 < nloop) prefetch(n + 1);
+        if (n + 1 < nloop) prefetch(n + 1, EDGE_TILE && is_edge(n + 1));
         if (LMIN && !isref) {
             float m = 3.0e38f;
 #pragma unroll
@@ -1704,6 +1789,7 @@ __global__ void __launch_bounds__(256, HHSR_XS_OCC) k_merge_xs(BurstArgs a, Geo 
             }
             return t;
         };
+        const bool EDGE = edge;  // (false at compile time in the common tiles' copy of the loop)
         Sub cur = load_sub(0, 0);
 #pragma unroll
         for (int q = 0; q < S * S; ++q) {
@@ -1712,8 +1798,28 @@ __global__ void __launch_bounds__(256, HHSR_XS_OCC) k_merge_xs(BurstArgs a, Geo 
             if (HHSR_XS_PIPE && q + 1 < S * S) nxt = load_sub((q + 1) / S, (q + 1) % S);
             float ixx = 2.f * X2_KEXP, ixy = 0.f, iyy = 2.f * X2_KEXP;
             bool finite = true;
+            float r_eff = local_r;
+            float gx_e = ax.f[sb], gy_e = ay.f[sa];
+            if (EDGE) {
+                // window centre of this sub-pixel = floor(position): c - 1 = org + t + e
+                const int cj = ax.org + tx + ax.e[sb] + 1, ci = ay.org + ty + ay.e[sa] + 1;
+                if (!isref) {
+                    if (!((unsigned)cj < (unsigned)g.W && (unsigned)ci < (unsigned)g.H)) r_eff = 0.f;  // position outside the frame
+                    // centre in column / row 0: cells 0 and 1 with the fraction (fr - 1) / 2 (the window read below took
+                    // cells -1 -> 0 (clamped) and 0 with (1 + fr) / 2: move one cell on, fraction - 1)
+                    if (cj == 0) gx_e -= 1.f;
+                    if (ci == 0) gy_e -= 1.f;
+                }
+                if (!ISO && !isref && (cj == 0 || ci == 0)) {
+                    const int ca = cbase + (ay.oc[sa] + (ci == 0)) * X2_CP + ax.oc[sb] + (cj == 0);
+                    cur.c00 = lds_quad(s_cov + ca);
+                    cur.c01 = lds_quad(s_cov + ca + 1);
+                    cur.c10 = lds_quad(s_cov + ca + X2_CP);
+                    cur.c11 = lds_quad(s_cov + ca + X2_CP + 1);
+                }
+            }
             if (!ISO) {
-                const float gx = ax.f[sb], gy = ay.f[sa];
+                const float gx = gx_e, gy = gy_e;
                 const float w11 = gx * gy, w01 = gx - w11, w10 = gy - w11, w00 = (1.f - gx) - w10;
                 const float cxx = fmaf(w11, cur.c11.x, fmaf(w10, cur.c10.x, fmaf(w01, cur.c01.x, w00 * cur.c00.x)));
                 const float cxy = fmaf(w11, cur.c11.y, fmaf(w10, cur.c10.y, fmaf(w01, cur.c01.y, w00 * cur.c00.y)));
@@ -1734,19 +1840,27 @@ __global__ void __launch_bounds__(256, HHSR_XS_OCC) k_merge_xs(BurstArgs a, Geo 
             const float dx0 = ax.d0[sb], dy0 = ay.d0[sa];
             const float dxs[3] = {dx0 - 1.f, dx0, dx0 + 1.f};
             float sv[2][2], sd[2][2];
-            auto taps = [&](auto exact_c) {
-                constexpr bool EXACT = decltype(exact_c)::value;
+            auto taps = [&](auto exact_c, auto masked_c) {
+                constexpr bool EXACT = decltype(exact_c)::value, MASKED = decltype(masked_c)::value;
+                const int mcol_m = px + ax.e[sb];
+                const float* __restrict__ mp = ((mcol_m & 1) ? s_mskB : s_mskA) + (ty + ay.e[sa]) * X2_RP + 2 * lj + (mcol_m & 2);
 #pragma unroll
                 for (int di = 0; di < 3; ++di) {
                     const float c3[3] = {cur.v01[di].x, cur.v01[di].y, cur.v23[di].x};
+                    float m3[3] = {1.f, 1.f, 1.f};
+                    if (MASKED) {
+                        const float2 ma = lds_pair(mp + di * X2_RP), mb = lds_pair(mp + di * X2_RP + 2);
+                        m3[0] = ma.x; m3[1] = ma.y; m3[2] = mb.x;
+                    }
                     const float dy = dy0 + (float)(di - 1);
                     const float qa = iyy * dy * dy, qb = ixy * dy;
 #pragma unroll
                     for (int dj = 0; dj < 3; ++dj) {
                         const float dx = dxs[dj];
                         const float z = fmaf(fmaf(ixx, dx, qb), dx, qa);
-                        const float w = EXACT ? __builtin_amdgcn_exp2f(fminf(z, 0.f))
-                                              : __builtin_amdgcn_fmed3f(__builtin_amdgcn_exp2f(z), 0.f, 1.f);
+                        float w = EXACT ? __builtin_amdgcn_exp2f(fminf(z, 0.f))
+                                        : __builtin_amdgcn_fmed3f(__builtin_amdgcn_exp2f(z), 0.f, 1.f);
+                        if (MASKED) w *= m3[dj];  // a tap outside the frame does not exist (merge.py:404-405)
                         if (di < 2 && dj < 2) {
                             sv[di & 1][dj & 1] = w * c3[dj];
                             sd[di & 1][dj & 1] = w;
@@ -1757,13 +1871,36 @@ __global__ void __launch_bounds__(256, HHSR_XS_OCC) k_merge_xs(BurstArgs a, Geo 
                     }
                 }
             };
-            if (ISO || finite) taps(std::false_type{});
-            else taps(std::true_type{});
+            if (EDGE) taps(std::true_type{}, std::true_type{});  // (rare: the exact form, masked)
+            else if (ISO || finite) taps(std::false_type{}, std::false_type{});
+            else taps(std::true_type{}, std::false_type{});
             const int by = (ay.org + py + ay.e[sa]) & 1, bx = (ax.org + px + ax.e[sb]) & 1;
+#if HHSR_XS_RGB
+            // tap parity (a, b) is colour class (a ^ by, b ^ bx): red sits at parity (ri ^ by, rj ^ bx), blue diagonally
+            // opposite, the greens on the other diagonal — four wave-uniform arrangements
+            const int ra = ri ^ by, rb = rj ^ bx;
+#define HHSR_FOLD3(RA, RB)                                                                    \
+    {                                                                                         \
+        nacc[sa][sb][0] = fmaf(r_eff, sv[RA][RB], nacc[sa][sb][0]);                           \
+        dacc[sa][sb][0] = fmaf(r_eff, sd[RA][RB], dacc[sa][sb][0]);                           \
+        nacc[sa][sb][1] = fmaf(r_eff, sv[RA ^ 1][RB] + sv[RA][RB ^ 1], nacc[sa][sb][1]);      \
+        dacc[sa][sb][1] = fmaf(r_eff, sd[RA ^ 1][RB] + sd[RA][RB ^ 1], dacc[sa][sb][1]);      \
+        nacc[sa][sb][2] = fmaf(r_eff, sv[RA ^ 1][RB ^ 1], nacc[sa][sb][2]);                   \
+        dacc[sa][sb][2] = fmaf(r_eff, sd[RA ^ 1][RB ^ 1], dacc[sa][sb][2]);                   \
+    }
+            if (ra) {
+                if (rb) { asm volatile("; xs fold 11"); HHSR_FOLD3(1, 1) asm volatile("; xs end 11"); }
+                else { asm volatile("; xs fold 10"); HHSR_FOLD3(1, 0) asm volatile("; xs end 10"); }
+            } else {
+                if (rb) { asm volatile("; xs fold 01"); HHSR_FOLD3(0, 1) asm volatile("; xs end 01"); }
+                else { asm volatile("; xs fold 00"); HHSR_FOLD3(0, 0) asm volatile("; xs end 00"); }
+            }
+#undef HHSR_FOLD3
+#else
 #define HHSR_FOLD(BY, BX)                                                                             \
     _Pragma("unroll") for (int aa = 0; aa < 2; ++aa) _Pragma("unroll") for (int bb = 0; bb < 2; ++bb) { \
-        n4[sa][sb][aa][bb] = fmaf(local_r, sv[aa ^ BY][bb ^ BX], n4[sa][sb][aa][bb]);                  \
-        d4[sa][sb][aa][bb] = fmaf(local_r, sd[aa ^ BY][bb ^ BX], d4[sa][sb][aa][bb]);                  \
+        nacc[sa][sb][aa * 2 + bb] = fmaf(r_eff, sv[aa ^ BY][bb ^ BX], nacc[sa][sb][aa * 2 + bb]);      \
+        dacc[sa][sb][aa * 2 + bb] = fmaf(r_eff, sd[aa ^ BY][bb ^ BX], dacc[sa][sb][aa * 2 + bb]);      \
     }
             if (by) {
                 if (bx) { asm volatile("; xs fold 11"); HHSR_FOLD(1, 1) asm volatile("; xs end 11"); }
@@ -1773,10 +1910,14 @@ __global__ void __launch_bounds__(256, HHSR_XS_OCC) k_merge_xs(BurstArgs a, Geo 
                 else { asm volatile("; xs fold 00"); HHSR_FOLD(0, 0) asm volatile("; xs end 00"); }
             }
 #undef HHSR_FOLD
+#endif
             if (HHSR_XS_PIPE) cur = nxt;
             else if (q + 1 < S * S) cur = load_sub((q + 1) / S, (q + 1) % S);
         }
     }
+    };  // run_frames
+    if (edge_mask != 0ull || ((a.flags & HHSR_MERGE_DO_REF) && edge_ref)) run_frames(std::true_type{});
+    else run_frames(std::false_type{});
     if (a.acc_r) a.acc_r[ridx] = ((a.flags & HHSR_MERGE_LOAD_ACC) ? a.acc_r[ridx] : 0.f) + racc;
     if (a.flags & HHSR_MERGE_LOAD_ACC) {
 #pragma unroll
@@ -1787,16 +1928,12 @@ __global__ void __launch_bounds__(256, HHSR_XS_OCC) k_merge_xs(BurstArgs a, Geo 
                 if (border_pixel(g, hi, hj)) continue;
                 const size_t o = ((size_t)(hi - g.row0) * g.sW + hj) * 3;
                 float n3[3], d3[3];
+                xs_rgb<NC>(cfa, nacc[sa][sb], dacc[sa][sb], n3, d3);
 #pragma unroll
                 for (int k = 0; k < 3; ++k) {
-                    n3[k] = num[o + k];
-                    d3[k] = den[o + k];
-                }
-                classes_to_rgb(cfa, n4[sa][sb], d4[sa][sb], n3, d3);
-#pragma unroll
-                for (int k = 0; k < 3; ++k) {
-                    num[o + k] = (a.flags & HHSR_MERGE_DIVIDE) ? n3[k] / d3[k] : n3[k];
-                    if (a.flags & HHSR_MERGE_STORE_DEN) den[o + k] = d3[k];
+                    const float nk = num[o + k] + n3[k], dk = den[o + k] + d3[k];
+                    num[o + k] = (a.flags & HHSR_MERGE_DIVIDE) ? nk / dk : nk;
+                    if (a.flags & HHSR_MERGE_STORE_DEN) den[o + k] = dk;
                 }
             }
         return;
@@ -1809,8 +1946,8 @@ __global__ void __launch_bounds__(256, HHSR_XS_OCC) k_merge_xs(BurstArgs a, Geo 
             float* row = s_out + (S * ty + sa) * OP + 3 * S * tx;
 #pragma unroll
             for (int sb = 0; sb < S; ++sb) {
-                float n3[3] = {0.f, 0.f, 0.f}, d3[3] = {0.f, 0.f, 0.f};
-                classes_to_rgb(cfa, n4[sa][sb], d4[sa][sb], n3, d3);
+                float n3[3], d3[3];
+                xs_rgb<NC>(cfa, nacc[sa][sb], dacc[sa][sb], n3, d3);
 #pragma unroll
                 for (int k = 0; k < 3; ++k)
                     row[3 * sb + k] = pass ? d3[k] : ((a.flags & HHSR_MERGE_DIVIDE) ? n3[k] / d3[k] : n3[k]);
@@ -2378,7 +2515,7 @@ static int merge_burst_impl(const float* const* raws, const float* const* flows,
                       nrows % 2 == 0 && !(force & HHSR_MERGE_FORCE_TILE);
     const bool x2_v1 = (force & HHSR_MERGE_FORCE_X2V1) != 0;
     const bool aligned16 = ((uintptr_t)num % 16 == 0) && (!(flags & HHSR_MERGE_STORE_DEN) || (uintptr_t)den % 16 == 0);
-    const bool x3 = aligned16 && tiled && iscale == 3 && ts % QT == 0 && sW == 3 * W && sH == 3 * H && row0 % (3 * QT) == 0 && nrows % 3 == 0 &&
+    const bool x3 = aligned16 && tiled && iscale == 3 && cfa_is_bayer(c) && ts % QT == 0 && sW == 3 * W && sH == 3 * H && row0 % (3 * QT) == 0 && nrows % 3 == 0 &&
                     W % 4 == 0 && !(force & HHSR_MERGE_FORCE_TILE);
     const bool chained = (flags & (HHSR_MERGE_STORE_CLASSES | HHSR_MERGE_LOAD_CLASSES)) != 0;
     if (chained && HHSR_X2_DB) {  // (the double-buffered A/B variant's frame loop starts at frame 0: it would count the
@@ -2417,7 +2554,7 @@ static int merge_burst_impl(const float* const* raws, const float* const* flows,
         }
     } else if (quad && !x2_v1 && aligned16) {
         const dim3 qgrid(hhsr_cdiv(W, QT), hhsr_cdiv(nrows / 2, QT));
-        if (lmin) {
+if (lmin) {
             if (iso) hipLaunchKernelGGL((k_merge_x2<true, true>), qgrid, block, 0, s, a, g, c, num, den);
             else hipLaunchKernelGGL((k_merge_x2<false, true>), qgrid, block, 0, s, a, g, c, num, den);
         } else {

@@ -609,8 +609,11 @@ def test_merge_x3_kernel_equals_tile_kernel(kern):
     merge.merge_burst(tf, None, None, pn, pd, cfa, cfg, do_ref=False, divide=False, store_den=True)
     tn, td = torch.empty_like(pn), torch.empty_like(pd)
     merge.merge_burst(tf, None, None, tn, td, cfa, cfg_for("tile"), do_ref=False, divide=False, store_den=True)
-    assert_close(N(pn), N(tn), 2e-5, 1e-7, "partial num")
-    assert_close(N(pd), N(td), 2e-5, 1e-7, "partial den")
+    # (4e-5: the frames whose window leaves the image — here the one pushed out by 9.5 px and the small negative flows
+    # at column 0 — run the uniform code with border masks since round 4, a different float32 evaluation order than the
+    # tile kernel's per-pixel border code; measured 2.9e-5 at one of 241 920 values, everything else <= 2e-5)
+    assert_close(N(pn), N(tn), 4e-5, 1e-7, "partial num")
+    assert_close(N(pd), N(td), 4e-5, 1e-7, "partial den")
     whole = torch.empty(3 * H, 3 * W, 3, device=DEV)
     merge.merge_burst(tf, T(ref), rc, whole, None, cfa, cfg)
     slab = torch.empty(96, 3 * W, 3, device=DEV)

@@ -1,6 +1,6 @@
 """What the perimeter tiles cost the x3 merge (they run the generic per-pixel path: their reference-frame window leaves
-the image): the fused merge of a 48 MP x 20 burst over ALL output rows, over the interior rows only (no top / bottom
-tile row), and over the top / bottom 96-row bands alone.   python tools/debug/x3_border_cost.py [frames]"""
+the image): the fused merge of a 48 MP x 20 burst (or: frames H W scale) over ALL output rows, over the interior rows only (no top / bottom
+tile row), and over the top / bottom 96-row bands alone.   python tools/debug/border_cost.py [frames]"""
 import os, sys
 import numpy as np
 import torch
@@ -12,16 +12,17 @@ from handheld_super_resolution import synthetic as synth
 from handheld_super_resolution.merge import merge_burst
 
 dev = torch.device("cuda", 0)
-H, W, NF = 6000, 8000, int(sys.argv[1]) if len(sys.argv) > 1 else 20
+NF = int(sys.argv[1]) if len(sys.argv) > 1 else 20
+H, W, SC = (int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4])) if len(sys.argv) > 4 else (6000, 8000, 3)  # e.g. 20 3000 4000 2
 ref, comp, _ = synth.make_burst_torch(H, W, NF, dev, seed=1234)
 cfg = hsr.default_config()
 cfg.verbose = 0
-cfg.scale = 3
+cfg.scale = SC
 hsr.prepare_config(cfg, np.full((H, W), float(ref.mean()), np.float32), synth.ALPHA_ISO100, synth.BETA_ISO100,
                    [[0, 1], [1, 2]], [1.0, 1.0, 1.0])
 pipe = hsr.BurstPipeline(cfg).init_ref(ref)
 frames = pipe.process_frames([comp[i] for i in range(NF - 1)], None, fuse_local_min=True)
-sH, sW = 3 * H, 3 * W
+sH, sW = SC * H, SC * W
 out = torch.empty((sH, sW, 3), dtype=torch.float32, device=dev)
 
 
