@@ -18,12 +18,14 @@ COMMON = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno
 SOURCES = {
     "hhsr_api.hip": ["-ffp-contract=off"],
     "hhsr_pyramid.hip": ["-ffp-contract=off"],
-    "hhsr_align.hip": ["-ffp-contract=off"],
+    "hhsr_align.hip": ["-ffp-contract=off", "-fno-slp-vectorize"],  # (SLP off: level 0 172.5 -> 167.2 us, coarse levels 55.7 -> 54.5)
     "hhsr_kernels.hip": ["-ffp-contract=off", "-fno-slp-vectorize"],
     "hhsr_robustness.hip": ["-ffp-contract=off", "-fno-slp-vectorize"],
     "hhsr_merge.hip": [],
     "hhsr_grey.hip": ["-ffp-contract=off"],
-    "hhsr_fft.hip": [],
+    # (the SLP vectoriser packs the complex butterflies into v_pk_* instructions: measured 121 -> 98 us per launch of the
+    # row kernels, 94 -> 89 us of the column kernel at 12 MP x 3-4 frames — tools/debug/r04_call11.sh)
+    "hhsr_fft.hip": ["-fno-slp-vectorize"],
     "hhsr_io.hip": ["-ffp-contract=off"],
     "hhsr_post.hip": ["-ffp-contract=off"],
 }

@@ -8,6 +8,8 @@
 struct HhsrRadices {
     int n;
     int r[HHSR_MAX_RADICES];
+    int pow_min;  // passes whose twiddle table would hold more than this many entries keep only w^k and raise it to the
+                  // powers 2 .. R-1 in registers (hhsr_fft.hip: stockham_pass); <= 0: every pass has its full table
 };
 
 struct HhsrFft {

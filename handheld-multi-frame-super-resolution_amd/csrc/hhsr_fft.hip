@@ -23,6 +23,11 @@
 #include <math.h>
 #include <vector>
 
+#define HHSR_FFT_POW_RMAX 6  // radices up to this may take the power form (the schedule puts the small radices last)
+#ifndef HHSR_FFT_POW_MIN
+#define HHSR_FFT_POW_MIN 1024  // entries of one pass's twiddle table above which it is kept as w^k only (0: never)
+#endif
+
 // ---- complex helpers ------------------------------------------------------------------------------------
 __device__ __forceinline__ float2 cadd(float2 a, float2 b) { return make_float2(a.x + b.x, a.y + b.y); }
 __device__ __forceinline__ float2 csub(float2 a, float2 b) { return make_float2(a.x - b.x, a.y - b.y); }
@@ -206,9 +211,13 @@ __host__ __device__ constexpr int fft_maxit(int R) { return R <= 3 ? 4 : R <= 5 
 // ping-pong — twice the resident workgroups for kernels that are bound by barrier / memory latency.
 // twp: this pass's twiddles, twp[(r-1)*Ns + k] = exp(-2 pi i r k / (Ns R)) — contiguous in k, so the lanes of
 // a wave (consecutive butterflies -> consecutive k) read consecutive LDS words (no bank conflicts).
+// pw: this pass's table holds only w^k = exp(-2 pi i k / (Ns R)), k < Ns — the twiddles of inputs 2 .. R-1 are its powers,
+// formed in registers by a product tree (w^r = w^(r/2) w^(r - r/2): depth <= 4, ~4e-7 relative).  The LAST passes' tables
+// are (R - 1) N / R entries each — as large as the data they serve: 6000-point columns took 96 kB of LDS (one workgroup
+// per CU), 4000-point row pairs 96 kB; with the power form they take 58 / 74 kB (two per CU).
 template <int R>
 __device__ __forceinline__ void stockham_pass(float2* __restrict__ buf, int bstride, int NB,
-                                              const float2* __restrict__ twp, int N, int Ns, int tid, int nt) {
+                                              const float2* __restrict__ twp, int N, int Ns, int tid, int nt, bool pw) {
     constexpr int MAXIT = fft_maxit(R);
     const int L = N / R, total = NB * L;
     const float rNs = 1.0f / (float)Ns, rL = 1.0f / (float)L;
@@ -226,8 +235,17 @@ __device__ __forceinline__ void stockham_pass(float2* __restrict__ buf, int bstr
 #pragma unroll
             for (int r = 0; r < R; ++r) v[it][r] = ib[j + r * L];
             if (Ns > 1) {
+                if (R <= HHSR_FFT_POW_RMAX && pw) {  // (compile time: the large radices never get the power form's registers)
+                    float2 w[R];
+                    w[1] = twp[k];
 #pragma unroll
-                for (int r = 1; r < R; ++r) v[it][r] = cmul(v[it][r], twp[(r - 1) * Ns + k]);
+                    for (int r = 2; r < R; ++r) w[r] = cmul(w[r >> 1], w[r - (r >> 1)]);
+#pragma unroll
+                    for (int r = 1; r < R; ++r) v[it][r] = cmul(v[it][r], w[r]);
+                } else {
+#pragma unroll
+                    for (int r = 1; r < R; ++r) v[it][r] = cmul(v[it][r], twp[(r - 1) * Ns + k]);
+                }
             }
             dft_reg<R>(v[it]);
             dst[it] = bidx * bstride + q * Ns * R + k;
@@ -257,14 +275,15 @@ __device__ __forceinline__ void fft_lds(float2* buf, int bstride, int NB, const 
         // hoisted out of the pass loop, where they stay live together and spill
         int Np = N;
         asm volatile("" : "+s"(Np));
+        const bool pw = rad.pow_min > 0 && R <= HHSR_FFT_POW_RMAX && (R - 1) * Ns > rad.pow_min;  // (= pass_twiddles on the host)
         switch (R) {
-#define HHSR_PASS(RR) case RR: stockham_pass<RR>(buf, bstride, NB, tw + toff, Np, Ns, tid, nt); break;
+#define HHSR_PASS(RR) case RR: stockham_pass<RR>(buf, bstride, NB, tw + toff, Np, Ns, tid, nt, pw); break;
             HHSR_PASS(2) HHSR_PASS(3) HHSR_PASS(4) HHSR_PASS(5) HHSR_PASS(6) HHSR_PASS(7) HHSR_PASS(8) HHSR_PASS(9)
             HHSR_PASS(10) HHSR_PASS(12) HHSR_PASS(14) HHSR_PASS(15) HHSR_PASS(16)
 #undef HHSR_PASS
             default: break;  // the host only schedules the radices above
         }
-        toff += (R - 1) * Ns;
+        toff += pw ? Ns : (R - 1) * Ns;
         Ns *= R;
     }
 }
@@ -522,6 +541,8 @@ __global__ void __launch_bounds__(FFT_NT, FFT_ROWS_WPE) k_rows_inv(const float2*
 }
 
 // ---- host side --------------------------------------------------------------------------------------------
+static std::vector<float2> pass_twiddles(const HhsrRadices& rad);
+
 // Radix schedule: fewest passes over the supported radices, then the smallest maximum radix (registers, idle
 // lanes), then an odd / small first radix (the Ns = 1 pass stores with stride R: even R collide on LDS banks).
 // HHSR_FFT_RADIX_MAX (experiments) caps the radix; 5 reproduces the original 5/4/3/2 schedule.
@@ -561,6 +582,8 @@ static bool factorize(int n, int nb, HhsrRadices& out) {
     for (int i = 1; i < best_n; ++i)
         if (collide(best[i]) < collide(best[first]) || (collide(best[i]) == collide(best[first]) && best[i] > best[first]))
             first = i;
+    static const int pow_min = getenv("HHSR_FFT_POW_MIN") ? atoi(getenv("HHSR_FFT_POW_MIN")) : HHSR_FFT_POW_MIN;
+    out.pow_min = pow_min;
     out.n = 0;
     out.r[out.n++] = best[first];
     for (int i = 0; i < best_n; ++i)
@@ -603,7 +626,8 @@ static std::vector<float2> pass_twiddles(const HhsrRadices& rad) {
     int Ns = 1;
     for (int p = 0; p < rad.n; ++p) {
         const int R = rad.r[p];
-        for (int r = 1; r < R; ++r)
+        const bool pw = rad.pow_min > 0 && R <= HHSR_FFT_POW_RMAX && (R - 1) * Ns > rad.pow_min;  // only w^k: the kernel forms the powers
+        for (int r = 1; r < (pw ? 2 : R); ++r)
             for (int k = 0; k < Ns; ++k) {
                 const double a = -2.0 * M_PI * (double)r * (double)k / ((double)Ns * (double)R);
                 h.push_back(make_float2((float)cos(a), (float)sin(a)));
@@ -622,9 +646,10 @@ static int pick_rb(int M, HhsrRadices& rad) {
     for (int c = 0; c < 3; ++c) {
         const int rb = cands[c];
         if (forced && rb != forced) continue;
-        if (sizeof(float2) * ((size_t)M + (size_t)rb * M) > 76 * 1024 && rb > 1) continue;
         if (rb * (M / 2) >= 65536) continue;
-        if (factorize(M, rb, rad)) return rb;
+        if (!factorize(M, rb, rad)) continue;
+        if (sizeof(float2) * (pass_twiddles(rad).size() + (size_t)rb * M) > 76 * 1024 && rb > 1) continue;
+        return rb;
     }
     return 0;
 }
@@ -640,7 +665,7 @@ bool hhsr_fft_create(HhsrFft& f, int H, int W, int batch) {
     f.nc = 0;
     const char* enc = getenv("HHSR_FFT_NC");  // experiments / tests: force the columns-per-workgroup choice
     for (int nc = enc ? atoi(enc) : 2; nc >= 1 && !f.nc; --nc)  // two columns per workgroup unless their passes / LDS do not fit
-        if (sizeof(float2) * ((size_t)H + (size_t)nc * H) <= 150 * 1024 && factorize(H, nc, f.radH)) f.nc = nc;
+        if (factorize(H, nc, f.radH) && sizeof(float2) * (pass_twiddles(f.radH).size() + (size_t)nc * H) <= 150 * 1024) f.nc = nc;
     if (!f.nc) return false;
     int Wk = 0;
     for (int x = 0; x <= M; ++x)
