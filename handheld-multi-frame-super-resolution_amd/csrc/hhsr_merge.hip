@@ -1009,6 +1009,9 @@ __global__ void __launch_bounds__(256) k_merge_burst_quad(BurstArgs a, Geo g, Cf
 #ifndef HHSR_XS_OCC
 #define HHSR_XS_OCC 2  // k_merge_xs<3>: 72 accumulators per thread; 3 waves per SIMD (168 VGPRs) spills 50 dwords
 #endif
+#ifndef HHSR_X2_RGB
+#define HHSR_X2_RGB 1  // k_merge_x2: 3 + 3 channel accumulators per sub-pixel (Bayer) instead of 4 + 4 parity classes
+#endif
 #ifndef HHSR_XS_EDGE
 #define HHSR_XS_EDGE 1  // k_merge_xs: frames whose window leaves the image run the uniform code with masks (0: per-pixel path)
 #endif
@@ -1091,6 +1094,23 @@ __device__ __forceinline__ X2Axis x2_ref_axis(int l0, int p) {
     return u;
 }
 
+// the R, G, B sums of one sub-pixel from its NC accumulators (3: channels already; 4: parity classes -> channels)
+template <int NC>
+__device__ __forceinline__ void xs_rgb(const Cfa4 cfa, const float* nsub, const float* dsub, float n3[3], float d3[3]) {
+#pragma unroll
+    for (int k = 0; k < 3; ++k) n3[k] = d3[k] = 0.f;
+    if (NC == 3) {
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            n3[k] = nsub[k];
+            d3[k] = dsub[k];
+        }
+    } else {
+        const float n4[2][2] = {{nsub[0], nsub[1]}, {nsub[2], nsub[3]}}, d4[2][2] = {{dsub[0], dsub[1]}, {dsub[2], dsub[3]}};
+        classes_to_rgb(cfa, n4, d4, n3, d3);
+    }
+}
+
 template <bool ISO, bool LMIN>
 __global__ void __launch_bounds__(256, HHSR_X2_OCC) k_merge_x2(BurstArgs a, Geo g, Cfa4 cfa, float* __restrict__ num,
                                                    float* __restrict__ den) {
@@ -1166,20 +1186,26 @@ __global__ void __launch_bounds__(256, HHSR_X2_OCC) k_merge_x2(BurstArgs a, Geo 
     const int li = lane >> 3, lj = lane & 7;
     const int ty = 2 * li + py, tx = 2 * lj + px;                   // LR pixel inside the tile
     const int ridx = (ly0 + ty) * g.W + lx0 + tx;
-    float n4[2][2][2][2], d4[2][2][2][2];
+    // HHSR_X2_RGB (round 4; Bayer layouts — the only ones this kernel is launched for): the two green parity classes are
+    // summed when a frame is folded: 3 + 3 accumulators per sub-pixel instead of 4 + 4 (24 instead of 32 per thread),
+    // and the epilogue has no class -> channel step (whose private arrays lived in scratch).  0: round 3's four classes.
+    constexpr int NC = HHSR_X2_RGB ? 3 : 4, NA = 4 * NC;
+    float nacc[2][2][NC], dacc[2][2][NC];
+    const int rcl = cfa.c[0] == 0 ? 0 : cfa.c[1] == 0 ? 1 : cfa.c[2] == 0 ? 2 : 3;  // parity class of the red samples
+    const int ri = rcl >> 1, rj = rcl & 1;
     float racc = 0.f;
     if (chain_load) {  // (coalesced: 256 consecutive floats per accumulator and tile)
 #pragma unroll
-        for (int k = 0; k < 16; ++k) {
-            (&n4[0][0][0][0])[k] = cls[k * 256];
-            (&d4[0][0][0][0])[k] = cls[(16 + k) * 256];
+        for (int k = 0; k < NA; ++k) {  // (the parking layout keeps 16 + 16 + 1 slots per thread)
+            (&nacc[0][0][0])[k] = cls[k * 256];
+            (&dacc[0][0][0])[k] = cls[(16 + k) * 256];
         }
         racc = cls[32 * 256];
     } else {
 #pragma unroll
-        for (int k = 0; k < 16; ++k) {
-            (&n4[0][0][0][0])[k] = 0.f;
-            (&d4[0][0][0][0])[k] = 0.f;
+        for (int k = 0; k < NA; ++k) {
+            (&nacc[0][0][0])[k] = 0.f;
+            (&dacc[0][0][0])[k] = 0.f;
         }
     }
 
@@ -1359,16 +1385,38 @@ __global__ void __launch_bounds__(256, HHSR_X2_OCC) k_merge_x2(BurstArgs a, Geo 
                 if (!HHSR_X2_CLAMP) taps(std::true_type{});
                 else if (ISO || finite) taps(std::false_type{});
                 else taps(std::true_type{});
-                // tap-offset parity -> absolute raw-coordinate parity (uniform): n4[a][b] += r * sv[a ^ by][b ^ bx]
+                // tap-offset parity -> absolute raw-coordinate parity (uniform): class (a, b) += r * sv[a ^ by][b ^ bx]
                 const int by = (ay.org + py + ay.e[sa]) & 1, bx = (ax.org + px + ax.e[sb]) & 1;
-#define HHSR_FOLD(BY, BX)                                                                             \
-    _Pragma("unroll") for (int aa = 0; aa < 2; ++aa) _Pragma("unroll") for (int bb = 0; bb < 2; ++bb) { \
-        n4[sa][sb][aa][bb] = fmaf(local_r, sv[aa ^ BY][bb ^ BX], n4[sa][sb][aa][bb]);                  \
-        d4[sa][sb][aa][bb] = fmaf(local_r, sd[aa ^ BY][bb ^ BX], d4[sa][sb][aa][bb]);                  \
-    }
                 // (the empty asm statements keep the four arms real branches: if-converted, the permutation costs 16
                 // v_cndmask per sub-pixel, twice the FMAs it feeds;
                 // and distinct, so that the FMAs are not sunk below the arms leaving 8 permutation moves in each)
+#if HHSR_X2_RGB
+                // tap parity (a, b) is colour class (a ^ by, b ^ bx): red sits at parity (ri ^ by, rj ^ bx), blue diagonally
+                // opposite, the greens on the other diagonal — four wave-uniform arrangements
+                const int ra = ri ^ by, rb = rj ^ bx;
+#define HHSR_FOLD3(RA, RB)                                                                    \
+    {                                                                                         \
+        nacc[sa][sb][0] = fmaf(local_r, sv[RA][RB], nacc[sa][sb][0]);                         \
+        dacc[sa][sb][0] = fmaf(local_r, sd[RA][RB], dacc[sa][sb][0]);                         \
+        nacc[sa][sb][1] = fmaf(local_r, sv[RA ^ 1][RB] + sv[RA][RB ^ 1], nacc[sa][sb][1]);    \
+        dacc[sa][sb][1] = fmaf(local_r, sd[RA ^ 1][RB] + sd[RA][RB ^ 1], dacc[sa][sb][1]);    \
+        nacc[sa][sb][2] = fmaf(local_r, sv[RA ^ 1][RB ^ 1], nacc[sa][sb][2]);                 \
+        dacc[sa][sb][2] = fmaf(local_r, sd[RA ^ 1][RB ^ 1], dacc[sa][sb][2]);                 \
+    }
+                if (ra) {
+                    if (rb) { asm volatile("; fold 11"); HHSR_FOLD3(1, 1) asm volatile("; end 11"); }
+                    else { asm volatile("; fold 10"); HHSR_FOLD3(1, 0) asm volatile("; end 10"); }
+                } else {
+                    if (rb) { asm volatile("; fold 01"); HHSR_FOLD3(0, 1) asm volatile("; end 01"); }
+                    else { asm volatile("; fold 00"); HHSR_FOLD3(0, 0) asm volatile("; end 00"); }
+                }
+#undef HHSR_FOLD3
+#else
+#define HHSR_FOLD(BY, BX)                                                                             \
+    _Pragma("unroll") for (int aa = 0; aa < 2; ++aa) _Pragma("unroll") for (int bb = 0; bb < 2; ++bb) { \
+        nacc[sa][sb][aa * 2 + bb] = fmaf(local_r, sv[aa ^ BY][bb ^ BX], nacc[sa][sb][aa * 2 + bb]);    \
+        dacc[sa][sb][aa * 2 + bb] = fmaf(local_r, sd[aa ^ BY][bb ^ BX], dacc[sa][sb][aa * 2 + bb]);    \
+    }
                 if (by) {
                     if (bx) { asm volatile("; fold 11"); HHSR_FOLD(1, 1) asm volatile("; end 11"); }
                     else { asm volatile("; fold 10"); HHSR_FOLD(1, 0) asm volatile("; end 10"); }
@@ -1377,6 +1425,7 @@ __global__ void __launch_bounds__(256, HHSR_X2_OCC) k_merge_x2(BurstArgs a, Geo 
                     else { asm volatile("; fold 00"); HHSR_FOLD(0, 0) asm volatile("; end 00"); }
                 }
 #undef HHSR_FOLD
+#endif
             }
     };
     auto frame_n = [&](int n, const float2 fl, float lr, int bo) {
@@ -1415,9 +1464,9 @@ __global__ void __launch_bounds__(256, HHSR_X2_OCC) k_merge_x2(BurstArgs a, Geo 
 #endif
     if (chain_store) {  // park the accumulators for the final link
 #pragma unroll
-        for (int k = 0; k < 16; ++k) {
-            cls[k * 256] = (&n4[0][0][0][0])[k];
-            cls[(16 + k) * 256] = (&d4[0][0][0][0])[k];
+        for (int k = 0; k < NA; ++k) {
+            cls[k * 256] = (&nacc[0][0][0])[k];
+            cls[(16 + k) * 256] = (&dacc[0][0][0])[k];
         }
         cls[32 * 256] = racc;
         return;
@@ -1436,16 +1485,12 @@ __global__ void __launch_bounds__(256, HHSR_X2_OCC) k_merge_x2(BurstArgs a, Geo 
                 if (border_pixel(g, hi, hj)) continue;
                 const size_t o = ((size_t)(hi - g.row0) * g.sW + hj) * 3;
                 float n3[3], d3[3];
+                xs_rgb<NC>(cfa, nacc[sa][sb], dacc[sa][sb], n3, d3);
 #pragma unroll
                 for (int k = 0; k < 3; ++k) {
-                    n3[k] = num[o + k];
-                    d3[k] = den[o + k];
-                }
-                classes_to_rgb(cfa, n4[sa][sb], d4[sa][sb], n3, d3);
-#pragma unroll
-                for (int k = 0; k < 3; ++k) {
-                    num[o + k] = (a.flags & HHSR_MERGE_DIVIDE) ? n3[k] / d3[k] : n3[k];
-                    if (a.flags & HHSR_MERGE_STORE_DEN) den[o + k] = d3[k];
+                    const float nk = num[o + k] + n3[k], dk = den[o + k] + d3[k];
+                    num[o + k] = (a.flags & HHSR_MERGE_DIVIDE) ? nk / dk : nk;
+                    if (a.flags & HHSR_MERGE_STORE_DEN) den[o + k] = dk;
                 }
             }
         return;
@@ -1459,8 +1504,8 @@ __global__ void __launch_bounds__(256, HHSR_X2_OCC) k_merge_x2(BurstArgs a, Geo 
             float v[2][3];
 #pragma unroll
             for (int sb = 0; sb < 2; ++sb) {
-                float n3[3] = {0.f, 0.f, 0.f}, d3[3] = {0.f, 0.f, 0.f};
-                classes_to_rgb(cfa, n4[sa][sb], d4[sa][sb], n3, d3);
+                float n3[3], d3[3];
+                xs_rgb<NC>(cfa, nacc[sa][sb], dacc[sa][sb], n3, d3);
 #pragma unroll
                 for (int k = 0; k < 3; ++k)
                     v[sb][k] = pass ? d3[k] : ((a.flags & HHSR_MERGE_DIVIDE) ? n3[k] / d3[k] : n3[k]);
@@ -1557,23 +1602,6 @@ __device__ __forceinline__ XsAxis<S> xs_ref_axis(int l, int l0, int off_lr, doub
         u.f[s] = gq - truncf(gq);
     }
     return u;
-}
-
-// the R, G, B sums of one sub-pixel from its NC accumulators (3: channels already; 4: parity classes -> channels)
-template <int NC>
-__device__ __forceinline__ void xs_rgb(const Cfa4 cfa, const float* nsub, const float* dsub, float n3[3], float d3[3]) {
-#pragma unroll
-    for (int k = 0; k < 3; ++k) n3[k] = d3[k] = 0.f;
-    if (NC == 3) {
-#pragma unroll
-        for (int k = 0; k < 3; ++k) {
-            n3[k] = nsub[k];
-            d3[k] = dsub[k];
-        }
-    } else {
-        const float n4[2][2] = {{nsub[0], nsub[1]}, {nsub[2], nsub[3]}}, d4[2][2] = {{dsub[0], dsub[1]}, {dsub[2], dsub[3]}};
-        classes_to_rgb(cfa, n4, d4, n3, d3);
-    }
 }
 
 template <int S, bool ISO, bool LMIN>
@@ -2522,7 +2550,7 @@ static int merge_burst_impl(const float* const* raws, const float* const* flows,
         hhsr_set_error("hhsr_merge_burst_chain: not available in the HHSR_X2_DB variant build");  // parked frames twice)
         return -3;
     }
-    if (chained && !(quad && !x2_v1 && aligned16 && !mono)) {
+    if (chained && !(quad && !x2_v1 && aligned16 && !mono && (cfa_is_bayer(c) || !HHSR_X2_RGB))) {
         hhsr_set_error("hhsr_merge_burst_chain: needs the wave-per-class x2 kernel (scale 2, ts %% 16 == 0, sH = 2 H, "
                        "sW = 2 W, 16-byte aligned output, float32 weights, Bayer)");
         return -3;
@@ -2552,7 +2580,7 @@ static int merge_burst_impl(const float* const* raws, const float* const* flows,
             if (iso) hipLaunchKernelGGL((k_merge_burst_quad<true, false, true>), qgrid, block, 0, s, a, g, c, num, den);
             else hipLaunchKernelGGL((k_merge_burst_quad<false, false, true>), qgrid, block, 0, s, a, g, c, num, den);
         }
-    } else if (quad && !x2_v1 && aligned16) {
+    } else if (quad && !x2_v1 && aligned16 && (cfa_is_bayer(c) || !HHSR_X2_RGB)) {
         const dim3 qgrid(hhsr_cdiv(W, QT), hhsr_cdiv(nrows / 2, QT));
 if (lmin) {
             if (iso) hipLaunchKernelGGL((k_merge_x2<true, true>), qgrid, block, 0, s, a, g, c, num, den);

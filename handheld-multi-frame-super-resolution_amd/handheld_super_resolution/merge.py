@@ -71,7 +71,7 @@ def can_fuse_local_min(config, shape):
     ok = not (kflags & (WEIGHT_F64 | FORCE_GENERIC | FORCE_TILE)) and int(config.block_matching.tuning.tile_size) % 16 == 0
     if kflags & SENSOR_MONO:  # monochrome: the x2 tile kernel only
         return ok and scale == 2.0 and not (kflags & FORCE_X2V1)
-    return ok and ((scale == 2.0 and H % 2 == 0 and W % 2 == 0) or (scale == 3.0 and W % 4 == 0))
+    return ok and ((scale == 2.0 and H % 2 == 0 and W % 2 == 0) or (scale == 3.0 and W % 4 == 0 and _is_bayer(config)))
 
 
 def merge_burst(frames, ref_img, ref_kernels, num, den, cfa_pattern, config, load_acc=False, do_ref=True,
@@ -123,10 +123,23 @@ def merge_burst(frames, ref_img, ref_kernels, num, den, cfa_pattern, config, loa
                   _lib.ptr(acc_r if chunk else None), sH, sW, int(row0), int(nrows), int(lr_row_offset), _lib.stream())
 
 
+def _is_bayer(config):
+    """2 x 2 colour layout with red and blue on one diagonal and green on the other (what the wave-per-class kernels
+    fold their parity classes into; other layouts take the first-generation tile kernels) — mirrors cfa_is_bayer()."""
+    try:
+        c = [int(v) for row in config.exif.cfa_pattern for v in row]
+    except Exception:
+        return False
+    for k in range(4):
+        if c[k] == 0:
+            return c[3 - k] == 2 and c[k ^ 1] == 1 and c[k ^ 2] == 1
+    return False
+
+
 def can_chain(config, shape):
-    """merge_burst_chain applies: the wave-per-class x2 kernel (same conditions as can_fuse_local_min at scale 2)."""
+    """merge_burst_chain applies: the wave-per-class x2 kernel (same conditions as can_fuse_local_min at scale 2, Bayer)."""
     scale, kflags = _common(config)
-    return scale == 2.0 and not (kflags & SENSOR_MONO) and can_fuse_local_min(config, shape)
+    return scale == 2.0 and not (kflags & SENSOR_MONO) and can_fuse_local_min(config, shape) and _is_bayer(config)
 
 
 def chain_buffer(shape, device):
