@@ -339,7 +339,7 @@ def main():
                       else "k_merge_burst_tile" if float(scale).is_integer() else "k_merge_burst")
             traffic, valu, pmc_note = None, None, None
             try:  # HBM bytes / VALU instructions per launch from the committed rocprofv3 --pmc passes of this exact kernel
-                pmc_file = "r03_pmc_merge_x3.json" if float(scale) == 3.0 else "r03_pmc_merge.json"
+                pmc_file = "r04_pmc_merge_x3.json" if float(scale) == 3.0 else "r04_pmc_merge.json"
                 with open(os.path.join(ROOT, "profiles", pmc_file)) as f:
                     pm = json.load(f)
                 sha = hashlib.sha256(open(MERGE_SRC, "rb").read()).hexdigest()[:16]

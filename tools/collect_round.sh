@@ -1,6 +1,6 @@
 #!/bin/bash
 # Everything the round's profiles / PARITY.md are made from, in one GPU call.  usage: tools/collect_round.sh <name>
-NAME=${1:-r03}
+NAME=${1:-r04}
 OUT=gpurun_out/$NAME
 mkdir -p $OUT
 HHSR_PARITY_LOG=$PWD/$OUT/parity.jsonl timeout 2400 python -m pytest tests -q -m gpu --timeout 1200 > $OUT/tests.log 2>&1
@@ -35,16 +35,12 @@ bash tools/debug/kt_mono.sh 2>&1 | grep -v amdgpu.ids > $OUT/kernel_trace_mono.m
 bash tools/debug/kt_c5.sh 2>&1 | grep -v amdgpu.ids > $OUT/kernel_trace_c5.md
 python tools/debug/hwqueue_probe.py 2>&1 | grep -v amdgpu.ids > $OUT/hwqueue_probe.txt
 python tools/debug/copy_contention_probe.py 2>&1 | grep -v amdgpu.ids >> $OUT/hwqueue_probe.txt
-# the randomised sweep in report mode (the asserting run is part of the test suite above)
-rm -f $OUT/fuzz_report.txt
-HHSR_FUZZ_REPORT=$PWD/$OUT/fuzz_report.txt python -m pytest tests/test_fuzz_parity.py -m gpu -q > /dev/null 2>&1
-python tools/fuzz_report.py $OUT/fuzz_report.txt >> $OUT/PARITY.md
-# ... and the same assertions on held-out generator seeds (eleven more sets of 64; ~28 GPU-minutes)
-bash tools/debug/fuzz_sets.sh > $OUT/fuzz_sets.log 2>&1
-bash tools/debug/fuzz_more_sets.sh 50 60 70 80 90 100 110 >> $OUT/fuzz_sets.log 2>&1
-cat gpurun_out/fuzz/set1.txt gpurun_out/fuzz/set2.txt gpurun_out/fuzz/set3.txt gpurun_out/fuzz/set4.txt gpurun_out/fuzz/set50.txt \
-    gpurun_out/fuzz/set60.txt gpurun_out/fuzz/set70.txt gpurun_out/fuzz/set80.txt gpurun_out/fuzz/set90.txt gpurun_out/fuzz/set100.txt \
-    gpurun_out/fuzz/set110.txt > $OUT/fuzz_heldout.txt
-python tools/fuzz_report.py $OUT/fuzz_heldout.txt | sed 's/704 cases, HIP main/704 HELD-OUT cases (eleven sets of 64 from other generator seeds; same assertions), HIP main/' >> $OUT/PARITY.md
+# round 4: per-rank compute of the multi-GPU strategies on this one GPU (tools/debug/emulate_ranks.py), the x3 border tiles,
+# VALU issue rate against occupancy
+python tools/debug/emulate_ranks.py --worlds 1,2,4,8 --steps 10 2>&1 | grep "^{" > $OUT/emulate_ranks_c3.jsonl
+python tools/debug/emulate_ranks.py --worlds 2,4,8 --steps 10 --strategies rows --stage-frames 4 2>&1 | grep "^{" > $OUT/emulate_ranks_c3_staged.jsonl
+python tools/debug/emulate_ranks.py --worlds 1,2,4,8 --steps 3 --height 6000 --width 8000 --scale 3 --strategies rows 2>&1 | grep "^{" > $OUT/emulate_ranks_c5.jsonl
+python tools/debug/border_cost.py 2>&1 | grep " ms" > $OUT/border_cost_x3.txt
+tools/ubench/valu_occupancy > $OUT/valu_occupancy.txt 2>&1
 find $OUT -name "*agent_info*" -delete
 cut -c1-600 $OUT/bench_n1.json

@@ -31,7 +31,7 @@ def main():
     ap.add_argument("--scale", type=float, default=2)
     ap.add_argument("--worlds", default="1,2,4,8")
     ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--stage-frames", type=int, default=4)
+    ap.add_argument("--stage-frames", type=int, default=0, help="frames per stage (0 = one stage: the library default)")
     ap.add_argument("--align-cost", type=float, default=None)
     ap.add_argument("--strategies", default="rows,reduce")
     a = ap.parse_args()
@@ -47,6 +47,7 @@ def main():
         cfg.verbose = 0
         cfg.scale = scale
         cfg.hip = {"stage_frames": a.stage_frames}
+        sf = a.stage_frames if a.stage_frames > 0 else max(n, 1)
         if a.align_cost is not None:
             cfg.hip["align_cost"] = a.align_cost
         hsr.prepare_config(cfg, np.full((H, W), float(ref.mean()), np.float32), synth.ALPHA_ISO100, synth.BETA_ISO100,
@@ -79,7 +80,7 @@ def main():
                 eng = hdist.HipEngine(cfg)
                 if strategy == "rows":
                     cost = float(cfg.hip.get("align_cost", hdist.ALIGN_COST))
-                    stages = hdist.stage_plan(n, G, a.stage_frames)
+                    stages = hdist.stage_plan(n, G, a.stage_frames if a.stage_frames > 0 else max(n, 1))
                     bounds = hdist.slab_bounds(sH, G, n, cost)
                     r0, r1 = bounds[j], bounds[j + 1]
                     if r1 <= r0:
