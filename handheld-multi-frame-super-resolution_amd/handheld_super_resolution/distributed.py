@@ -80,8 +80,15 @@ STAGE_FRAMES = 0  # frames per stage of strategy "rows" (config.hip.stage_frames
                   # >= 4 frames (3 stages) 2.22 ms — the step-A kernels of ONE frame per launch are latency-bound (they were
                   # sized for chunks of 4), and step A and step B on two streams do not overlap: either fills the GPU
                   # (G = 1: 9.81 ms pipelined, 3.81 + 5.84 alone).  Staging pays only where the all-gather's latency does.
-ALIGN_COST = 0.9  # step A of one frame costs about as much as step B of one frame over this fraction of the image
-                  # (12 MP x2, profiles/r03_kernel_trace_1stream.md: 0.24 ms against 5.1 ms / 19 frames); config.hip.align_cost
+def align_cost(scale):
+    """rho: step A of one frame costs about as much as step B of one frame over this fraction of the image.  Step A does
+    not depend on the scale, step B grows with the output: B / A = 0.20 + 0.32 scale^2 fits the per-rank measurements of
+    tools/debug/emulate_ranks.py at x2 (12 MP: A 0.18 ms per frame, B 0.27 ms per frame and image: rho 0.67) and x3
+    (48 MP: 0.70 / 2.2 ms: rho 0.32).  config.hip.align_cost overrides it."""
+    return 1.0 / (0.20 + 0.32 * float(scale) ** 2)
+
+
+ALIGN_COST = align_cost(2)  # (the x2 value; main_sharded uses align_cost(config.scale))
 
 
 def slab_bounds(sH, world, n_frames=0, align_cost=0.0):
@@ -89,7 +96,7 @@ def slab_bounds(sH, world, n_frames=0, align_cost=0.0):
     align_cost = 0: equal slabs (strategy "reduce": the reduce-scatter moves equal chunks).  Strategy "rows" passes the
     frame count and align_cost = rho: rank j aligns a_j = |{j, j+G, ...}| frames, and its slab is sized so that
     a_j rho sH + rows_j n is the same for every rank — rows_j = sH ((1 + rho) / G - a_j rho / n): with 19 frames on 8 ranks
-    the three ranks that align 3 frames get 576 rows, the five that align 2 get 864 (x2 of 12 MP)."""
+    and rho = 0.9 the three ranks that align 3 frames get 576 rows, the five that align 2 get 864 (x2 of 12 MP)."""
     if not n_frames or align_cost <= 0.0 or world == 1:
         rows = slab_rows(sH, world)
         return [min(j * rows, sH) for j in range(world + 1)]
@@ -778,7 +785,9 @@ def main_sharded(ref_img, comp_imgs, config, group=None, engine=None, gather=Tru
         hip = config.get("hip", None) if hasattr(config, "get") else None
         if max_flow is None and hip is not None:
             max_flow = hip.get("max_flow", None)
-        cost = float(hip.get("align_cost", ALIGN_COST)) if hip is not None else ALIGN_COST
+        cost = align_cost(config.scale)
+        if hip is not None and hip.get("align_cost", None) is not None:
+            cost = float(hip.get("align_cost"))
         sf = int(hip.get("stage_frames", STAGE_FRAMES)) if hip is not None else STAGE_FRAMES
         stages = stage_plan(n, world, sf if sf > 0 else max(n, 1))
         bounds = slab_bounds(sH, world, n, cost)

@@ -79,7 +79,7 @@ def main():
                 cfg = config()
                 eng = hdist.HipEngine(cfg)
                 if strategy == "rows":
-                    cost = float(cfg.hip.get("align_cost", hdist.ALIGN_COST))
+                    cost = float(cfg.hip.get("align_cost", hdist.align_cost(scale)))
                     stages = hdist.stage_plan(n, G, a.stage_frames if a.stage_frames > 0 else max(n, 1))
                     bounds = hdist.slab_bounds(sH, G, n, cost)
                     r0, r1 = bounds[j], bounds[j + 1]
