@@ -696,7 +696,10 @@ struct RobGroup {
     int n;
 };
 
-__global__ void __launch_bounds__(256) k_rob_frames_row4(RobGroup gq, int lh, int lw, const float* __restrict__ rmean,
+#ifndef HHSR_ROB_OCC
+#define HHSR_ROB_OCC 8  // waves per SIMD the grouped kernel is held to (<= 64 VGPRs, as before the prefetch; A/B below)
+#endif
+__global__ void __launch_bounds__(256, HHSR_ROB_OCC) k_rob_frames_row4(RobGroup gq, int lh, int lw, const float* __restrict__ rmean,
                                                           const float* __restrict__ ssq,
                                                           const uint32_t* __restrict__ cidx, int ny, int nx, int ts,
                                                           const double* __restrict__ difc, double t, int H, int W,
@@ -774,16 +777,12 @@ __global__ void __launch_bounds__(256) k_rob_frames_row4(RobGroup gq, int lh, in
         s_tab[fr][vv][gg][1] = make_float4(__int_as_float(ax.fi), ax.h, __int_as_float(wx0), Sv);
     }
     __syncthreads();
-    for (int fr = 0; fr < gq.n; ++fr) {
+    // the guide-means window of frame fr + 1 is fetched into registers while frame fr is evaluated (round 4: the loads
+    // used to be issued at the top of their own iteration and waited for right away — 56 % of the wave time was parked)
+    float st[NST];
+    auto fetch = [&](int fr) {
         const float* __restrict__ cm = gq.cm[fr];
-        const float4 t0 = s_tab[fr][v][grp][0], t1 = s_tab[fr][v][grp][1];
-        const int flags = __float_as_int(t0.w);
-        RobAxis ay, ax;
-        ay.fi = __float_as_int(t0.x); ay.h = t0.y; ay.lt = flags & 1; ay.eq = flags & 2; ay.ok = flags & 4;
-        ax.fi = __float_as_int(t1.x); ax.h = t1.y; ax.lt = flags & 8; ax.eq = flags & 16; ax.ok = flags & 32;
-        const int wy0 = __float_as_int(t0.z), wx0 = __float_as_int(t1.z);
-        const float Sv = t1.w;
-        float st[NST];
+        const int wy0 = __float_as_int(s_tab[fr][v][grp][0].z), wx0 = __float_as_int(s_tab[fr][v][grp][1].z);
 #pragma unroll
         for (int u = 0; u < NST; ++u) {
             const int p = tg + 64 * u;
@@ -794,6 +793,16 @@ __global__ void __launch_bounds__(256) k_rob_frames_row4(RobGroup gq, int lh, in
                 st[u] = cm[c * gplane + (size_t)gy * lw + gx];
             }
         }
+    };
+    if (gq.n > 0) fetch(0);
+    for (int fr = 0; fr < gq.n; ++fr) {
+        const float4 t0 = s_tab[fr][v][grp][0], t1 = s_tab[fr][v][grp][1];
+        const int flags = __float_as_int(t0.w);
+        RobAxis ay, ax;
+        ay.fi = __float_as_int(t0.x); ay.h = t0.y; ay.lt = flags & 1; ay.eq = flags & 2; ay.ok = flags & 4;
+        ax.fi = __float_as_int(t1.x); ax.h = t1.y; ax.lt = flags & 8; ax.eq = flags & 16; ax.ok = flags & 32;
+        const int wy0 = __float_as_int(t0.z), wx0 = __float_as_int(t1.z);
+        const float Sv = t1.w;
         if (fr) __syncthreads();  // the previous frame's taps are done with the window
 #pragma unroll
         for (int u = 0; u < NST; ++u) {
@@ -805,6 +814,7 @@ __global__ void __launch_bounds__(256) k_rob_frames_row4(RobGroup gq, int lh, in
             }
         }
         __syncthreads();
+        if (fr + 1 < gq.n) fetch(fr + 1);
         if (!live) continue;
         float out[4];
         rob_row4(s_g[grp][v], ay, ax, wy0, wx0, y, x0, lh, lw, rbk, d_t2, iss, Sv, (float)t, out);

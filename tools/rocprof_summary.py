@@ -12,7 +12,10 @@ def main(db, steps=1):
                        "max(end-start)/1e3, max(vgpr_count), max(sgpr_count), max(lds_size) from kernels group by name "
                        "order by 3 desc").fetchall()
     tot = sum(r[2] for r in rows)
-    print(f"Total kernel time {tot:.2f} ms over {steps} step(s) = {tot / steps:.2f} ms/step\n")
+    print(f"Total kernel time {tot:.2f} ms over {steps} step(s) = {tot / steps:.2f} ms/step")
+    own = sum(r[2] for r in rows if r[0].startswith("k_") or r[0].startswith("void k_"))
+    print(f"hhsr kernels only (`k_*`; the rest of the total is the synthetic burst's generation — GEMMs, sin / cos, elementwise — "
+          f"and torch copies): {own:.2f} ms = {own / steps:.2f} ms/step\n")
     print("| kernel | calls | total ms | % | avg us | min us | max us | vgpr | sgpr | lds B |")
     print("|---|---:|---:|---:|---:|---:|---:|---:|---:|---:|")
     for n, c, t, a, mn, mx, v, s, l in rows:
