@@ -696,10 +696,9 @@ struct RobGroup {
     int n;
 };
 
-#ifndef HHSR_ROB_OCC
-#define HHSR_ROB_OCC 8  // waves per SIMD the grouped kernel is held to (<= 64 VGPRs, as before the prefetch; A/B below)
-#endif
-__global__ void __launch_bounds__(256, HHSR_ROB_OCC) k_rob_frames_row4(RobGroup gq, int lh, int lw, const float* __restrict__ rmean,
+// (no occupancy bound: held to 64 VGPRs — 8 waves per SIMD — the kernel spills and takes 505 instead of 222 us per launch;
+// held to 80: 423 us.  The compiler's own choice is 56 VGPRs.)
+__global__ void __launch_bounds__(256) k_rob_frames_row4(RobGroup gq, int lh, int lw, const float* __restrict__ rmean,
                                                           const float* __restrict__ ssq,
                                                           const uint32_t* __restrict__ cidx, int ny, int nx, int ts,
                                                           const double* __restrict__ difc, double t, int H, int W,
@@ -778,7 +777,8 @@ __global__ void __launch_bounds__(256, HHSR_ROB_OCC) k_rob_frames_row4(RobGroup 
     }
     __syncthreads();
     // the guide-means window of frame fr + 1 is fetched into registers while frame fr is evaluated (round 4: the loads
-    // used to be issued at the top of their own iteration and waited for right away — 56 % of the wave time was parked)
+    // used to be issued at the top of their own iteration and waited for right away — 56 % of the wave time was parked;
+    // 228 -> 222 us per 4-frame launch at 12 MP)
     float st[NST];
     auto fetch = [&](int fr) {
         const float* __restrict__ cm = gq.cm[fr];
