@@ -234,7 +234,7 @@ class HipEngine:
         whose first output row lies in the slab: a disjoint cover over the slabs — or None)."""
         return self._merge_rows(comp_imgs, flows, r0, r1, max_flow_y, self.pipe.ref if ref_dev is None else ref_dev)
 
-    def rows_open(self, ref_img, comp_imgs, stages, rank, world, rows, max_flow):
+    def rows_open(self, ref_img, comp_imgs, stages, rank, world, rows, max_flow, group=None, every_rank_has_rows=True):
         """Strategy "rows": the per-rank context main_sharded drives stage by stage (align / gather buffer / front /
         finish).  Device-resident float32 bursts that an engine sees again are replayed from HIP graphs, pipelined over
         two streams (RowsPlan: first call eager — it measures the flow bound —, second call captures); everything else
@@ -243,8 +243,9 @@ class HipEngine:
 
         packed = torch.is_tensor(comp_imgs)
         tensors = (ref_img, comp_imgs) if packed else (ref_img, *comp_imgs)
+        # (every condition is the same on every rank — the ranks must agree on eager / plan: see the consensus below)
         ok = capturable(self.config, tensors) and all(t.dtype == torch.float32 and t.is_contiguous() for t in tensors) \
-            and len(comp_imgs) > 0 and rows[1] > rows[0]
+            and len(comp_imgs) > 0 and every_rank_has_rows
         if not ok:
             return EagerRows(self, ref_img, comp_imgs, stages, rank, world, rows, max_flow)
         self._check_config()
@@ -258,14 +259,25 @@ class HipEngine:
         bound = float(max_flow) if max_flow is not None else self._bounds.get(key)
         if bound is None:  # (cannot happen: the eager call stored it)
             return EagerRows(self, ref_img, comp_imgs, stages, rank, world, rows, max_flow, remember=key)
+        if self._plan_seen.get(key) == "failed":
+            return EagerRows(self, ref_img, comp_imgs, stages, rank, world, rows, max_flow)
+        plan = None
         try:
             plan = RowsPlan(self, ref_img, comp_imgs, stages, rank, world, rows, bound, check=max_flow is None, key=key)
         except Exception as e:  # not capturable after all: stay eager for this input set
             self._plan_error = e
             torch.cuda.synchronize(ref_img.device)
+        # every rank or none: a plan that finds its flow bound exceeded re-runs the burst eagerly (more all-gathers), an
+        # eager rank never does — ranks in different modes would stop matching each other's collectives.  One all-reduce,
+        # once per input set (the capture call), settles it.
+        if world > 1 and dist.is_available() and dist.is_initialized():
+            ok_t = torch.tensor([1 if plan is not None else 0], dtype=torch.int32,
+                                device=ref_img.device if dist.get_backend(group) == "nccl" else "cpu")
+            dist.all_reduce(ok_t, op=dist.ReduceOp.MIN, group=group)
+            if int(ok_t.item()) == 0:
+                plan = None
+        if plan is None:
             self._plan_seen[key] = "failed"
-            return EagerRows(self, ref_img, comp_imgs, stages, rank, world, rows, max_flow)
-        if self._plan_seen.get(key) == "failed":
             return EagerRows(self, ref_img, comp_imgs, stages, rank, world, rows, max_flow)
         while len(self._plans) >= 2:  # (a plan holds a burst's intermediates of this rank)
             self._plans.pop(next(iter(self._plans)))
@@ -803,7 +815,8 @@ def main_sharded(ref_img, comp_imgs, config, group=None, engine=None, gather=Tru
             return ctx.finish()
 
         open_ = getattr(eng, "rows_open", None)
-        ctx = open_(ref_img, comp_imgs, stages, rank, world, (r0, r1), max_flow) if open_ is not None else \
+        nonempty = all(b1 > b0 for b0, b1 in zip(bounds[:-1], bounds[1:]))
+        ctx = open_(ref_img, comp_imgs, stages, rank, world, (r0, r1), max_flow, group, nonempty) if open_ is not None else \
             EagerRows(eng, ref_img, comp_imgs, stages, rank, world, (r0, r1), max_flow)
         slab, acc_r, extra, retry = run(ctx)
         if retry:
