@@ -102,12 +102,24 @@ def slab_bounds(sH, world, n_frames=0, align_cost=0.0):
         return [min(j * rows, sH) for j in range(world + 1)]
     want = [max(0.0, sH * ((1.0 + align_cost) / world - len(range(j, n_frames, world)) * align_cost / n_frames))
             for j in range(world)]
+    # apportion the SLAB_ALIGN-row units: every rank at least one (while there are enough — a rank without rows would
+    # make the whole job fall back to the eager path), the rest by the model, largest remainders first
+    units = -(-sH // SLAB_ALIGN)
+    if units < world:
+        rows = slab_rows(sH, world)
+        return [min(j * rows, sH) for j in range(world + 1)]
     total = sum(want) or 1.0
-    b, acc = [0], 0.0
-    for j in range(world - 1):
-        acc += want[j] * sH / total
-        b.append(min(sH, max(b[-1], int(round(acc / SLAB_ALIGN)) * SLAB_ALIGN)))
-    b.append(sH)
+    share = [max(0.0, w / total * units - 1.0) for w in want]      # beyond the guaranteed unit
+    scale_ = (units - world) / (sum(share) or 1.0)
+    exact = [1.0 + sh * scale_ for sh in share]
+    got = [int(e) for e in exact]
+    for j in sorted(range(world), key=lambda j: exact[j] - got[j], reverse=True)[: units - sum(got)]:
+        got[j] += 1
+    b, acc = [0], 0
+    for j in range(world):
+        acc += got[j]
+        b.append(min(sH, acc * SLAB_ALIGN))
+    b[-1] = sH
     return b
 
 
