@@ -664,8 +664,13 @@ def _all_gather_stage(out, src, world, group, streams=None):
     streams of a RowsPlan: RCCL reads `src` once the producer stream has written it and only the CONSUMER stream waits
     for the collective — the producer goes on aligning the next stage.  None: everything on the current stream.
     Host-only backends (gloo: CPU tests, ranks sharing one GPU) stage through host memory."""
-    if world == 1 and not (dist.is_available() and dist.is_initialized()):
-        out.copy_(src.unsqueeze(0))
+    if world == 1 and not (dist.is_available() and dist.is_initialized()):  # (force_sharded without a process group)
+        if streams is None or not src.is_cuda:
+            out.copy_(src.unsqueeze(0))
+        else:  # the "gather" runs on the consumer stream, behind the producer's work — like the collective would
+            with torch.cuda.stream(streams[1]):
+                streams[1].wait_stream(streams[0])
+                out.copy_(src.unsqueeze(0))
         return
     if src.is_cuda and dist.get_backend(group) == "nccl":
         if streams is None:

@@ -2525,3 +2525,37 @@ def test_main_runner_is_thread_safe():
     for t in threads:
         t.join()
     assert not errors, errors
+
+
+def test_rows_plan_flow_bound_retry():
+    """distributed.RowsPlan sizes its sub-image for the flow bound its first burst measured; a later burst in the same
+    buffers whose flows exceed it is detected ON THE DEVICE, recomputed eagerly with its own bound (bit-identical to
+    main()) and the next capture takes the larger bound over."""
+    from handheld_super_resolution import distributed as hdist
+
+    cfg = base_config(ts=16, scale=2)
+    cfg.robustness.save_mask = True
+    ref1, comp1, _ = synth.make_burst(512, 640, 5, seed=41, max_shift=0.4)
+    seed2 = next(sd for sd in range(42, 200) if np.abs(synth.frame_shifts(5, sd, 12.0)[1:, 1]).max() > 10.0)  # |dy| > 10 px
+    ref2, comp2, _ = synth.make_burst(512, 640, 5, seed=seed2, max_shift=12.0)
+    dref, dcomp = T(ref1), T(comp1)
+    eng = hdist.HipEngine(cfg)
+    for it in range(3):  # eager (measures the bound), capture, replay
+        out, dbg = hdist.main_sharded(dref, dcomp, cfg, engine=eng, force_sharded=True)
+        assert not dbg.get("flow_bound_recomputed", False)
+    assert eng._plans and not getattr(eng, "_plan_error", None)
+    bound1 = next(iter(eng._plans.values())).bound
+    want1, _ = hsr.main(ref1, comp1, base_config(ts=16, scale=2))
+    assert torch.equal(torch.nan_to_num(out), torch.nan_to_num(want1))
+    dref.copy_(T(ref2))
+    dcomp.copy_(T(comp2))
+    want2, _ = hsr.main(ref2, comp2, base_config(ts=16, scale=2))
+    out, dbg = hdist.main_sharded(dref, dcomp, cfg, engine=eng, force_sharded=True)
+    assert dbg.get("flow_bound_recomputed", False), "flows of ~12 px must exceed the bound sized for 0.4 px"
+    assert torch.equal(torch.nan_to_num(out), torch.nan_to_num(want2))
+    assert not eng._plans  # dropped: the next call captures again with the larger bound
+    for it in range(2):    # capture, replay
+        out, dbg = hdist.main_sharded(dref, dcomp, cfg, engine=eng, force_sharded=True)
+        assert not dbg.get("flow_bound_recomputed", False)
+        assert torch.equal(torch.nan_to_num(out), torch.nan_to_num(want2))
+    assert eng._plans and next(iter(eng._plans.values())).bound > bound1
