@@ -2559,3 +2559,12 @@ def test_rows_plan_flow_bound_retry():
         assert not dbg.get("flow_bound_recomputed", False)
         assert torch.equal(torch.nan_to_num(out), torch.nan_to_num(want2))
     assert eng._plans and next(iter(eng._plans.values())).bound > bound1
+    # a caller's bound: no host read at all — the plan is sized for it and the device flag comes back in the debug dict
+    eng3 = hdist.HipEngine(cfg)
+    for it in range(3):
+        out, dbg = hdist.main_sharded(dref, dcomp, cfg, engine=eng3, force_sharded=True, max_flow=16.0)
+        assert torch.equal(torch.nan_to_num(out), torch.nan_to_num(want2)) and not bool(dbg["flow_bound_exceeded"])
+    assert eng3._plans and next(iter(eng3._plans.values())).bound == 16.0 and not next(iter(eng3._plans.values())).check
+    for it in range(3):  # ... and one that is too small is REPORTED (the result near slab seams is then the caller's risk)
+        out, dbg = hdist.main_sharded(dref, dcomp, cfg, engine=eng3, force_sharded=True, max_flow=4.0)
+        assert bool(dbg["flow_bound_exceeded"])
