@@ -27,7 +27,7 @@ One process per GPU, two selectable strategies (`main_sharded(..., strategy=)`, 
   chain on its frames and merges them into float32 accumulators num / den [sH, sW, 3] (reference merge.py:432-434);
   ONE reduce-scatter (sum) over row slabs — one RCCL call on the packed [world, 2, rows, sW, 3] buffer — leaves rank j with the summed
   accumulators of slab j, to which it adds the reference frame and normalises.  1.15 GB of accumulators per rank at
-  12 MP x2 cross xGMI (per-link bound for a ring: modelled 8-10 ms against 1.1 ms of compute per rank at G = 8), so
+  12 MP x2 cross xGMI (per-link bound for a ring: modelled 8-10 ms against 2.7 ms of measured compute per rank at G = 8), so
   this strategy only pays for very long bursts; it exists so that both can be measured.  Results differ from the
   single-GPU run by float32 summation order (partial sums are added), ~1e-7 relative.
 

@@ -13,6 +13,7 @@ class _GreyPlan:
         import ctypes
         import os
 
+        _free_deferred_plans()
         h = ctypes.c_void_p()
         _lib.call("hhsr_grey_plan_create", H, W, int(os.environ.get("HHSR_GREY_PLAN", "4")) | (int(batch) << 8),
                   ctypes.byref(h))
@@ -20,11 +21,33 @@ class _GreyPlan:
         self.batch = int(batch)
 
     def __del__(self):
+        # A plan owns hipMalloc'd buffers: destroying it calls hipFree, which is not permitted while the calling thread
+        # captures a stream — and the garbage collector can run THIS finaliser in the middle of somebody's capture (an
+        # engine dropped earlier whose graphs kept the plan alive: seen as "operation not permitted when stream is
+        # capturing" + abort in tools/debug/emulate_ranks.py).  During a capture the handle is parked and freed later.
         try:
-            if self.handle:
-                _lib.load().hhsr_grey_plan_destroy(self.handle)
+            if not self.handle:
+                return
+            h, self.handle = self.handle, None
+            if torch.cuda.is_available() and torch.cuda.is_current_stream_capturing():
+                _deferred_plans.append(h)
+            else:
+                _lib.load().hhsr_grey_plan_destroy(h)
         except Exception:
             pass
+
+
+_deferred_plans = []  # handles of plans whose owner died during a stream capture
+
+
+def _free_deferred_plans():
+    """Destroy the parked plans (called where plans are created: never during a capture)."""
+    if _deferred_plans and not (torch.cuda.is_available() and torch.cuda.is_current_stream_capturing()):
+        while _deferred_plans:
+            try:
+                _lib.load().hhsr_grey_plan_destroy(_deferred_plans.pop())
+            except Exception:
+                pass
 
 
 _grey_plans = {}  # (H, W, device, stream) -> plan, least recently used first

@@ -267,6 +267,10 @@ int hhsr_add(float* A, const float* B, int64_t n, void* stream);          /* A +
  * keeps idx / scale in float32) and therefore the results do not depend on how the frame was split.
  * acc_r (optional, float32 [H][W], integer scales only) receives sum_n r_n — the accumulated robustness of
  * super_resolution.py:158-159 — at no extra HBM traffic (+= with HHSR_MERGE_LOAD_ACC).
+ * Kernel choice (float32 weights): scale 2 and scale 3 with a BAYER cfa (red and blue on one diagonal, green on the other),
+ * ts % 16 == 0 and even / exact output sizes run the wave-per-parity-class kernels (three channel accumulators per
+ * sub-pixel; scale 3: frames whose window leaves the image are evaluated by the same code with border masks); other
+ * 2 x 2 colour layouts and other integer scales the 16 x 16 tile kernels; non-integer scales the per-pixel kernel.
  * flags: */
 #define HHSR_MERGE_LOAD_ACC 1   /* start from the existing num/den instead of zero          */
 #define HHSR_MERGE_DO_REF 2     /* add the reference frame (ref_raw/ref_covs) after the comps */
@@ -274,8 +278,9 @@ int hhsr_add(float* A, const float* B, int64_t n, void* stream);          /* A +
 #define HHSR_MERGE_STORE_DEN 8  /* also store den                                            */
 #define HHSR_MERGE_LOCAL_MIN 16 /* rs[] hold the thresholded maps R of hhsr_rob_frame; their 5x5 clamp-border minimum
                                    (robustness.py:641-686, hhsr_local_min5) is taken inside the merge.  Only with the
-                                   x2 kernels: scale 2, ts % 16 == 0, sH = 2 H, sW = 2 W, row0 % 32 == 0, float32
-                                   weights, no HHSR_MERGE_FORCE_GENERIC / _TILE; error -3 otherwise.             */
+                                   x2 kernels (scale 2, ts % 16 == 0, sH = 2 H, sW = 2 W, row0 % 32 == 0) and the
+                                   x3 kernel (scale 3, Bayer cfa, W % 4 == 0, row0 % 48 == 0); float32 weights, no
+                                   HHSR_MERGE_FORCE_GENERIC / _TILE; error -3 otherwise.                             */
 int hhsr_merge_burst(const float* const* raws, const float* const* flows, const float* const* covs,
                      const float* const* rs, int n_frames, int H, int W, int pitch,
                      int ny, int nx, int ts, const float* ref_raw, const float* ref_covs,
