@@ -2568,3 +2568,44 @@ def test_rows_plan_flow_bound_retry():
     for it in range(3):  # ... and one that is too small is REPORTED (the result near slab seams is then the caller's risk)
         out, dbg = hdist.main_sharded(dref, dcomp, cfg, engine=eng3, force_sharded=True, max_flow=4.0)
         assert bool(dbg["flow_bound_exceeded"])
+
+
+@pytest.mark.parametrize("kern", ["handheld", "iso"])
+def test_merge_x3_edge_frames_all_sides(kern):
+    """k_merge_xs<3>'s EDGE frames (round 4): frames whose window leaves the image on every side and at the corners — uniform
+    flows of +-20 px along each axis, a diagonal one, one that pushes every position of the left tile column out of the
+    frame (no contribution at all) and per-tile random flows of +-6 px — evaluated by the uniform code with clamped staging
+    and border masks, against BOTH other implementations of the same arithmetic rules: the 16 x 16 HR tile kernel
+    (per-pixel float64 geometry, LDS windows with explicit bounds tests) and the per-pixel kernel (operands from global
+    memory).  Every perimeter tile of the image takes the EDGE path for the reference frame."""
+    H, W, ts = 96, 112, 16
+    ny, nx = H // ts, W // ts
+    ref, fr = _frames(H, W, 8, ts, 91, base_config(ts=ts, scale=3))
+    rng = np.random.default_rng(5)
+    flows = [np.full((ny, nx, 2), v, np.float32) for v in ((20.25, 0.4), (-20.25, -0.4), (0.3, 19.6), (-0.3, -19.6),
+                                                             (-13.3, 7.7), (-40.0, 0.0))]
+    flows.append(rng.uniform(-6, 6, (ny, nx, 2)).astype(np.float32))
+    flows.append((rng.uniform(-6, 6, (ny, nx, 2)) - np.array([0.0, 0.999])).astype(np.float32))
+    fr = [(f[0], fl, f[2], f[3]) for f, fl in zip(fr, flows)]
+    cfa = [[1, 2], [0, 1]]  # GBRG: red in parity class (1, 0)
+    tf = [tuple(T(a) for a in f) for f in fr]
+
+    def cfg_for(which):
+        c = base_config(ts=ts, scale=3)
+        c.merging.kernel = kern
+        c.hip = {"merge_kernel": which}
+        return c
+
+    rc = T(oracle.estimate_kernels(ref, cfg_for("auto")))
+    outs = {}
+    for which in ("auto", "tile", "generic"):
+        out, den = torch.empty(3 * H, 3 * W, 3, device=DEV), torch.empty(3 * H, 3 * W, 3, device=DEV)
+        acc = torch.zeros(H, W, device=DEV)
+        merge.merge_burst(tf, T(ref), rc, out, den, cfa, cfg_for(which), divide=False, store_den=True, acc_r=acc)
+        outs[which] = (N(out), N(den), N(acc))
+    for other in ("tile", "generic"):
+        for k, what in enumerate(("num", "den", "accumulated robustness")):
+            assert_close(outs["auto"][k], outs[other][k], 4e-5, 1e-7, f"EDGE frames, k_merge_xs<3> vs {other} kernel: {what}")
+    # (the two reference implementations agree with each other to 2.4e-6: the same per-pixel arithmetic, the generic kernel
+    # with the float64 geometry of the fall-back path)
+    assert_close(outs["tile"][0], outs["generic"][0], 2e-5, 1e-7, "tile vs generic num")
