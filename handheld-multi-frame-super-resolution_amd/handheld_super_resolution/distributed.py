@@ -266,6 +266,10 @@ class HipEngine:
         if plan is not None:
             return plan.open()
         if key not in self._plan_seen:  # first burst of this input set: eager; remembers the bound it measured
+            while len(self._plan_seen) >= 64:  # (a caller that hands over fresh tensors every burst never replays: bounded)
+                old = next(iter(self._plan_seen))
+                self._plan_seen.pop(old)
+                self._bounds.pop(old, None)
             self._plan_seen[key] = True
             return EagerRows(self, ref_img, comp_imgs, stages, rank, world, rows, max_flow, remember=key)
         bound = float(max_flow) if max_flow is not None else self._bounds.get(key)
