@@ -227,13 +227,16 @@ __device__ __forceinline__ void stockham_pass(float2* __restrict__ buf, int bstr
     for (int it = 0; it < MAXIT; ++it) {
         const int jj = tid + it * nt;
         if (jj < total) {
-            const int bidx = (int)(((float)jj + 0.5f) * rL);  // exact floor for jj < 2^16 ... guarded by the host
-            const int j = jj - bidx * L;
+            // (index arithmetic in 24-bit multiplies and 32-bit offsets: v_mul_lo_u32 and the 64-bit v_mad_u64_u32 of a
+            // size_t offset issue at a quarter of the v_mad_u32_u24 rate, and these kernels are VALU-bound)
+            const int bidx = NB > 1 ? (int)(((float)jj + 0.5f) * rL) : 0;  // exact floor for jj < 2^16 ... guarded by the host
+            const int j = jj - __mul24(bidx, L);
             const int q = (int)(((float)j + 0.5f) * rNs);
-            const int k = j - q * Ns;
-            const float2* ib = buf + (size_t)bidx * bstride;
+            const int k = j - __mul24(q, Ns);
+            const int base = __mul24(bidx, bstride);
+            const float2* ib = buf + base + j;
 #pragma unroll
-            for (int r = 0; r < R; ++r) v[it][r] = ib[j + r * L];
+            for (int r = 0; r < R; ++r) v[it][r] = ib[__mul24(r, L)];
             if (Ns > 1) {
                 if (R <= HHSR_FFT_POW_RMAX && pw) {  // (compile time: the large radices never get the power form's registers)
                     float2 w[R];
@@ -244,11 +247,11 @@ __device__ __forceinline__ void stockham_pass(float2* __restrict__ buf, int bstr
                     for (int r = 1; r < R; ++r) v[it][r] = cmul(v[it][r], w[r]);
                 } else {
 #pragma unroll
-                    for (int r = 1; r < R; ++r) v[it][r] = cmul(v[it][r], twp[(r - 1) * Ns + k]);
+                    for (int r = 1; r < R; ++r) v[it][r] = cmul(v[it][r], twp[__mul24(r - 1, Ns) + k]);
                 }
             }
             dft_reg<R>(v[it]);
-            dst[it] = bidx * bstride + q * Ns * R + k;
+            dst[it] = base + __mul24(q * R, Ns) + k;
         }
     }
     __syncthreads();
@@ -257,7 +260,7 @@ __device__ __forceinline__ void stockham_pass(float2* __restrict__ buf, int bstr
         const int jj = tid + it * nt;
         if (jj < total) {
 #pragma unroll
-            for (int r = 0; r < R; ++r) buf[dst[it] + r * Ns] = v[it][r];
+            for (int r = 0; r < R; ++r) buf[dst[it] + __mul24(r, Ns)] = v[it][r];
         }
     }
     __syncthreads();
@@ -359,6 +362,22 @@ __device__ __forceinline__ int row_block(int it, int nblocks) {
     return blk < nblocks ? blk : -1;
 }
 
+// idx -> (rb, n) = (idx / len, idx % len) for rb < RB without the ~30-instruction integer division (these kernels are
+// VALU-bound: round 4).  rlen = 1.0f / len; exact for idx < 2^16 (hhsr_fft_create checks RB * len).
+template <int RB>
+__device__ __forceinline__ void split_row(int idx, int len, float rlen, int& rb, int& n) {
+    if (RB == 1) {
+        rb = 0;
+        n = idx;
+    } else if (RB == 2) {
+        rb = idx >= len;
+        n = rb ? idx - len : idx;
+    } else {
+        rb = (int)(((float)idx + 0.5f) * rlen);
+        n = idx - __mul24(rb, len);
+    }
+}
+
 // Row kernels: RB rows per workgroup, transformed SIMULTANEOUSLY (RB x fewer barriers, RB x more independent
 // butterflies per thread).  LDS: tw[twlen] | RB x row[M]  (float2 each).
 // Frames of a batch: the row kernels walk the row blocks of ALL frames of the launch (block b of frame f is virtual block
@@ -397,14 +416,13 @@ __global__ void __launch_bounds__(FFT_NT, FFT_ROWS_WPE) k_rows_fwd(FftFrames fr,
     const int nrows = min(RB, H - y0);
     if ((M & 1) == 0 && (W & 3) == 0) {  // two complex samples (16 bytes) per lane
         const int Mh = M / 2;
-        batched_for<float4>(nrows * Mh, tid,
-                            [&](int idx) {
-                                const int rb = idx / Mh, n = idx - rb * Mh;
-                                return reinterpret_cast<const float4*>(src + (size_t)(y0 + rb) * W)[n];
-                            },
+        const float rMh = 1.0f / (float)Mh;
+        const float4* __restrict__ src4 = reinterpret_cast<const float4*>(src + (size_t)y0 * W);  // rows are Mh float4 apart
+        batched_for<float4>(nrows * Mh, tid, [&](int idx) { return src4[idx]; },
                             [&](int idx, float4 v) {
-                                const int rb = idx / Mh, n = idx - rb * Mh;
-                                reinterpret_cast<float4*>(buf + rb * M)[n] = v;
+                                int rb, n;
+                                split_row<RB>(idx, Mh, rMh, rb, n);
+                                reinterpret_cast<float4*>(buf + __mul24(rb, M))[n] = v;
                             });
     } else {
         for (int idx = tid; idx < nrows * M; idx += FFT_NT) {  // z[n] = x[2n] + i x[2n+1]
@@ -416,6 +434,23 @@ __global__ void __launch_bounds__(FFT_NT, FFT_ROWS_WPE) k_rows_fwd(FftFrames fr,
     // X[k] = 1/2 [(Z[k] + conj Z[M-k]) - i w_k (Z[k] - conj Z[M-k])],  w_k = exp(-2 pi i k / W); kept bins only,
     // straight from LDS to the blocked-transposed spectrum
     const int nblk = (Wk + TB - 1) / TB;
+    if (TB == 2 && (M & 1) == 0 && nrows == RB) {
+        // one thread per (bin pair, row): Z[k], Z[k+1] as one 16-byte LDS read, the pair of kept bins as one 16-byte
+        // store — the rows of the block are adjacent in T, so RB consecutive lanes write RB x 16 contiguous bytes.  (An odd
+        // Wk writes bin Wk into T's padding: tstride covers ceil(Wk / 8) * 8 bins and nobody reads it.)
+        for (int idx = tid; idx < nblk * RB; idx += FFT_NT) {
+            const int b = idx / RB, rb = idx - b * RB, k = 2 * b;  // (RB is a power of two)
+            const float2* Z = buf + __mul24(rb, M);
+            const float4 zz = *reinterpret_cast<const float4*>(Z + k);
+            const float2 zm0 = cconj(Z[k == 0 ? 0 : M - k]), zm1 = cconj(Z[M - k - 1]);
+            const float4 ww = *reinterpret_cast<const float4*>(twW + k);
+            const float2 z0 = make_float2(zz.x, zz.y), z1 = make_float2(zz.z, zz.w);
+            const float2 s0 = cadd(z0, zm0), d0 = mul_mi(cmul(make_float2(ww.x, ww.y), csub(z0, zm0)));
+            const float2 s1 = cadd(z1, zm1), d1 = mul_mi(cmul(make_float2(ww.z, ww.w), csub(z1, zm1)));
+            const float2 o0 = cscale(cadd(s0, d0), 0.5f), o1 = cscale(cadd(s1, d1), 0.5f);
+            *reinterpret_cast<float4*>(T + ((size_t)b * H + y0 + rb) * 2) = make_float4(o0.x, o0.y, o1.x, o1.y);
+        }
+    } else
     for (int idx = tid; idx < nblk * nrows * TB; idx += FFT_NT) {  // in the order the bins lie in T (see k_rows_inv)
         const int b = idx / (nrows * TB), q = idx - b * (nrows * TB);
         const int rb = q / TB, k = b * TB + (q - rb * TB);
@@ -458,13 +493,25 @@ __global__ void __launch_bounds__(FFT_NT, FFT_COLS_WPE) k_cols(float2* __restric
         batched_for<float2>(H, tid, [&](int k) { return colb[(size_t)TB * k]; }, [&](int k, float2 v) { buf[k] = v; });
     }
     fft_lds(buf, H, NC, tw, H, rad, tid, FFT_NT);
-    for (int idx = tid; idx < NC * H; idx += FFT_NT) {
-        const int c = idx >= H, ky = idx - c * H;
-        const int x = kx + c, nx = x == 0 ? 0 : W - x;
-        const int nky = ky == 0 ? 0 : H - ky;
-        const int m = x < Wk ? (int)(fft_kept(ky, H) && fft_kept(x, W)) + (int)(fft_kept(nky, H) && fft_kept(nx, W)) : 0;
-        // masked, normalised and conjugated: the inverse is conj(FFT(conj(.)))
-        buf[idx] = cconj(cscale(buf[idx], 0.5f * (float)m * norm));
+    {
+        // fft_kept(u, H) with its constants hoisted: the shifted index of u lies in [lo, hi)
+        const int hh = H / 2, lo = H / 4, hi = H - (H + 3) / 4;
+        auto kept_y = [&](int u) {
+            int i = u + hh;
+            if (i >= H) i -= H;
+            return i >= lo && i < hi;
+        };
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+            const int x = kx + c, nx = x == 0 ? 0 : W - x;  // (uniform: the x factors of the mask are per column)
+            const bool fx = x < Wk && fft_kept(x, W), fnx = x < Wk && fft_kept(nx, W);
+            for (int ky = tid; ky < H; ky += FFT_NT) {
+                const int nky = ky == 0 ? 0 : H - ky;
+                const int m = (int)(fx && kept_y(ky)) + (int)(fnx && kept_y(nky));
+                // masked, normalised and conjugated: the inverse is conj(FFT(conj(.)))
+                buf[c * H + ky] = cconj(cscale(buf[c * H + ky], 0.5f * (float)m * norm));
+            }
+        }
     }
     fft_lds(buf, H, NC, tw, H, rad, tid, FFT_NT);
     for (int y = tid; y < H; y += FFT_NT) {
@@ -505,6 +552,36 @@ __global__ void __launch_bounds__(FFT_NT, FFT_ROWS_WPE) k_rows_inv(const float2*
     // X[M-k]: every kept bin is read from global memory exactly once, in the order it lies there — blocks of TB bins,
     // the workgroup's rows adjacent (the former element-wise loop read every bin twice, the second time in descending k).
     const int half = M / 2 + 1, nblk = (half + TB - 1) / TB;
+    auto z_of = [&](float2 xk, float2 xm_, int k) {  // (xm_ = X[M-k], not yet conjugated)
+        const float2 xm = cconj(xm_);
+        const float2 s = cadd(xk, xm), d = mul_pi(cmul(cconj(twW[k]), csub(xk, xm)));
+        return cconj(cscale(cadd(s, d), 0.5f));
+    };
+    if (TB == 2 && (M & 1) == 0 && nrows == RB) {
+        // one thread per (bin pair, row): X[k], X[k+1] as one 16-byte load (the rows of the block are adjacent in T), no
+        // integer division per bin; the mirrored bins X[M-k] are zero except around k = M/2
+        for (int idx = tid; idx < nblk * RB; idx += FFT_NT) {
+            const int b = idx / RB, rb = idx - b * RB, k0 = 2 * b, y = y0 + rb;  // (RB is a power of two)
+            float4 x4 = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (k0 < Wk) x4 = *reinterpret_cast<const float4*>(T + ((size_t)b * H + y) * 2);
+            const float2 xa0 = make_float2(x4.x, x4.y);
+            const float2 xa1 = k0 + 1 < Wk ? make_float2(x4.z, x4.w) : make_float2(0.f, 0.f);  // (bin Wk of an odd Wk is padding)
+            float2* Zr = buf + __mul24(rb, M);
+            float2 zk[2];
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+                const int k = k0 + e, mk = M - k;
+                const float2 xa = e ? xa1 : xa0;
+                float2 xb = make_float2(0.f, 0.f);
+                if (mk == k) xb = xa;
+                else if (mk < Wk) xb = T[t_index(mk, y, H)];
+                zk[e] = z_of(xa, xb, k < M ? k : 0);
+                if (k < half && mk != k && mk < M) Zr[mk] = z_of(xb, xa, mk);
+            }
+            if (k0 + 1 < half) *reinterpret_cast<float4*>(Zr + k0) = make_float4(zk[0].x, zk[0].y, zk[1].x, zk[1].y);
+            else if (k0 < half) Zr[k0] = zk[0];
+        }
+    } else
     for (int idx = tid; idx < nblk * nrows * TB; idx += FFT_NT) {  // (batching these loads like batched_for: 2 us slower)
         const int b = idx / (nrows * TB), q = idx - b * (nrows * TB);
         const int rb = q / TB, k = b * TB + (q - rb * TB);
@@ -526,10 +603,13 @@ __global__ void __launch_bounds__(FFT_NT, FFT_ROWS_WPE) k_rows_inv(const float2*
     fft_lds(buf, M, nrows, tw, M, rad, tid, FFT_NT);
     if ((M & 1) == 0 && (W & 3) == 0) {
         const int Mh = M / 2;
+        const float rMh = 1.0f / (float)Mh;
+        float4* __restrict__ dst4 = reinterpret_cast<float4*>(dst + (size_t)y0 * W);  // rows are Mh float4 apart
         for (int idx = tid; idx < nrows * Mh; idx += FFT_NT) {  // x[2n] = Re z[n], x[2n+1] = -Im conj-stored z[n]
-            const int rb = idx / Mh, n = idx - rb * Mh;
-            const float4 z = reinterpret_cast<const float4*>(buf + rb * M)[n];
-            reinterpret_cast<float4*>(dst + (size_t)(y0 + rb) * W)[n] = make_float4(z.x, -z.y, z.z, -z.w);
+            int rb, n;
+            split_row<RB>(idx, Mh, rMh, rb, n);
+            const float4 z = reinterpret_cast<const float4*>(buf + __mul24(rb, M))[n];
+            dst4[idx] = make_float4(z.x, -z.y, z.z, -z.w);
         }
     } else {
         for (int idx = tid; idx < nrows * M; idx += FFT_NT) {  // x[2n] = Re z[n], x[2n+1] = Im z[n]
