@@ -319,7 +319,13 @@ constexpr int FFT_NT = 512;          // threads per workgroup
                         // copy: 32 KB of LDS per workgroup -> four workgroups per CU (<= 64 VGPRs).  Measured: 248 / 221 us
                         // per 3-4 frame launch instead of 118 / 116 — the twiddle loads sit on every pass's critical path
 #endif
-constexpr int FFT_ROWS_WPE = HHSR_FFT_TWG ? 8 : 6;  // row kernels: 48 KB of LDS -> three workgroups per CU need <= 85 VGPRs
+#ifndef HHSR_FFT_PF
+#define HHSR_FFT_PF 0
+#endif
+#ifndef HHSR_FFT_ROWS_WPE_
+#define HHSR_FFT_ROWS_WPE_ (HHSR_FFT_TWG ? 8 : 6)
+#endif
+constexpr int FFT_ROWS_WPE = HHSR_FFT_ROWS_WPE_;  // row kernels: 48 KB of LDS -> three workgroups per CU need <= 85 VGPRs
 constexpr int FFT_COLS_WPE = 4;     // column kernel: 72 KB of LDS -> two workgroups per CU (<= 128 VGPRs)
 
 // n elements global -> LDS (or any load / store pair) with the loads of a 4-iteration batch all in flight before the first
@@ -407,6 +413,22 @@ __global__ void __launch_bounds__(FFT_NT, FFT_ROWS_WPE) k_rows_fwd(FftFrames fr,
     // persistent workgroups: the grid is one resident round (HHSR_FFT_PERSIST), every workgroup walks the row blocks
     // (row_block): one twiddle copy and one dispatch per workgroup slot instead of per block
     const int nb = (H + RB - 1) / RB;
+#if HHSR_FFT_PF
+    // register prefetch of the NEXT block's rows (4 x 16 bytes per thread) issued before this block's passes.  (Four
+    // scalars and a macro: as an array captured by a lambda the values lived in scratch, every load waited for at once.)
+    const bool pf_ok = (M & 1) == 0 && (W & 3) == 0 && RB * (M / 2) <= 4 * FFT_NT;
+    float4 pf0 = make_float4(0.f, 0.f, 0.f, 0.f), pf1 = pf0, pf2 = pf0, pf3 = pf0;
+#define HHSR_PF_ISSUE(VB)                                                                                      \
+    {                                                                                                          \
+        const int frame_ = (VB) / nb, blk_ = (VB) - frame_ * nb, y0_ = blk_ * RB, n4_ = min(RB, H - y0_) * (M / 2); \
+        const float4* __restrict__ s4_ = reinterpret_cast<const float4*>(fr.src[frame_] + (size_t)y0_ * W);     \
+        pf0 = s4_[min(tid, n4_ - 1)];                  /* (clamped, unconditional: four loads back to back) */    \
+        pf1 = s4_[min(tid + FFT_NT, n4_ - 1)];                                                                 \
+        pf2 = s4_[min(tid + 2 * FFT_NT, n4_ - 1)];                                                             \
+        pf3 = s4_[min(tid + 3 * FFT_NT, n4_ - 1)];                                                             \
+    }
+    if (pf_ok) { const int v0 = row_block<RB>(0, nb * fr.n); if (v0 >= 0) HHSR_PF_ISSUE(v0) }
+#endif
     for (int it = 0, vblk; (vblk = row_block<RB>(it, nb * fr.n)) >= 0; ++it) {
     if (it) __syncthreads();  // the previous block's stores have read the buffer
     const int frame = vblk / nb, blk = vblk - frame * nb;
@@ -414,6 +436,24 @@ __global__ void __launch_bounds__(FFT_NT, FFT_ROWS_WPE) k_rows_fwd(FftFrames fr,
     float2* __restrict__ T = Tall + (size_t)frame * fr.tstride;
     const int y0 = blk * RB;
     const int nrows = min(RB, H - y0);
+#if HHSR_FFT_PF
+    if (pf_ok) {
+        const int Mh = M / 2, n4 = nrows * Mh;
+        const float rMh = 1.0f / (float)Mh;
+#define HHSR_PF_PUT(U, V)                                                    \
+    {                                                                        \
+        const int i_ = tid + (U) * FFT_NT;                                   \
+        if (i_ < n4) {                                                       \
+            int rb_, n_;                                                     \
+            split_row<RB>(i_, Mh, rMh, rb_, n_);                             \
+            reinterpret_cast<float4*>(buf + __mul24(rb_, M))[n_] = (V);      \
+        }                                                                    \
+    }
+        HHSR_PF_PUT(0, pf0) HHSR_PF_PUT(1, pf1) HHSR_PF_PUT(2, pf2) HHSR_PF_PUT(3, pf3)
+        const int vn = row_block<RB>(it + 1, nb * fr.n);
+        if (vn >= 0) HHSR_PF_ISSUE(vn)
+    } else
+#endif
     if ((M & 1) == 0 && (W & 3) == 0) {  // two complex samples (16 bytes) per lane
         const int Mh = M / 2;
         const float rMh = 1.0f / (float)Mh;
