@@ -21,6 +21,7 @@ struct HhsrFft {
     size_t lds_rows = 0, lds_cols = 0;
     int twlenM = 0, twlenH = 0;     // lengths of the per-pass twiddle tables
     int rb = 0;                     // rows per workgroup of the row kernels (4, 2 or 1 by LDS budget)
+    int nt_rows = 0;                // threads per workgroup of the row kernels (256 with rb = 1 when the row fits, else 512)
     int nc = 0;                     // kept columns per workgroup of the column kernel (2 or 1)
     int batch = 1;                  // frames one launch may carry: T holds this many spectra, tstride elements apart
     size_t tstride = 0;

@@ -313,36 +313,39 @@ __device__ __forceinline__ bool fft_kept(int u, int n) {
 constexpr int TB = HHSR_FFT_TB;
 __device__ __forceinline__ size_t t_index(int kx, int y, int H) { return ((size_t)(kx / TB) * H + y) * TB + (kx % TB); }
 
-constexpr int FFT_NT = 512;          // threads per workgroup
+constexpr int FFT_NT = 512;          // threads per workgroup: column kernel, and the row kernels' long rows
+// Row kernels, rows that fit: ONE row per 256-thread workgroup — 16 KB of data + the twiddles = 32 KB of LDS, five
+// workgroups per CU instead of three 512-thread row pairs.  The phases of a workgroup (load a row / barrier-separated
+// passes / store) only overlap with OTHER workgroups' phases, and five independent ones overlap better than three:
+// measured at 12 MP (tools/debug/r04_call37.sh) rows fwd 96.3 -> 85.1 us, rows inv 101.5 -> 89.9 us per 3-4 frame launch
+// (four resident workgroups: 91.9 / 97.2; six — more than fit — 97.1 / 104.7).  The column kernel LOSES with 256 threads
+// (one column per workgroup: 90 -> 111 us) and keeps 512.
+constexpr int FFT_NT_SMALL = 256;
 #ifndef HHSR_FFT_TWG
 #define HHSR_FFT_TWG 0  // 1 (A/B, round 3): row kernels read their pass twiddles from global memory (L1 / L2) instead of an LDS
                         // copy: 32 KB of LDS per workgroup -> four workgroups per CU (<= 64 VGPRs).  Measured: 248 / 221 us
                         // per 3-4 frame launch instead of 118 / 116 — the twiddle loads sit on every pass's critical path
 #endif
-#ifndef HHSR_FFT_PF
-#define HHSR_FFT_PF 0
-#endif
-#ifndef HHSR_FFT_ROWS_WPE_
-#define HHSR_FFT_ROWS_WPE_ (HHSR_FFT_TWG ? 8 : 6)
-#endif
-constexpr int FFT_ROWS_WPE = HHSR_FFT_ROWS_WPE_;  // row kernels: 48 KB of LDS -> three workgroups per CU need <= 85 VGPRs
+// row kernels: 512 threads, 48 KB of LDS -> three workgroups per CU need <= 85 VGPRs (6 waves per SIMD);
+//              256 threads, 32 KB -> five workgroups per CU = 5 waves per SIMD (<= 102 VGPRs)
+__host__ __device__ constexpr int fft_rows_wpe(int nt) { return HHSR_FFT_TWG ? 8 : nt == FFT_NT ? 6 : 5; }
 constexpr int FFT_COLS_WPE = 4;     // column kernel: 72 KB of LDS -> two workgroups per CU (<= 128 VGPRs)
 
 // n elements global -> LDS (or any load / store pair) with the loads of a 4-iteration batch all in flight before the first
 // store: written as load -> store per iteration the compiler keeps ONE load outstanding, and a phase of 4-6 iterations
 // costs 4-6 memory round trips (timed with wall_clock64: 4.8 us to load two rows, 7.6-9.4 us to gather a row pair's bins)
-template <typename V, class Load, class Store>
+template <typename V, int NT = FFT_NT, class Load, class Store>
 __device__ __forceinline__ void batched_for(int n, int tid, Load load, Store store) {
-    for (int base = tid; base < n; base += 4 * FFT_NT) {
+    for (int base = tid; base < n; base += 4 * NT) {
         V v[4];
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
-            const int i = base + u * FFT_NT;
+            const int i = base + u * NT;
             if (i < n) v[u] = load(i);
         }
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
-            const int i = base + u * FFT_NT;
+            const int i = base + u * NT;
             if (i < n) store(i, v[u]);
         }
     }
@@ -395,8 +398,8 @@ struct FftFrames {
     size_t tstride;  // float2 elements between the spectra of consecutive frames
 };
 
-template <int RB>
-__global__ void __launch_bounds__(FFT_NT, FFT_ROWS_WPE) k_rows_fwd(FftFrames fr, int H, int W,
+template <int RB, int NT>
+__global__ void __launch_bounds__(NT, fft_rows_wpe(NT)) k_rows_fwd(FftFrames fr, int H, int W,
                                                                         float2* __restrict__ Tall, int Wk, HhsrRadices rad,
                                                                         const float2* __restrict__ twM, int twlen,
                                                                         const float2* __restrict__ twW) {
@@ -408,27 +411,11 @@ __global__ void __launch_bounds__(FFT_NT, FFT_ROWS_WPE) k_rows_fwd(FftFrames fr,
 #else
     float2* tw = fl;
     float2* buf = tw + ((twlen + 1) & ~1);  // 16-byte aligned
-    batched_for<float2>(twlen, tid, [&](int k) { return twM[k]; }, [&](int k, float2 v) { tw[k] = v; });
+    batched_for<float2, NT>(twlen, tid, [&](int k) { return twM[k]; }, [&](int k, float2 v) { tw[k] = v; });
 #endif
     // persistent workgroups: the grid is one resident round (HHSR_FFT_PERSIST), every workgroup walks the row blocks
     // (row_block): one twiddle copy and one dispatch per workgroup slot instead of per block
     const int nb = (H + RB - 1) / RB;
-#if HHSR_FFT_PF
-    // register prefetch of the NEXT block's rows (4 x 16 bytes per thread) issued before this block's passes.  (Four
-    // scalars and a macro: as an array captured by a lambda the values lived in scratch, every load waited for at once.)
-    const bool pf_ok = (M & 1) == 0 && (W & 3) == 0 && RB * (M / 2) <= 4 * FFT_NT;
-    float4 pf0 = make_float4(0.f, 0.f, 0.f, 0.f), pf1 = pf0, pf2 = pf0, pf3 = pf0;
-#define HHSR_PF_ISSUE(VB)                                                                                      \
-    {                                                                                                          \
-        const int frame_ = (VB) / nb, blk_ = (VB) - frame_ * nb, y0_ = blk_ * RB, n4_ = min(RB, H - y0_) * (M / 2); \
-        const float4* __restrict__ s4_ = reinterpret_cast<const float4*>(fr.src[frame_] + (size_t)y0_ * W);     \
-        pf0 = s4_[min(tid, n4_ - 1)];                  /* (clamped, unconditional: four loads back to back) */    \
-        pf1 = s4_[min(tid + FFT_NT, n4_ - 1)];                                                                 \
-        pf2 = s4_[min(tid + 2 * FFT_NT, n4_ - 1)];                                                             \
-        pf3 = s4_[min(tid + 3 * FFT_NT, n4_ - 1)];                                                             \
-    }
-    if (pf_ok) { const int v0 = row_block<RB>(0, nb * fr.n); if (v0 >= 0) HHSR_PF_ISSUE(v0) }
-#endif
     for (int it = 0, vblk; (vblk = row_block<RB>(it, nb * fr.n)) >= 0; ++it) {
     if (it) __syncthreads();  // the previous block's stores have read the buffer
     const int frame = vblk / nb, blk = vblk - frame * nb;
@@ -436,41 +423,23 @@ __global__ void __launch_bounds__(FFT_NT, FFT_ROWS_WPE) k_rows_fwd(FftFrames fr,
     float2* __restrict__ T = Tall + (size_t)frame * fr.tstride;
     const int y0 = blk * RB;
     const int nrows = min(RB, H - y0);
-#if HHSR_FFT_PF
-    if (pf_ok) {
-        const int Mh = M / 2, n4 = nrows * Mh;
-        const float rMh = 1.0f / (float)Mh;
-#define HHSR_PF_PUT(U, V)                                                    \
-    {                                                                        \
-        const int i_ = tid + (U) * FFT_NT;                                   \
-        if (i_ < n4) {                                                       \
-            int rb_, n_;                                                     \
-            split_row<RB>(i_, Mh, rMh, rb_, n_);                             \
-            reinterpret_cast<float4*>(buf + __mul24(rb_, M))[n_] = (V);      \
-        }                                                                    \
-    }
-        HHSR_PF_PUT(0, pf0) HHSR_PF_PUT(1, pf1) HHSR_PF_PUT(2, pf2) HHSR_PF_PUT(3, pf3)
-        const int vn = row_block<RB>(it + 1, nb * fr.n);
-        if (vn >= 0) HHSR_PF_ISSUE(vn)
-    } else
-#endif
     if ((M & 1) == 0 && (W & 3) == 0) {  // two complex samples (16 bytes) per lane
         const int Mh = M / 2;
         const float rMh = 1.0f / (float)Mh;
         const float4* __restrict__ src4 = reinterpret_cast<const float4*>(src + (size_t)y0 * W);  // rows are Mh float4 apart
-        batched_for<float4>(nrows * Mh, tid, [&](int idx) { return src4[idx]; },
+        batched_for<float4, NT>(nrows * Mh, tid, [&](int idx) { return src4[idx]; },
                             [&](int idx, float4 v) {
                                 int rb, n;
                                 split_row<RB>(idx, Mh, rMh, rb, n);
                                 reinterpret_cast<float4*>(buf + __mul24(rb, M))[n] = v;
                             });
     } else {
-        for (int idx = tid; idx < nrows * M; idx += FFT_NT) {  // z[n] = x[2n] + i x[2n+1]
+        for (int idx = tid; idx < nrows * M; idx += NT) {  // z[n] = x[2n] + i x[2n+1]
             const int rb = idx / M, n = idx - rb * M;
             buf[rb * M + n] = reinterpret_cast<const float2*>(src + (size_t)(y0 + rb) * W)[n];
         }
     }
-    fft_lds(buf, M, nrows, tw, M, rad, tid, FFT_NT);
+    fft_lds(buf, M, nrows, tw, M, rad, tid, NT);
     // X[k] = 1/2 [(Z[k] + conj Z[M-k]) - i w_k (Z[k] - conj Z[M-k])],  w_k = exp(-2 pi i k / W); kept bins only,
     // straight from LDS to the blocked-transposed spectrum
     const int nblk = (Wk + TB - 1) / TB;
@@ -478,7 +447,7 @@ __global__ void __launch_bounds__(FFT_NT, FFT_ROWS_WPE) k_rows_fwd(FftFrames fr,
         // one thread per (bin pair, row): Z[k], Z[k+1] as one 16-byte LDS read, the pair of kept bins as one 16-byte
         // store — the rows of the block are adjacent in T, so RB consecutive lanes write RB x 16 contiguous bytes.  (An odd
         // Wk writes bin Wk into T's padding: tstride covers ceil(Wk / 8) * 8 bins and nobody reads it.)
-        for (int idx = tid; idx < nblk * RB; idx += FFT_NT) {
+        for (int idx = tid; idx < nblk * RB; idx += NT) {
             const int b = idx / RB, rb = idx - b * RB, k = 2 * b;  // (RB is a power of two)
             const float2* Z = buf + __mul24(rb, M);
             const float4 zz = *reinterpret_cast<const float4*>(Z + k);
@@ -491,7 +460,7 @@ __global__ void __launch_bounds__(FFT_NT, FFT_ROWS_WPE) k_rows_fwd(FftFrames fr,
             *reinterpret_cast<float4*>(T + ((size_t)b * H + y0 + rb) * 2) = make_float4(o0.x, o0.y, o1.x, o1.y);
         }
     } else
-    for (int idx = tid; idx < nblk * nrows * TB; idx += FFT_NT) {  // in the order the bins lie in T (see k_rows_inv)
+    for (int idx = tid; idx < nblk * nrows * TB; idx += NT) {  // in the order the bins lie in T (see k_rows_inv)
         const int b = idx / (nrows * TB), q = idx - b * (nrows * TB);
         const int rb = q / TB, k = b * TB + (q - rb * TB);
         if (k >= Wk) continue;
@@ -564,8 +533,8 @@ __global__ void __launch_bounds__(FFT_NT, FFT_COLS_WPE) k_cols(float2* __restric
     }
 }
 
-template <int RB>
-__global__ void __launch_bounds__(FFT_NT, FFT_ROWS_WPE) k_rows_inv(const float2* __restrict__ Tall, int H, int W, int Wk,
+template <int RB, int NT>
+__global__ void __launch_bounds__(NT, fft_rows_wpe(NT)) k_rows_inv(const float2* __restrict__ Tall, int H, int W, int Wk,
                                                                         FftFrames fr, HhsrRadices rad,
                                                                         const float2* __restrict__ twM, int twlen,
                                                                         const float2* __restrict__ twW) {
@@ -577,7 +546,7 @@ __global__ void __launch_bounds__(FFT_NT, FFT_ROWS_WPE) k_rows_inv(const float2*
 #else
     float2* tw = fl;
     float2* buf = tw + ((twlen + 1) & ~1);  // 16-byte aligned
-    batched_for<float2>(twlen, tid, [&](int k) { return twM[k]; }, [&](int k, float2 v) { tw[k] = v; });
+    batched_for<float2, NT>(twlen, tid, [&](int k) { return twM[k]; }, [&](int k, float2 v) { tw[k] = v; });
 #endif
     const int nb = (H + RB - 1) / RB;
     for (int it = 0, vblk; (vblk = row_block<RB>(it, nb * fr.n)) >= 0; ++it) {  // persistent workgroups, see k_rows_fwd
@@ -600,7 +569,7 @@ __global__ void __launch_bounds__(FFT_NT, FFT_ROWS_WPE) k_rows_inv(const float2*
     if (TB == 2 && (M & 1) == 0 && nrows == RB) {
         // one thread per (bin pair, row): X[k], X[k+1] as one 16-byte load (the rows of the block are adjacent in T), no
         // integer division per bin; the mirrored bins X[M-k] are zero except around k = M/2
-        for (int idx = tid; idx < nblk * RB; idx += FFT_NT) {
+        for (int idx = tid; idx < nblk * RB; idx += NT) {
             const int b = idx / RB, rb = idx - b * RB, k0 = 2 * b, y = y0 + rb;  // (RB is a power of two)
             float4 x4 = make_float4(0.f, 0.f, 0.f, 0.f);
             if (k0 < Wk) x4 = *reinterpret_cast<const float4*>(T + ((size_t)b * H + y) * 2);
@@ -622,7 +591,7 @@ __global__ void __launch_bounds__(FFT_NT, FFT_ROWS_WPE) k_rows_inv(const float2*
             else if (k0 < half) Zr[k0] = zk[0];
         }
     } else
-    for (int idx = tid; idx < nblk * nrows * TB; idx += FFT_NT) {  // (batching these loads like batched_for: 2 us slower)
+    for (int idx = tid; idx < nblk * nrows * TB; idx += NT) {  // (batching these loads like batched_for: 2 us slower)
         const int b = idx / (nrows * TB), q = idx - b * (nrows * TB);
         const int rb = q / TB, k = b * TB + (q - rb * TB);
         if (k >= half) continue;
@@ -640,19 +609,19 @@ __global__ void __launch_bounds__(FFT_NT, FFT_ROWS_WPE) k_rows_inv(const float2*
             buf[rb * M + mk] = cconj(cscale(cadd(s, d), 0.5f));
         }
     }
-    fft_lds(buf, M, nrows, tw, M, rad, tid, FFT_NT);
+    fft_lds(buf, M, nrows, tw, M, rad, tid, NT);
     if ((M & 1) == 0 && (W & 3) == 0) {
         const int Mh = M / 2;
         const float rMh = 1.0f / (float)Mh;
         float4* __restrict__ dst4 = reinterpret_cast<float4*>(dst + (size_t)y0 * W);  // rows are Mh float4 apart
-        for (int idx = tid; idx < nrows * Mh; idx += FFT_NT) {  // x[2n] = Re z[n], x[2n+1] = -Im conj-stored z[n]
+        for (int idx = tid; idx < nrows * Mh; idx += NT) {  // x[2n] = Re z[n], x[2n+1] = -Im conj-stored z[n]
             int rb, n;
             split_row<RB>(idx, Mh, rMh, rb, n);
             const float4 z = reinterpret_cast<const float4*>(buf + __mul24(rb, M))[n];
             dst4[idx] = make_float4(z.x, -z.y, z.z, -z.w);
         }
     } else {
-        for (int idx = tid; idx < nrows * M; idx += FFT_NT) {  // x[2n] = Re z[n], x[2n+1] = Im z[n]
+        for (int idx = tid; idx < nrows * M; idx += NT) {  // x[2n] = Re z[n], x[2n+1] = Im z[n]
             const int rb = idx / M, n = idx - rb * M;
             reinterpret_cast<float2*>(dst + (size_t)(y0 + rb) * W)[n] = cconj(buf[rb * M + n]);
         }
@@ -668,7 +637,7 @@ static std::vector<float2> pass_twiddles(const HhsrRadices& rad);
 // HHSR_FFT_RADIX_MAX (experiments) caps the radix; 5 reproduces the original 5/4/3/2 schedule.
 static const int k_radices[] = {16, 15, 14, 12, 10, 9, 8, 7, 6, 5, 4, 3, 2};
 
-static void radix_search(int n, int rmax, int cap, int depth, int* cur, int& best_n, int* best, int& best_max) {
+static void radix_search(int n, int rmax, int cap, int nt, int depth, int* cur, int& best_n, int* best, int& best_max) {
     if (n == 1) {
         int mx = 0;
         for (int i = 0; i < depth; ++i) mx = cur[i] > mx ? cur[i] : mx;
@@ -683,18 +652,18 @@ static void radix_search(int n, int rmax, int cap, int depth, int* cur, int& bes
     for (int r : k_radices) {
         if (r > rmax || n % r) continue;
         if (depth > 0 && r > cur[depth - 1]) continue;  // non-increasing: each multiset once
-        if (cap / r > fft_maxit(r) * FFT_NT) continue;  // butterflies of this pass must fit the threads' registers
+        if (cap / r > fft_maxit(r) * nt) continue;  // butterflies of this pass must fit the threads' registers
         cur[depth] = r;
-        radix_search(n / r, rmax, cap, depth + 1, cur, best_n, best, best_max);
+        radix_search(n / r, rmax, cap, nt, depth + 1, cur, best_n, best, best_max);
     }
 }
 
-// nb: sequences transformed together by one workgroup (every pass runs nb * n / R butterflies)
-static bool factorize(int n, int nb, HhsrRadices& out) {
+// nb: sequences transformed together by one workgroup of nt threads (every pass runs nb * n / R butterflies)
+static bool factorize(int n, int nb, HhsrRadices& out, int nt = FFT_NT) {
     const char* e = getenv("HHSR_FFT_RADIX_MAX");
     const int rmax = e ? atoi(e) : 16;  // (radix 20 / 25 butterflies would exceed the 128-VGPR budget)
     int cur[HHSR_MAX_RADICES], best[HHSR_MAX_RADICES], best_n = HHSR_MAX_RADICES + 1, best_max = 1 << 30;
-    radix_search(n, rmax, nb * n, 0, cur, best_n, best, best_max);
+    radix_search(n, rmax, nb * n, nt, 0, cur, best_n, best, best_max);
     if (best_n > HHSR_MAX_RADICES) return false;
     // order: the radix with the fewest bank collisions at stride R first, then descending
     auto collide = [](int r) { int g = 2 * r, b = 64; while (b) { int t = g % b; g = b; b = t; } return g; };
@@ -759,9 +728,19 @@ static std::vector<float2> pass_twiddles(const HhsrRadices& rad) {
 
 // rows per workgroup of the row kernels: the first candidate whose LDS footprint leaves room for two workgroups
 // per CU and whose passes fit the per-thread butterfly capacity
-static int pick_rb(int M, HhsrRadices& rad) {
+// First choice: one row per 256-thread workgroup when its passes fit 256 threads and row + twiddles fit 32 KB (five
+// workgroups per CU; see FFT_NT_SMALL) — rows up to 4000 pixels.  HHSR_FFT_NT_ROWS=512 (experiments / tests) skips it.
+static int pick_rb(int M, HhsrRadices& rad, int& nt) {
     const char* e = getenv("HHSR_FFT_RB");  // experiments
     const int forced = e ? atoi(e) : 0;
+    const char* ent = getenv("HHSR_FFT_NT_ROWS");
+    const int forced_nt = ent ? atoi(ent) : 0;
+    if (!HHSR_FFT_TWG && (!forced || forced == 1) && forced_nt != FFT_NT && factorize(M, 1, rad, FFT_NT_SMALL) &&
+        sizeof(float2) * (((pass_twiddles(rad).size() + 1) & ~(size_t)1) + (size_t)M) <= 32 * 1024) {
+        nt = FFT_NT_SMALL;
+        return 1;
+    }
+    nt = FFT_NT;
     const int cands[3] = {2, 4, 1};
     for (int c = 0; c < 3; ++c) {
         const int rb = cands[c];
@@ -780,7 +759,7 @@ bool hhsr_fft_create(HhsrFft& f, int H, int W, int batch) {
     if (W % 2 || H < 2 || W < 4) return false;
     const int M = W / 2;
     if (M >= 65536 || H >= 65536) return false;
-    f.rb = pick_rb(M, f.radM);
+    f.rb = pick_rb(M, f.radM, f.nt_rows);
     if (!f.rb) return false;
     f.nc = 0;
     const char* enc = getenv("HHSR_FFT_NC");  // experiments / tests: force the columns-per-workgroup choice
@@ -800,8 +779,11 @@ bool hhsr_fft_create(HhsrFft& f, int H, int W, int batch) {
     f.lds_rows = sizeof(float2) * ((HHSR_FFT_TWG ? 0 : (size_t)((f.twlenM + 1) & ~1)) + (size_t)f.rb * M);
     f.lds_cols = sizeof(float2) * ((size_t)((f.twlenH + 1) & ~1) + (size_t)f.nc * H);
     if (f.lds_cols > 150 * 1024 || f.lds_rows > 150 * 1024) return false;
-    const void* kf = f.rb == 4 ? (const void*)k_rows_fwd<4> : f.rb == 2 ? (const void*)k_rows_fwd<2> : (const void*)k_rows_fwd<1>;
-    const void* ki = f.rb == 4 ? (const void*)k_rows_inv<4> : f.rb == 2 ? (const void*)k_rows_inv<2> : (const void*)k_rows_inv<1>;
+    const bool small = f.nt_rows == FFT_NT_SMALL;  // (only with rb = 1)
+    const void* kf = small ? (const void*)k_rows_fwd<1, FFT_NT_SMALL> : f.rb == 4 ? (const void*)k_rows_fwd<4, FFT_NT>
+                   : f.rb == 2 ? (const void*)k_rows_fwd<2, FFT_NT> : (const void*)k_rows_fwd<1, FFT_NT>;
+    const void* ki = small ? (const void*)k_rows_inv<1, FFT_NT_SMALL> : f.rb == 4 ? (const void*)k_rows_inv<4, FFT_NT>
+                   : f.rb == 2 ? (const void*)k_rows_inv<2, FFT_NT> : (const void*)k_rows_inv<1, FFT_NT>;
     if (hipFuncSetAttribute(kf, hipFuncAttributeMaxDynamicSharedMemorySize, (int)f.lds_rows) != hipSuccess ||
         hipFuncSetAttribute(ki, hipFuncAttributeMaxDynamicSharedMemorySize, (int)f.lds_rows) != hipSuccess ||
         hipFuncSetAttribute(f.nc == 2 ? (const void*)k_cols<2> : (const void*)k_cols<1>,
@@ -832,8 +814,11 @@ void hhsr_fft_destroy(HhsrFft& f) {
 }
 
 int hhsr_fft_lowpass(const HhsrFft& f, const float* const* srcs, float* const* dsts, int n, hipStream_t s) {
-    // row kernels: at most one resident round of workgroups (3 per CU by their 48 kB of LDS), each walking several blocks
-    static const int persist = getenv("HHSR_FFT_PERSIST") ? atoi(getenv("HHSR_FFT_PERSIST")) : (HHSR_FFT_TWG ? 1024 : 768);
+    // row kernels: at most one resident round of workgroups (3 per CU by their 48 kB of LDS, 5 per CU for the 256-thread
+    // single-row workgroups with 32 kB), each walking several blocks
+    static const int persist_env = getenv("HHSR_FFT_PERSIST") ? atoi(getenv("HHSR_FFT_PERSIST")) : -1;
+    const bool small = f.nt_rows == FFT_NT_SMALL;
+    const int persist = persist_env >= 0 ? persist_env : HHSR_FFT_TWG ? 1024 : small ? 1280 : 768;
     // unnormalised inverse transforms multiply by (W/2) and H
     const float norm = (float)(1.0 / ((double)(f.W / 2) * (double)f.H));
     for (int n0 = 0; n0 < n; n0 += f.batch) {  // the plan holds f.batch spectra: longer lists run in rounds
@@ -846,18 +831,20 @@ int hhsr_fft_lowpass(const HhsrFft& f, const float* const* srcs, float* const* d
         }
         const int nrb_all = hhsr_cdiv(f.H, f.rb) * fr.n;
         const int nrb = persist > 0 && persist < nrb_all ? persist : nrb_all;
-#define ROWS_FWD(RB) hipLaunchKernelGGL(k_rows_fwd<RB>, dim3(nrb), dim3(FFT_NT), f.lds_rows, s, fr, f.H, f.W, f.T, f.Wk, \
-                                        f.radM, f.twM, f.twlenM, f.twW)
-#define ROWS_INV(RB) hipLaunchKernelGGL(k_rows_inv<RB>, dim3(nrb), dim3(FFT_NT), f.lds_rows, s, f.T, f.H, f.W, f.Wk, fr, \
-                                        f.radM, f.twM, f.twlenM, f.twW)
-        if (f.rb == 4) ROWS_FWD(4); else if (f.rb == 2) ROWS_FWD(2); else ROWS_FWD(1);
+#define ROWS_FWD(RB, NT) hipLaunchKernelGGL((k_rows_fwd<RB, NT>), dim3(nrb), dim3(NT), f.lds_rows, s, fr, f.H, f.W, f.T, f.Wk, \
+                                            f.radM, f.twM, f.twlenM, f.twW)
+#define ROWS_INV(RB, NT) hipLaunchKernelGGL((k_rows_inv<RB, NT>), dim3(nrb), dim3(NT), f.lds_rows, s, f.T, f.H, f.W, f.Wk, fr, \
+                                            f.radM, f.twM, f.twlenM, f.twW)
+        if (small) ROWS_FWD(1, FFT_NT_SMALL); else if (f.rb == 4) ROWS_FWD(4, FFT_NT); else if (f.rb == 2) ROWS_FWD(2, FFT_NT);
+        else ROWS_FWD(1, FFT_NT);
         if (f.nc == 2)
             hipLaunchKernelGGL(k_cols<2>, dim3(((f.Wk + 63) / 64) * 32, fr.n), dim3(FFT_NT), f.lds_cols, s, f.T, f.tstride,
                                f.H, f.W, f.Wk, f.radH, f.twH, f.twlenH, norm);
         else
             hipLaunchKernelGGL(k_cols<1>, dim3(((f.Wk + 63) / 64) * 64, fr.n), dim3(FFT_NT), f.lds_cols, s, f.T, f.tstride,
                                f.H, f.W, f.Wk, f.radH, f.twH, f.twlenH, norm);
-        if (f.rb == 4) ROWS_INV(4); else if (f.rb == 2) ROWS_INV(2); else ROWS_INV(1);
+        if (small) ROWS_INV(1, FFT_NT_SMALL); else if (f.rb == 4) ROWS_INV(4, FFT_NT); else if (f.rb == 2) ROWS_INV(2, FFT_NT);
+        else ROWS_INV(1, FFT_NT);
 #undef ROWS_FWD
 #undef ROWS_INV
     }

@@ -87,6 +87,24 @@ def test_grey_fused_one_column_per_workgroup(monkeypatch):
     assert np.array_equal(outs["1"], outs["2"])
 
 
+def test_grey_fused_row_kernel_variants(monkeypatch):
+    """Row kernels: one row per 256-thread workgroup where the row fits (the default up to 4000-pixel rows) and row pairs in
+    512-thread workgroups (forced here with HHSR_FFT_NT_ROWS=512; long rows) — both against the float64 oracle, on an image
+    with the bench's row length, an odd row count (a ragged last row pair) and on a small one."""
+    for shape in ((26, 4000), (241, 400), (378, 504)):
+        img = np.random.default_rng(6).random(shape, dtype=np.float32)
+        want = oracle.grey_fft(img)
+        outs = {}
+        for nt in ("256", "512"):
+            monkeypatch.setenv("HHSR_FFT_NT_ROWS", nt)
+            utils_image._grey_plans.clear()
+            outs[nt] = N(utils_image.compute_grey_images(T(img), "FFT"))
+            assert_close(outs[nt], want, 0, 3e-6, f"{shape} row kernels with {nt} threads")
+        assert np.abs(outs["256"] - outs["512"]).max() < 2e-6
+    monkeypatch.delenv("HHSR_FFT_NT_ROWS")
+    utils_image._grey_plans.clear()
+
+
 def test_grey_fused_radix7_sensor_size(monkeypatch):
     """4032 x 3024 (the common 12 MP sensor; 2016 = 2^5 3^2 7, 3024 = 2^4 3^3 7) runs on the fused FFT kernels
     (radix 7 / 14 butterflies) and agrees with the library plans."""
