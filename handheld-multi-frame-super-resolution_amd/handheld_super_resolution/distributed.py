@@ -67,6 +67,14 @@ def shard_indices(n_frames, rank, world):
     return list(range(rank, n_frames, world))
 
 
+def slab_align(scale):
+    """Row granularity of the UNEVEN slabs of strategy "rows": the workgroup grid of the merge kernel that scale runs —
+    16 LR rows = 16 * scale output rows at integer scales (32 at x2, 48 at x3), SLAB_ALIGN otherwise.  (At x2 of 12 MP on 8
+    ranks the model wants 643 / 814 rows; in 96-row units that became 576 / 864 and the ranks differed by 8 %.)"""
+    s = float(scale)
+    return 16 * int(s) if s.is_integer() and s >= 1.0 else SLAB_ALIGN
+
+
 def slab_rows(sH, world):
     """Rows per EQUAL slab: ceil(sH / world) rounded up to SLAB_ALIGN.  All slabs have this (padded) size so that
     every collective moves equal chunks; slab j covers output rows [j*rows, min((j+1)*rows, sH))."""
@@ -84,19 +92,22 @@ def align_cost(scale):
     """rho: step A of one frame costs about as much as step B of one frame over this fraction of the image.  Step A does
     not depend on the scale, step B grows with the output: B / A = 0.20 + 0.32 scale^2 fits the per-rank measurements of
     tools/debug/emulate_ranks.py at x2 (12 MP: A 0.18 ms per frame, B 0.27 ms per frame and image: rho 0.67) and x3
-    (48 MP: 0.70 / 2.2 ms: rho 0.32).  config.hip.align_cost overrides it."""
-    return 1.0 / (0.20 + 0.32 * float(scale) ** 2)
+    (48 MP: 0.70 / 2.2 ms: rho 0.32).  Re-fitted late in round 4 (the FFT got faster: A 0.15 ms per frame at 12 MP,
+    0.68 ms at 48 MP; B 0.276 / 2.2 ms per frame and image): B / A = 0.74 + 0.276 scale^2, rho 0.54 at x2 and 0.31 at x3.
+    config.hip.align_cost overrides it."""
+    return 1.0 / (0.74 + 0.276 * float(scale) ** 2)
 
 
 ALIGN_COST = align_cost(2)  # (the x2 value; main_sharded uses align_cost(config.scale))
 
 
-def slab_bounds(sH, world, n_frames=0, align_cost=0.0):
-    """Valid (un-padded) row range [b[j], b[j+1]) of every slab, boundaries on multiples of SLAB_ALIGN.
+def slab_bounds(sH, world, n_frames=0, align_cost=0.0, align=SLAB_ALIGN):
+    """Valid (un-padded) row range [b[j], b[j+1]) of every slab, boundaries on multiples of `align` (uneven slabs; equal
+    slabs: SLAB_ALIGN).
     align_cost = 0: equal slabs (strategy "reduce": the reduce-scatter moves equal chunks).  Strategy "rows" passes the
     frame count and align_cost = rho: rank j aligns a_j = |{j, j+G, ...}| frames, and its slab is sized so that
     a_j rho sH + rows_j n is the same for every rank — rows_j = sH ((1 + rho) / G - a_j rho / n): with 19 frames on 8 ranks
-    and rho = 0.9 the three ranks that align 3 frames get 576 rows, the five that align 2 get 864 (x2 of 12 MP)."""
+    and rho = 0.54, align = 32 the three ranks that align 3 frames get 640 rows, the five that align 2 get 784 - 832 (x2 of 12 MP)."""
     if not n_frames or align_cost <= 0.0 or world == 1:
         rows = slab_rows(sH, world)
         return [min(j * rows, sH) for j in range(world + 1)]
@@ -104,7 +115,7 @@ def slab_bounds(sH, world, n_frames=0, align_cost=0.0):
             for j in range(world)]
     # apportion the SLAB_ALIGN-row units: every rank at least one (while there are enough — a rank without rows would
     # make the whole job fall back to the eager path), the rest by the model, largest remainders first
-    units = -(-sH // SLAB_ALIGN)
+    units = -(-sH // align)
     if units < world:
         rows = slab_rows(sH, world)
         return [min(j * rows, sH) for j in range(world + 1)]
@@ -118,7 +129,7 @@ def slab_bounds(sH, world, n_frames=0, align_cost=0.0):
     b, acc = [0], 0
     for j in range(world):
         acc += got[j]
-        b.append(min(sH, acc * SLAB_ALIGN))
+        b.append(min(sH, acc * align))
     b[-1] = sH
     return b
 
@@ -435,7 +446,7 @@ class SlabWork:
             self.den = torch.zeros_like(self.num)
         else:
             self.fuse_acc = self.acc_r is not None and can_fuse_acc_r(cfg)
-            self.fuse_min = sub.fuses_local_min() and (self.fuse_acc or self.acc_r is None) and row0 % SLAB_ALIGN == 0
+            self.fuse_min = sub.fuses_local_min() and (self.fuse_acc or self.acc_r is None) and row0 % slab_align(scale) == 0
 
     def front(self, imgs, flows):
         """`imgs`: full frames (their rows [S0, S1) are used); `flows`: their FULL flow fields [ny, nx, 2] (views welcome)."""
@@ -823,7 +834,7 @@ def main_sharded(ref_img, comp_imgs, config, group=None, engine=None, gather=Tru
             cost = float(hip.get("align_cost"))
         sf = int(hip.get("stage_frames", STAGE_FRAMES)) if hip is not None else STAGE_FRAMES
         stages = stage_plan(n, world, sf if sf > 0 else max(n, 1))
-        bounds = slab_bounds(sH, world, n, cost)
+        bounds = slab_bounds(sH, world, n, cost, slab_align(config.scale))
         rows = max(b1 - b0 for b0, b1 in zip(bounds[:-1], bounds[1:]))  # (padded chunk of the optional gather)
         r0, r1 = bounds[rank], bounds[rank + 1]
 

@@ -192,6 +192,15 @@ def test_uneven_slabs_and_stages():
     # the modelled per-rank cost a_j rho sH + rows_j n is level to within one slab-alignment step
     cost = [len(range(j, 19, 8)) * 0.9 * 6000 + sizes[j] * 19 for j in range(8)]
     assert max(cost) - min(cost) <= 2 * 96 * 19
+    # the scale's own tile grid (32 output rows at x2, 48 at x3, 96 at fractional scales) levels the ranks further
+    assert (hdist.slab_align(2), hdist.slab_align(3), hdist.slab_align(1.5), hdist.slab_align(1)) == (32, 48, 96, 16)
+    for scale, sH in ((2, 6000), (3, 18000)):
+        rho, al = hdist.align_cost(scale), hdist.slab_align(scale)
+        bf = hdist.slab_bounds(sH, 8, 19, rho, al)
+        assert bf[0] == 0 and bf[-1] == sH and all(x % al == 0 for x in bf[:-1]) and bf == sorted(bf)
+        sz = [b1 - b0 for b0, b1 in zip(bf[:-1], bf[1:])]
+        cost = [len(range(j, 19, 8)) * rho * sH + sz[j] * 19 for j in range(8)]
+        assert max(cost) - min(cost) <= 2 * al * 19 and max(sz[:3]) < min(sz[3:])
     assert hdist.slab_bounds(6000, 8, 19, 0.0) == hdist.slab_bounds(6000, 8)
     assert hdist.slab_bounds(6000, 1, 19, 0.9) == [0, 6000]
     assert hdist.stage_plan(19, 8) == [(0, 1), (1, 1), (2, 1)]

@@ -7,6 +7,7 @@ copy of the flows a single-GPU alignment computed) — so max_j T_j(G) is the st
     python tools/debug/emulate_ranks.py [--height 3000 --width 4000 --frames 20 --scale 2] [--worlds 1,2,4,8] [--steps 10]
 """
 import argparse
+import gc
 import json
 import os
 import sys
@@ -72,6 +73,10 @@ def main():
         torch.cuda.synchronize()
         return (time.perf_counter() - t0) / steps * 1e3
 
+    # Plans and engines stay alive until their (world, strategy) row is printed and are then collected OUTSIDE any capture: a CUDAGraph finalised (hipGraphDestroy) by a garbage collection
+    # that happens to run while the NEXT plan's streams are capturing aborts the process ("operation not permitted when
+    # stream is capturing" from a destructor).  The product keeps its plans in the engine for the same reason.
+    keep = []
     for G in [int(g) for g in a.worlds.split(",")]:
         for strategy in a.strategies.split(","):
             per_rank, detail = [], []
@@ -81,7 +86,7 @@ def main():
                 if strategy == "rows":
                     cost = float(cfg.hip.get("align_cost", hdist.align_cost(scale)))
                     stages = hdist.stage_plan(n, G, a.stage_frames if a.stage_frames > 0 else max(n, 1))
-                    bounds = hdist.slab_bounds(sH, G, n, cost)
+                    bounds = hdist.slab_bounds(sH, G, n, cost, hdist.slab_align(scale))
                     r0, r1 = bounds[j], bounds[j + 1]
                     if r1 <= r0:
                         per_rank.append(0.0)
@@ -130,7 +135,7 @@ def main():
                     ta, tb = timed(only_a, a.steps), timed(only_b, a.steps)
                     detail.append({"rank": j, "rows": [r0, r1], "frames_aligned": len(range(j, n, G)), "ms": round(t, 3),
                                    "ms_A_alone": round(ta, 3), "ms_B_alone": round(tb, 3)})
-                    del plan
+                    keep.append(plan)  # (see `keep`)
                 else:
                     rows = hdist.slab_rows(sH, G)
                     bounds = hdist.slab_bounds(sH, G)
@@ -148,7 +153,7 @@ def main():
                     t = timed(step, a.steps)
                     detail.append({"rank": j, "rows": [r0, r1], "frames": len(mine), "ms": round(t, 3)})
                 per_rank.append(t)
-                del eng
+                keep.append(eng)
                 torch.cuda.empty_cache()
             rec = {"workload": f"{H}x{W}x{NF} x{scale}", "world": G, "strategy": strategy, "stage_frames": a.stage_frames,
                    "max_rank_ms": round(max(per_rank), 3), "mean_rank_ms": round(float(np.mean(per_rank)), 3),
@@ -158,6 +163,10 @@ def main():
                 rec["accumulator_GB_per_rank"] = round(gb, 3)
                 rec["modelled_reduce_scatter_ms"] = round(gb * (G - 1) / G / 100.0 * 1e3, 2) if G > 1 else 0.0
             print(json.dumps(rec), flush=True)
+            plan = eng = None
+            keep.clear()
+            torch.cuda.synchronize()
+            gc.collect()
 
 
 if __name__ == "__main__":
