@@ -14,13 +14,13 @@ from .grey import compute_grey_images
 from .align import init_alignment, align
 from .robustness import init_robustness, compute_robustness
 from .kernels import estimate_kernels
-from .merge import merge, merge_ref, divide
+from .merge import merge as _merge, merge_ref as _merge_ref, divide
 
 F32 = np.float32
 _state = {}
 
 
-def _init(ref, comp_imgs, config):
+def _init(ref, comp_imgs, config, fast=False, flows=None):
     # one NumPy / BLAS thread per worker: the parallelism is over frames
     for var in ("OMP_NUM_THREADS", "OPENBLAS_NUM_THREADS", "MKL_NUM_THREADS"):
         os.environ[var] = "1"
@@ -33,7 +33,8 @@ def _init(ref, comp_imgs, config):
     cfa = np.array(config.exif.cfa_pattern)
     wb = np.array(config.exif.white_balance, dtype=np.float64)
     grey_ref = compute_grey_images(ref, config.grey_method) if config.mode == "bayer" else ref
-    _state.update(ref=ref, comp=comp_imgs, config=config, cfa=cfa, wb=wb, align=init_alignment(grey_ref, config),
+    _state.update(ref=ref, comp=comp_imgs, config=config, cfa=cfa, wb=wb, fast=fast, flows=flows,
+                  align=init_alignment(grey_ref, config) if flows is None else None,
                   rob=init_robustness(ref, cfa, wb, config),
                   curves=(np.array(config.noise_model.std_curve, np.float64),
                           np.array(config.noise_model.diff_curve, np.float64)))
@@ -42,21 +43,33 @@ def _init(ref, comp_imgs, config):
 def _frame(n):
     s = _state
     cfg, img = s["config"], s["comp"][n]
-    grey = compute_grey_images(img, cfg.grey_method) if cfg.mode == "bayer" else img
-    flow = align(*s["align"], grey, cfg)
+    if s["flows"] is None:
+        grey = compute_grey_images(img, cfg.grey_method) if cfg.mode == "bayer" else img
+        flow = align(*s["align"], grey, cfg)
+    else:
+        flow = np.asarray(s["flows"][n], dtype=F32)
     r = compute_robustness(img, *s["rob"], flow, s["cfa"], s["wb"], s["curves"], cfg)
     covs = estimate_kernels(img, cfg)
     H, W = img.shape
     osz = (round(cfg.scale * H), round(cfg.scale * W))
     num = np.zeros((*osz, 3), F32)
     den = np.zeros((*osz, 3), F32)
-    merge(img, flow, covs, r, num, den, s["cfa"], cfg)
+    _merge_fn(s["fast"])[0](img, flow, covs, r, num, den, s["cfa"], cfg)
     return n, flow, r, num, den
 
 
-def main_parallel(ref_img, comp_imgs, config, workers=None, capture=None):
+def _merge_fn(fast):
+    if fast:
+        from . import cfast
+
+        return cfast.merge, cfast.merge_ref
+    return _merge, _merge_ref
+
+
+def main_parallel(ref_img, comp_imgs, config, workers=None, capture=None, fast=False, flows=None):
     """Same result as ``oracle.main(ref_img, comp_imgs, config)`` (bit for bit), computed by ``workers`` processes
-    (default: all host cores, at most one per comp frame).  Returns (output, debug_dict, workers_used)."""
+    (default: all host cores, at most one per comp frame).  Returns (output, debug_dict, workers_used).
+    ``fast`` / ``flows``: as in ``oracle.main`` (C accumulation; given flow fields instead of the alignment)."""
     ref = np.asarray(ref_img, dtype=F32)
     comp_imgs = np.asarray(comp_imgs, dtype=F32)
     n = comp_imgs.shape[0]
@@ -73,11 +86,11 @@ def main_parallel(ref_img, comp_imgs, config, workers=None, capture=None):
     results = {}
     if n:
         if workers == 1:
-            _init(ref, comp_imgs, config)
+            _init(ref, comp_imgs, config, fast, flows)
             it = map(_frame, range(n))
         else:
             ctx = mp.get_context("fork")  # workers inherit the burst; nothing is pickled on the way in
-            pool = ctx.Pool(workers, initializer=_init, initargs=(ref, comp_imgs, config))
+            pool = ctx.Pool(workers, initializer=_init, initargs=(ref, comp_imgs, config, fast, flows))
             it = pool.imap_unordered(_frame, range(n))
         for k, flow, r, nk, dk in it:
             results[k] = (flow, r, nk, dk)
@@ -98,7 +111,9 @@ def main_parallel(ref_img, comp_imgs, config, workers=None, capture=None):
         assert not results and len(debug["flow"]) == n
     cfa = np.array(config.exif.cfa_pattern)
     covs = estimate_kernels(ref, config)
-    merge_ref(ref, covs, num, den, cfa, config, acc_r if accumulate_r else None)
+    _merge_fn(fast)[1](ref, covs, num, den, cfa, config, acc_r if accumulate_r else None)
+    if capture is not None:
+        capture["den"] = den.copy()
     divide(num, den)
     if not config.debug:
         debug = {"robustness": [], "flow": []}

@@ -1,12 +1,17 @@
-"""Randomised end-to-end parity sweep as a test (VERDICT r2 #2): HIP main() against oracle.main() on 64 random bursts —
+"""Randomised end-to-end parity sweep as a test (VERDICT r2 #2, r4 #1): HIP main() against oracle.main() on 64 random bursts —
 sizes (also odd multiples of 2), 2-4 frames, scales 1 / 1.5 / 2 / 3, the four Bayer patterns, white balances, tile sizes
 16 / 32, iso kernel, robustness and merge denoiser on / off, moving occluders, level-0 metric L2 / L1 / L1_ref_effective.
 
-Asserted per case (helpers.fuzz_verdict and its constants FLIP_PX, CLUSTER, MAX_ICA_TILES, MAX_OUTLIERS, MAX_OUTLIER,
-NUM_ERR; every case also runs with the oracle's flow fields injected, config.hip.inject_flows — that run
-exercises kernels + robustness + merge on identical geometry, the flow comparison exercises the alignment):
-  * identical NaN pattern (and equal infinities);
-  * flow <= 1e-4 px (measured <= 9.9e-5) on every tile EXCEPT
+The contract is TWO-SIDED (round 5).  Per case FOUR images exist:
+
+    o       HIP,    its own flows            want    oracle, its own flows
+    oi      HIP,    the oracle's flows       want_h  oracle, HIP's flows   (oracle.main(flows=...): the oracle's
+            (config.hip.inject_flows)                compute_robustness + estimate_kernels + merge + merge_ref on them)
+
+and every image value is compared between two computations on IDENTICAL flow fields (o vs want_h, oi vs want); the flow
+fields themselves are compared with each other.  Asserted per case (helpers.fuzz_verdict and its constants FLIP_PX,
+CLUSTER, MAX_ICA_TILES, MAX_FLIP_TILES, MAX_OUTLIER, DEN_FLOOR, NUM_ERR):
+  * alignment — flow <= 1e-4 px (measured <= 9.9e-5) on every tile EXCEPT
       - the tiles under ONE flipped block-matching decision per case: a float32 near-tie somewhere in the pyramid, which
         all finest-level tiles under that coarser tile inherit — the tiles whose flow differs by > FLIP_PX = 1e-3 px
         (measured 0.04 - 0.11 px) must lie in one frame inside a bounding box of CLUSTER x CLUSTER tiles (measured: a
@@ -14,35 +19,33 @@ exercises kernels + robustness + merge on identical geometry, the flow compariso
       - at most MAX_ICA_TILES tiles per case between 1e-4 and 1e-3 px: ill-conditioned Lucas-Kanade systems at a moving
         occluder, where three ICA iterations amplify the float32 noise of the gradient sums (measured: 1, 1 and 10 tiles,
         <= 3.4e-4 px, in 3 of the 576 held-out cases, none in the 64);
-    robustness r <= 1e-4 outside the footprint of all those tiles;
-  * oracle flows injected: image <= 1e-4 wherever every frame is fully accepted (r = 1 in the 5 x 5 raw-pixel
-    neighbourhood; with the robustness off: everywhere); where some frame is being rejected at most two raw
-    pixels' worth of isolated values per case (2 x 3 x ceil(scale)^2: one raw pixel is scale^2 output pixels x 3
-    channels), each <= MAX_OUTLIER or, where the value's accumulated weight den is smaller than NUM_ERR / MAX_OUTLIER,
-    <= NUM_ERR / den (case 101.9: 0.104 at den = 3.4e-7 — every outlier of set 100 has |d out| x den <= 8.9e-8, float32
-    rounding of num and den themselves) — mechanism (a) below.  Measured: the 64 cases: 63 <= 9.6e-5, one with 2 values at
-    1.01e-4; nine held-out sets of 64 (HHSR_FUZZ_BATCHES=10:22,11:22,12:20 ... 90:22,91:22,92:20): 546 of 576 <= 1e-4,
-    30 cases with 1 - 4 values each (18 and 22 — one raw pixel — in two cases at scale 3) between 1.1e-4 and 2.3e-3.
-    (Earlier forms of this assertion — each value <= 3e-4; values above 1.05e-4 only in tiles displaced by > 30 px; <= 16
-    values per case — were calibrated on the 64 fixed cases and FAILED on held-out sets: r in its transition band is
-    what the exceptions have in common, not a diverged alignment.)
-  * own flows: image <= 1e-4 outside the footprint of a flipped tile EXCEPT
-      (a) isolated pixels where some frame is being rejected: at most MAX_OUTLIERS values per case, each <= MAX_OUTLIER;
-      (b) flow-sensitive pixels — pixels that agree (<= 1e-4) once the oracle's flows are injected, i.e. whose whole
-          difference comes from the <= 1e-4 px by which the flows differ: at most two tiles' worth per case.
+  * on either side (HIP's flows: o vs want_h; the oracle's flows: oi vs want) —
+      - identical NaN pattern (and equal infinities) EVERYWHERE (no footprint exemption: a flipped border tile changes which
+        border pixels have no sample of a colour in BOTH computations alike);
+      - robustness r <= 1e-4 everywhere;
+      - image <= 1e-4 wherever every frame is fully accepted (r = 1 in the 5 x 5 raw-pixel neighbourhood; with the
+        robustness off: everywhere); where some frame is being rejected at most two raw pixels' worth of isolated values
+        per case (2 x 3 x ceil(scale)^2: one raw pixel is scale^2 output pixels x 3 channels), each <= MAX_OUTLIER or, where
+        the value's accumulated weight den is smaller than NUM_ERR / MAX_OUTLIER, <= NUM_ERR / den — mechanism (a) below.
+Nothing is excused by magnitude or count outside those rules: round 4's "flow-sensitive values" allowance (values that
+differ between o and want but agree once the oracle's flows are injected, capped at MAX_SENS = 0.15 and violated at 0.177,
+0.187 and 0.671 on held-out seeds) is gone — such a value now has to be reproduced by the ORACLE run on HIP's flows.
+Reported per case but not asserted (implied by the rules above): o vs want outside the footprint of deviating tiles, next
+to |want_h - want| there — how far the ORACLE's OWN image moves under the <= 1e-4 px by which the flows differ.
 
-Why those pixels exist — conditioning of the reference algorithm, not arithmetic differences:
+Why rejecting regions get an allowance — conditioning of the reference algorithm, not arithmetic:
 (a) where a frame is being rejected, r sits in its transition band (1e-5 ... 1e-3) at some taps: R = S e - t cancels to
 1e-4 of its operands, and where the frame's sample and the reference sample weigh about the same the normalised value
 (a w_ref + b r w) / (w_ref + r w) moves by (b - a) / 4r per unit of r — HIP and oracle r differing by 8e-7 around r =
 5.9e-4 is 1.5e-4 in the image (case 32.7, no occluder, two frames); under a moving occluder or a diverged alignment the
 same happens with larger (b - a) (6.3e-4, case 10.0).  The reference's own float32 buffers carry the same rounding noise.
-(b) the 3 x 3 tap window is centred on round(position) (merge.py:343-361): the output is
-DISCONTINUOUS in the flow where a tile's position (h + 0.5) / s + flow crosses a rounding boundary — a 1e-5 px flow
-difference then swaps a row of taps for the opposite one for every pixel of the tile with that sub-pixel phase (measured:
-one tile of one case, 6.9e-2 with own flows, 1.8e-7 with the oracle's flows).
+Why o and want can differ by more than that although the flows agree to 1e-4 px: the 3 x 3 tap window is centred on
+round(position) (merge.py:343-361), so the output is DISCONTINUOUS in the flow where a tile's position (h + 0.5) / s + flow
+crosses a rounding boundary — the oracle's image jumps by the same amount when it is given HIP's flows (`orc_max` in the
+report), which is what the side-H comparison checks.
 
-The oracle runs are independent: a fork pool computes them on the host cores while the GPU works through the cases."""
+The oracle runs use the C form of the accumulation (oracle.cfast, bit-identical to oracle/merge.py on the cases
+tests/test_oracle_kat.py compares) on a fork pool of the host cores while the GPU works through the cases."""
 import multiprocessing as mp
 import os
 
@@ -108,70 +111,103 @@ def burst(c):
                             cfa=c["cfa"], wb=c["wb"])[:2]
 
 
-def _oracle_case(c):
+def _oracle_case(c, gflow):
+    """Both oracle runs of a case: own flows (alignment included), then robustness + merge on HIP's flows `gflow`."""
     os.environ["OMP_NUM_THREADS"] = "1"
     torch.set_num_threads(1)
     ref, comp = burst(c)
-    cap = {}
-    want, _ = oracle.main(ref, comp, config(c), capture=cap)
-    return ref, comp, want, np.stack(cap["flow"]), (np.stack(cap["r"]) if c["rob"] else None), cap["den"]
+    cap, cap_h = {}, {}
+    want, _ = oracle.main(ref, comp, config(c), capture=cap, fast=True)
+    want_h, _ = oracle.main(ref, comp, config(c), capture=cap_h, fast=True, flows=list(gflow), reuse=cap)
+    rob = c["rob"]
+    return (want, want_h, np.stack(cap["flow"]), np.stack(cap["r"]) if rob else None, np.stack(cap_h["r"]) if rob else None,
+            cap["den"], cap_h["den"])
 
 
-def check(c, ref, comp, want, oflow, o_r, den_o, report=None):
-    """Returns the number of flipped block-matching decisions (clusters of tiles) of the case: 0 or 1."""
+def hip_own(c):
+    """HIP main() with its own alignment: (ref, comp, image, flows, robustness maps)."""
+    ref, comp = burst(c)
     cfg = config(c)
     cfg.debug = True
     out, dbg = hsr.main(ref, comp, cfg)
-    o = out.cpu().numpy()
+    return ref, comp, out.cpu().numpy(), np.stack(dbg["flow"]), (np.stack(dbg["robustness"]) if c["rob"] else None)
+
+
+def check(c, own, orc, report=None):
+    """Returns the number of flipped block-matching decisions (clusters of tiles) of the case: 0 or 1."""
+    ref, comp, o, gflow, hr = own
+    want, want_h, oflow, o_r, o_r_h, den_o, den_h = orc
     cfg_i = config(c, inject_flows=[f for f in oflow])
     cfg_i.debug = True
     out_i, dbg_i = hsr.main(ref, comp, cfg_i)
     oi = out_i.cpu().numpy()
     H, W, ts, scale = c["H"], c["W"], c["ts"], c["scale"]
     tag = f"case {c['id']} ({H}x{W} x{c['nf']} s={scale} ts={ts} {c['metric0']} rob={c['rob']} den={c['den']} occ={c['occ']})"
-    v, failed = fuzz_verdict((H, W), ts, scale, o, oi, want, np.stack(dbg["flow"]), oflow,
-                             np.stack(dbg["robustness"]) if c["rob"] else None,
-                             np.stack(dbg_i["robustness"]) if c["rob"] else None, o_r, den_o)
-    nflip, one_cluster, n_ica, nan_mis, dflow, dr, dr_i = (v[k] for k in ("nflip", "one_cluster", "n_ica", "nan_mis", "dflow", "dr", "dr_i"))
-    inj_max, n_inj, inj_outside, inj_q = v["inj_max"], v["n_inj"], v["inj_outside"], v["inj_q"]
-    n_sens, sens_max, n_rest, rest_max, rest_outside = v["n_sens"], v["sens_max"], v["n_rest"], v["rest_max"], v["rest_outside"]
+    v, failed = fuzz_verdict((H, W), ts, scale, o, oi, want, want_h, gflow, oflow, hr,
+                             np.stack(dbg_i["robustness"]) if c["rob"] else None, o_r, o_r_h, den_o, den_h)
     if report is not None:
-        report.append(f"{tag}: flipped {nflip}{'' if one_cluster else ' (NOT one cluster)'}, ica {n_ica}, nan {nan_mis}, flow {dflow:.1e}, r {dr:.1e} / injected {dr_i:.1e}; injected "
-                      f"image max {inj_max:.2e} ({n_inj} > 1e-4, {inj_outside} outside rejecting regions); own flows: flow-"
-                      f"sensitive {n_sens} (max {sens_max:.1e}), other {n_rest} (max {rest_max:.1e}, {rest_outside} outside "
-                      f"rejecting regions); injected outliers x den max {inj_q:.2e}" + (f"  ASSERTIONS FAILED: {'; '.join(failed)}" if failed else ""))
-        return int(nflip > 0)
+        side = lambda s: (f"nan {s['nan_mis']}, r {s['dr']:.1e}, image max {s['max']:.2e} ({s['n']} > 1e-4, {s['outside']} outside "
+                          f"rejecting regions, {s['over']} over the bound, x den max {s['q']:.2e})")
+        report.append(f"{tag}: flipped {v['nflip']}{'' if v['one_cluster'] else ' (NOT one cluster)'}, ica {v['n_ica']}, flow "
+                      f"{v['dflow']:.1e}; HIP's flows [{side(v['side_h'])}]; oracle's flows [{side(v['side_o'])}]; own vs own "
+                      f"outside deviating tiles: {v['n_own']} > 1e-4 (max {v['own_max']:.1e}), oracle's own move under HIP's flows: "
+                      f"{v['n_orc']} (max {v['orc_max']:.1e})" + (f"  ASSERTIONS FAILED: {'; '.join(failed)}" if failed else ""))
+        return int(v["nflip"] > 0)
     assert not failed, f"{tag}: " + "; ".join(failed)
-    return int(nflip > 0)
-
-
-_pool, _jobs = None, {}
+    return int(v["nflip"] > 0)
 
 
 @pytest.fixture(scope="module")
-def oracle_jobs():
-    """All 64 oracle runs are submitted at once to a fork pool (NumPy-only children: they never touch the GPU) and the
-    batches consume them as they finish: the sweep takes about as long as the slowest oracle case."""
-    all_cases = [c for gs, n in BATCHES for c in cases(gs, n)]
-    # every core the container may use (cgroup quota: 16 of the GPU boxes' 256 logical CPUs) minus two for this process:
-    # with one worker per case the workers starved the checking thread (the sweep took 290 s instead of ~2 min)
-    workers = max(1, min(len(all_cases), oracle.available_cores() - 2))
-    pool = mp.get_context("fork").Pool(workers)
-    jobs = {c["id"]: pool.apply_async(_oracle_case, (c,)) for c in all_cases}
-    yield jobs
+def oracle_pool():
+    """A fork pool for the oracle runs (NumPy / C children: they never touch the GPU).  Every core the container may use
+    (cgroup quota: 16 of the GPU boxes' 256 logical CPUs) minus two for this process: with one worker per case the workers
+    starved the checking thread."""
+    from oracle import cfast
+
+    cfast.load()  # built once, before the fork
+    pool = mp.get_context("fork").Pool(max(1, oracle.available_cores() - 2))
+    yield pool
     pool.terminate()
     pool.join()
 
 
-@pytest.mark.timeout(1800)
-@pytest.mark.parametrize("gen_seed,n", BATCHES)
-def test_fuzz_sweep(oracle_jobs, gen_seed, n):
-    report = [] if os.environ.get("HHSR_FUZZ_REPORT") else None
-    flipped = 0
-    for c in cases(gen_seed, n):
-        flipped += check(c, *oracle_jobs[c["id"]].get(timeout=1500), report=report)
-    if report is not None:
+def sweep(pool, cs, report=None, ahead=None):
+    """HIP runs case i + `ahead` (its flows are what the oracle's second run needs) while the pool computes the oracle
+    pairs of the cases before it; returns the number of flipped decisions."""
+    ahead = ahead or 2 * pool._processes
+    inflight, flipped = [], 0
+    for c in cs + [None] * ahead:
+        if c is not None:
+            own = hip_own(c)
+            inflight.append((c, own, pool.apply_async(_oracle_case, (c, own[3]))))
+        if len(inflight) > ahead or (c is None and inflight):
+            c0, own0, job = inflight.pop(0)
+            flipped += check(c0, own0, job.get(timeout=1500), report=report)
+    assert not inflight
+    return flipped
+
+
+class _ReportFile(list):
+    """Report mode (HHSR_FUZZ_REPORT=file): every case's line goes to the file as soon as it is judged."""
+
+    def append(self, line):
         with open(os.environ["HHSR_FUZZ_REPORT"], "a") as f:
-            f.write("\n".join(report) + "\n")
-    else:
-        assert flipped <= FLIPPED_PER_BATCH, f"batch {gen_seed}: {flipped} flipped decisions"
+            f.write(line + "\n")
+
+
+REPORT = bool(os.environ.get("HHSR_FUZZ_REPORT"))
+
+
+@pytest.mark.timeout(1800)
+@pytest.mark.skipif(REPORT, reason="report mode: test_fuzz_report runs all batches as one sweep")
+@pytest.mark.parametrize("gen_seed,n", BATCHES)
+def test_fuzz_sweep(oracle_pool, gen_seed, n):
+    flipped = sweep(oracle_pool, cases(gen_seed, n))
+    assert flipped <= FLIPPED_PER_BATCH, f"batch {gen_seed}: {flipped} flipped decisions"
+
+
+@pytest.mark.timeout(4 * 3600)
+@pytest.mark.skipif(not REPORT, reason="HHSR_FUZZ_REPORT=<file> HHSR_FUZZ_BATCHES=... : lists every case next to its numbers")
+def test_fuzz_report(oracle_pool):
+    """tools/fuzz_final.sh: ALL batches as one sweep (no draining between batches), failures listed instead of raised."""
+    sweep(oracle_pool, [c for gs, n in BATCHES for c in cases(gs, n)], report=_ReportFile())

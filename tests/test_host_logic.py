@@ -168,7 +168,8 @@ def test_config_watch_sees_every_in_place_edit():
 
 def test_fuzz_verdict_rules():
     """The per-case rules of the randomised parity sweep (helpers.fuzz_verdict, used by tests/test_fuzz_parity.py on the GPU)
-    on hand-made arrays: what passes, and that each rule trips on the violation it exists for."""
+    on hand-made arrays: what passes, and that each rule trips on the violation it exists for.  The contract is two-sided:
+    o (HIP, own flows) is judged against want_h (oracle on HIP's flows), oi (HIP on the oracle's flows) against want."""
     from helpers import fuzz_verdict, max_inj_outliers
 
     H, W, ts, scale, n = 64, 96, 16, 2, 2
@@ -182,73 +183,88 @@ def test_fuzz_verdict_rules():
     o_r[0, 20:30, 40:50] = 0.3          # a region where frame 0 is being rejected
     den = np.full_like(want, 2.0)
 
-    def run(o=None, oi=None, gflow=None, hr=None, hr_i=None, den_o=None, rob=True):
-        o = want.copy() if o is None else o
+    def run(o=None, oi=None, want_h=None, gflow=None, hr=None, hr_i=None, o_r_h=None, den_o=None, den_h=None, rob=True):
+        wh = want.copy() if want_h is None else want_h
+        o = wh.copy() if o is None else o
         oi = want.copy() if oi is None else oi
-        return fuzz_verdict((H, W), ts, scale, o, oi, want, oflow if gflow is None else gflow, oflow,
+        return fuzz_verdict((H, W), ts, scale, o, oi, want, wh, oflow if gflow is None else gflow, oflow,
                             (o_r if hr is None else hr) if rob else None, (o_r if hr_i is None else hr_i) if rob else None,
-                            o_r if rob else None, den if den_o is None else den_o)
+                            o_r if rob else None, (o_r if o_r_h is None else o_r_h) if rob else None,
+                            den if den_o is None else den_o, den if den_h is None else den_h)
 
     v, failed = run()
-    assert not failed and v["n_inj"] == 0 and v["nflip"] == 0 and v["nan_mis"] == 0  # NaN == NaN, inf == inf
-    assert not run(rob=False)[1]
+    assert not failed and v["side_h"]["n"] == 0 and v["side_o"]["n"] == 0 and v["nflip"] == 0  # NaN == NaN, inf == inf
+    assert v["side_h"]["nan_mis"] == 0 and not run(rob=False)[1]
     # arithmetic noise below 1e-4 everywhere
     assert not run(o=want + 5e-5, oi=want - 5e-5)[1]
-    # an outlier where every frame is accepted: fails, with own and with injected flows
+    # an outlier where every frame is accepted fails on EITHER side
     bad = want.copy()
     bad[100, 20, 0] += 3e-4
-    assert run(oi=bad)[1] and run(o=bad, oi=bad)[1]
+    assert run(oi=bad)[1] and run(o=bad)[1]
     # ... inside the rejecting region (HR rows 40-60, cols 80-100): tolerated up to MAX_OUTLIER, counted
     ok = want.copy()
     ok[50, 90, 0] += 3e-3
-    v, failed = run(oi=ok)
-    assert not failed and v["n_inj"] == 1 and v["inj_outside"] == 0
+    for side, kw in (("side_o", dict(oi=ok)), ("side_h", dict(o=ok))):
+        v, failed = run(**kw)
+        assert not failed and v[side]["n"] == 1 and v[side]["outside"] == 0
     ok[50, 90, 0] += 0.1                 # too large for a normal accumulated weight ...
-    assert run(oi=ok)[1]
+    assert run(oi=ok)[1] and run(o=ok)[1]
     tiny = den.copy()
     tiny[50, 90, 0] = 1e-6               # ... but not where the accumulated weight vanishes: 0.103 x 1e-6 <= NUM_ERR
-    assert not run(oi=ok, den_o=tiny)[1]
+    assert not run(oi=ok, den_o=tiny)[1] and not run(o=ok, den_h=tiny)[1]
+    assert run(oi=ok, den_h=tiny)[1]     # (each side is judged with ITS oracle run's weights)
     many = want.copy()
     many[44:48, 84:88, :] += 2e-4        # 48 values > two raw pixels' worth at scale 2 (24)
-    assert max_inj_outliers(scale) == 24 and run(oi=many)[1]
-    # flow-sensitive values: differ with own flows, agree once the flows are the oracle's
-    v, failed = run(o=bad)
-    assert not failed and v["n_sens"] == 1 and v["n_rest"] == 0
-    wild = want.copy()
-    wild[100, 20, 0] += 0.3              # ... but not of any size (MAX_SENS)
-    assert run(o=wild)[1]
+    assert max_inj_outliers(scale) == 24 and run(oi=many)[1] and run(o=many)[1]
+    # the rejecting region of side H comes from the oracle's robustness on HIP's flows
+    r_h = np.ones_like(o_r)
+    assert not run(o_r_h=r_h, hr=r_h)[1]
+    ok2 = want.copy()
+    ok2[50, 90, 0] += 3e-3
+    assert run(o=ok2, o_r_h=r_h, hr=r_h)[1]   # nothing is being rejected under HIP's flows there: no allowance
+    # a flow-sensitive jump is fine when — and only when — the oracle reproduces it on HIP's flows (no magnitude cap)
+    jump = want.copy()
+    jump[100:110, 20:30, :] += 0.6
+    v, failed = run(o=jump, want_h=jump)
+    assert not failed and v["n_own"] == 300 and v["n_orc"] == 300 and abs(v["orc_max"] - 0.6) < 1e-6
+    assert run(o=jump)[1]                # HIP alone jumps: fails, whatever the size
+    small = want.copy()
+    small[100, 20, 0] += 3e-4
+    assert run(o=small)[1]
     # the den floor: just above it the image bound applies, just below it the numerator bound
     from helpers import DEN_FLOOR, MAX_OUTLIER, NUM_ERR, outlier_over
     assert abs(DEN_FLOOR * MAX_OUTLIER - NUM_ERR) < 1e-12
     assert outlier_over(np.array([6e-3]), np.array([1.0]))[0] and not outlier_over(np.array([4e-3]), np.array([1.0]))[0]
     assert outlier_over(np.array([0.2]), np.array([1e-5]))[0] and not outlier_over(np.array([0.05]), np.array([1e-5]))[0]
-    # flows: one flipped 2 x 2 block is one decision; its footprint is not compared
+    # flows: one flipped 2 x 2 block is one decision; what it does to the image must be in want_h too
     g = oflow.copy()
     g[1, 1:3, 2:4] += 0.08
     o2 = want.copy()
     o2[2 * ts * 1: 2 * ts * 3, 2 * ts * 2: 2 * ts * 4] += 0.05
-    v, failed = run(gflow=g, o=o2)
-    assert not failed and v["nflip"] == 4 and v["one_cluster"]
+    v, failed = run(gflow=g, o=o2, want_h=o2)
+    assert not failed and v["nflip"] == 4 and v["one_cluster"] and v["n_own"] == 0  # (inside the footprint: not counted)
+    assert run(gflow=g, o=o2)[1]         # the oracle on HIP's flows does not show it: fails
     g[0, 0, 0] += 0.08                   # a second decision in another frame
-    assert run(gflow=g, o=o2)[1]
+    assert run(gflow=g)[1]
     g = oflow.copy()
     g[1, 0:4, 0:6] += 0.08               # one cluster, but 24 tiles (MAX_FLIP_TILES = 16)
-    o3 = want.copy()
-    o3[: 2 * ts * 4, : 2 * ts * 6] += 0.05
-    assert run(gflow=g, o=o3)[1]
+    assert run(gflow=g)[1]
     g = oflow.copy()
     g[0, 2, 3] += 3e-4                   # an ill-conditioned ICA tile: counted, tolerated
     v, failed = run(gflow=g)
     assert not failed and v["n_ica"] == 1 and v["nflip"] == 0
     g[0] += 3e-4                         # ... not a whole frame of them
     assert run(gflow=g)[1]
-    # robustness beyond 1e-4 outside any deviating tile; NaN pattern; inf vs finite
+    g = oflow.copy()
+    g[0, 2, 3] += 9e-5                   # below 1e-4 px: flow agreement
+    assert not run(gflow=g)[1] and run(gflow=g)[0]["dflow"] > 8e-5
+    # robustness beyond 1e-4 ANYWHERE, on either side; NaN pattern (no footprint exemption); inf vs finite
     hr = o_r.copy()
     hr[1, 5, 5] -= 2e-4
     assert run(hr=hr)[1] and run(hr_i=hr)[1]
     nanned = want.copy()
     nanned[3, 3, 0] = np.nan
-    assert run(o=nanned)[1]
+    assert run(o=nanned)[1] and run(oi=nanned)[1] and not run(o=nanned, want_h=nanned)[1]
     finite = want.copy()
     finite[1, 1, 2] = 1.0
     assert run(oi=finite)[1]

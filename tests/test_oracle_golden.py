@@ -121,34 +121,46 @@ def test_robustness(golden):
     assert (g["r"][:3] == 0).all() and (g["r"][:, :3] == 0).all()  # D6: first 3 rows / columns
 
 
+def _merge_form(form):
+    import importlib
+
+    return importlib.import_module("oracle.merge" if form == "numpy" else "oracle.cfast")
+
+
 @pytest.mark.parametrize("tag,scale,kern,do_ref", [("s2", 2, "steerable", True), ("s15", 1.5, "steerable", True),
                                                    ("s1", 1, "steerable", True), ("s3", 3, "steerable", False),
                                                    ("s2iso", 2, "iso", True)])
-def test_merge(golden, tag, scale, kern, do_ref):
+@pytest.mark.parametrize("form", ["numpy", "c"])
+def test_merge(golden, tag, scale, kern, do_ref, form):
+    """Both forms of the accumulation — oracle/merge.py and its C restatement oracle/csrc/merge.c (oracle.cfast) —
+    against the outputs of the reference's own accumulate / accumulate_ref."""
     g = golden("merge")
+    om = _merge_form(form)
     H, W = g["comp"].shape
     cfg = base_config(ts=16, scale=scale)
     cfg.merging.kernel = kern
     oh, ow = round(scale * H), round(scale * W)
     num, den = acc_pattern(oh, ow, 0), acc_pattern(oh, ow, 5)
-    oracle.merge(g["comp"], g["flow"], g["covs"], g["r"], num, den, g["cfa"], cfg)
+    om.merge(g["comp"], g["flow"], g["covs"], g["r"], num, den, g["cfa"], cfg)
     assert_close(num, g[tag + "_num"], 2e-6, 1e-7, tag + " num")
     assert_close(den, g[tag + "_den"], 2e-6, 1e-7, tag + " den")
     if do_ref:
         num, den = acc_pattern(oh, ow, 0), acc_pattern(oh, ow, 5)
-        oracle.merge_ref(g["ref"], g["covs_ref"], num, den, g["cfa"], cfg)
+        om.merge_ref(g["ref"], g["covs_ref"], num, den, g["cfa"], cfg)
         assert_close(num, g[tag + "_numref"], 1e-5, 1e-7, tag + " numref")
         assert_close(den, g[tag + "_denref"], 1e-5, 1e-7, tag + " denref")
 
 
-def test_merge_ref_denoiser(golden):
+@pytest.mark.parametrize("form", ["numpy", "c"])
+def test_merge_ref_denoiser(golden, form):
     g = golden("merge")
+    om = _merge_form(form)
     H, W = g["ref"].shape
     cfg = base_config(ts=16, scale=2)
     cfg.accumulated_robustness_denoiser.enabled = True
     cfg.accumulated_robustness_denoiser.merge.enabled = True
     num, den = acc_pattern(2 * H, 2 * W, 0), acc_pattern(2 * H, 2 * W, 5)
-    oracle.merge_ref(g["ref"], g["covs_ref"], num, den, g["cfa"], cfg, g["acc_rob"].astype(np.float64))
+    om.merge_ref(g["ref"], g["covs_ref"], num, den, g["cfa"], cfg, g["acc_rob"].astype(np.float64))
     assert_close(num, g["den_numref"], 1e-5, 1e-7, "denoiser numref")
     assert_close(den, g["den_denref"], 1e-5, 1e-7, "denoiser denref")
 
@@ -203,8 +215,9 @@ def test_e2e_x1_denoiser(golden):
     assert_close(out, g["out"], 0, 5e-5, "output")
 
 
+@pytest.mark.parametrize("fast", [False, True])
 @pytest.mark.parametrize("tag", ["s15", "s3", "s2iso", "ts32"])
-def test_e2e_scales(golden, tag):
+def test_e2e_scales(golden, tag, fast):
     """main() as the reference itself computed it at x1.5 (GRBG, white balance), x3 (4 frames) and x2 with isotropic
     kernels (GBRG, white balance): tools/refsim stage e2e_scales."""
     from helpers import e2e_scales_case
@@ -213,7 +226,7 @@ def test_e2e_scales(golden, tag):
     ref, comp, shifts, cfg_fn = e2e_scales_case(tag)
     np.testing.assert_array_equal(shifts, g[f"{tag}_shifts"])
     cap = {}
-    out, dbg = oracle.main(ref, comp, cfg_fn(), capture=cap)
+    out, dbg = oracle.main(ref, comp, cfg_fn(), capture=cap, fast=fast)
     assert_close(np.stack(cap["flow"]), g[f"{tag}_flow"], 0, 5e-5, "flow")
     assert_close(np.stack(cap["r"]), g[f"{tag}_r"], 0, 5e-5, "r")
     assert_close(dbg["accumulated robustness"], g[f"{tag}_acc_r"], 0, 5e-5, "acc r")

@@ -95,3 +95,80 @@ def test_parallel_oracle_is_bit_identical_to_sequential():
     assert len(cap["flow"]) == 3 and all(f is not None for f in cap["flow"])
     got1, _, used1 = oracle.main_parallel(ref, comp, cfg0(), workers=1)
     assert used1 == 1 and np.array_equal(got1, want, equal_nan=True)
+
+
+def _ulp_report(a, b):
+    """(fraction bit-identical incl. NaN == NaN, largest difference in float32 ulps of the larger operand)."""
+    same = (a == b) | (np.isnan(a) & np.isnan(b))
+    with np.errstate(all="ignore"):
+        ulp = np.where(same, 0.0, np.abs(a.astype(np.float64) - b) / np.spacing(np.maximum(np.abs(a), np.abs(b)).astype(np.float32)))
+    return float(same.mean()), float(np.nanmax(ulp)) if ulp.size else 0.0
+
+
+def test_c_merge_equals_numpy_merge():
+    """oracle.cfast (oracle/csrc/merge.c: the accumulation compiled with gcc, what the sweeps and full-size comparisons
+    run) against oracle/merge.py (the form pinned by the reference's own outputs): num, den of Alg. 4 and Alg. 11 on every
+    scale family, iso kernels, grey mode, the accumulated-robustness rules (widened + overwriting reference splat), NaN
+    covariances (flat regions, D10), negative covariance fractions at the border (D11) and flows that push windows and
+    whole tiles over the image border.  Bit-identical, or one float32 ulp where libm's exp and NumPy's differ."""
+    from oracle import cfast
+    import importlib
+
+    npm = importlib.import_module("oracle.merge")
+    rng = np.random.default_rng(7)
+    worst = 0.0
+    for (H, W, scale, kernel, mode, den) in ((64, 80, 2, "steerable", "bayer", False), (64, 80, 1.5, "steerable", "bayer", True),
+                                              (48, 64, 3, "steerable", "bayer", False), (64, 64, 1, "iso", "bayer", True),
+                                              (48, 48, 2, "steerable", "grey", False), (48, 64, 2, "iso", "grey", False)):
+        cfg = base_config(ts=16, scale=scale)
+        cfg.merging.kernel = kernel
+        cfg.mode = mode
+        cfg.exif.cfa_pattern = [[1, 2], [0, 1]]
+        if den:
+            cfg.accumulated_robustness_denoiser.enabled = True
+        comp = rng.uniform(0, 1, (H, W)).astype(np.float32)
+        flow = rng.uniform(-3, 3, (H // 16, W // 16, 2)).astype(np.float32)
+        flow[0, 0] = (-20.5, 7.25)  # a tile pushed over the left border
+        flow[-1, -1] = (30.0, 30.0)  # ... and out of the frame
+        ch, cw = (H // 2, W // 2) if mode == "bayer" else (H, W)
+        a = rng.uniform(0.3, 2.0, (ch, cw)).astype(np.float32)
+        b = rng.uniform(-0.25, 0.25, (ch, cw)).astype(np.float32)
+        covs = np.stack([np.stack([a, b], -1), np.stack([b, a * 0.7], -1)], -2).astype(np.float32)
+        covs[3:6, 4:9] = np.nan  # D10
+        covs[10, 10] = 0         # singular
+        r = rng.uniform(0, 1, (H, W)).astype(np.float32)
+        r[:3] = 0
+        osz = (round(scale * H), round(scale * W))
+        base = rng.uniform(0, 2, (*osz, 3)).astype(np.float32)
+        acc_rob = rng.uniform(0, 12, (H, W)) if den else None
+        outs = []
+        for m in (npm, cfast):
+            num, dn = base.copy(), base.copy() * 0.5
+            m.merge(comp, flow, covs, r, num, dn, np.array(cfg.exif.cfa_pattern), cfg)
+            mid = (num.copy(), dn.copy())
+            m.merge_ref(comp[::-1].copy(), covs, num, dn, np.array(cfg.exif.cfa_pattern), cfg, acc_rob)
+            outs.append(mid + (num, dn))
+        for x, y in zip(*outs):
+            frac, ulps = _ulp_report(x, y)
+            worst = max(worst, ulps)
+            assert frac > 0.9999 and ulps <= 1.0, (H, W, scale, kernel, mode, den, frac, ulps)
+    # the whole pipeline through it (and main_parallel), incl. flows= / reuse= (the two-sided flow injection)
+    ref, comp, _ = synth.make_burst(128, 160, 3, seed=11, max_shift=2.0, occluder=True)
+    def cfg0():
+        c = base_config(ts=16, scale=2)
+        c.block_matching.tuning.factors = [1, 2, 2, 2]
+        c.robustness.save_mask = True
+        return c
+    cap = {}
+    want, _ = oracle.main(ref, comp, cfg0(), capture=cap)
+    got, _ = oracle.main(ref, comp, cfg0(), fast=True)
+    frac, ulps = _ulp_report(got, want)
+    assert frac > 0.9999 and ulps <= 2.0, (frac, ulps)
+    cap2 = {}
+    again, _ = oracle.main(ref, comp, cfg0(), fast=True, flows=cap["flow"], reuse=cap, capture=cap2)
+    assert np.array_equal(again, got, equal_nan=True) and np.array_equal(cap2["r"][1], cap["r"][1])
+    par, _, _ = oracle.main_parallel(ref, comp, cfg0(), workers=2, fast=True, flows=cap["flow"])
+    assert np.array_equal(par, got, equal_nan=True)
+    shifted = [f + np.float32(0.25) for f in cap["flow"]]
+    other, _ = oracle.main(ref, comp, cfg0(), fast=True, flows=shifted, reuse=cap)
+    assert not np.array_equal(other, got, equal_nan=True)

@@ -10,7 +10,11 @@ import handheld_super_resolution as hsr
 gs, k = int(sys.argv[1]), int(sys.argv[2])
 c = fz.cases(gs, k + 1)[k]
 print("case", c)
-ref, comp, want, oflow, o_r, den_o = fz._oracle_case(c)
+ref, comp, o_own, gflow, hr_own = fz.hip_own(c)
+want, want_h, oflow, o_r, o_r_h, den_o, den_h = fz._oracle_case(c, gflow)
+dh = np.where(np.isnan(want_h), 0.0, np.abs(o_own.astype(np.float64) - want_h))
+print(f"side H (HIP's flows): max |o - want_h| = {dh.max():.3e} ({int((dh > 1e-4).sum())} > 1e-4); oracle's own move under HIP's "
+      f"flows max |want_h - want| = {np.nanmax(np.abs(want_h.astype(np.float64) - want)):.3e}; max |flow diff| = {np.abs(gflow - oflow).max():.3e} px")
 cfg = fz.config(c, inject_flows=[f for f in oflow])
 cfg.debug = True
 out, dbg = hsr.main(ref, comp, cfg)

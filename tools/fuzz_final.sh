@@ -1,18 +1,25 @@
 #!/bin/bash
-# The FROZEN fuzz contract (tests/helpers.py: fuzz_verdict + constants) on every set in ONE run of ONE commit:
-# the 64 fixed cases, round 3's eleven held-out sets (generator seeds 10.. 110) and two seeds nobody had run (200, 300).
-#   tools/fuzz_final.sh <commit-hash> [out-file]        (on an MI355X; ~2 min per set of 64: the oracle runs on the host)
+# The two-sided fuzz contract (tests/helpers.py: fuzz_verdict + constants; tests/test_fuzz_parity.py) on every set in ONE run
+# of ONE commit, as ONE sweep: the 64 fixed cases, every set earlier rounds ran (generator seeds 10 .. 110, 200, 300, and the
+# 14 "unseen" seeds of round 4) and the seeds given on the command line (never run before).
+#   tools/fuzz_final.sh <commit-hash> <out-file> [new seed ...]        (on an MI355X; the oracle pairs run on the host cores)
 COMMIT=${1:-unknown}
-OUT=${2:-$PWD/gpurun_out/r04_fuzz_final.txt}
+OUT=${2:-$PWD/gpurun_out/r05_fuzz_final.txt}
+shift 2
+NEW="$*"
+OLD="10 20 30 40 50 60 70 80 90 100 110 200 300 400 500 600 700 800 900 1000 1100 1200 1300 1400 1500 1600 1700"
+[ -n "$HHSR_FUZZ_OLD" ] && OLD="$HHSR_FUZZ_OLD"      # (a subset, for a trial run)
 mkdir -p "$(dirname "$OUT")"
 RULES=$(cat tests/helpers.py tests/test_fuzz_parity.py | sha256sum | cut -c1-16)
 B="0:22,1:22,2:20"
-for g in 10 20 30 40 50 60 70 80 90 100 110 200 300; do B="$B,$g:22,$((g+1)):22,$((g+2)):20"; done
+for g in $OLD $NEW; do B="$B,$g:22,$((g+1)):22,$((g+2)):20"; done
 {
-  echo "# fuzz contract, final run: commit $COMMIT, rules sha256[:16] (tests/helpers.py + tests/test_fuzz_parity.py) $RULES"
-  echo "# sets: fixed 0-2 | held-out (round 3) 10 20 30 40 50 60 70 80 90 100 110 | NEW, never run before: 200 300"
-  echo "# constants: $(grep -E '^(FLIP_PX|MAX_ICA_TILES|CLUSTER|MAX_OUTLIERS|MAX_OUTLIER|DEN_FLOOR|NUM_ERR|MAX_SENS|MAX_FLIP_TILES) =' tests/helpers.py | sed 's/ *#.*//' | tr '\n' ';')"
+  echo "# two-sided fuzz contract: commit $COMMIT, rules sha256[:16] (tests/helpers.py + tests/test_fuzz_parity.py) $RULES"
+  echo "# sets: fixed 0-2 | run in earlier rounds: $OLD | NEW, never run before: ${NEW:-none}"
+  echo "# constants: $(grep -E '^(FLIP_PX|MAX_ICA_TILES|CLUSTER|MAX_OUTLIER|DEN_FLOOR|NUM_ERR|MAX_FLIP_TILES) =' tests/helpers.py | sed 's/ *#.*//' | tr '\n' ';')"
+  echo "# per case: alignment (flows) | side H: HIP own flows vs ORACLE ON HIP'S FLOWS | side O: HIP on oracle's flows vs oracle | informational"
 } > "$OUT"
-HHSR_FUZZ_BATCHES="$B" HHSR_FUZZ_REPORT="$OUT" python -m pytest tests/test_fuzz_parity.py -m gpu -q -p no:cacheprovider 2>&1 | tail -2
-echo "# cases: $(grep -c '^case' "$OUT"), cases violating an assertion: $(grep -c 'ASSERTIONS FAILED' "$OUT")" >> "$OUT"
+T0=$(date +%s)
+HHSR_FUZZ_BATCHES="$B" HHSR_FUZZ_REPORT="$OUT" python -m pytest tests/test_fuzz_parity.py -m gpu -q -p no:cacheprovider 2>&1 | tail -3
+echo "# cases: $(grep -c '^case' "$OUT"), cases violating an assertion: $(grep -c 'ASSERTIONS FAILED' "$OUT"), wall $(( $(date +%s) - T0 )) s" >> "$OUT"
 tail -1 "$OUT"
