@@ -48,6 +48,7 @@ for p in (ROOT, PKG_ROOT):
 VALU_PEAK_TLANEOPS = 78.6  # 256 CUs x 4 SIMD-32 x 2.4 GHz: one wave64 VALU instruction per 2 cycles (MI355X_MICROARCH.md)
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: 8.0 TB/s spec (6.3 TB/s achievable)
 MERGE_SRC = os.path.join(PKG_ROOT, "csrc", "hhsr_merge.hip")
+LEG_TIMEOUT_S = 300        # N > 1: an optional leg whose collectives hang must not lose the line (watchdog)
 
 
 def merge_burst_bytes(n_comp, P, S):
@@ -287,6 +288,100 @@ def main():
             ev.clear()
         timed_call.on = False
 
+    # ---- N > 1: BOTH strategies in one record (the driver passes --gpus N only: the north star's `reduce` curve would not
+    # exist otherwise), the per-rank compute without collectives measured live, and the committed single-GPU emulation of
+    # this rank count next to it — so a SCALE value can be checked against (compute per rank) + (RCCL time).  Optional leg:
+    # guarded on every rank, and a watchdog prints the line and ends the process if a collective of this leg hangs.
+    strategies, emulated = None, None
+    if world > 1:
+        import threading
+
+        def give_up():
+            errors["strategies_leg"] = f"watchdog: not finished after {LEG_TIMEOUT_S} s (a rank failed inside a collective?)"
+            line["strategies"], line["emulated_rank_ms"] = strategies, emulated
+            emit()
+            sys.stdout.flush()
+            os._exit(0)
+
+        watchdog = threading.Timer(LEG_TIMEOUT_S, give_up)
+        watchdog.daemon = True
+        watchdog.start()
+        sH_, sW_ = round(scale * H), round(scale * W)
+        ny_, nx_ = -(-H // int(cfg.block_matching.tuning.tile_size)), -(-W // int(cfg.block_matching.tuning.tile_size))
+
+        def rccl_bytes(strategy):
+            """Payload this rank hands to its collective(s) per burst (what crosses xGMI is (G - 1) / G of it per rank)."""
+            if strategy == "rows":  # all-gather of the flow fields: every rank contributes its rounds' slots
+                rounds = -(-(NF - 1) // world)
+                return {"all_gather_in_bytes": rounds * ny_ * nx_ * 2 * 4, "all_gather_out_bytes": world * rounds * ny_ * nx_ * 2 * 4}
+            rows_ = hdist.slab_rows(sH_, world)  # reduce-scatter of the packed accumulators [world, 2, rows, sW, 3]
+            return {"reduce_scatter_in_bytes": world * 2 * rows_ * sW_ * 3 * 4, "reduce_scatter_out_bytes": 2 * rows_ * sW_ * 3 * 4}
+
+        def max_over_ranks(v):
+            t = torch.tensor([float(v)], dtype=torch.float64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            return float(t.item())
+
+        def compute_only_ms(eng, strategy):
+            """max over ranks of the rank's step with its collectives left out (HipEngine with graphs only)."""
+            fn = None
+            if on_gpu and strategy == "rows" and getattr(eng, "_plans", None):
+                plan = next(iter(eng._plans.values()))
+                fn = plan.replay_compute_only
+            elif on_gpu and strategy == "reduce":
+                rows_ = hdist.slab_rows(sH_, world)
+                bounds_ = hdist.slab_bounds(sH_, world)
+                mine = [comp[i] for i in hdist.shard_indices(NF - 1, rank, world)]
+                red = torch.zeros((2, rows_, sW_, 3), dtype=torch.float32, device=dev)
+
+                def fn():
+                    acc, _, ref_dev, ref_covs = eng.partial(ref, mine, bounds_, rows_)
+                    red.copy_(acc[rank])  # stand-in for the reduce-scatter
+                    return eng.finish_rows(red, bounds_[rank], bounds_[rank + 1], ref_dev, ref_covs) if bounds_[rank + 1] > bounds_[rank] else None
+            ok = torch.tensor([1 if fn is not None else 0], dtype=torch.int32, device=dev)
+            dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+            if not int(ok.item()):
+                return None
+            for _ in range(3):
+                fn()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(args.steps):
+                fn()
+            torch.cuda.synchronize()
+            return max_over_ranks((time.perf_counter() - t0) / args.steps * 1e3)
+
+        try:
+            strategies = {args.strategy: {"ms_per_step": round(ms_per_step, 3), "value": round(value, 2), "headline": True,
+                                          "rccl_bytes_per_rank": rccl_bytes(args.strategy)}}
+            if on_gpu:
+                strategies[args.strategy]["compute_only_max_rank_ms"] = compute_only_ms(engine, args.strategy)
+            other = "reduce" if args.strategy == "rows" else "rows"
+            eng_o = engine_cls(cfg)
+            fn_o = lambda: hdist.main_sharded(ref, comp, cfg, engine=eng_o, gather=args.gather, strategy=other,  # noqa: E731
+                                              max_flow=args.max_flow)[0]
+            ms_o = timed(fn_o, args.steps, max(3, min(args.warmup, 5)) if on_gpu else min(args.warmup, 1))
+            strategies[other] = {"ms_per_step": round(ms_o, 3), "value": round(out_pix / (ms_o * 1e-3) / 1e6, 2), "headline": False,
+                                 "rccl_bytes_per_rank": rccl_bytes(other)}
+            if on_gpu:
+                strategies[other]["compute_only_max_rank_ms"] = compute_only_ms(eng_o, other)
+            del eng_o
+            # the committed single-GPU emulation of this rank count (tools/debug/emulate_ranks.py: every rank's graphs replayed
+            # alone on ONE MI355X, collectives left out) for the same workload, if there is one
+            emulated = {}
+            for fname in sorted(os.listdir(os.path.join(ROOT, "profiles")), reverse=True):
+                if "emulate_ranks" in fname and fname.endswith(".jsonl") and "staged" not in fname:
+                    for ln in open(os.path.join(ROOT, "profiles", fname)):
+                        rec = json.loads(ln)
+                        if rec.get("workload") == f"{H}x{W}x{NF} x{scale}" and rec.get("world") == world and \
+                                rec["strategy"] not in emulated:
+                            emulated[rec["strategy"]] = {"max_rank_ms": rec["max_rank_ms"], "mean_rank_ms": rec["mean_rank_ms"],
+                                                         "source": f"profiles/{fname}"}
+            emulated = emulated or None
+        except Exception as e:  # noqa: BLE001
+            errors["strategies_leg"] = f"{type(e).__name__}: {e}"
+        watchdog.cancel()
+
     # ---- descriptive fields + the whole-step roofline (nothing below this block can lose the measurement) -----------
     sb = step_bytes(NF - 1, P, S) / world  # per rank: every rank's kernels cover 1 / world of the burst's work
     line.update({
@@ -314,6 +409,8 @@ def main():
                    if graphed else "one launch per kernel from Python"),
         "ms_per_step_eager": round(ms_eager, 3) if ms_eager else None,
         "rccl_ranks": dist.get_world_size() if world > 1 else 1,
+        "ranks_agree": (dist.get_world_size() == world == args.gpus) if world > 1 else True,  # launcher, --gpus and the group
+        "strategies": strategies, "emulated_rank_ms": emulated,
         "backend": (args.backend if world > 1 else None),
         "engine": "HipEngine (libhhsr_hip.so)" if on_gpu else f"{args.engine} (launch-plumbing test, not a measurement)",
         "step_roofline": {"algorithmic_bytes": sb, "achieved": round(sb / (ms_per_step * 1e-3) / 1e9, 1),

@@ -266,7 +266,13 @@ class HipEngine:
 
         packed = torch.is_tensor(comp_imgs)
         tensors = (ref_img, comp_imgs) if packed else (ref_img, *comp_imgs)
-        # (every condition is the same on every rank — the ranks must agree on eager / plan: see the consensus below)
+        # The ranks must agree on eager / capture / replay — they run different collectives (an eager rank all-gathers, a
+        # capturing rank first all-reduces the consensus flag, a plan whose bound is exceeded re-runs eagerly).  Every
+        # condition below is therefore one that an SPMD caller produces identically on every rank: properties of the
+        # tensors, and whether the caller handed over THE SAME TENSORS (storages) as on an earlier call — NOT whether two
+        # calls' tensors merely share addresses: the caching allocator may give a fresh burst an old address on one rank
+        # and not on another (slab sizes differ per rank).  The address key is only trusted while the tensors it was
+        # made from are alive: a plan keeps them alive itself (RowsPlan.keep); a first sighting keeps weak references.
         ok = capturable(self.config, tensors) and all(t.dtype == torch.float32 and t.is_contiguous() for t in tensors) \
             and len(comp_imgs) > 0 and every_rank_has_rows
         if not ok:
@@ -276,17 +282,22 @@ class HipEngine:
         plan = self._plans.get(key)
         if plan is not None:
             return plan.open()
-        if key not in self._plan_seen:  # first burst of this input set: eager; remembers the bound it measured
+        seen = self._plan_seen.get(key)
+        if seen is not None and not all(w() is not None for w in seen["refs"]):
+            seen = None  # the burst this entry was made for is gone; another one got its addresses: a first sighting
+            self._plan_seen.pop(key)
+            self._bounds.pop(key, None)
+        if seen is None:  # first burst of this input set: eager; remembers the bound it measured
             while len(self._plan_seen) >= 64:  # (a caller that hands over fresh tensors every burst never replays: bounded)
                 old = next(iter(self._plan_seen))
                 self._plan_seen.pop(old)
                 self._bounds.pop(old, None)
-            self._plan_seen[key] = True
+            self._mark_seen(key, tensors)
             return EagerRows(self, ref_img, comp_imgs, stages, rank, world, rows, max_flow, remember=key)
         bound = float(max_flow) if max_flow is not None else self._bounds.get(key)
         if bound is None:  # (cannot happen: the eager call stored it)
             return EagerRows(self, ref_img, comp_imgs, stages, rank, world, rows, max_flow, remember=key)
-        if self._plan_seen.get(key) == "failed":
+        if seen["state"] == "failed":
             return EagerRows(self, ref_img, comp_imgs, stages, rank, world, rows, max_flow)
         plan = None
         try:
@@ -304,12 +315,21 @@ class HipEngine:
             if int(ok_t.item()) == 0:
                 plan = None
         if plan is None:
-            self._plan_seen[key] = "failed"
+            seen["state"] = "failed"
             return EagerRows(self, ref_img, comp_imgs, stages, rank, world, rows, max_flow)
         while len(self._plans) >= 2:  # (a plan holds a burst's intermediates of this rank)
             self._plans.pop(next(iter(self._plans)))
         self._plans[key] = plan
         return plan.open()
+
+    def _mark_seen(self, key, tensors):
+        """First sighting of an input set (or a fresh start after its plan was dropped): weak references to the tensors'
+        storages-owning objects — a later call with the same address key counts as "the same inputs again" only while
+        they are alive (see rows_open)."""
+        import weakref
+
+        self._plan_seen[key] = {"refs": tuple(weakref.ref(t._base if t._base is not None else t) for t in tensors),
+                                "state": "seen"}
 
     def _merge_rows(self, comp_imgs, flows, r0, r1, max_flow_y, ref_dev):
         flows = flows.contiguous()
@@ -645,6 +665,18 @@ class RowsPlan:
         with torch.cuda.stream(self.s_b):
             self.g_b[s].replay()
 
+    def replay_compute_only(self):
+        """This rank's whole step WITHOUT its collectives: every graph of the plan in order, the gather buffers still
+        holding the flows of the last real burst — per-rank compute of the G-rank job (what tools/debug/emulate_ranks.py
+        measures on one GPU, here on the rank's own GPU; bench.py reports max over ranks next to the real step time)."""
+        ctx = self.open()
+        for s in range(len(self.stages)):
+            ctx.align(s)
+            with torch.cuda.stream(self.s_b):
+                self.s_b.wait_stream(self.s_a)  # (the all-gather's dependency: step B of a stage follows its step A)
+            ctx.front(s, None)
+        return ctx.finish()
+
     def finish(self):
         with torch.cuda.stream(self.s_b):
             if self.check:
@@ -856,7 +888,8 @@ def main_sharded(ref_img, comp_imgs, config, group=None, engine=None, gather=Tru
             # flows, so every rank gets here): recompute eagerly with the measured bound; the next capture takes it over
             key = ctx.key
             eng._plans.pop(key, None)
-            eng._plan_seen[key] = True
+            packed = torch.is_tensor(comp_imgs)
+            eng._mark_seen(key, (ref_img, comp_imgs) if packed else (ref_img, *comp_imgs))
             ctx = EagerRows(eng, ref_img, comp_imgs, stages, rank, world, (r0, r1), None, remember=key)
             slab, acc_r, extra, _ = run(ctx)
             extra = dict(extra, flow_bound_recomputed=True)

@@ -227,6 +227,44 @@ def side_failures(tag, s, scale):
     return failed
 
 
+def alignment_part(gflow, oflow):
+    """The flow fields of the two alignments against each other: (numbers, mask of every tile whose flow deviates)."""
+    gflow = np.asarray(gflow)
+    big = flipped_tiles(gflow, oflow, FLIP_PX)
+    flipped = flipped_tiles(gflow, oflow, 1e-4)  # every tile whose flow deviates
+    nflip, n_ica = int(big.sum()), int((flipped & ~big).sum())
+    one_cluster = True
+    if nflip:
+        fn, fy, fx = np.nonzero(big)
+        one_cluster = len(set(fn.tolist())) == 1 and np.ptp(fy) < CLUSTER and np.ptp(fx) < CLUSTER
+    dflow = float(np.abs(gflow - oflow).max(-1)[~flipped].max()) if (~flipped).any() else 0.0
+    return dict(nflip=nflip, one_cluster=one_cluster, n_ica=n_ica, dflow=dflow), flipped
+
+
+def informational_part(shape, ts, scale, flipped, o, want, want_h):
+    """Reported, not asserted: own flows against own flows outside the footprint of deviating tiles, and how far the
+    ORACLE's own image moves there when it is given HIP's flows."""
+    out_fp = ~footprint(flipped, ts, shape, scale, ts + 3)[..., None]
+    with np.errstate(all="ignore"):
+        d_own = np.where(np.isnan(want) | (o == want) | ~out_fp, 0.0, np.abs(o.astype(np.float64) - want))
+        d_orc = np.where(np.isnan(want) | (want_h == want) | ~out_fp, 0.0, np.abs(want_h.astype(np.float64) - want))
+    d_own, d_orc = np.nan_to_num(d_own, nan=np.inf), np.nan_to_num(d_orc, nan=np.inf)
+    return dict(n_own=int((d_own > 1e-4).sum()), own_max=float(d_own.max()), n_orc=int((d_orc > 1e-4).sum()),
+                orc_max=float(d_orc.max()))
+
+
+def combine_verdict(scale, al, sh, so, info):
+    """(numbers, failed rules) from the parts: alignment, side H (HIP's flows), side O (the oracle's flows)."""
+    failed = []  # the assertions of the case (report mode lists them next to the numbers instead of stopping)
+    if not (al["one_cluster"] and al["nflip"] <= MAX_FLIP_TILES and al["n_ica"] <= MAX_ICA_TILES):
+        failed.append(f"{al['nflip']} flipped tiles (one cluster: {al['one_cluster']}), {al['n_ica']} tiles between 1e-4 and "
+                      f"{FLIP_PX:g} px")
+    if not al["dflow"] <= 1e-4:
+        failed.append(f"flow {al['dflow']:.2e} px")
+    failed += side_failures("HIP's flows", sh, scale) + side_failures("oracle's flows", so, scale)
+    return dict(al, side_h=sh, side_o=so, **info), failed
+
+
 def fuzz_verdict(shape, ts, scale, o, oi, want, want_h, gflow, oflow, hr, hr_i, o_r, o_r_h, den_o, den_h):
     """One case of the fuzz sweep, judged.  HIP outputs with its own flows `o` / with the oracle's flows injected `oi`;
     oracle outputs with its own flows `want` / with HIP's flows injected `want_h`; flows [n, ny, nx, 2]; robustness maps
@@ -237,31 +275,8 @@ def fuzz_verdict(shape, ts, scale, o, oi, want, want_h, gflow, oflow, hr, hr_i, 
       side H      o  vs want_h, hr   vs o_r_h     (everything downstream of the alignment on HIP's flows)
       side O      oi vs want,   hr_i vs o_r       (the same on the oracle's flows)
     and, reported but NOT asserted (it is implied by the three): o vs want, next to |want_h - want| — how far the ORACLE's
-    own image moves under the flow difference."""
-    H, W = shape
-    gflow = np.asarray(gflow)
-    big = flipped_tiles(gflow, oflow, FLIP_PX)
-    flipped = flipped_tiles(gflow, oflow, 1e-4)  # every tile whose flow deviates
-    nflip, n_ica = int(big.sum()), int((flipped & ~big).sum())
-    one_cluster = True
-    if nflip:
-        fn, fy, fx = np.nonzero(big)
-        one_cluster = len(set(fn.tolist())) == 1 and np.ptp(fy) < CLUSTER and np.ptp(fx) < CLUSTER
-    dflow = float(np.abs(gflow - oflow).max(-1)[~flipped].max()) if (~flipped).any() else 0.0
+    own image moves under the flow difference.  (The sweep evaluates the parts in its worker processes: same functions.)"""
+    al, flipped = alignment_part(gflow, oflow)
     sh = same_flow_side(shape, scale, o, want_h, hr, o_r_h, den_h)
     so = same_flow_side(shape, scale, oi, want, hr_i, o_r, den_o)
-    failed = []  # the assertions of the case (report mode lists them next to the numbers instead of stopping)
-    if not (one_cluster and nflip <= MAX_FLIP_TILES and n_ica <= MAX_ICA_TILES):
-        failed.append(f"{nflip} flipped tiles (one cluster: {one_cluster}), {n_ica} tiles between 1e-4 and {FLIP_PX:g} px")
-    if not dflow <= 1e-4:
-        failed.append(f"flow {dflow:.2e} px")
-    failed += side_failures("HIP's flows", sh, scale) + side_failures("oracle's flows", so, scale)
-    # informational: own flows against own flows outside the footprint of deviating tiles, and the oracle's own sensitivity
-    out_fp = ~footprint(flipped, ts, (H, W), scale, ts + 3)[..., None]
-    with np.errstate(all="ignore"):
-        d_own = np.where(np.isnan(want) | (o == want) | ~out_fp, 0.0, np.abs(o.astype(np.float64) - want))
-        d_orc = np.where(np.isnan(want) | (want_h == want) | ~out_fp, 0.0, np.abs(want_h.astype(np.float64) - want))
-    d_own, d_orc = np.nan_to_num(d_own, nan=np.inf), np.nan_to_num(d_orc, nan=np.inf)
-    v = dict(nflip=nflip, one_cluster=one_cluster, n_ica=n_ica, dflow=dflow, side_h=sh, side_o=so,
-             n_own=int((d_own > 1e-4).sum()), own_max=float(d_own.max()), n_orc=int((d_orc > 1e-4).sum()), orc_max=float(d_orc.max()))
-    return v, failed
+    return combine_verdict(scale, al, sh, so, informational_part(shape, ts, scale, flipped, o, want, want_h))

@@ -54,7 +54,7 @@ import pytest
 import torch
 
 import oracle
-from helpers import base_config, fuzz_verdict
+from helpers import base_config, alignment_part, same_flow_side, informational_part, combine_verdict
 from handheld_super_resolution import synthetic as synth
 import handheld_super_resolution as hsr
 
@@ -111,8 +111,15 @@ def burst(c):
                             cfa=c["cfa"], wb=c["wb"])[:2]
 
 
-def _oracle_case(c, gflow):
-    """Both oracle runs of a case: own flows (alignment included), then robustness + merge on HIP's flows `gflow`."""
+SHM = "/dev/shm" if os.path.isdir("/dev/shm") else None
+
+
+def _stage1(c, gflow, o, hr):
+    """Worker: both oracle runs of a case — own flows (alignment included), then robustness + kernels + merge on HIP's
+    flows `gflow` — and everything of the verdict that does not need HIP's injected run: the alignment numbers, side H
+    (o vs want_h), the informational numbers.  The own-flow results the second stage needs are parked in shared memory."""
+    import tempfile
+
     os.environ["OMP_NUM_THREADS"] = "1"
     torch.set_num_threads(1)
     ref, comp = burst(c)
@@ -120,8 +127,23 @@ def _oracle_case(c, gflow):
     want, _ = oracle.main(ref, comp, config(c), capture=cap, fast=True)
     want_h, _ = oracle.main(ref, comp, config(c), capture=cap_h, fast=True, flows=list(gflow), reuse=cap)
     rob = c["rob"]
-    return (want, want_h, np.stack(cap["flow"]), np.stack(cap["r"]) if rob else None, np.stack(cap_h["r"]) if rob else None,
-            cap["den"], cap_h["den"])
+    oflow = np.stack(cap["flow"])
+    shape = (c["H"], c["W"])
+    al, flipped = alignment_part(gflow, oflow)
+    sh = same_flow_side(shape, c["scale"], o, want_h, hr, np.stack(cap_h["r"]) if rob else None, cap_h["den"])
+    info = informational_part(shape, c["ts"], c["scale"], flipped, o, want, want_h)
+    fd, path = tempfile.mkstemp(suffix=".npz", prefix="hhsr_fuzz_", dir=SHM)
+    os.close(fd)
+    np.savez(path, want=want, den=cap["den"], **({"r": np.stack(cap["r"])} if rob else {}))
+    return oflow, al, sh, info, path
+
+
+def _stage2(c, path, oi, hr_i):
+    """Worker: side O — HIP on the oracle's flows against the oracle's own run (parked by stage 1)."""
+    with np.load(path) as z:
+        want, den, o_r = z["want"], z["den"], (z["r"] if c["rob"] else None)
+    os.unlink(path)
+    return same_flow_side((c["H"], c["W"]), c["scale"], oi, want, hr_i, o_r, den)
 
 
 def hip_own(c):
@@ -133,18 +155,18 @@ def hip_own(c):
     return ref, comp, out.cpu().numpy(), np.stack(dbg["flow"]), (np.stack(dbg["robustness"]) if c["rob"] else None)
 
 
-def check(c, own, orc, report=None):
-    """Returns the number of flipped block-matching decisions (clusters of tiles) of the case: 0 or 1."""
-    ref, comp, o, gflow, hr = own
-    want, want_h, oflow, o_r, o_r_h, den_o, den_h = orc
+def hip_injected(c, ref, comp, oflow):
     cfg_i = config(c, inject_flows=[f for f in oflow])
     cfg_i.debug = True
     out_i, dbg_i = hsr.main(ref, comp, cfg_i)
-    oi = out_i.cpu().numpy()
+    return out_i.cpu().numpy(), (np.stack(dbg_i["robustness"]) if c["rob"] else None)
+
+
+def judge(c, al, sh, so, info, report=None):
+    """Returns the number of flipped block-matching decisions (clusters of tiles) of the case: 0 or 1."""
     H, W, ts, scale = c["H"], c["W"], c["ts"], c["scale"]
     tag = f"case {c['id']} ({H}x{W} x{c['nf']} s={scale} ts={ts} {c['metric0']} rob={c['rob']} den={c['den']} occ={c['occ']})"
-    v, failed = fuzz_verdict((H, W), ts, scale, o, oi, want, want_h, gflow, oflow, hr,
-                             np.stack(dbg_i["robustness"]) if c["rob"] else None, o_r, o_r_h, den_o, den_h)
+    v, failed = combine_verdict(scale, al, sh, so, info)
     if report is not None:
         side = lambda s: (f"nan {s['nan_mis']}, r {s['dr']:.1e}, image max {s['max']:.2e} ({s['n']} > 1e-4, {s['outside']} outside "
                           f"rejecting regions, {s['over']} over the bound, x den max {s['q']:.2e})")
@@ -159,9 +181,9 @@ def check(c, own, orc, report=None):
 
 @pytest.fixture(scope="module")
 def oracle_pool():
-    """A fork pool for the oracle runs (NumPy / C children: they never touch the GPU).  Every core the container may use
-    (cgroup quota: 16 of the GPU boxes' 256 logical CPUs) minus two for this process: with one worker per case the workers
-    starved the checking thread."""
+    """A fork pool for the oracle runs and the comparisons (NumPy / C children: they never touch the GPU).  Every core the
+    container may use (cgroup quota: 16 of the GPU boxes' 256 logical CPUs) minus two for this process, which only
+    generates the bursts and drives the GPU."""
     from oracle import cfast
 
     cfast.load()  # built once, before the fork
@@ -172,18 +194,31 @@ def oracle_pool():
 
 
 def sweep(pool, cs, report=None, ahead=None):
-    """HIP runs case i + `ahead` (its flows are what the oracle's second run needs) while the pool computes the oracle
-    pairs of the cases before it; returns the number of flipped decisions."""
+    """Three overlapping steps per case: HIP with its own flows (this process) -> stage 1 in the pool (both oracle runs;
+    alignment, side H) -> HIP with the oracle's flows injected (this process) -> stage 2 in the pool (side O) -> verdict.
+    Up to `ahead` cases are in flight; returns the number of flipped decisions."""
     ahead = ahead or 2 * pool._processes
-    inflight, flipped = [], 0
-    for c in cs + [None] * ahead:
-        if c is not None:
-            own = hip_own(c)
-            inflight.append((c, own, pool.apply_async(_oracle_case, (c, own[3]))))
-        if len(inflight) > ahead or (c is None and inflight):
-            c0, own0, job = inflight.pop(0)
-            flipped += check(c0, own0, job.get(timeout=1500), report=report)
-    assert not inflight
+    q1, q2, flipped = [], [], 0
+
+    def drain(block1=False, block2=False):
+        nonlocal flipped
+        while q1 and (block1 or q1[0][3].ready()):
+            c, ref, comp, job = q1.pop(0)
+            oflow, al, sh, info, path = job.get(timeout=1500)
+            oi, hr_i = hip_injected(c, ref, comp, oflow)
+            q2.append((c, al, sh, info, pool.apply_async(_stage2, (c, path, oi, hr_i))))
+            block1 = False
+        while q2 and (block2 or q2[0][4].ready()):
+            c, al, sh, info, job = q2.pop(0)
+            flipped += judge(c, al, sh, job.get(timeout=1500), info, report=report)
+            block2 = False
+
+    for c in cs:
+        ref, comp, o, gflow, hr = hip_own(c)
+        q1.append((c, ref, comp, pool.apply_async(_stage1, (c, gflow, o, hr))))
+        drain(block1=len(q1) >= ahead, block2=len(q2) >= ahead)
+    while q1 or q2:
+        drain(block1=bool(q1), block2=bool(q2) and not q1)
     return flipped
 
 

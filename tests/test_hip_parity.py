@@ -2251,12 +2251,7 @@ def test_sharded_reduce_strategy(tmp_path, world):
     assert_close(got["acc_r"], N(wdbg["accumulated robustness"]), 0, 2e-6, "acc_r")
 
 
-@pytest.mark.timeout(900)
-@pytest.mark.parametrize("strategy", ["rows", "reduce"])
-def test_bench_two_ranks_share_the_gpu(strategy):
-    """`bench.py --gpus 2` with the real HipEngine: the script re-executes itself under torch.distributed.run, two ranks
-    rendezvous over gloo (RCCL needs one GPU per rank; HHSR_BENCH_SHARE_GPU=1 puts both on device 0), run
-    main_sharded with the chosen strategy from HIP graphs and rank 0 prints ONE JSON line with n_gpus = 2."""
+def _bench_shared_gpu(ranks, *extra):
     import json
     import os
     import subprocess
@@ -2266,15 +2261,46 @@ def test_bench_two_ranks_share_the_gpu(strategy):
     env = dict(os.environ, HHSR_BENCH_SHARE_GPU="1")
     for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT"):
         env.pop(k, None)
-    p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--backend", "gloo", "--strategy",
-                        strategy, "--height", "768", "--width", "1024", "--frames", "6", "--steps", "3", "--warmup", "2",
+    p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", str(ranks), "--backend", "gloo", *extra,
                         "--no-cpu-baseline"], capture_output=True, text=True, env=env, timeout=850)  # (host legs: N = 1 only)
     lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
     assert p.returncode == 0 and len(lines) == 1, p.stderr[-3000:]
-    rec = json.loads(lines[0])
-    assert rec["n_gpus"] == 2 and rec["rccl_ranks"] == 2 and rec["backend"] == "gloo" and rec["value"] > 0
-    assert rec["strategy"] == strategy and strategy in rec["config"]["parallelism"]
+    return json.loads(lines[0])
+
+
+def _check_two_strategy_line(rec, ranks, headline):
+    other = "reduce" if headline == "rows" else "rows"
+    assert rec["n_gpus"] == ranks and rec["rccl_ranks"] == ranks and rec["ranks_agree"] and rec["backend"] == "gloo"
+    assert rec["value"] > 0 and rec["strategy"] == headline and headline in rec["config"]["parallelism"]
     assert rec["engine"].startswith("HipEngine") and "HIP graph replay" in rec["launch"]
+    assert not rec.get("errors"), rec.get("errors")
+    st = rec["strategies"]  # BOTH curves in one record (VERDICT r4 #2a): the driver only passes --gpus N
+    assert st[headline]["headline"] and st[headline]["ms_per_step"] == rec["ms_per_step"] and not st[other]["headline"]
+    for k in (headline, other):
+        assert st[k]["value"] > 0 and st[k]["compute_only_max_rank_ms"] is not None
+        assert 0 < st[k]["compute_only_max_rank_ms"] <= st[k]["ms_per_step"] * 1.5  # (shared GPU: ranks contend; sanity only)
+    assert "all_gather_in_bytes" in st["rows"]["rccl_bytes_per_rank"] and "reduce_scatter_in_bytes" in st["reduce"]["rccl_bytes_per_rank"]
+
+
+@pytest.mark.timeout(900)
+@pytest.mark.parametrize("strategy", ["rows", "reduce"])
+def test_bench_two_ranks_share_the_gpu(strategy):
+    """`bench.py --gpus 2` with the real HipEngine: the script re-executes itself under torch.distributed.run, two ranks
+    rendezvous over gloo (RCCL needs one GPU per rank; HHSR_BENCH_SHARE_GPU=1 puts both on device 0), run
+    main_sharded with the chosen strategy from HIP graphs and rank 0 prints ONE JSON line with n_gpus = 2 that carries
+    BOTH strategies' timings."""
+    rec = _bench_shared_gpu(2, "--strategy", strategy, "--height", "768", "--width", "1024", "--frames", "6", "--steps", "3",
+                            "--warmup", "2")
+    _check_two_strategy_line(rec, 2, strategy)
+
+
+@pytest.mark.timeout(900)
+def test_bench_eight_ranks_share_the_gpu():
+    """VERDICT r4 #2b: the rank count the target names through the command the driver runs — `bench.py --gpus 8` (only the
+    backend differs: gloo, eight processes on the one GPU), 20 frames (19 comp frames: 3, 3, 3, 2, 2, 2, 2, 2) at 1024 x 1024,
+    default strategy `rows` as the headline and `reduce` next to it in the same record, every rank replaying HIP graphs."""
+    rec = _bench_shared_gpu(8, "--height", "1024", "--width", "1024", "--frames", "20", "--steps", "3", "--warmup", "2")
+    _check_two_strategy_line(rec, 8, "rows")
 
 
 # ------------------------------------------------------------------------------------------ round 4: RCCL, C3 / C5 multi-rank
@@ -2586,6 +2612,39 @@ def test_rows_plan_flow_bound_retry():
     for it in range(3):  # ... and one that is too small is REPORTED (the result near slab seams is then the caller's risk)
         out, dbg = hdist.main_sharded(dref, dcomp, cfg, engine=eng3, force_sharded=True, max_flow=4.0)
         assert bool(dbg["flow_bound_exceeded"])
+
+
+def test_rows_plan_needs_the_same_tensors_not_the_same_addresses():
+    """whether a rank replays / captures a RowsPlan or runs eagerly decides which collectives it
+    issues, so the decision must be one every rank takes alike.  "The same device addresses as an earlier call" is not: the
+    caching allocator may hand a FRESH burst the addresses of a freed one on one rank and not on another.  The address key
+    is only trusted while the tensors of its first sighting are alive: a fresh burst at recycled addresses is a first
+    sighting again (eager), the caller's SAME tensors coming back are captured on their second call."""
+    from handheld_super_resolution import distributed as hdist
+
+    cfg = base_config(ts=16, scale=2)
+    ref1, comp1, _ = synth.make_burst(512, 640, 4, seed=41, max_shift=1.0)
+    want, _ = hsr.main(ref1, comp1, base_config(ts=16, scale=2))
+    eng = hdist.HipEngine(cfg)
+    addrs = set()
+    for it in range(4):  # a fresh pair of device tensors per burst; freed before the next one is allocated
+        dref, dcomp = T(ref1), T(comp1)
+        addrs.add((dref.data_ptr(), dcomp.data_ptr()))
+        out, _ = hdist.main_sharded(dref, dcomp, cfg, engine=eng, force_sharded=True)
+        assert torch.equal(torch.nan_to_num(out), torch.nan_to_num(want))
+        assert not eng._plans, "a fresh burst must not be taken for the second call of the freed one"
+        del dref, dcomp, out
+    assert len(addrs) < 4, "(the allocator did recycle addresses: the situation this test is about)"
+    dref, dcomp = T(ref1), T(comp1)
+    for it in range(3):  # the SAME tensors: eager, capture, replay
+        out, _ = hdist.main_sharded(dref, dcomp, cfg, engine=eng, force_sharded=True)
+        assert torch.equal(torch.nan_to_num(out), torch.nan_to_num(want))
+        assert bool(eng._plans) == (it >= 1)
+    views = [dcomp[i] for i in range(len(dcomp))]  # fresh view objects of the same live storage: the same inputs
+    eng2 = hdist.HipEngine(cfg)
+    for it in range(2):
+        hdist.main_sharded(dref, [dcomp[i] for i in range(len(dcomp))], cfg, engine=eng2, force_sharded=True)
+    assert eng2._plans and views[0]._base is dcomp
 
 
 @pytest.mark.parametrize("kern", ["handheld", "iso"])
