@@ -24,7 +24,7 @@ SOURCES = {
     "hhsr_merge.hip": [],
     "hhsr_grey.hip": ["-ffp-contract=off"],
     # (the SLP vectoriser packs the complex butterflies into v_pk_* instructions: measured 121 -> 98 us per launch of the
-    # row kernels, 94 -> 89 us of the column kernel at 12 MP x 3-4 frames — tools/debug/r04_call11.sh)
+    # row kernels, 94 -> 89 us of the column kernel at 12 MP x 3-4 frames — tools/ab.sh --kernels "k_rows|k_cols" slp@fft_slp default)
     "hhsr_fft.hip": ["-fno-slp-vectorize"],
     "hhsr_io.hip": ["-ffp-contract=off"],
     "hhsr_post.hip": ["-ffp-contract=off"],

@@ -317,7 +317,7 @@ constexpr int FFT_NT = 512;          // threads per workgroup: column kernel, an
 // Row kernels, rows that fit: ONE row per 256-thread workgroup — 16 KB of data + the twiddles = 32 KB of LDS, five
 // workgroups per CU instead of three 512-thread row pairs.  The phases of a workgroup (load a row / barrier-separated
 // passes / store) only overlap with OTHER workgroups' phases, and five independent ones overlap better than three:
-// measured at 12 MP (tools/debug/r04_call37.sh) rows fwd 96.3 -> 85.1 us, rows inv 101.5 -> 89.9 us per 3-4 frame launch
+// measured at 12 MP (tools/ab.sh --kernels "k_rows|k_cols" default rows512,HHSR_FFT_NT_ROWS=512) rows fwd 96.3 -> 85.1 us, rows inv 101.5 -> 89.9 us per 3-4 frame launch
 // (four resident workgroups: 91.9 / 97.2; six — more than fit — 97.1 / 104.7).  The column kernel LOSES with 256 threads
 // (one column per workgroup: 90 -> 111 us) and keeps 512.
 constexpr int FFT_NT_SMALL = 256;

@@ -197,28 +197,44 @@ def sweep(pool, cs, report=None, ahead=None):
     """Three overlapping steps per case: HIP with its own flows (this process) -> stage 1 in the pool (both oracle runs;
     alignment, side H) -> HIP with the oracle's flows injected (this process) -> stage 2 in the pool (side O) -> verdict.
     Up to `ahead` cases are in flight; returns the number of flipped decisions."""
+    import time
+
     ahead = ahead or 2 * pool._processes
     q1, q2, flipped = [], [], 0
+    tm = {"hip_own": 0.0, "hip_injected": 0.0, "wait_stage1": 0.0, "wait_stage2": 0.0}
+    t_start = time.perf_counter()
 
     def drain(block1=False, block2=False):
         nonlocal flipped
         while q1 and (block1 or q1[0][3].ready()):
             c, ref, comp, job = q1.pop(0)
+            t0 = time.perf_counter()
             oflow, al, sh, info, path = job.get(timeout=1500)
+            t1 = time.perf_counter()
             oi, hr_i = hip_injected(c, ref, comp, oflow)
+            tm["wait_stage1"] += t1 - t0
+            tm["hip_injected"] += time.perf_counter() - t1
             q2.append((c, al, sh, info, pool.apply_async(_stage2, (c, path, oi, hr_i))))
             block1 = False
         while q2 and (block2 or q2[0][4].ready()):
             c, al, sh, info, job = q2.pop(0)
-            flipped += judge(c, al, sh, job.get(timeout=1500), info, report=report)
+            t0 = time.perf_counter()
+            so = job.get(timeout=1500)
+            tm["wait_stage2"] += time.perf_counter() - t0
+            flipped += judge(c, al, sh, so, info, report=report)
             block2 = False
 
     for c in cs:
+        t0 = time.perf_counter()
         ref, comp, o, gflow, hr = hip_own(c)
+        tm["hip_own"] += time.perf_counter() - t0
         q1.append((c, ref, comp, pool.apply_async(_stage1, (c, gflow, o, hr))))
         drain(block1=len(q1) >= ahead, block2=len(q2) >= ahead)
     while q1 or q2:
         drain(block1=bool(q1), block2=bool(q2) and not q1)
+    if report is not None:
+        report.append(f"# sweep of {len(cs)} cases: {time.perf_counter() - t_start:.0f} s wall on {pool._processes} oracle workers; this "
+                      f"process: " + ", ".join(f"{k} {v:.0f} s" for k, v in tm.items()))
     return flipped
 
 

@@ -2626,15 +2626,19 @@ def test_rows_plan_needs_the_same_tensors_not_the_same_addresses():
     ref1, comp1, _ = synth.make_burst(512, 640, 4, seed=41, max_shift=1.0)
     want, _ = hsr.main(ref1, comp1, base_config(ts=16, scale=2))
     eng = hdist.HipEngine(cfg)
-    addrs = set()
-    for it in range(4):  # a fresh pair of device tensors per burst; freed before the next one is allocated
-        dref, dcomp = T(ref1), T(comp1)
-        addrs.add((dref.data_ptr(), dcomp.data_ptr()))
+    packed = np.concatenate([ref1[None], comp1])  # one allocation of an unusual size: the allocator hands the block back
+    seen, recycled = set(), 0
+    for it in range(6):  # a fresh burst per call; the previous one is freed before the next is allocated
+        buf = T(packed)
+        dref, dcomp = buf[0], buf[1:]
+        recycled += (dref.data_ptr(), dcomp.data_ptr()) in seen
+        seen.add((dref.data_ptr(), dcomp.data_ptr()))
         out, _ = hdist.main_sharded(dref, dcomp, cfg, engine=eng, force_sharded=True)
         assert torch.equal(torch.nan_to_num(out), torch.nan_to_num(want))
         assert not eng._plans, "a fresh burst must not be taken for the second call of the freed one"
-        del dref, dcomp, out
-    assert len(addrs) < 4, "(the allocator did recycle addresses: the situation this test is about)"
+        del buf, dref, dcomp, out
+    if not recycled:
+        pytest.skip("the caching allocator did not recycle the burst's addresses in 6 bursts: situation not reproduced")
     dref, dcomp = T(ref1), T(comp1)
     for it in range(3):  # the SAME tensors: eager, capture, replay
         out, _ = hdist.main_sharded(dref, dcomp, cfg, engine=eng, force_sharded=True)
