@@ -47,7 +47,7 @@ for p in (ROOT, PKG_ROOT):
 
 VALU_PEAK_TLANEOPS = 78.6  # 256 CUs x 4 SIMD-32 x 2.4 GHz: one wave64 VALU instruction per 2 cycles (MI355X_MICROARCH.md)
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: 8.0 TB/s spec (6.3 TB/s achievable)
-MERGE_SRC = os.path.join(PKG_ROOT, "csrc", "hhsr_merge.hip")
+MERGE_SRC = {2.0: ("hhsr_merge.h", "hhsr_merge_x2.hip"), 3.0: ("hhsr_merge.h", "hhsr_merge_xs.hip")}  # kernel sources (csrc/)
 LEG_TIMEOUT_S = 300        # N > 1: an optional leg whose collectives hang must not lose the line (watchdog)
 
 
@@ -430,16 +430,19 @@ def main():
             # whole-image launch on one GPU; on N ranks each launch covers 1/N of the output rows (+ halo rows of input)
             nbytes = merge_burst_bytes(NF - 1, P, S) / world
             achieved = nbytes / (avg_ms * 1e-3) / 1e9
-            # the kernel hhsr_merge_burst picks for this scale (csrc/hhsr_merge.hip: x2 and x3 have wave-per-parity-class
+            # the kernel hhsr_merge_burst picks for this scale (csrc/hhsr_merge*.hip: x2 and x3 have wave-per-parity-class
             # kernels, other integer scales the tile kernel, non-integer scales the generic one)
             kernel = ("k_merge_x2" if float(scale) == 2.0 else "k_merge_xs<3>" if float(scale) == 3.0 and W % 4 == 0
                       else "k_merge_burst_tile" if float(scale).is_integer() else "k_merge_burst")
             traffic, valu, pmc_note = None, None, None
             try:  # HBM bytes / VALU instructions per launch from the committed rocprofv3 --pmc passes of this exact kernel
-                pmc_file = "r04_pmc_merge_x3.json" if float(scale) == 3.0 else "r04_pmc_merge.json"
+                pmc_file = "r05_pmc_merge_x3.json" if float(scale) == 3.0 else "r05_pmc_merge.json"
                 with open(os.path.join(ROOT, "profiles", pmc_file)) as f:
                     pm = json.load(f)
-                sha = hashlib.sha256(open(MERGE_SRC, "rb").read()).hexdigest()[:16]
+                h = hashlib.sha256()
+                for src in MERGE_SRC.get(float(scale), ("hhsr_merge.h", "hhsr_merge.hip")):
+                    h.update(open(os.path.join(PKG_ROOT, "csrc", src), "rb").read())
+                sha = h.hexdigest()[:16]
                 if pm.get("workload") == f"{H}x{W}x{NF} x{scale}" and world == 1:
                     if pm.get("source_sha16") == sha:
                         traffic = pm["traffic_bytes_per_launch"]

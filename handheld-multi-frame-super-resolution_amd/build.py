@@ -21,7 +21,10 @@ SOURCES = {
     "hhsr_align.hip": ["-ffp-contract=off", "-fno-slp-vectorize"],  # (SLP off: level 0 172.5 -> 167.2 us, coarse levels 55.7 -> 54.5)
     "hhsr_kernels.hip": ["-ffp-contract=off", "-fno-slp-vectorize"],
     "hhsr_robustness.hip": ["-ffp-contract=off", "-fno-slp-vectorize"],
-    "hhsr_merge.hip": [],
+    "hhsr_merge.hip": [],       # C ABI + kernel choice, per-pixel kernels, border bands
+    "hhsr_merge_tile.hip": [],  # first-generation LDS tile kernels
+    "hhsr_merge_x2.hip": [],    # k_merge_x2
+    "hhsr_merge_xs.hip": [],    # k_merge_xs<3>
     "hhsr_grey.hip": ["-ffp-contract=off"],
     # (the SLP vectoriser packs the complex butterflies into v_pk_* instructions: measured 121 -> 98 us per launch of the
     # row kernels, 94 -> 89 us of the column kernel at 12 MP x 3-4 frames — tools/ab.sh --kernels "k_rows|k_cols" slp@fft_slp default)
@@ -40,7 +43,7 @@ def _stale(target, deps):
 
 def build(force=False, verbose=True):
     os.makedirs(OBJ, exist_ok=True)
-    headers = [os.path.join(CSRC, "hhsr_common.h"), os.path.join(CSRC, "hhsr_fft.h"), os.path.join(HERE, "..", "include", "hhsr.h"), __file__]
+    headers = [os.path.join(CSRC, "hhsr_common.h"), os.path.join(CSRC, "hhsr_fft.h"), os.path.join(CSRC, "hhsr_merge.h"), os.path.join(HERE, "..", "include", "hhsr.h"), __file__]
     jobs = []
     objs = []
     for src, extra in SOURCES.items():

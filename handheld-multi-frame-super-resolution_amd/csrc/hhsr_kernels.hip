@@ -39,8 +39,7 @@ __device__ __forceinline__ double sqrt_pos(double t) {
     g = fma(g, r, g);
     h = fma(h, r, h);
     const double d = fma(-g, g, t);
-    g = fma(d, h, g);
-    return t > 0.0 ? g : 0.0;  // rsq(0) = inf -> NaN above
+    return fma(d, h, g);  // (t = 0: rsq = inf -> NaN; gat1 keeps its argument >= 1e-300, the eigenvalue root guards itself)
 #else
     return sqrt(t);
 #endif
@@ -63,8 +62,9 @@ __device__ __forceinline__ float div_f32(float x, float y) {
 
 __device__ __forceinline__ float gat1(float v, double alpha, double c0, double two_over_alpha) {
     // VST = alpha*I + 3/8*alpha^2 + beta ; max(0, .) ; 2/alpha * sqrt(.)   (utils_image.py:167-170)
-    double t = alpha * (double)v + c0;
-    t = t > 0.0 ? t : 0.0;
+    // max(0, .) as max(1e-300, .): the float32 result of an argument <= 0 is 0 either way (2 / alpha * 1e-150 rounds to 0)
+    // and sqrt_pos needs no zero test (a float64 compare and two selects per pixel, 12 pixels per thread)
+    const double t = fmax(alpha * (double)v + c0, 1.0e-300);
     return (float)(two_over_alpha * sqrt_pos(t));
 }
 
@@ -100,7 +100,7 @@ __device__ __forceinline__ float4 quad_cov(const float* __restrict__ sg, int ly,
     const float bb = b * b;
     double delta = (double)bb - 4.0 * (double)c;
     delta = delta > 0.0 ? delta : 0.0;
-    const double sq = sqrt_pos(delta);
+    const double sq = delta > 0.0 ? sqrt_pos(delta) : 0.0;
     const double r1 = (-(double)b + sq) / 2.0, r2 = (-(double)b - sq) / 2.0;
     float l1, l2;
     if (fabs(r1) >= fabs(r2)) {
@@ -185,6 +185,7 @@ struct FrameStatsArgs {
     double rwb[3];  // 1 / white balance
     double rwbk[4]; // ... of the colour at quad position k
     int pat;        // 0 RGGB, 1 BGGR, 2 GRBG, 3 GBRG (compile-time channel routing per case); -1: any other 2 x 2 pattern
+    int unit_wb;    // white balance (1, 1, 1): the guide channels are the raw values (float32-exact fast path)
     float* means;   // [3][gh][gw] or NULL
     float* vars;    // [3][gh][gw] or NULL
     float4* covs;   // [gh][gw] or NULL
@@ -229,7 +230,15 @@ __global__ void __launch_bounds__(256) k_frame_stats(FrameStatsArgs A, FsFrames 
                 float ch[3] = {0.f, 0.f, 0.f};
                 const double x0 = (double)v[0] * A.rwbk[0], x1 = (double)v[1] * A.rwbk[1];
                 const double x2 = (double)v[2] * A.rwbk[2], x3 = (double)v[3] * A.rwbk[3];
-                if (A.pat == 0) {         // R G / G B
+                if (A.unit_wb && A.pat >= 0) {
+                    // white balance (1, 1, 1): raw / 1.0 is the raw value, and the float64 green mean ((0 + a) + b) / 2
+                    // rounded to float32 IS the float32 sum halved (a + b is exact in float64, halving is exact) — no
+                    // float64 instruction left in this block (11 per staged quad)
+                    const float g01 = 0.5f * (v[1] + v[2]), g03 = 0.5f * (v[0] + v[3]);
+                    ch[1] = A.pat <= 1 ? g01 : g03;
+                    ch[0] = A.pat == 0 ? v[0] : A.pat == 1 ? v[3] : A.pat == 2 ? v[1] : v[2];
+                    ch[2] = A.pat == 0 ? v[3] : A.pat == 1 ? v[0] : A.pat == 2 ? v[2] : v[1];
+                } else if (A.pat == 0) {  // R G / G B
                     ch[0] = (float)x0; ch[1] = (float)(((0.0 + x1) + x2) / 2.0); ch[2] = (float)x3;
                 } else if (A.pat == 1) {  // B G / G R
                     ch[2] = (float)x0; ch[1] = (float)(((0.0 + x1) + x2) / 2.0); ch[0] = (float)x3;
@@ -287,9 +296,16 @@ __global__ void __launch_bounds__(256) k_frame_stats(FrameStatsArgs A, FsFrames 
                         s0 += v;
                         s1 += v * v;
                     }
-                const double m = div_by((double)s0, 9.0, 1.0 / 9.0);
-                A.means[c * plane + o] = (float)m;
-                if (A.vars) A.vars[c * plane + o] = (float)(div_by((double)s1, 9.0, 1.0 / 9.0) - m * m);
+                // mean = float32(float64(s0) / 9): the correctly rounded float32 quotient (a float32 over 9 never lies within
+                // 2^-28 relative of a float32 rounding boundary, so rounding through float64 changes nothing), which
+                // q = s0 r, q + (s0 - 9 q) r with r = RN(1 / 9) delivers in float32 — checked exhaustively over all 2^23
+                // mantissas (Markstein); the variance keeps the float64 mean
+                const float r9 = 1.0f / 9.0f, q9 = s0 * r9;
+                A.means[c * plane + o] = fmaf(fmaf(-9.0f, q9, s0), r9, q9);
+                if (A.vars) {
+                    const double m = div_by((double)s0, 9.0, 1.0 / 9.0);
+                    A.vars[c * plane + o] = (float)(div_by((double)s1, 9.0, 1.0 / 9.0) - m * m);
+                }
             }
         }
         if (COV) A.covs[o] = quad_cov<FS_P>(s_g, ly, lx, gy, gx, gh, gw, A.P);
@@ -307,6 +323,7 @@ static int frame_stats_launch_batch(const float* const* raws, int n_frames, int 
     const int code = A.cfa.c[0] * 27 + A.cfa.c[1] * 9 + A.cfa.c[2] * 3 + A.cfa.c[3];
     A.pat = code == 0 * 27 + 1 * 9 + 1 * 3 + 2 ? 0 : code == 2 * 27 + 1 * 9 + 1 * 3 + 0 ? 1
           : code == 1 * 27 + 0 * 9 + 2 * 3 + 1 ? 2 : code == 1 * 27 + 2 * 9 + 0 * 3 + 1 ? 3 : -1;
+    A.unit_wb = A.rwb[0] == 1.0 && A.rwb[1] == 1.0 && A.rwb[2] == 1.0;
     A.means = nullptr; A.vars = nullptr; A.covs = nullptr; A.P = P;
     A.P.r_D_tr = 1.0 / P.D_tr;
     A.P.inv_k_shrink = 1.0 / P.k_shrink;
@@ -443,9 +460,12 @@ __global__ void __launch_bounds__(256) k_mono_stats(MonoStatsArgs A) {
                     s0 += t;
                     s1 += t * t;
                 }
-            const double m = div_by((double)s0, 9.0, 1.0 / 9.0);
-            A.means[o] = (float)m;
-            if (A.vars) A.vars[o] = (float)(div_by((double)s1, 9.0, 1.0 / 9.0) - m * m);
+            const float r9 = 1.0f / 9.0f, q9 = s0 * r9;  // (see k_frame_stats)
+            A.means[o] = fmaf(fmaf(-9.0f, q9, s0), r9, q9);
+            if (A.vars) {
+                const double m = div_by((double)s0, 9.0, 1.0 / 9.0);
+                A.vars[o] = (float)(div_by((double)s1, 9.0, 1.0 / 9.0) - m * m);
+            }
         }
         if (COV) A.covs[o] = quad_cov<FS_P>(s_g, ly, lx, gy, gx, H, W, A.P);
     }

@@ -7,8 +7,8 @@ from . import _lib
 
 
 # kflags of the C ABI (include/hhsr.h)
-KERNEL_ISO, WEIGHT_F64, FORCE_GENERIC, FORCE_TILE, FORCE_X2V1, SENSOR_MONO, FORCE_X3W = 1, 2, 4, 8, 16, 32, 64
-_FORCE = {"auto": 0, "generic": FORCE_GENERIC, "tile": FORCE_TILE, "x2_v1": FORCE_X2V1, "x3w": FORCE_X3W}
+KERNEL_ISO, WEIGHT_F64, FORCE_GENERIC, FORCE_TILE, FORCE_X2V1, SENSOR_MONO = 1, 2, 4, 8, 16, 32
+_FORCE = {"auto": 0, "generic": FORCE_GENERIC, "tile": FORCE_TILE, "x2_v1": FORCE_X2V1}
 # process-wide A/B switches, read once like the library reads them
 _ENV_FORCE = ((FORCE_GENERIC if os.environ.get("HHSR_MERGE_NO_LDS") else 0) |
               (FORCE_TILE if os.environ.get("HHSR_MERGE_NO_QUAD") else 0) |

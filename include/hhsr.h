@@ -232,7 +232,6 @@ int hhsr_mono_rob_frame(const float* comp_means, int H, int W, const float* ref_
 #define HHSR_MERGE_FORCE_GENERIC 4  /* no LDS staging: one thread per HR pixel, operands from global memory     */
 #define HHSR_MERGE_FORCE_TILE 8     /* no x2 kernel: the 16 x 16 HR tile kernel                                  */
 #define HHSR_MERGE_FORCE_X2V1 16    /* x2: first-generation kernel (per-pixel geometry) instead of k_merge_x2    */
-#define HHSR_MERGE_FORCE_X3W 64     /* x3, Bayer: the 768-thread kernel (wave = parity class x output sub-row)     */
 /* all three merge entry points: */
 #define HHSR_SENSOR_MONO 32  /* `mode: grey`: every sample goes to channel 0; the per-frame entry points and the generic
                                 burst kernel leave channels 1, 2 of num / den as they are, the x2 tile kernel of

@@ -607,20 +607,6 @@ def test_merge_x3_kernel_equals_tile_kernel(kern):
             out_x, acc_x = run("auto", chained, lmin)
             assert_close(out_x, out_t, 2e-5, 1e-6, f"k_merge_xs<3> vs tile kernel (chained={chained}, lmin={lmin})")
             assert_close(acc_x, acc_t, 1e-6, 1e-6, f"accumulated robustness (chained={chained}, lmin={lmin})")
-            # round 4's 768-thread kernel (wave = parity class x output sub-row; measured slower, opt-in): same contract
-            if lmin:
-                frames_w = tf
-                cfg_w = cfg_for("x3w")
-                out_w, den_w = torch.empty(3 * H, 3 * W, 3, device=DEV), torch.empty(3 * H, 3 * W, 3, device=DEV)
-                acc_w = torch.zeros(H, W, device=DEV)
-                if chained:
-                    merge.merge_burst(frames_w[:2], None, None, out_w, den_w, cfa, cfg_w, do_ref=False, divide=False,
-                                      store_den=True, acc_r=acc_w, local_min=True)
-                    merge.merge_burst(frames_w[2:], T(ref), rc, out_w, den_w, cfa, cfg_w, load_acc=True, acc_r=acc_w, local_min=True)
-                else:
-                    merge.merge_burst(frames_w, T(ref), rc, out_w, None, cfa, cfg_w, acc_r=acc_w, local_min=True)
-                assert_close(N(out_w), out_t, 2e-5, 1e-6, f"k_merge_x3w vs tile kernel (chained={chained})")
-                assert_close(N(acc_w), acc_t, 1e-6, 1e-6, f"k_merge_x3w accumulated robustness (chained={chained})")
     # partial sums (num, den) and a row slab
     cfg = cfg_for("auto")
     pn, pd = torch.empty(3 * H, 3 * W, 3, device=DEV), torch.empty(3 * H, 3 * W, 3, device=DEV)

@@ -1,6 +1,6 @@
 #!/bin/bash
 # Everything the round's profiles / PARITY.md are made from, in one GPU call.  usage: tools/collect_round.sh <name>
-NAME=${1:-r04}
+NAME=${1:-r05}
 OUT=gpurun_out/$NAME
 mkdir -p $OUT
 HHSR_PARITY_LOG=$PWD/$OUT/parity.jsonl timeout 2400 python -m pytest tests -q -m gpu --timeout 1200 > $OUT/tests.log 2>&1
@@ -8,13 +8,14 @@ tail -3 $OUT/tests.log
 python tools/parity_report.py $OUT/parity.jsonl > $OUT/PARITY.md
 # the merge kernel's counters first: bench.py's roofline.traffic reads the record (keyed to the kernel source's hash)
 bash tools/pmc_merge.sh "k_merge_x2" $NAME/pmc_x2 --no-h2d --steps 1 --warmup 0 > /dev/null 2>&1
-MSRC=handheld-multi-frame-super-resolution_amd/csrc/hhsr_merge.hip
+CS=handheld-multi-frame-super-resolution_amd/csrc
+MSRC=$CS/hhsr_merge.h,$CS/hhsr_merge_x2.hip
 python tools/pmc_report.py $OUT/pmc_x2 k_merge_x2 profiles/${NAME}_pmc_merge.json $MSRC "3000x4000x20 x2" \
   "tools/pmc_merge.sh k_merge_x2 (bench.py --no-cpu-baseline --no-h2d --steps 1 --warmup 0), profiles/${NAME}_pmc_merge_x2.md" > $OUT/pmc_x2.md
 cp profiles/${NAME}_pmc_merge.json $OUT/pmc_merge.json
 # ... and the x3 kernel's on the C5 geometry (48 MP x 20 x3 on one GPU)
 bash tools/pmc_merge.sh "k_merge_xs" $NAME/pmc_x3 --no-h2d --steps 1 --warmup 0 --height 6000 --width 8000 --scale 3 > /dev/null 2>&1
-python tools/pmc_report.py $OUT/pmc_x3 k_merge_xs profiles/${NAME}_pmc_merge_x3.json $MSRC "6000x8000x20 x3" \
+python tools/pmc_report.py $OUT/pmc_x3 k_merge_xs profiles/${NAME}_pmc_merge_x3.json $CS/hhsr_merge.h,$CS/hhsr_merge_xs.hip "6000x8000x20 x3" \
   "tools/pmc_merge.sh k_merge_xs (bench.py --no-cpu-baseline --no-h2d --steps 1 --warmup 0 --height 6000 --width 8000 --scale 3), profiles/${NAME}_pmc_merge_x3.md" > $OUT/pmc_x3.md
 cp profiles/${NAME}_pmc_merge_x3.json $OUT/pmc_merge_x3.json
 T0=$(date +%s); python bench.py > $OUT/bench_n1.json 2> $OUT/bench_n1.err; echo "bench.py default run: $(( $(date +%s) - T0 )) s wall" > $OUT/bench_n1.time

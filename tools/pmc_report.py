@@ -52,8 +52,10 @@ def write_record(out, path, source, workload, note):
     edit of the kernel invalidates it instead of leaving a stale number."""
     import hashlib
 
-    out = dict(out, workload=workload, source=source,
-               source_sha16=hashlib.sha256(open(source, "rb").read()).hexdigest()[:16], collected_by=note)
+    h = hashlib.sha256()
+    for f in source.split(","):  # (the kernel's translation unit and the internal header it is written against)
+        h.update(open(f, "rb").read())
+    out = dict(out, workload=workload, source=source, source_sha16=h.hexdigest()[:16], collected_by=note)
     with open(path, "w") as f:
         json.dump(out, f, indent=1)
         f.write("\n")
