@@ -549,6 +549,24 @@ def main():
                 errors["h2d_numpy_leg"] = f"{type(e).__name__}: {e}"
         del ref_h, comp_h
 
+    # ---- the reference's weight typing, timed: Numba types the merge's coordinates and weights as float64
+    # (merge.py:319-426); the timed step above computes them in float32 within the stated tolerance.
+    # config.hip.weight_fp64 runs the float64 chain on every pixel (the generic per-pixel kernel): what reference-typed
+    # arithmetic costs on this chip.  N = 1, guarded like the other legs.
+    if on_gpu and world == 1 and not args.no_h2d:
+        import copy
+
+        try:
+            cfg64 = copy.deepcopy(cfg)
+            cfg64.hip = dict(cfg64.get("hip", None) or {}, weight_fp64=True)
+            eng64 = engine_cls(cfg64)
+            fn64 = lambda: hdist.main_sharded(ref, comp, cfg64, engine=eng64, gather=args.gather)[0]  # noqa: E731
+            ms64 = timed(fn64, max(3, args.steps // 4), 3)
+            line.update(ms_per_step_weight_fp64=round(ms64, 3), value_weight_fp64=round(out_pix / (ms64 * 1e-3) / 1e6, 2))
+            del eng64
+        except Exception as e:  # noqa: BLE001
+            errors["weight_fp64_leg"] = f"{type(e).__name__}: {e}"
+
     # ---- CPU baseline (all host cores) + parity with attribution, on a crop of the same burst ----------------------
     cpu, parity = None, None
     if rank == 0 and world == 1 and on_gpu and not args.no_cpu_baseline:
@@ -592,16 +610,27 @@ def main():
             cfg_i.hip = dict(cfg.get("hip", None) or {}, inject_flows=[f for f in cap["flow"]])
             _, dinj, _ = diff(cfg_i)
             fin_i = np.isfinite(dinj)
+            # ... and the other side (round 5): the ORACLE's robustness + kernels + merge on HIP's flows (C form of the
+            # accumulation, oracle.cfast) against HIP's own-flow image — identical flows on both sides again
+            want_h, _, _ = oracle.main_parallel(ref_c, comp_c, cfg, workers=min(cores, NF - 1), fast=True, flows=list(gflow))
+            with np.errstate(all="ignore"):
+                dh = np.abs(got.astype(np.float64) - want_h.astype(np.float64))
+            fin_h = np.isfinite(dh)
             parity = {"max_abs_diff": float(dabs[fin].max()), "p999_abs_diff": float(np.percentile(dabs[fin], 99.9)),
                       "frac_above_1e-4": float((dabs[fin] > 1e-4).mean()),
                       "nan_mismatch": int((np.isnan(got) != np.isnan(want)).sum()),
                       "flipped_tiles": int(flipped.sum()), "tiles": int(flipped.size),
                       "max_flow_diff_unflipped_px": float(np.abs(gflow - oflow).max(-1)[~flipped].max()),
                       "max_abs_diff_oracle_flows_injected": float(dinj[fin_i].max()),
+                      "max_abs_diff_vs_oracle_on_hip_flows": float(dh[fin_h].max()),
+                      "nan_mismatch_vs_oracle_on_hip_flows": int((np.isnan(got) != np.isnan(want_h)).sum()),
                       "vs": "oracle (golden-pinned port)", "sample": f"{c}x{c} crop, {NF} frames, x{scale}",
                       "note": "flipped_tiles = tiles (over all comp frames) whose flow differs from the oracle's by > 0.05 px: "
                               "float32 near-ties of one block-matching decision; with the oracle's flow fields injected "
-                              "(config.hip.inject_flows) the remaining difference is the arithmetic of robustness + kernels + merge"}
+                              "(config.hip.inject_flows) the remaining difference is the arithmetic of robustness + kernels + merge; "
+                              "max_abs_diff_vs_oracle_on_hip_flows is the same comparison the other way round: the oracle's "
+                              "robustness + kernels + merge run on HIP's flow fields (the two-sided contract of "
+                              "tests/test_fuzz_parity.py)"}
 
         except Exception as e:  # noqa: BLE001
             errors["cpu_parity_leg"] = f"{type(e).__name__}: {e}"

@@ -50,6 +50,7 @@ The engine that does the per-rank compute is injected so that the sharding / exc
 a GPU (tests run it on gloo with the NumPy oracle as the engine, world_size 2 and 3).
 """
 import math
+import os
 
 import torch
 import torch.distributed as dist
@@ -554,6 +555,13 @@ class EagerRows:
         return slab, acc_r, extra, False
 
 
+def _flow_grid_of(shape, config):
+    """(ny, nx) of the flow field of an [H, W] frame: tiles of the reference frame padded up to whole tiles
+    (alignment.py:27-37; BurstPipeline.flow_grid once the reference state exists)."""
+    ts = int(config.block_matching.tuning.tile_size)
+    return -(-int(shape[0]) // ts), -(-int(shape[1]) // ts)
+
+
 _plan_streams = {}  # device index -> the step-A stream of every RowsPlan of the process (step B: graph.shared_streams()[0])
 
 
@@ -603,13 +611,23 @@ class RowsPlan:
                         _grey_plan(H, W, dev, _lib.MAX_BATCH)
             torch.cuda.synchronize(dev)
             mode = dict(capture_error_mode="thread_local")
-            self.g_ref_a = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(self.g_ref_a, stream=self.s_a, **mode):
-                pipe.init_ref(ref, robustness=False)
+            # Round 5: the reference alignment state and step A of the rank's first stage are ONE graph — the frames' own
+            # grey images and pyramids (side streams forked at the start of the reference precompute,
+            # BurstPipeline._on_streams) run next to the single-frame, latency-bound reference kernels instead of behind
+            # them: at G = 8 the replicated reference state was 0.27 ms of a rank's 1.65 ms.  (A rank without frames in
+            # stage 0 keeps the separate reference graph.)
+            ny_nx = _flow_grid_of(ref.shape, cfg)
             eng.pipe, eng.device = pipe, dev
-            ny, nx = pipe.flow_grid()
+            first = stage_frames(stages[0], n, G, rank) if stages else []
+            fuse_ref = bool(first) and os.environ.get("HHSR_ROWS_SPLIT_REF") is None  # (A/B switch, read at capture)
+            self.g_ref_a = None
+            if not fuse_ref:
+                self.g_ref_a = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(self.g_ref_a, stream=self.s_a, **mode):
+                    pipe.init_ref(ref, robustness=False)
+            ny, nx = ny_nx
             self.local, self.gath, self.g_a = [], [], []
-            for st in stages:
+            for k, st in enumerate(stages):
                 mine = stage_frames(st, n, G, rank)
                 loc = torch.zeros((st[1], ny, nx, 2), dtype=torch.float32, device=dev)
                 self.local.append(loc)
@@ -618,8 +636,13 @@ class RowsPlan:
                 if mine:
                     g = torch.cuda.CUDAGraph()
                     with torch.cuda.graph(g, stream=self.s_a, **mode):
+                        if k == 0 and fuse_ref:
+                            pipe.ref_wait = True
+                            pipe.init_ref(ref, robustness=False)
                         loc[: len(mine)].copy_(eng.align_frames([comps[i] for i in mine]))
+                        pipe.ref_wait = False
                 self.g_a.append(g)
+            assert tuple(pipe.flow_grid()) == (ny, nx)
             self.flag = torch.zeros((1,), dtype=torch.bool, device=dev)
             self.flag_host = torch.zeros((1,), dtype=torch.bool).pin_memory()
             self.g_ref_b = torch.cuda.CUDAGraph()
@@ -645,8 +668,9 @@ class RowsPlan:
         self.cur = cur = torch.cuda.current_stream(self.device)
         self.s_a.wait_stream(cur)
         self.s_b.wait_stream(cur)
-        with torch.cuda.stream(self.s_a):
-            self.g_ref_a.replay()
+        if self.g_ref_a is not None:  # (else: part of the first stage's step-A graph)
+            with torch.cuda.stream(self.s_a):
+                self.g_ref_a.replay()
         with torch.cuda.stream(self.s_b):
             self.g_ref_b.replay()
         self.eng.pipe, self.eng.device = self.pipe, self.device

@@ -14,6 +14,7 @@ MI355X design notes (vs the reference's per-frame Python loop):
   * multi-GPU (distributed.py): alignment frame-parallel, one all-gather of the flow fields, robustness / kernels /
     merge row-parallel (default), or frames one per GPU with one reduce-scatter of the num / den accumulators.
 """
+import os
 import time
 
 import numpy as np
@@ -77,6 +78,9 @@ class _Staged:
 
 
 _upload_streams = {}  # device index -> the stream all prefetched uploads are queued on, in frame order
+
+
+_LATE_FORK = os.environ.get("HHSR_LATE_FORK") is not None  # A/B switch (read once): side streams fork behind the reference precompute
 
 
 class BurstPipeline:
@@ -187,6 +191,7 @@ class BurstPipeline:
         main = torch.cuda.current_stream(self.device)
         self._entry = torch.cuda.Event()  # everything the caller enqueued before (e.g. the frames' upload) is done
         self._entry.record(main)
+        self._entry_fresh = True  # the next _on_streams() forks its side streams HERE, not behind the reference precompute
         self.ref = self._ingest(ref_img)
         self.align_state = self.grey_ref = None
         if alignment:
@@ -398,7 +403,15 @@ class BurstPipeline:
     def _on_streams(self, n, n_streams, serial, work):
         """work(i, wait_event) for i < n; on one stream (wait_event None) or round-robin on the side streams."""
         n_streams = self._n_streams(n_streams)
-        if n_streams <= 1 or serial or n < 2:
+        # Round 5: the side streams fork at the START of the reference precompute (self._entry), not behind it: a frame's own
+        # grey image and pyramid do not need the reference frame, the alignment waits for _align_ready, the robustness
+        # for `entry` below (the whole precompute and whatever else the caller's stream holds).  Until now the fork event
+        # was recorded here, i.e. behind the ~0.5 ms of single-frame, latency-bound reference kernels — 6 % of the 12 MP
+        # step, a sixth of a rank's step on 8 GPUs — and the _align_ready / _ref_ready waits had nothing left to wait for.
+        early = bool(self.ref_wait and getattr(self, "_entry_fresh", False) and n_streams > 1 and not serial and n >= 1
+                     and not _LATE_FORK)
+        self._entry_fresh = False
+        if not early and (n_streams <= 1 or serial or n < 2):
             return [work(i, None) for i in range(n)]
         main = torch.cuda.current_stream(self.device)
         if len(self._streams) < n_streams:
@@ -409,12 +422,12 @@ class BurstPipeline:
         entry = torch.cuda.Event()
         entry.record(main)
         for s in pool:
-            s.wait_event(entry)
+            s.wait_event(self._entry if early else entry)
         results = []
         for i in range(n):
             s = pool[i % n_streams]
             with torch.cuda.stream(s):
-                f = work(i, self._ref_ready if self.ref_wait else None)
+                f = work(i, entry if early else (self._ref_ready if self.ref_wait else None))
             for t in _tensors(f):
                 t.record_stream(main)  # consumed by the merge on the caller's stream (raw too: it is allocated on
                 # the side stream when the frame was uploaded / converted there)

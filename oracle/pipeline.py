@@ -10,7 +10,7 @@ from .merge import merge as _merge, merge_ref as _merge_ref, divide
 F32 = np.float32
 
 
-def main(ref_img, comp_imgs, config, capture=None, fast=False, flows=None, reuse=None):
+def main(ref_img, comp_imgs, config, capture=None, fast=False, flows=None, reuse=None, rob=None):
     """Returns (output float32[sH, sW, 3] = num/den, debug_dict) like the reference.
 
     ``capture``: optional dict that receives per-frame intermediates (grey, flow, r, covs, the reference statistics).
@@ -18,6 +18,8 @@ def main(ref_img, comp_imgs, config, capture=None, fast=False, flows=None, reuse
     every case the tests compare).
     ``flows``: per-frame flow fields to use INSTEAD of aligning — the two-sided flow injection of the sweeps (the oracle's
     robustness + kernels + merge on the flows of the implementation under test, tests/test_fuzz_parity.py).
+    ``rob``: per-frame robustness maps r [H, W] to use INSTEAD of computing them (with ``flows``: the merge alone, on the
+    flows and the robustness of the implementation under test — the third comparison of the sweeps).
     ``reuse``: the ``capture`` of an earlier run on the same burst and config: its flow-independent intermediates
     (kernel covariances, reference statistics) are taken over instead of being recomputed."""
     if fast:
@@ -56,7 +58,8 @@ def main(ref_img, comp_imgs, config, capture=None, fast=False, flows=None, reuse
             flow = align(pyr, gxs, gys, hs, grey, config)
         else:
             flow = np.asarray(flows[n], dtype=F32)
-        r = compute_robustness(img, ref_means, ref_vars, flow, cfa, wb, curves, config)
+        r = (np.asarray(rob[n], dtype=F32) if rob is not None else
+             compute_robustness(img, ref_means, ref_vars, flow, cfa, wb, curves, config))
         if accumulate_r:
             acc_r += r
         covs = reuse["covs"][n] if reuse else estimate_kernels(img, config)

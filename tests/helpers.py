@@ -164,66 +164,70 @@ def assert_explained(got, want, atol, flipped, ts, shape, scale, what, max_flipp
 FLIP_PX = 1e-3          # flow difference that marks a tile as following another block-matching decision
 MAX_ICA_TILES = 16      # tiles per case with a flow difference between 1e-4 and FLIP_PX (measured: <= 10, in 3 of 768 cases)
 CLUSTER = 8             # tiles per side of the finest-level tiles under one level-2 tile of the default pyramid
-MAX_OUTLIER = 5e-3      # where a frame is being rejected: the largest value above 1e-4, for accumulated weights den >= DEN_FLOOR
-DEN_FLOOR = 2e-4        # below this accumulated weight a value is a quotient of two numbers near zero: it is compared on its
-NUM_ERR = 1e-6          # NUMERATOR instead, |d out| x den <= NUM_ERR (measured <= 8.9e-8: set 100).  DEN_FLOOR = NUM_ERR /
-                        # MAX_OUTLIER: the two bounds meet at the floor
 MAX_FLIP_TILES = 16     # finest-level tiles per case under the ONE flipped decision (measured: 1, or a 2 x 2 block)
-# ---- Round 5: the contract is TWO-SIDED.  Round 4's rules compared HIP's own-flow image with the oracle's
-# own-flow image and excused "flow-sensitive" values (agree once the oracle's flows are injected into HIP) up to a cap,
-# MAX_SENS = 0.15 — violated at 0.177, 0.187 and 0.671 on held-out seeds.  The cap is gone: the oracle's robustness + kernels +
-# merge now ALSO run on HIP's flows (oracle.main(flows=...)), and HIP's own-flow image must equal THAT image under the same
-# rule as the other direction.  Every image value is therefore compared between two computations on IDENTICAL flows; the
-# flows themselves are compared at 1e-4 px outside flipped tiles; nothing is excused by magnitude or count any more.
+NUM_ERR = 1e-6          # identical flows AND identical robustness: a value may differ by more than 1e-4 only where its
+                        # accumulated weight den is so small that the NUMERATOR differs by <= NUM_ERR (|d out| x den): the
+                        # conditioning of a quotient of two numbers near zero, not arithmetic
+# ---- Round 5: the contract is STAGE BY STAGE ON IDENTICAL INPUTS, in both directions.  Round 4's rules
+# compared HIP's own-flow image with the oracle's own-flow image and excused "flow-sensitive" values (agree once the oracle's
+# flows are injected into HIP) up to a cap, MAX_SENS = 0.15 — violated at 0.177, 0.187 and 0.671 on held-out seeds.  Now
+#   alignment     HIP's flows vs the oracle's flows                                            (<= 1e-4 px off flipped tiles)
+#   robustness    on IDENTICAL flows (HIP's: side H; the oracle's: side O): r                  (<= 1e-4)
+#   merge         on IDENTICAL flows AND IDENTICAL robustness maps (HIP's r injected into the oracle, oracle.main(rob=...)):
+#                 image <= 1e-4 / NUM_ERR on the numerator, identical NaN pattern              (no region, count or size excuse)
+#   whole chain   on identical flows (o vs want_h, oi vs want): <= 1e-4 wherever every frame is accepted; where a frame is
+#                 being rejected a value may exceed 1e-4 only if the merge comparison above shows it to be the effect of the
+#                 <= 1e-4 by which r differs (it agrees once HIP's r is injected) — round 4's count / magnitude caps
+#                 (MAX_OUTLIERS, MAX_OUTLIER, two raw pixels' worth) are gone with MAX_SENS: nothing is excused by magnitude.
 
 
-def outlier_over(d, den_o):
-    """Mask of differences `d` that exceed the outlier bound: MAX_OUTLIER at accumulated weights >= DEN_FLOOR, NUM_ERR on
-    the numerator d x den below it."""
-    return np.where(den_o >= DEN_FLOOR, d > MAX_OUTLIER, d * den_o > NUM_ERR)
-
-
-def max_inj_outliers(scale):
-    """Identical flows on both sides: values > 1e-4 allowed per case (all where a frame is being rejected): two raw pixels'
-    worth.  Measured per case: <= 4 at scales 1 - 2, 18 and 22 at scale 3 (one raw pixel = 27 values), each <= 2.3e-3."""
-    return 2 * 3 * int(np.ceil(scale)) ** 2
-
-
-def same_flow_side(shape, scale, out, want, r_hip, r_or, den):
-    """HIP image `out` against the oracle image `want` computed from the SAME flow fields (either HIP's or the oracle's):
-    NaN pattern, robustness maps [n, H, W] (None with the robustness off), image differences split into those where every
-    frame is fully accepted (none may exceed 1e-4) and those where some frame is being rejected — r < 1 somewhere in the
-    5 x 5 raw-pixel neighbourhood (the merge reads r at its 3 x 3 taps): the only places where the r-sensitivity of the
-    normalisation can act."""
+def same_flow_side(shape, scale, out, want, r_hip, r_or, den, want_m=None, den_m=None):
+    """HIP image `out` against the oracle image `want` computed from the SAME flow fields (either HIP's or the oracle's),
+    and against `want_m`: the oracle's MERGE ALONE on the same flows and HIP's own robustness maps `r_hip` (None with the
+    robustness off: then want_m is want).  Robustness maps [n, H, W].  Returns the numbers of the side:
+      nan_mis, dr                       NaN pattern out vs want, max |r_hip - r_or|
+      n, max, outside, unexplained      values > 1e-4 vs want; those where every frame is fully accepted (r = 1 in the 5 x 5
+                                        raw-pixel neighbourhood on both sides: nothing may differ there); those where a frame
+                                        is being rejected that do NOT agree once HIP's r is injected
+      m_nan, m_n, m_max, m_over, m_q    merge alone: NaN mismatches, values > 1e-4, the largest, those whose numerator differs
+                                        by more than NUM_ERR, the largest |d out| x den among the values > 1e-4"""
     H, W = shape
+    if want_m is None:
+        want_m, den_m = want, den
     nan_mis = int((np.isnan(out) != np.isnan(want)).sum())
     dr = float(np.abs(r_hip - r_or).max()) if r_or is not None else 0.0
     with np.errstate(all="ignore"):  # NaN == NaN (the pattern is compared above), inf == inf; inf vs finite stays inf
         d = np.where(np.isnan(want) | (out == want), 0.0, np.abs(out.astype(np.float64) - want))
+        dm = np.where(np.isnan(want_m) | (out == want_m), 0.0, np.abs(out.astype(np.float64) - want_m))
     rej = np.zeros(out.shape[:2], bool)
     if r_or is not None:
         from scipy.ndimage import minimum_filter
 
-        low = minimum_filter(r_or.min(0), size=5, mode="nearest") < 0.999
+        low = minimum_filter(np.minimum(r_or.min(0), r_hip.min(0)), size=5, mode="nearest") < 0.999
         yy = np.minimum(((np.arange(out.shape[0]) + 0.5) / scale).astype(int), H - 1)
         xx = np.minimum(((np.arange(out.shape[1]) + 0.5) / scale).astype(int), W - 1)
         rej = low[np.ix_(yy, xx)]
-    bad = d > 1e-4
+    bad, bad_m = d > 1e-4, dm > 1e-4
+    with np.errstate(all="ignore"):
+        over_m = bad_m & ~(dm * den_m <= NUM_ERR)
     return dict(nan_mis=nan_mis, dr=dr, n=int(bad.sum()), max=float(d.max()), outside=int((bad & ~rej[..., None]).sum()),
-                # the same differences referred to the numerator: |d out| x den — what an absolute error of num of that size
-                # produces; large image differences at tiny den are the normalisation's conditioning, not arithmetic
-                q=float(np.where(bad, d * den, 0.0).max()), over=int((bad & outlier_over(d, den)).sum()))
+                unexplained=int((bad & rej[..., None] & over_m).sum()),
+                m_nan=int((np.isnan(out) != np.isnan(want_m)).sum()), m_n=int(bad_m.sum()), m_max=float(dm.max()),
+                m_over=int(over_m.sum()), m_q=float(np.where(bad_m, dm * den_m, 0.0).max()))
 
 
-def side_failures(tag, s, scale):
+def side_failures(tag, s):
     failed = []
-    if s["nan_mis"]:
-        failed.append(f"{tag}: {s['nan_mis']} NaN mismatches")
+    if s["nan_mis"] or s["m_nan"]:
+        failed.append(f"{tag}: {s['nan_mis']} / {s['m_nan']} NaN mismatches (whole chain / merge alone)")
     if not s["dr"] <= 1e-4:
         failed.append(f"{tag}: r {s['dr']:.2e}")
-    if not (s["n"] <= max_inj_outliers(scale) and s["over"] == 0 and s["outside"] == 0):
-        failed.append(f"{tag}: {s['n']} values above 1e-4 (max {s['max']:.2e}), {s['outside']} where every frame is accepted, "
-                      f"{s['over']} beyond the outlier bound")
+    if s["m_over"]:
+        failed.append(f"{tag}, merge on identical flows and robustness: {s['m_n']} values above 1e-4 (max {s['m_max']:.2e}), "
+                      f"{s['m_over']} with a numerator difference above {NUM_ERR:g} (max {s['m_q']:.2e})")
+    if s["outside"] or s["unexplained"]:
+        failed.append(f"{tag}: {s['n']} values above 1e-4 (max {s['max']:.2e}): {s['outside']} where every frame is accepted, "
+                      f"{s['unexplained']} where a frame is being rejected that HIP's robustness does not explain")
     return failed
 
 
@@ -261,22 +265,25 @@ def combine_verdict(scale, al, sh, so, info):
                       f"{FLIP_PX:g} px")
     if not al["dflow"] <= 1e-4:
         failed.append(f"flow {al['dflow']:.2e} px")
-    failed += side_failures("HIP's flows", sh, scale) + side_failures("oracle's flows", so, scale)
+    failed += side_failures("HIP's flows", sh) + side_failures("oracle's flows", so)
     return dict(al, side_h=sh, side_o=so, **info), failed
 
 
-def fuzz_verdict(shape, ts, scale, o, oi, want, want_h, gflow, oflow, hr, hr_i, o_r, o_r_h, den_o, den_h):
+def fuzz_verdict(shape, ts, scale, o, oi, want, want_h, gflow, oflow, hr, hr_i, o_r, o_r_h, den_o, den_h, want_hm=None,
+                 den_hm=None, want_om=None, den_om=None):
     """One case of the fuzz sweep, judged.  HIP outputs with its own flows `o` / with the oracle's flows injected `oi`;
     oracle outputs with its own flows `want` / with HIP's flows injected `want_h`; flows [n, ny, nx, 2]; robustness maps
     [n, H, W] of the two HIP runs (`hr`, `hr_i`) and of the two oracle runs (`o_r`: own flows, `o_r_h`: HIP's flows), None with
-    the robustness off; accumulated weights of the two oracle runs (`den_o`, `den_h`).  Returns (numbers, failed rules) —
-    the rules are spelled out in the docstring of tests/test_fuzz_parity.py:
+    the robustness off; accumulated weights of the two oracle runs (`den_o`, `den_h`); `want_hm` / `want_om` (+ weights): the
+    oracle's merge alone on HIP's flows + `hr` / on its own flows + `hr_i` (None: robustness off, the runs above).
+    Returns (numbers, failed rules) — the rules are spelled out above the constants and in the docstring of
+    tests/test_fuzz_parity.py:
       alignment   gflow vs oflow
-      side H      o  vs want_h, hr   vs o_r_h     (everything downstream of the alignment on HIP's flows)
-      side O      oi vs want,   hr_i vs o_r       (the same on the oracle's flows)
+      side H      o  vs want_h, hr   vs o_r_h, o  vs want_hm   (everything downstream of the alignment on HIP's flows)
+      side O      oi vs want,   hr_i vs o_r,   oi vs want_om   (the same on the oracle's flows)
     and, reported but NOT asserted (it is implied by the three): o vs want, next to |want_h - want| — how far the ORACLE's
     own image moves under the flow difference.  (The sweep evaluates the parts in its worker processes: same functions.)"""
     al, flipped = alignment_part(gflow, oflow)
-    sh = same_flow_side(shape, scale, o, want_h, hr, o_r_h, den_h)
-    so = same_flow_side(shape, scale, oi, want, hr_i, o_r, den_o)
+    sh = same_flow_side(shape, scale, o, want_h, hr, o_r_h, den_h, want_hm, den_hm)
+    so = same_flow_side(shape, scale, oi, want, hr_i, o_r, den_o, want_om, den_om)
     return combine_verdict(scale, al, sh, so, informational_part(shape, ts, scale, flipped, o, want, want_h))

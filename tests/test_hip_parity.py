@@ -2355,16 +2355,18 @@ def _spawn_big(tmp_path, world, *a):
 
 
 @pytest.mark.timeout(1500)
-@pytest.mark.parametrize("strategy", ["rows", "reduce"])
-def test_c3_full_size_two_ranks(tmp_path, strategy):
-    """BASELINE config C3 at FULL size — 3000 x 4000, 20 frames, x2 — through main_sharded with 2 ranks sharing the GPU
-    (gloo rendezvous; engine kept: eager, capture, replay): "rows" (pipelined stages, uneven slabs) equals main() bit for
-    bit on every slab, "reduce" within float32 summation order (2e-6)."""
+@pytest.mark.parametrize("world,strategy", [(2, "rows"), (2, "reduce"), (8, "rows"), (8, "reduce")])
+def test_c3_full_size_sharded(tmp_path, world, strategy):
+    """BASELINE config C3 at FULL size — 3000 x 4000, 20 frames, x2 — through main_sharded with 2 and with 8 ranks (the rank
+    count C3 names: 19 comp frames -> 3, 3, 3, 2, 2, 2, 2, 2; round 5) sharing the GPU (gloo rendezvous; engine kept: eager,
+    capture, replay): "rows" (uneven slabs on the x2 tile grid) equals main() bit for bit on every slab, "reduce" within
+    float32 summation order (2e-6)."""
     H, W, nf = 3000, 4000, 20
-    recs = _spawn_big(tmp_path, 2, H, W, nf, 2, strategy, strategy == "reduce")
+    recs = _spawn_big(tmp_path, world, H, W, nf, 2, strategy, strategy == "reduce")
     ref, comp, _ = synth.make_burst_torch(H, W, nf, DEV, seed=1234)
     want, _ = hsr.main(ref, comp, _big_cfg(2))
-    assert recs[0]["rows"][0] == 0 and recs[-1]["rows"][1] == 2 * H and recs[0]["rows"][1] == recs[1]["rows"][0]
+    assert recs[0]["rows"][0] == 0 and recs[-1]["rows"][1] == 2 * H
+    assert all(recs[r]["rows"][1] == recs[r + 1]["rows"][0] and recs[r]["rows"][1] > recs[r]["rows"][0] for r in range(world - 1))
     for r, rec in enumerate(recs):
         r0, r1 = rec["rows"]
         if strategy == "rows":
@@ -2379,11 +2381,13 @@ def test_c3_full_size_two_ranks(tmp_path, strategy):
 
 
 @pytest.mark.timeout(1800)
-def test_c5_geometry_two_ranks(tmp_path):
-    """BASELINE config C5's geometry — 6000 x 8000, x3 -> 18000 x 24000 — with 7 frames through main_sharded("rows") on 2
-    ranks sharing the GPU: every slab bitwise equal to main() (checksums of the bit patterns: a slab is 2.6 GB)."""
-    H, W, nf = 6000, 8000, 7
-    recs = _spawn_big(tmp_path, 2, H, W, nf, 3, "rows", False)
+@pytest.mark.parametrize("world,nf", [(2, 7), (8, 20)])
+def test_c5_geometry_sharded(tmp_path, world, nf):
+    """BASELINE config C5's geometry — 6000 x 8000, x3 -> 18000 x 24000 — through main_sharded("rows"): 7 frames on 2 ranks,
+    and (round 5) C5 ITSELF — 20 frames on 8 ranks — all sharing the one GPU: every slab bitwise equal to main()
+    (checksums of the bit patterns: a slab is 0.65 - 2.6 GB)."""
+    H, W = 6000, 8000
+    recs = _spawn_big(tmp_path, world, H, W, nf, 3, "rows", False)
     ref, comp, _ = synth.make_burst_torch(H, W, nf, DEV, seed=1234)
     want, _ = hsr.main(ref, comp, _big_cfg(3))
     assert recs[0]["rows"][0] == 0 and recs[-1]["rows"][1] == 3 * H

@@ -115,7 +115,8 @@ def main():
                     def only_a():
                         plan.s_a.wait_stream(torch.cuda.current_stream())
                         with torch.cuda.stream(plan.s_a):
-                            plan.g_ref_a.replay()
+                            if plan.g_ref_a is not None:  # (else: inside the first stage's graph)
+                                plan.g_ref_a.replay()
                             for g in plan.g_a:
                                 if g is not None:
                                     g.replay()

@@ -10,11 +10,26 @@ import handheld_super_resolution as hsr
 gs, k = int(sys.argv[1]), int(sys.argv[2])
 c = fz.cases(gs, k + 1)[k]
 print("case", c)
-ref, comp, o_own, gflow, hr_own = fz.hip_own(c)
-want, want_h, oflow, o_r, o_r_h, den_o, den_h = fz._oracle_case(c, gflow)
+import oracle
+ref, comp = fz.burst(c)
+ref, comp, o_own, gflow, hr_own = fz.hip_own(c, ref, comp)
+cap, cap_h, cap_m = {}, {}, {}
+want, _ = oracle.main(ref, comp, fz.config(c), capture=cap, fast=True)
+want_h, _ = oracle.main(ref, comp, fz.config(c), capture=cap_h, fast=True, flows=list(gflow), reuse=cap)
+oflow, o_r, den_o = np.stack(cap["flow"]), (np.stack(cap["r"]) if c["rob"] else None), cap["den"]
 dh = np.where(np.isnan(want_h), 0.0, np.abs(o_own.astype(np.float64) - want_h))
 print(f"side H (HIP's flows): max |o - want_h| = {dh.max():.3e} ({int((dh > 1e-4).sum())} > 1e-4); oracle's own move under HIP's "
       f"flows max |want_h - want| = {np.nanmax(np.abs(want_h.astype(np.float64) - want)):.3e}; max |flow diff| = {np.abs(gflow - oflow).max():.3e} px")
+if c["rob"]:
+    want_m, _ = oracle.main(ref, comp, fz.config(c), capture=cap_m, fast=True, flows=list(gflow), rob=list(hr_own), reuse=cap)
+    dm = np.where(np.isnan(want_m), 0.0, np.abs(o_own.astype(np.float64) - want_m))
+    print(f"merge alone (HIP's flows and HIP's robustness): max |o - want_hm| = {dm.max():.3e} ({int((dm > 1e-4).sum())} > 1e-4); "
+          f"max |r_hip - r_oracle(HIP's flows)| = {np.abs(hr_own - np.stack(cap_h['r'])).max():.3e}")
+    for (y, x, ch) in np.argwhere(dh > 1e-4)[:6]:
+        ly, lx = int((y + 0.5) / c["scale"]), int((x + 0.5) / c["scale"])
+        print(f"   HR ({y}, {x}) ch {ch}: hip {o_own[y, x, ch]:.6f} oracle(HIP flows) {want_h[y, x, ch]:.6f} oracle(HIP flows + r) "
+              f"{want_m[y, x, ch]:.6f}; sum of r at LR ({ly}, {lx}): hip {hr_own[:, ly, lx].astype(np.float64).sum():.9f} oracle "
+              f"{np.stack(cap_h['r'])[:, ly, lx].astype(np.float64).sum():.9f}")
 cfg = fz.config(c, inject_flows=[f for f in oflow])
 cfg.debug = True
 out, dbg = hsr.main(ref, comp, cfg)

@@ -1,35 +1,65 @@
-"""Summary of a tests/test_fuzz_parity.py report run for PARITY.md.
-    HHSR_FUZZ_REPORT=/tmp/fuzz.txt python -m pytest tests/test_fuzz_parity.py -m gpu -q      # on an MI355X
-    python tools/fuzz_report.py /tmp/fuzz.txt >> PARITY.md"""
+"""Summary of a tests/test_fuzz_parity.py report run (two-sided contract, round 5) for PARITY.md.
+    bash tools/fuzz_final.sh <commit> gpurun_out/r05_fuzz_final.txt <new seeds...>       # on an MI355X
+    python tools/fuzz_report.py profiles/r05_fuzz_final.txt >> PARITY.md"""
 import re
 import sys
 
-rows = []
+SIDE = (r"\[nan (\d+), r (\S+), image max (\S+) \((\d+) > 1e-4, (\d+) outside rejecting regions, (\d+) not explained by r\); "
+        r"merge alone: nan (\d+), max (\S+) \((\d+) > 1e-4, (\d+) with numerator > \S+, x den max (\S+)\)\]")
+RX = re.compile(r"case (\S+) \((.*?)\): flipped (\d+)( \(NOT one cluster\))?, ica (\d+), flow (\S+); HIP's flows " + SIDE +
+                r"; oracle's flows " + SIDE + r"; own vs own outside deviating tiles: (\d+) > 1e-4 \(max (\S+)\), oracle's own "
+                r"move under HIP's flows: (\d+) \(max (\S+)\)")
+
+
+def side(g):
+    return dict(nan=int(g[0]), r=float(g[1]), max=float(g[2]), n=int(g[3]), outside=int(g[4]), unexpl=int(g[5]),
+                m_nan=int(g[6]), m_max=float(g[7]), m_n=int(g[8]), m_over=int(g[9]), m_q=float(g[10]))
+
+
+rows, header, failed = [], [], []
 for line in open(sys.argv[1]):
-    m = re.match(r"case (\S+) \((.*?)\): flipped (\d+)(?: \(NOT one cluster\))?,(?: ica (\d+),)? nan (\d+), flow (\S+), r (\S+) / injected (\S+); injected image max (\S+) "
-                 r"\((\d+) > 1e-4, (\d+) outside rejecting regions\); own flows: flow-sensitive (\d+) \(max (\S+)\), other (\d+) "
-                 r"\(max (\S+), (\d+) outside", line)
+    if line.startswith("#"):
+        header.append(line.rstrip())
+        continue
+    m = RX.match(line)
     if m:
         g = m.groups()
-        rows.append(dict(id=g[0], desc=g[1], flipped=int(g[2]), ica=int(g[3] or 0), nan=int(g[4]), flow=float(g[5].rstrip(",")),
-                         r=float(g[6]), r_inj=float(g[7]), inj=float(g[8]), n_inj=int(g[9]), sens=int(g[11]),
-                         sens_max=float(g[12]), other=int(g[13]), other_max=float(g[14])))
+        rows.append(dict(id=g[0], desc=g[1], flipped=int(g[2]), clusters_ok=g[3] is None, ica=int(g[4]), flow=float(g[5]),
+                         h=side(g[6:17]), o=side(g[17:28]), n_own=int(g[28]), own_max=float(g[29]), n_orc=int(g[30]),
+                         orc_max=float(g[31])))
+        if "ASSERTIONS FAILED" in line:
+            failed.append(line[line.index("ASSERTIONS FAILED"):].rstrip())
 n = len(rows)
-print(f"\n## Randomised end-to-end sweep (tests/test_fuzz_parity.py, {n} cases, HIP main() vs oracle.main())\n")
-print(f"* NaN pattern mismatches: {sum(r['nan'] for r in rows)}; tiles that follow another block-matching decision (flow differs by > 1e-3 px): "
-      f"{sum(r['flipped'] for r in rows)} (in case{'s' if sum(1 for r in rows if r['flipped']) != 1 else ''} "
-      f"{', '.join(r['id'] for r in rows if r['flipped']) or '-'})")
-print(f"* tiles whose flow differs by 1e-4 ... 1e-3 px (ill-conditioned ICA): {sum(r['ica'] for r in rows)} "
-      f"(in case{'s' if sum(1 for r in rows if r['ica']) != 1 else ''} {', '.join(r['id'] for r in rows if r['ica']) or '-'})")
-print(f"* flow, all other tiles: max {max(r['flow'] for r in rows):.1e} px (asserted 1e-4); robustness r: max "
-      f"{max(r['r'] for r in rows):.1e} own flows / {max(r['r_inj'] for r in rows):.1e} oracle flows injected (asserted 1e-4)")
-clean = [r for r in rows if r["n_inj"] == 0]
-print(f"* image, oracle flows injected: {len(clean)} cases <= {max(r['inj'] for r in clean):.2e}; "
-      + "; ".join(f"case {r['id']}: {r['n_inj']} values > 1e-4, max {r['inj']:.2e}" for r in rows if r["n_inj"]))
-print("* image, own flows, outside the footprint of the flipped tile: "
-      f"{sum(1 for r in rows if r['sens'] == 0 and r['other'] == 0)} cases <= 1e-4; flow-sensitive values (agree once the "
-      "flows are the oracle's): "
-      + "; ".join(f"case {r['id']} ({r['desc']}): {r['sens']} values, max {r['sens_max']:.1e}" for r in rows if r["sens"])
-      + "; other values > 1e-4: " + ("; ".join(f"case {r['id']}: {r['other']}, max {r['other_max']:.1e}" for r in rows if r["other"]) or "none"))
-nfail = sum(1 for line in open(sys.argv[1]) if "ASSERTIONS FAILED" in line)
-print(f"* cases violating an assertion of the test: {nfail}")
+print(f"\n## Randomised end-to-end sweep, TWO-SIDED contract (tests/test_fuzz_parity.py, {n} cases: {sys.argv[1]})\n")
+for h in header[:4]:
+    print("    " + h)
+print()
+fl = [r for r in rows if r["flipped"]]
+print(f"* alignment: tiles that follow another block-matching decision (flow differs by > 1e-3 px): {sum(r['flipped'] for r in rows)} in "
+      f"{len(fl)} cases ({', '.join(r['id'] for r in fl) or '-'}); tiles between 1e-4 and 1e-3 px (ill-conditioned ICA): "
+      f"{sum(r['ica'] for r in rows)} (cases {', '.join(r['id'] for r in rows if r['ica']) or '-'}); every other tile: max "
+      f"{max(r['flow'] for r in rows):.1e} px (asserted 1e-4)")
+for key, name in (("h", "side H — HIP, own flows, vs the ORACLE RUN ON HIP'S FLOWS"), ("o", "side O — HIP on the oracle's flows vs the oracle")):
+    s = [r[key] for r in rows]
+    clean = [x for x in s if x["n"] == 0]
+    dirty = [(r["id"], r[key]) for r in rows if r[key]["n"]]
+    mdirty = [(r["id"], r[key]) for r in rows if r[key]["m_n"]]
+    print(f"* {name}: NaN-pattern mismatches {sum(x['nan'] for x in s)} (whole chain) / {sum(x['m_nan'] for x in s)} (merge alone); "
+          f"robustness r max {max(x['r'] for x in s):.1e} (asserted 1e-4); MERGE ALONE (identical flows and robustness): "
+          f"{len(s) - len(mdirty)} cases <= {max(x['m_max'] for x in s if x['m_n'] == 0):.2e} everywhere, {len(mdirty)} cases with "
+          f"values > 1e-4 ({sum(x['m_over'] for x in s)} of them with a numerator difference above the bound; largest |d out| x den "
+          f"{max(x['m_q'] for x in s):.2e}): " + ("; ".join(f"{i}: {x['m_n']} (max {x['m_max']:.2e})" for i, x in mdirty) or "-")
+          + f"; WHOLE CHAIN on identical flows: {len(clean)} cases <= {max(x['max'] for x in clean):.2e} everywhere; {len(dirty)} cases "
+          f"with values > 1e-4 — {sum(x['outside'] for x in s)} where every frame is accepted, {sum(x['unexpl'] for x in s)} not "
+          f"explained by the robustness difference: " + ("; ".join(f"{i}: {x['n']} (max {x['max']:.2e})" for i, x in dirty) or "-"))
+own = [r for r in rows if r["n_own"] or r["n_orc"]]
+print(f"* what a one-sided comparison shows (reported, not asserted): in {len(own)} cases HIP's own-flow image differs from the "
+      f"oracle's own-flow image by > 1e-4 outside the footprint of deviating tiles — and in every one of them the ORACLE's own "
+      f"image moves by the same amount when it is given HIP's flows: "
+      + ("; ".join(f"{r['id']}: {r['n_own']} values, max {r['own_max']:.1e} (oracle moves {r['n_orc']}, max {r['orc_max']:.1e})"
+                   for r in sorted(own, key=lambda r: -r['own_max'])[:24]) or "-") + (" ..." if len(own) > 24 else ""))
+print(f"* largest own-vs-own difference of the sweep: {max(r['own_max'] for r in rows):.3g} — reproduced by the oracle on HIP's flows "
+      f"to {max((r['h']['max'] for r in rows if r['own_max'] == max(x['own_max'] for x in rows)), default=0):.1e}")
+print(f"* cases violating an assertion of the test: {len(failed)}")
+for f in failed:
+    print("    " + f[:600])
