@@ -698,30 +698,26 @@ struct RobGroup {
 
 // (no occupancy bound: held to 64 VGPRs — 8 waves per SIMD — the kernel spills and takes 505 instead of 222 us per launch;
 // held to 80: 423 us.  The compiler's own choice is 56 VGPRs.)
-//
-// WAVE (round 5): a wave owns ONE 16 x 16 sub-tile — lane = (row of the sub-tile, 4-pixel group) — so the guide window it
-// stages is read back by the same wave only: the two workgroup barriers per frame become wave-level fences and the window
-// is double-buffered in LDS (frame fr + 1 is stored while nothing else waits for it).  The per-wave counters of round 4
-// had 54 % of the wave time parked at those barriers with the VALU 78 % busy.  Same arithmetic per pixel: bit-identical
-// to the workgroup-barrier mapping (WAVE = false: a row of the 32 x 32 block per 8 threads; kept for the A/B).
-template <bool WAVE>
+// Measured without gain (round 5, after round 4's counters showed 54 % of the wave time parked with the VALU 78 % busy): a
+// wave-private mapping — wave = one 16 x 16 sub-tile, lane = (row, 4-pixel group), the guide window double-buffered in LDS,
+// the two workgroup barriers per frame replaced by wave-level fences: 218.7 against 218.5 us per 4-frame launch at 12 MP
+// (60 against 56 VGPRs, 14.2 against 7.4 KB of LDS; bit-identical).  The waves do not wait for each other at those
+// barriers; what they wait for is their own dependent chains (27 taps x 4 pixels of FMAs behind 72 LDS reads, 12 v_rcp_f32,
+// 4 v_exp_f32 per thread and frame) — the kernel is at ~6 cycles per VALU instruction like the other tap kernels.
 __global__ void __launch_bounds__(256) k_rob_frames_row4(RobGroup gq, int lh, int lw, const float* __restrict__ rmean,
                                                           const float* __restrict__ ssq,
                                                           const uint32_t* __restrict__ cidx, int ny, int nx, int ts,
                                                           const double* __restrict__ difc, double t, int H, int W,
                                                           double Mt2, float s1, float s2, int rows_lo, int rows_hi) {
-    __shared__ float s_g[WAVE ? 2 : 1][2][2][3][RF_WN][RF_WN + 2];
+    __shared__ float s_g[2][2][3][RF_WN][RF_WN + 2];
     __shared__ float4 s_tab[ROB_GROUP][2][2][2];  // per (frame, sub-tile): flow split, window origin, S — see below
-    // WAVE: wave w = sub-tile (grp = w & 1, v = w >> 1), lane = 4 * row + group; else 8 threads x 4 pixels per row, 32 rows
-    const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int lx4 = WAVE ? 4 * (wv & 1) + (lane & 3) : threadIdx.x & 7;
-    const int ly_ = WAVE ? 16 * (wv >> 1) + (lane >> 2) : threadIdx.x >> 3;
+    const int lx4 = threadIdx.x & 7, ly_ = threadIdx.x >> 3;  // 8 threads x 4 pixels per row, 32 rows
     const int grp = lx4 >> 2, v = ly_ >> 4;                   // the thread's 16 x 16 sub-tile
     const int bid = xcd_remap(blockIdx.y * gridDim.x + blockIdx.x, gridDim.x * gridDim.y);  // bands of tile rows per XCD
     const int bxi = bid % gridDim.x, byi = bid / gridDim.x;
     const int x0 = bxi * RF_BX + 4 * lx4, y = byi * RF_BY + ly_;
     const size_t gplane = (size_t)lh * lw, plane = (size_t)H * W;
-    const int tg = (ly_ & (RF_T - 1)) * 4 + (lx4 & 3);  // 0..63 within the sub-tile (WAVE: the lane)
+    const int tg = (ly_ & (RF_T - 1)) * 4 + (lx4 & 3);  // 0..63 within the sub-tile
     constexpr int WSZ = 3 * RF_WN * RF_WN, NST = (WSZ + 63) / 64;
     const bool live = x0 < W && y < H;
     const size_t o = live ? (size_t)y * W + x0 : 0;
@@ -802,27 +798,7 @@ __global__ void __launch_bounds__(256) k_rob_frames_row4(RobGroup gq, int lh, in
             }
         }
     };
-    auto store = [&](int buf) {
-#pragma unroll
-        for (int u = 0; u < NST; ++u) {
-            const int p = tg + 64 * u;
-            if (p < WSZ) {
-                const int c = p / (RF_WN * RF_WN), q = p - c * (RF_WN * RF_WN);
-                const int i = q / RF_WN, j = q - i * RF_WN;
-                s_g[buf][grp][v][c][i][j] = st[u];
-            }
-        }
-    };
-    auto wave_sync = [] {  // LDS writes of this wave's lanes -> visible to its lanes (the window is wave-private)
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    };
     if (gq.n > 0) fetch(0);
-    if (WAVE && gq.n > 0) {
-        store(0);
-        wave_sync();
-    }
     for (int fr = 0; fr < gq.n; ++fr) {
         const float4 t0 = s_tab[fr][v][grp][0], t1 = s_tab[fr][v][grp][1];
         const int flags = __float_as_int(t0.w);
@@ -831,22 +807,22 @@ __global__ void __launch_bounds__(256) k_rob_frames_row4(RobGroup gq, int lh, in
         ax.fi = __float_as_int(t1.x); ax.h = t1.y; ax.lt = flags & 8; ax.eq = flags & 16; ax.ok = flags & 32;
         const int wy0 = __float_as_int(t0.z), wx0 = __float_as_int(t1.z);
         const float Sv = t1.w;
-        const int buf = WAVE ? fr & 1 : 0;
-        if (!WAVE) {
-            if (fr) __syncthreads();  // the previous frame's taps are done with the window
-            store(0);
-            __syncthreads();
+        if (fr) __syncthreads();  // the previous frame's taps are done with the window
+#pragma unroll
+        for (int u = 0; u < NST; ++u) {
+            const int p = tg + 64 * u;
+            if (p < WSZ) {
+                const int c = p / (RF_WN * RF_WN), q = p - c * (RF_WN * RF_WN);
+                const int i = q / RF_WN, j = q - i * RF_WN;
+                s_g[grp][v][c][i][j] = st[u];
+            }
         }
+        __syncthreads();
         if (fr + 1 < gq.n) fetch(fr + 1);
-        if (live) {
-            float out[4];
-            rob_row4(s_g[buf][grp][v], ay, ax, wy0, wx0, y, x0, lh, lw, rbk, d_t2, iss, Sv, (float)t, out);
-            *reinterpret_cast<float4*>(gq.R[fr] + o) = make_float4(out[0], out[1], out[2], out[3]);
-        }
-        if (WAVE && fr + 1 < gq.n) {  // (the other buffer: frame fr - 1's taps were finished before frame fr's began)
-            store(buf ^ 1);
-            wave_sync();
-        }
+        if (!live) continue;
+        float out[4];
+        rob_row4(s_g[grp][v], ay, ax, wy0, wx0, y, x0, lh, lw, rbk, d_t2, iss, Sv, (float)t, out);
+        *reinterpret_cast<float4*>(gq.R[fr] + o) = make_float4(out[0], out[1], out[2], out[3]);
     }
 }
 
@@ -912,15 +888,9 @@ extern "C" int hhsr_rob_frames(const float* const* comp_means, int n_frames, int
             g.S[k] = S ? S[n] : nullptr;
             g.R[k] = R[n];
         }
-        static const bool wave = getenv("HHSR_ROB_WAVE") != nullptr;  // A/B switch, read once (round 5: being measured)
-        if (!wave)
-            hipLaunchKernelGGL(k_rob_frames_row4<false>, dim3(hhsr_cdiv(W, RF_BX), hhsr_cdiv(H, RF_BY)), dim3(256), 0,
-                               (hipStream_t)stream, g, lh, lw, ref_means, ref_sigma_sq, ref_curve_index, ny, nx, ts, diff_curve, t,
-                               H, W, Mt * Mt, s1, s2, flow_rows_before, flow_rows_after);
-        else
-            hipLaunchKernelGGL(k_rob_frames_row4<true>, dim3(hhsr_cdiv(W, RF_BX), hhsr_cdiv(H, RF_BY)), dim3(256), 0,
-                               (hipStream_t)stream, g, lh, lw, ref_means, ref_sigma_sq, ref_curve_index, ny, nx, ts, diff_curve, t,
-                               H, W, Mt * Mt, s1, s2, flow_rows_before, flow_rows_after);
+        hipLaunchKernelGGL(k_rob_frames_row4, dim3(hhsr_cdiv(W, RF_BX), hhsr_cdiv(H, RF_BY)), dim3(256), 0,
+                           (hipStream_t)stream, g, lh, lw, ref_means, ref_sigma_sq, ref_curve_index, ny, nx, ts, diff_curve, t,
+                           H, W, Mt * Mt, s1, s2, flow_rows_before, flow_rows_after);
     }
     HHSR_LAUNCHED();
 }
