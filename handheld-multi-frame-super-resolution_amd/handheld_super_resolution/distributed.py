@@ -580,7 +580,7 @@ class RowsPlan:
 
     def __init__(self, eng, ref, comp_imgs, stages, rank, world, rows, bound, check, key):
         from . import _lib
-        from .graph import shared_streams
+        from .graph import shared_streams, capture
         from .super_resolution import BurstPipeline, _stream_pool
         from .utils_image import _grey_plan, _grey_plans
 
@@ -610,7 +610,6 @@ class RowsPlan:
                     with torch.cuda.stream(st):
                         _grey_plan(H, W, dev, _lib.MAX_BATCH)
             torch.cuda.synchronize(dev)
-            mode = dict(capture_error_mode="thread_local")
             # Round 5: the reference alignment state and step A of the rank's first stage are ONE graph — the frames' own
             # grey images and pyramids (side streams forked at the start of the reference precompute,
             # BurstPipeline._on_streams) run next to the single-frame, latency-bound reference kernels instead of behind
@@ -623,7 +622,7 @@ class RowsPlan:
             self.g_ref_a = None
             if not fuse_ref:
                 self.g_ref_a = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(self.g_ref_a, stream=self.s_a, **mode):
+                with capture(self.g_ref_a, self.s_a):
                     pipe.init_ref(ref, robustness=False)
             ny, nx = ny_nx
             self.local, self.gath, self.g_a = [], [], []
@@ -635,7 +634,7 @@ class RowsPlan:
                 g = None
                 if mine:
                     g = torch.cuda.CUDAGraph()
-                    with torch.cuda.graph(g, stream=self.s_a, **mode):
+                    with capture(g, self.s_a):
                         if k == 0 and fuse_ref:
                             pipe.ref_wait = True
                             pipe.init_ref(ref, robustness=False)
@@ -646,19 +645,19 @@ class RowsPlan:
             self.flag = torch.zeros((1,), dtype=torch.bool, device=dev)
             self.flag_host = torch.zeros((1,), dtype=torch.bool).pin_memory()
             self.g_ref_b = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(self.g_ref_b, stream=self.s_b, **mode):
+            with capture(self.g_ref_b, self.s_b):
                 self.flag.zero_()
                 work = self.work = SlabWork(eng, ref, r0, r1, self.bound, ny, ref_wait=False)
             self.g_b = []
             for st, gat in zip(stages, self.gath):
                 fr = stage_frames(st, n, G)
                 g = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(g, stream=self.s_b, **mode):
+                with capture(g, self.s_b):
                     self.flag.logical_or_(~(gat[..., 1].abs().amax() <= self.bound))
                     work.front([comps[i] for i in fr], [gat[i % G, i // G - st[0]] for i in fr])
                 self.g_b.append(g)
             self.g_fin = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(self.g_fin, stream=self.s_b, **mode):
+            with capture(self.g_fin, self.s_b):
                 self.out, self.acc_r = work.finish()
             self.e_flag = torch.cuda.Event()
             self.plans = list(_grey_plans.values())  # the graphs hold the FFT plans' spectrum buffers: keep them alive

@@ -13,6 +13,9 @@ per configuration.  The first call with a new key runs eagerly (it also creates 
 tables, which allocate), the second captures, every later one replays.  Outputs are static tensors of the graph's memory
 pool: valid until the next call with the same inputs.
 """
+import contextlib
+import gc
+
 import torch
 
 
@@ -42,6 +45,24 @@ def shared_streams(device):
 
 def _key(tensors):
     return tuple((t.data_ptr(), tuple(t.shape), t.dtype) for t in tensors)
+
+
+@contextlib.contextmanager
+def capture(graph, stream):
+    """torch.cuda.graph(graph, stream=...) with the cyclic garbage collector held off while the stream is capturing.
+    torch collects once before the capture begins; a collection that an allocation triggers DURING the capture can
+    finalise HIP objects of dropped plans / runners that sat in reference cycles (hipGraphDestroy and friends are not
+    permitted while a stream of the thread is capturing: the runtime aborts the process — seen as "Fatal Python error:
+    Aborted ... Garbage-collecting" in the middle of a RowsPlan capture).  What became garbage meanwhile is collected
+    after the capture."""
+    was = gc.isenabled()
+    gc.disable()
+    try:
+        with torch.cuda.graph(graph, stream=stream, capture_error_mode="thread_local"):
+            yield
+    finally:
+        if was:
+            gc.enable()
 
 
 class GraphRunner:
@@ -94,7 +115,7 @@ class GraphRunner:
         try:
             # thread_local: only this thread's calls are checked — the RCCL watchdog thread of a multi-GPU job queries
             # events while we capture
-            with torch.cuda.graph(graph, stream=self.stream, capture_error_mode="thread_local"):
+            with capture(graph, self.stream):
                 out = self.fn(*tensors)
         except Exception as e:  # not capturable in this configuration: stay eager
             self.disabled = True
@@ -283,7 +304,7 @@ class HostBurstRunner:
             pipe = st.pipe = BurstPipeline(cfg, dev)
             staged = [_Staged(st.stage[i], None) for i in range(n + 1)]
             st.g_ref = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(st.g_ref, stream=st.main, capture_error_mode="thread_local"):
+            with capture(st.g_ref, st.main):
                 pipe.init_ref(staged[0])
             sH, sW = pipe.output_size()
             fuse_acc = accumulate_r and can_fuse_acc_r(cfg)
@@ -319,7 +340,7 @@ class HostBurstRunner:
             st.g_chunks, results = [], []
             for idx, s in zip(st.chunks, st.streams):
                 g = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(g, stream=s, capture_error_mode="thread_local"):
+                with capture(g, s):
                     fronts = pipe._front_chunk([staged[1 + i] for i in idx], None, idx, None)
                     results.append(pipe._robustness(fronts, None, fuse_min))
                 st.g_chunks.append(g)
@@ -353,13 +374,13 @@ class HostBurstRunner:
                 prev = 0
                 for c, done in st.links:
                     g = torch.cuda.CUDAGraph()
-                    with torch.cuda.graph(g, stream=st.main, capture_error_mode="thread_local"):
+                    with capture(g, st.main):
                         merge_burst_chain(st.frames[:done], prev, pipe.ref, pipe.ref_covs, st.num, pipe.cfa, cfg, st.cls, False,
                                           local_min=fuse_min)
                     st.g_links.append(g)
                     prev = done
             st.g_merge = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(st.g_merge, stream=st.main, capture_error_mode="thread_local"):
+            with capture(st.g_merge, st.main):
                 if st.chain:
                     merge_burst_chain(st.frames, st.links[-1][1], pipe.ref, pipe.ref_covs, st.num, pipe.cfa, cfg, st.cls, True,
                                       acc_r=acc_r, local_min=fuse_min)

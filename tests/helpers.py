@@ -165,16 +165,14 @@ FLIP_PX = 1e-3          # flow difference that marks a tile as following another
 MAX_ICA_TILES = 16      # tiles per case with a flow difference between 1e-4 and FLIP_PX (measured: <= 10, in 3 of 768 cases)
 CLUSTER = 8             # tiles per side of the finest-level tiles under one level-2 tile of the default pyramid
 MAX_FLIP_TILES = 16     # finest-level tiles per case under the ONE flipped decision (measured: 1, or a 2 x 2 block)
-NUM_ERR = 1e-6          # identical flows AND identical robustness: a value may differ by more than 1e-4 only where its
-                        # accumulated weight den is so small that the NUMERATOR differs by <= NUM_ERR (|d out| x den): the
-                        # conditioning of a quotient of two numbers near zero, not arithmetic
 # ---- Round 5: the contract is STAGE BY STAGE ON IDENTICAL INPUTS, in both directions.  Round 4's rules
 # compared HIP's own-flow image with the oracle's own-flow image and excused "flow-sensitive" values (agree once the oracle's
 # flows are injected into HIP) up to a cap, MAX_SENS = 0.15 — violated at 0.177, 0.187 and 0.671 on held-out seeds.  Now
 #   alignment     HIP's flows vs the oracle's flows                                            (<= 1e-4 px off flipped tiles)
 #   robustness    on IDENTICAL flows (HIP's: side H; the oracle's: side O): r                  (<= 1e-4)
 #   merge         on IDENTICAL flows AND IDENTICAL robustness maps (HIP's r injected into the oracle, oracle.main(rob=...)):
-#                 image <= 1e-4 / NUM_ERR on the numerator, identical NaN pattern              (no region, count or size excuse)
+#                 image <= 1e-4 EVERYWHERE, identical NaN pattern                              (no region, count, size or
+#                 small-weight excuse: measured <= 1.9e-5 over 448 cases incl. the value whose accumulated weight is 3.4e-7)
 #   whole chain   on identical flows (o vs want_h, oi vs want): <= 1e-4 wherever every frame is accepted; where a frame is
 #                 being rejected a value may exceed 1e-4 only if the merge comparison above shows it to be the effect of the
 #                 <= 1e-4 by which r differs (it agrees once HIP's r is injected) — round 4's count / magnitude caps
@@ -189,8 +187,7 @@ def same_flow_side(shape, scale, out, want, r_hip, r_or, den, want_m=None, den_m
       n, max, outside, unexplained      values > 1e-4 vs want; those where every frame is fully accepted (r = 1 in the 5 x 5
                                         raw-pixel neighbourhood on both sides: nothing may differ there); those where a frame
                                         is being rejected that do NOT agree once HIP's r is injected
-      m_nan, m_n, m_max, m_over, m_q    merge alone: NaN mismatches, values > 1e-4, the largest, those whose numerator differs
-                                        by more than NUM_ERR, the largest |d out| x den among the values > 1e-4"""
+      m_nan, m_n, m_max                 merge alone: NaN mismatches, values > 1e-4 (none allowed), the largest difference"""
     H, W = shape
     if want_m is None:
         want_m, den_m = want, den
@@ -208,12 +205,9 @@ def same_flow_side(shape, scale, out, want, r_hip, r_or, den, want_m=None, den_m
         xx = np.minimum(((np.arange(out.shape[1]) + 0.5) / scale).astype(int), W - 1)
         rej = low[np.ix_(yy, xx)]
     bad, bad_m = d > 1e-4, dm > 1e-4
-    with np.errstate(all="ignore"):
-        over_m = bad_m & ~(dm * den_m <= NUM_ERR)
     return dict(nan_mis=nan_mis, dr=dr, n=int(bad.sum()), max=float(d.max()), outside=int((bad & ~rej[..., None]).sum()),
-                unexplained=int((bad & rej[..., None] & over_m).sum()),
-                m_nan=int((np.isnan(out) != np.isnan(want_m)).sum()), m_n=int(bad_m.sum()), m_max=float(dm.max()),
-                m_over=int(over_m.sum()), m_q=float(np.where(bad_m, dm * den_m, 0.0).max()))
+                unexplained=int((bad & rej[..., None] & bad_m).sum()),
+                m_nan=int((np.isnan(out) != np.isnan(want_m)).sum()), m_n=int(bad_m.sum()), m_max=float(dm.max()))
 
 
 def side_failures(tag, s):
@@ -222,9 +216,8 @@ def side_failures(tag, s):
         failed.append(f"{tag}: {s['nan_mis']} / {s['m_nan']} NaN mismatches (whole chain / merge alone)")
     if not s["dr"] <= 1e-4:
         failed.append(f"{tag}: r {s['dr']:.2e}")
-    if s["m_over"]:
-        failed.append(f"{tag}, merge on identical flows and robustness: {s['m_n']} values above 1e-4 (max {s['m_max']:.2e}), "
-                      f"{s['m_over']} with a numerator difference above {NUM_ERR:g} (max {s['m_q']:.2e})")
+    if s["m_n"]:
+        failed.append(f"{tag}, merge on identical flows and robustness: {s['m_n']} values above 1e-4 (max {s['m_max']:.2e})")
     if s["outside"] or s["unexplained"]:
         failed.append(f"{tag}: {s['n']} values above 1e-4 (max {s['max']:.2e}): {s['outside']} where every frame is accepted, "
                       f"{s['unexplained']} where a frame is being rejected that HIP's robustness does not explain")

@@ -16,7 +16,7 @@ for g in $OLD $NEW; do B="$B,$g:22,$((g+1)):22,$((g+2)):20"; done
 {
   echo "# two-sided fuzz contract: commit $COMMIT, rules sha256[:16] (tests/helpers.py + tests/test_fuzz_parity.py) $RULES"
   echo "# sets: fixed 0-2 | run in earlier rounds: $OLD | NEW, never run before: ${NEW:-none}"
-  echo "# constants: $(grep -E '^(FLIP_PX|MAX_ICA_TILES|CLUSTER|NUM_ERR|MAX_FLIP_TILES) =' tests/helpers.py | sed 's/ *#.*//' | tr '\n' ';')"
+  echo "# constants: $(grep -E '^(FLIP_PX|MAX_ICA_TILES|CLUSTER|MAX_FLIP_TILES) =' tests/helpers.py | sed 's/ *#.*//' | tr '\n' ';')"
   echo "# per case: alignment (flows) | side H: HIP own flows vs ORACLE ON HIP'S FLOWS (whole chain; merge alone on HIP's flows + HIP's r) | side O: the same on the oracle's flows | informational"
 } > "$OUT"
 T0=$(date +%s)
