@@ -214,7 +214,7 @@ def oracle_pool():
     pool.join()
 
 
-def sweep(pool, cs, report=None, ahead=None):
+def sweep(pool, cs, report=None, ahead=None, flips=None):
     """Per case, overlapping: burst generation (pool) -> HIP with its own flows (this process) -> stage 1 in the pool (three
     oracle runs; alignment, side H) -> HIP with the oracle's flows injected (this process) -> stage 2 in the pool (side O) ->
     verdict.  Up to `ahead` cases are in flight per step; returns the number of flipped decisions."""
@@ -242,7 +242,10 @@ def sweep(pool, cs, report=None, ahead=None):
             t0 = time.perf_counter()
             so = job.get(timeout=1500)
             tm["wait_stage2"] += time.perf_counter() - t0
-            flipped += judge(c, al, sh, so, info, report=report)
+            k = judge(c, al, sh, so, info, report=report)
+            flipped += k
+            if flips is not None:
+                flips[c["id"]] = k
             block2 = False
 
     todo = list(cs)
@@ -279,11 +282,15 @@ REPORT = bool(os.environ.get("HHSR_FUZZ_REPORT"))
 
 
 @pytest.mark.timeout(1800)
-@pytest.mark.skipif(REPORT, reason="report mode: test_fuzz_report runs all batches as one sweep")
-@pytest.mark.parametrize("gen_seed,n", BATCHES)
-def test_fuzz_sweep(oracle_pool, gen_seed, n):
-    flipped = sweep(oracle_pool, cases(gen_seed, n))
-    assert flipped <= FLIPPED_PER_BATCH, f"batch {gen_seed}: {flipped} flipped decisions"
+@pytest.mark.skipif(REPORT, reason="report mode: test_fuzz_report lists every case instead of stopping at the first")
+def test_fuzz_sweep(oracle_pool):
+    """All batches as ONE sweep (draining the pipeline between batches cost a third of the test's time)."""
+    cs = [c for gs, n in BATCHES for c in cases(gs, n)]
+    flips = {}
+    sweep(oracle_pool, cs, flips=flips)
+    for gs, n in BATCHES:
+        k = sum(flips.get(c["id"], 0) for c in cases(gs, n))
+        assert k <= FLIPPED_PER_BATCH, f"batch {gs}: {k} flipped decisions"
 
 
 @pytest.mark.timeout(4 * 3600)

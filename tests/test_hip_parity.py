@@ -884,8 +884,9 @@ def _e2e_vs_oracle(ref, comp, cfg_fn, ts, what, max_flipped, out_atol=1e-4, flow
     robustness and the output image equal to their tolerances everywhere OUTSIDE the footprint of those tiles."""
     H, W = ref.shape
     cap = {}
-    if parallel:  # one worker process per frame (bit-identical to oracle.main, tests/test_oracle_kat.py)
-        want, wdbg, _ = oracle.main_parallel(ref, comp, cfg_fn(), capture=cap)
+    if parallel:  # one worker process per frame (bit-identical to oracle.main, tests/test_oracle_kat.py), the accumulation
+        # in its C form (oracle.cfast: bit-identical to oracle/merge.py on what the same file compares)
+        want, wdbg, _ = oracle.main_parallel(ref, comp, cfg_fn(), capture=cap, fast=True)
     else:
         want, wdbg = oracle.main(ref, comp, cfg_fn(), capture=cap)
     cfg = cfg_fn()

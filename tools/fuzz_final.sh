@@ -1,13 +1,14 @@
 #!/bin/bash
 # The two-sided fuzz contract (tests/helpers.py: fuzz_verdict + constants; tests/test_fuzz_parity.py) on every set in ONE run
 # of ONE commit, as ONE sweep: the 64 fixed cases, every set earlier rounds ran (generator seeds 10 .. 110, 200, 300, and the
-# 14 "unseen" seeds of round 4) and the seeds given on the command line (never run before).
+# 14 "unseen" seeds of round 4, the 8 seeds 2000 .. 2700 that round 5's first two-sided run saw) and the seeds given on the
+# command line (never run before).
 #   tools/fuzz_final.sh <commit-hash> <out-file> [new seed ...]        (on an MI355X; the oracle pairs run on the host cores)
 COMMIT=${1:-unknown}
 OUT=${2:-$PWD/gpurun_out/r05_fuzz_final.txt}
 shift 2
 NEW="$*"
-OLD="10 20 30 40 50 60 70 80 90 100 110 200 300 400 500 600 700 800 900 1000 1100 1200 1300 1400 1500 1600 1700"
+OLD="10 20 30 40 50 60 70 80 90 100 110 200 300 400 500 600 700 800 900 1000 1100 1200 1300 1400 1500 1600 1700 2000 2100 2200 2300 2400 2500 2600 2700"
 [ -n "$HHSR_FUZZ_OLD" ] && OLD="$HHSR_FUZZ_OLD"      # (a subset, for a trial run)
 mkdir -p "$(dirname "$OUT")"
 RULES=$(cat tests/helpers.py tests/test_fuzz_parity.py | sha256sum | cut -c1-16)
