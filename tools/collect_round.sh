@@ -23,25 +23,22 @@ python bench.py --height 6000 --width 8000 --scale 3 --frames 20 --steps 5 --war
 python bench.py --frames 8 --steps 10 --warmup 3 --no-cpu-baseline > $OUT/bench_c2.json 2> /dev/null
 bash tools/kernel_trace.sh $NAME/kt 5 > /dev/null 2>&1
 bash tools/pmc_all.sh $NAME/pmc_all > /dev/null 2>&1
-tools/ubench/valu_rate > $OUT/valu_rate.txt
-bash tools/traffic_calib.sh $NAME > /dev/null 2>&1
-(cd /tmp && export TMPDIR=/tmp && rocprofv3 --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_LDS --output-format csv -d /tmp/ldsp -o lds -- $GRAFT_REPO_ROOT/tools/ubench/lds_patterns > /dev/null 2>&1; python $GRAFT_REPO_ROOT/tools/ubench/pmc_lds.py /tmp/ldsp > $GRAFT_REPO_ROOT/$OUT/lds_patterns.txt)
 # host-resident legs, the copy / kernel timelines of one host-resident step, measured bounds
 python tools/debug/host_leg_timing.py 2>&1 | grep -v amdgpu.ids > $OUT/host_legs.txt
 bash tools/debug/h2d_trace.sh f32 2>&1 | grep -v "^\[" | grep -v "^\['id'" > $OUT/h2d_trace_f32.txt
 bash tools/debug/h2d_trace.sh u16 2>&1 | grep -v "^\[" | grep -v "^\['id'" > $OUT/h2d_trace_u16.txt
-python tools/debug/cov_inline_bound.py 2>&1 | grep -v amdgpu.ids > $OUT/cov_inline_bound.txt
 python tools/debug/mono_timing.py 2>&1 | grep -v amdgpu.ids > $OUT/mono_timing.txt
 bash tools/debug/kt_mono.sh 2>&1 | grep -v amdgpu.ids > $OUT/kernel_trace_mono.md
 bash tools/debug/kt_c5.sh 2>&1 | grep -v amdgpu.ids > $OUT/kernel_trace_c5.md
-python tools/debug/hwqueue_probe.py 2>&1 | grep -v amdgpu.ids > $OUT/hwqueue_probe.txt
-python tools/debug/copy_contention_probe.py 2>&1 | grep -v amdgpu.ids >> $OUT/hwqueue_probe.txt
-# round 4: per-rank compute of the multi-GPU strategies on this one GPU (tools/debug/emulate_ranks.py), the x3 border tiles,
-# VALU issue rate against occupancy
+# per-rank compute of the multi-GPU strategies on this one GPU (tools/debug/emulate_ranks.py)
 python tools/debug/emulate_ranks.py --worlds 1,2,4,8 --steps 10 2>&1 | grep "^{" > $OUT/emulate_ranks_c3.jsonl
 python tools/debug/emulate_ranks.py --worlds 2,4,8 --steps 10 --strategies rows --stage-frames 4 2>&1 | grep "^{" > $OUT/emulate_ranks_c3_staged.jsonl
 python tools/debug/emulate_ranks.py --worlds 1,2,4,8 --steps 3 --height 6000 --width 8000 --scale 3 --strategies rows 2>&1 | grep "^{" > $OUT/emulate_ranks_c5.jsonl
-python tools/debug/border_cost.py 2>&1 | grep " ms" > $OUT/border_cost_x3.txt
-tools/ubench/valu_occupancy > $OUT/valu_occupancy.txt 2>&1
+# round 5: the overlap changes of the per-rank step A/B; the headline burst and the C5 geometry against the oracle at full size
+# (two-sided; minutes of all host cores).  (The micro-benchmarks and probes of round 4 — VALU rates, occupancy, LDS patterns,
+# counter calibration, hardware queues, border cost, covariance-inline bound — did not change: profiles/r04_*.)
+bash tools/debug/ab_rows_overlap.sh > $OUT/rows_overlap_ab.txt 2>&1
+python tools/full_size_oracle.py --workers 8 --out $OUT/c3_full_oracle.txt > /dev/null 2>&1
+python tools/full_size_oracle.py --height 3000 --width 8000 --frames 5 --scale 3 --workers 4 --out $OUT/c5_geometry_oracle.txt > /dev/null 2>&1
 find $OUT -name "*agent_info*" -delete
 cut -c1-600 $OUT/bench_n1.json
