@@ -20,7 +20,7 @@ F32 = np.float32
 _state = {}
 
 
-def _init(ref, comp_imgs, config, fast=False, flows=None):
+def _init(ref, comp_imgs, config, fast=False, flows=None, rob=None):
     # one NumPy / BLAS thread per worker: the parallelism is over frames
     for var in ("OMP_NUM_THREADS", "OPENBLAS_NUM_THREADS", "MKL_NUM_THREADS"):
         os.environ[var] = "1"
@@ -33,7 +33,7 @@ def _init(ref, comp_imgs, config, fast=False, flows=None):
     cfa = np.array(config.exif.cfa_pattern)
     wb = np.array(config.exif.white_balance, dtype=np.float64)
     grey_ref = compute_grey_images(ref, config.grey_method) if config.mode == "bayer" else ref
-    _state.update(ref=ref, comp=comp_imgs, config=config, cfa=cfa, wb=wb, fast=fast, flows=flows,
+    _state.update(ref=ref, comp=comp_imgs, config=config, cfa=cfa, wb=wb, fast=fast, flows=flows, rob_maps=rob,
                   align=init_alignment(grey_ref, config) if flows is None else None,
                   rob=init_robustness(ref, cfa, wb, config),
                   curves=(np.array(config.noise_model.std_curve, np.float64),
@@ -48,7 +48,8 @@ def _frame(n):
         flow = align(*s["align"], grey, cfg)
     else:
         flow = np.asarray(s["flows"][n], dtype=F32)
-    r = compute_robustness(img, *s["rob"], flow, s["cfa"], s["wb"], s["curves"], cfg)
+    r = (np.asarray(s["rob_maps"][n], dtype=F32) if s["rob_maps"] is not None else
+         compute_robustness(img, *s["rob"], flow, s["cfa"], s["wb"], s["curves"], cfg))
     covs = estimate_kernels(img, cfg)
     H, W = img.shape
     osz = (round(cfg.scale * H), round(cfg.scale * W))
@@ -66,10 +67,11 @@ def _merge_fn(fast):
     return _merge, _merge_ref
 
 
-def main_parallel(ref_img, comp_imgs, config, workers=None, capture=None, fast=False, flows=None):
+def main_parallel(ref_img, comp_imgs, config, workers=None, capture=None, fast=False, flows=None, rob=None):
     """Same result as ``oracle.main(ref_img, comp_imgs, config)`` (bit for bit), computed by ``workers`` processes
     (default: all host cores, at most one per comp frame).  Returns (output, debug_dict, workers_used).
-    ``fast`` / ``flows``: as in ``oracle.main`` (C accumulation; given flow fields instead of the alignment)."""
+    ``fast`` / ``flows`` / ``rob``: as in ``oracle.main`` (C accumulation; given flow fields instead of the alignment; given
+    robustness maps instead of computing them)."""
     ref = np.asarray(ref_img, dtype=F32)
     comp_imgs = np.asarray(comp_imgs, dtype=F32)
     n = comp_imgs.shape[0]
@@ -86,11 +88,11 @@ def main_parallel(ref_img, comp_imgs, config, workers=None, capture=None, fast=F
     results = {}
     if n:
         if workers == 1:
-            _init(ref, comp_imgs, config, fast, flows)
+            _init(ref, comp_imgs, config, fast, flows, rob)
             it = map(_frame, range(n))
         else:
             ctx = mp.get_context("fork")  # workers inherit the burst; nothing is pickled on the way in
-            pool = ctx.Pool(workers, initializer=_init, initargs=(ref, comp_imgs, config, fast, flows))
+            pool = ctx.Pool(workers, initializer=_init, initargs=(ref, comp_imgs, config, fast, flows, rob))
             it = pool.imap_unordered(_frame, range(n))
         for k, flow, r, nk, dk in it:
             results[k] = (flow, r, nk, dk)

@@ -1,12 +1,13 @@
 """Builder-side, not part of the driver's suite (minutes of all host cores, tens of GB of host memory): one burst at FULL
 size through HIP main() and through the oracle, two-sided like tests/test_fuzz_parity.py —
 
-    o      HIP, own flows            want    oracle (all cores, C accumulation), own flows
-    oi     HIP, oracle's flows       want_h  oracle's robustness + kernels + merge on HIP's flows
+    o      HIP, own flows            want     oracle (all cores, C accumulation), own flows
+    oi     HIP, oracle's flows       want_h   oracle's robustness + kernels + merge on HIP's flows
+                                     want_hm  oracle's merge alone on HIP's flows AND HIP's robustness maps
 
 and one report: flipped tiles, flow / robustness agreement, for each side NaN pattern, max-abs, p99.9, values above 1e-4
-by region (where some frame is being rejected / where every frame is accepted; image border bands / interior), and what
-round 4's one-sided comparison would have shown (o vs want).  VERDICT r4 #6: the headline burst (3000 x 4000 x 20, x2) had
+by region (where some frame is being rejected / where every frame is accepted; image border bands / interior) and how many
+of them the merge comparison does not explain, the merge alone, and what a one-sided comparison shows (o vs want).  VERDICT r4 #6: the headline burst (3000 x 4000 x 20, x2) had
 only been compared with the oracle on a 1024^2 crop.
 
     python tools/full_size_oracle.py [--height 3000 --width 4000 --frames 20 --scale 2] [--workers 8] [--out FILE]
@@ -23,29 +24,38 @@ for p in (ROOT, os.path.join(ROOT, "handheld-multi-frame-super-resolution_amd"),
 import numpy as np  # noqa: E402
 
 
-def chunked_side(shape, scale, out, want, r_hip, r_or, den, band=64):
+def chunked_side(shape, scale, out, want, r_hip, r_or, want_m=None, band=64):
     """helpers.same_flow_side in row chunks (48 MP x 3 channels of float64 temporaries do not fit comfortably), plus the
-    percentile and the split border band / interior."""
+    percentile and the split border band / interior.  `want_m`: the oracle's merge alone on the same flows and HIP's
+    robustness maps (None: the whole-chain image)."""
     from scipy.ndimage import minimum_filter
-    from helpers import outlier_over
 
     H, W = shape
     sH, sW = out.shape[:2]
-    low = minimum_filter(r_or.min(0), size=5, mode="nearest") < 0.999 if r_or is not None else np.zeros((H, W), bool)
+    if want_m is None:
+        want_m = want
+    low = (minimum_filter(np.minimum(r_or.min(0), r_hip.min(0)), size=5, mode="nearest") < 0.999 if r_or is not None
+           else np.zeros((H, W), bool))
     dr = 0.0
     if r_or is not None:
         for n in range(len(r_or)):
             dr = max(dr, float(np.abs(r_hip[n] - r_or[n]).max()))
     xx = np.minimum(((np.arange(sW) + 0.5) / scale).astype(int), W - 1)
-    res = dict(nan_mis=0, dr=dr, n=0, max=0.0, outside=0, over=0, q=0.0, n_border=0, n_interior=0, max_interior=0.0)
+    res = dict(nan_mis=0, dr=dr, n=0, max=0.0, outside=0, unexplained=0, m_nan=0, m_n=0, m_max=0.0, n_border=0, n_interior=0,
+               max_interior=0.0)
     hist = np.zeros(64, np.int64)  # log2 histogram of the differences for the percentile
     step = 512
     for y0 in range(0, sH, step):
         y1 = min(sH, y0 + step)
-        o, w, dn = out[y0:y1], want[y0:y1], den[y0:y1]
+        o, w, wm = out[y0:y1], want[y0:y1], want_m[y0:y1]
         res["nan_mis"] += int((np.isnan(o) != np.isnan(w)).sum())
+        res["m_nan"] += int((np.isnan(o) != np.isnan(wm)).sum())
         with np.errstate(all="ignore"):
             d = np.where(np.isnan(w) | (o == w), 0.0, np.abs(o.astype(np.float64) - w))
+            dm = np.where(np.isnan(wm) | (o == wm), 0.0, np.abs(o.astype(np.float64) - wm))
+        bad_m = dm > 1e-4
+        res["m_n"] += int(bad_m.sum())
+        res["m_max"] = max(res["m_max"], float(dm.max()))
         yy = np.minimum(((np.arange(y0, y1) + 0.5) / scale).astype(int), H - 1)
         rej = low[np.ix_(yy, xx)][..., None]
         bad = d > 1e-4
@@ -58,8 +68,7 @@ def chunked_side(shape, scale, out, want, r_hip, r_or, den, band=64):
         res["n"] += int(bad.sum())
         res["max"] = max(res["max"], float(d.max()))
         res["outside"] += int((bad & ~rej).sum())
-        res["over"] += int((bad & outlier_over(d, dn)).sum())
-        res["q"] = max(res["q"], float(np.where(bad, d * dn, 0.0).max()))
+        res["unexplained"] += int((bad & rej & bad_m).sum())
         res["n_border"] += int((bad & edge[..., None]).sum())
         res["n_interior"] += int((bad & ~edge[..., None]).sum())
         res["max_interior"] = max(res["max_interior"], float(np.where(edge[..., None], 0.0, d).max()))
@@ -131,13 +140,16 @@ def main():
     t0 = time.time()
     cap = {}
     want, _, used = oracle.main_parallel(ref, comp, cfg_fn(), workers=a.workers, capture=cap, fast=True)
-    oflow, o_r, den_o = np.stack(cap["flow"]), np.stack(cap["r"]), cap["den"]
+    oflow, o_r = np.stack(cap["flow"]), np.stack(cap["r"])
     say(f"# oracle own flows: {time.time() - t0:.1f} s on {used} workers")
     t0 = time.time()
     cap_h = {}
     want_h, _, _ = oracle.main_parallel(ref, comp, cfg_fn(), workers=a.workers, capture=cap_h, fast=True, flows=list(gflow))
-    o_r_h, den_h = np.stack(cap_h["r"]), cap_h["den"]
+    o_r_h = np.stack(cap_h["r"])
     say(f"# oracle on HIP's flows: {time.time() - t0:.1f} s")
+    t0 = time.time()
+    want_hm, _, _ = oracle.main_parallel(ref, comp, cfg_fn(), workers=a.workers, fast=True, flows=list(gflow), rob=list(hr))
+    say(f"# oracle's merge alone on HIP's flows and HIP's robustness: {time.time() - t0:.1f} s")
     cfg_i = cfg_fn(inject_flows=[f for f in oflow])
     cfg_i.debug = True
     out_i, dbg_i = hsr.main(ref, comp, cfg_i)
@@ -148,13 +160,15 @@ def main():
     say(f"alignment: {gflow[..., 0].size} tiles over {NF - 1} frames; flipped (> 1e-3 px) {al['nflip']}"
         f"{'' if al['one_cluster'] else ' (more than one cluster)'}, between 1e-4 and 1e-3 px {al['n_ica']}, max flow difference on "
         f"the others {al['dflow']:.2e} px")
-    for tag, (x, w, rh, ro, dn) in (("side H (HIP's flows): HIP vs oracle-on-HIP's-flows", (o, want_h, hr, o_r_h, den_h)),
-                                     ("side O (oracle's flows): HIP-on-oracle's-flows vs oracle", (oi, want, hr_i, o_r, den_o))):
-        s = chunked_side((H, W), scale, x, w, rh, ro, dn)
+    want_om, _, _ = oracle.main_parallel(ref, comp, cfg_fn(), workers=a.workers, fast=True, flows=list(oflow), rob=list(hr_i))
+    for tag, (x, w, rh, ro, wm) in (("side H (HIP's flows): HIP vs oracle-on-HIP's-flows", (o, want_h, hr, o_r_h, want_hm)),
+                                     ("side O (oracle's flows): HIP-on-oracle's-flows vs oracle", (oi, want, hr_i, o_r, want_om))):
+        s = chunked_side((H, W), scale, x, w, rh, ro, wm)
         say(f"{tag}: NaN mismatches {s['nan_mis']}, r max {s['dr']:.2e}, image max-abs {s['max']:.3e} (interior {s['max_interior']:.3e}), "
             f"p99.9 <= {s['p999_upper']:.1e}, values > 1e-4: {s['n']} of {x.size} ({s['outside']} where every frame is accepted, "
-            f"{s['over']} beyond the outlier bound, {s['n_border']} in the 64-pixel border band, {s['n_interior']} inside; "
-            f"x den max {s['q']:.2e})")
+            f"{s['unexplained']} not explained by the robustness difference, {s['n_border']} in the 64-pixel border band, "
+            f"{s['n_interior']} inside); MERGE ALONE on identical flows and robustness: NaN mismatches {s['m_nan']}, max-abs "
+            f"{s['m_max']:.3e}, values > 1e-4: {s['m_n']}")
     # what a one-sided comparison shows: own flows vs own flows, and the oracle's own movement under HIP's flows
     fp = footprint(flipped, 16, (H, W), scale, 19)
     n_own = n_orc = 0
