@@ -460,7 +460,6 @@ class SlabWork:
         self.L0 = int(math.ceil(r0 / scale)) - S0
         self.L1 = min(Hs, int(math.ceil(r1 / scale)) - S0)
         self.frames = []
-        self.stats = None  # pre(): the frames' raw pass on the sub-image, done before their flows exist
         if eng.denoiser_on:
             # the accumulated-robustness denoiser (merge.py:223-228) needs sum_n r_n before the reference frame is
             # merged: sequential operator path on the sub-image
@@ -470,26 +469,8 @@ class SlabWork:
             self.fuse_acc = self.acc_r is not None and can_fuse_acc_r(cfg)
             self.fuse_min = sub.fuses_local_min() and (self.fuse_acc or self.acc_r is None) and row0 % slab_align(scale) == 0
 
-    def pre(self, imgs):
-        """The raw pass (guide means + kernel covariances, hhsr_frame_stats_batch) of ALL comp frames on the sub-image.  It
-        needs no flow field, so RowsPlan replays it on the step-B stream while step A is still aligning (round 5: at G = 8
-        it is ~0.1 ms of a rank's 0.8 ms step B that no longer waits for the all-gather).  No-op where the batched
-        flow-given path of BurstPipeline._front_chunk does not apply."""
-        from .kernels import frame_stats_batch
-
-        sub, cfg = self.sub, self.cfg
-        if not self.can_pre(len(imgs)):
-            return
-        raws = [sub._ingest(img[self.S0:self.S1]) for img in imgs]
-        self.stats = frame_stats_batch(raws, sub.cfa, sub.wb, cfg)
-
-    def can_pre(self, n):
-        sub = self.sub
-        return not (self.eng.denoiser_on or n < 2 or not sub._batch or not self.cfg.robustness.enabled or sub.mono)
-
-    def front(self, imgs, flows, idx=None):
-        """`imgs`: full frames (their rows [S0, S1) are used); `flows`: their FULL flow fields [ny, nx, 2] (views welcome);
-        `idx`: their indices in the burst (for the statistics pre() computed)."""
+    def front(self, imgs, flows):
+        """`imgs`: full frames (their rows [S0, S1) are used); `flows`: their FULL flow fields [ny, nx, 2] (views welcome)."""
         from .merge import merge
 
         sub, S0, S1 = self.sub, self.S0, self.S1
@@ -499,9 +480,8 @@ class SlabWork:
                 raw, flow, covs, r = sub.process_frame(img[S0:S1], self.acc_r, flow=fl)
                 merge(raw, flow, covs, r, self.num, self.den, sub.cfa, self.cfg)
         elif imgs:
-            st = [self.stats[i] for i in idx] if (self.stats is not None and idx is not None and len(imgs) >= 2) else None
             self.frames += sub.process_frames([img[S0:S1] for img in imgs], None if self.fuse_acc else self.acc_r,
-                                              fuse_local_min=self.fuse_min, flows=sub_flows, stats=st)
+                                              fuse_local_min=self.fuse_min, flows=sub_flows)
 
     def finish(self):
         from .merge import merge_ref, merge_burst
@@ -668,18 +648,13 @@ class RowsPlan:
             with capture(self.g_ref_b, self.s_b):
                 self.flag.zero_()
                 work = self.work = SlabWork(eng, ref, r0, r1, self.bound, ny, ref_wait=False)
-            self.g_pre = None
-            if work.can_pre(n) and os.environ.get("HHSR_ROWS_NO_PRE") is None:  # (A/B switch, read at capture)
-                self.g_pre = torch.cuda.CUDAGraph()
-                with capture(self.g_pre, self.s_b):
-                    work.pre(comps)
             self.g_b = []
             for st, gat in zip(stages, self.gath):
                 fr = stage_frames(st, n, G)
                 g = torch.cuda.CUDAGraph()
                 with capture(g, self.s_b):
                     self.flag.logical_or_(~(gat[..., 1].abs().amax() <= self.bound))
-                    work.front([comps[i] for i in fr], [gat[i % G, i // G - st[0]] for i in fr], idx=fr)
+                    work.front([comps[i] for i in fr], [gat[i % G, i // G - st[0]] for i in fr])
                 self.g_b.append(g)
             self.g_fin = torch.cuda.CUDAGraph()
             with capture(self.g_fin, self.s_b):
@@ -697,8 +672,6 @@ class RowsPlan:
                 self.g_ref_a.replay()
         with torch.cuda.stream(self.s_b):
             self.g_ref_b.replay()
-            if self.g_pre is not None:
-                self.g_pre.replay()
         self.eng.pipe, self.eng.device = self.pipe, self.device
         return self
 

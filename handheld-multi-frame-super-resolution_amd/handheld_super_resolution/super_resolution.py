@@ -267,7 +267,7 @@ class BurstPipeline:
                                    lambda ci, wait: self._align_chunk([comp_imgs[i] for i in chunks[ci]], wait_ref=wait))
             return [f for chunk in out for f in chunk]
 
-    def _front_chunk(self, imgs, wait_ref, indices, flows, stats=None):
+    def _front_chunk(self, imgs, wait_ref, indices, flows):
         """_front() of a chunk of frames.  With the default configuration (Bayer frames, FFT grey image, fused level
         kernels) every stage is ONE launch for the whole chunk — 3 transform phases, 3 pyramid levels, 4 alignment
         levels, 1 raw pass: 11 launches per chunk instead of per frame — and the latency-bound stages (FFT phases,
@@ -281,9 +281,8 @@ class BurstPipeline:
             # every flow is given (multi-GPU step B on a row slab): no alignment, ONE raw pass for the chunk — on a slab
             # a per-frame launch is a few hundred workgroups and leaves most of the GPU idle
             raws = [self._ingest(img) for img in imgs]
-            # (`stats`: the raw pass was done ahead — it needs no flow; distributed.SlabWork.pre runs it next to step A)
-            st_ = [stats[i] for i in indices] if stats is not None else frame_stats_batch(raws, self.cfa, self.wb, cfg)
-            return [(raw, _lib.f32c(f, self.device), st[2], st[0]) for raw, f, st in zip(raws, inj, st_)]
+            stats = frame_stats_batch(raws, self.cfa, self.wb, cfg)
+            return [(raw, _lib.f32c(f, self.device), st[2], st[0]) for raw, f, st in zip(raws, inj, stats)]
         if len(imgs) < 2 or not self._batch or not can_align_batch(cfg) or any(f is not None for f in inj):
             return [self._front(img, wait_ref, i, f) for img, i, f in zip(imgs, indices, inj)]
         raws = [self._ingest(img) for img in imgs]
@@ -356,20 +355,19 @@ class BurstPipeline:
         """True when the fused merge can take the un-filtered robustness maps (see merge.can_fuse_local_min)."""
         return bool(self.config.robustness.enabled) and can_fuse_local_min(self.config, tuple(self.ref.shape))
 
-    def process_frames(self, comp_imgs, accumulate_r=None, n_streams=None, fuse_local_min=False, flows=None, stats=None):
+    def process_frames(self, comp_imgs, accumulate_r=None, n_streams=None, fuse_local_min=False, flows=None):
         """process_frame() over a list of frames.  Frames are independent until the merge, so they are
         issued round-robin on `n_streams` HIP streams (config.hip.streams, default 3): the launch-latency-
         bound coarse pyramid levels of one frame overlap the bandwidth-bound kernels of another.  The caller's
         stream waits for all of them before returning.  A per-frame `accumulate_r` (read-modify-write of one
-        map) forces a single stream.  `flows`: per-frame flow fields that replace the alignment; `stats` (with flows for
-        every frame): per-frame (means, None, covs) of a raw pass done ahead (frame_stats_batch)."""
+        map) forces a single stream.  `flows`: per-frame flow fields that replace the alignment."""
         with torch.cuda.device(self.device):
             n = len(comp_imgs)
             comp_imgs = self.prefetch(comp_imgs)
             chunks = self._chunks(n, n_streams)
 
             def work(ci, wait):
-                fronts = self._front_chunk([comp_imgs[i] for i in chunks[ci]], wait, chunks[ci], flows, stats)
+                fronts = self._front_chunk([comp_imgs[i] for i in chunks[ci]], wait, chunks[ci], flows)
                 if wait is not None:  # the robustness needs the second half of the reference precompute
                     torch.cuda.current_stream(self.device).wait_event(wait)
                 return self._robustness(fronts, accumulate_r if wait is None else None, fuse_local_min)

@@ -126,8 +126,6 @@ def main():
                         plan.s_b.wait_stream(torch.cuda.current_stream())
                         with torch.cuda.stream(plan.s_b):
                             plan.g_ref_b.replay()
-                            if plan.g_pre is not None:
-                                plan.g_pre.replay()
                             for g in plan.g_b:
                                 g.replay()
                             plan.g_fin.replay()
