@@ -10,7 +10,7 @@ from .merge import merge as _merge, merge_ref as _merge_ref, divide
 F32 = np.float32
 
 
-def main(ref_img, comp_imgs, config, capture=None, fast=False, flows=None, reuse=None, rob=None):
+def main(ref_img, comp_imgs, config, capture=None, fast=False, flows=None, reuse=None, rob=None, acc_rob=None):
     """Returns (output float32[sH, sW, 3] = num/den, debug_dict) like the reference.
 
     ``capture``: optional dict that receives per-frame intermediates (grey, flow, r, covs, the reference statistics).
@@ -20,6 +20,9 @@ def main(ref_img, comp_imgs, config, capture=None, fast=False, flows=None, reuse
     robustness + kernels + merge on the flows of the implementation under test, tests/test_fuzz_parity.py).
     ``rob``: per-frame robustness maps r [H, W] to use INSTEAD of computing them (with ``flows``: the merge alone, on the
     flows and the robustness of the implementation under test — the third comparison of the sweeps).
+    ``acc_rob``: the accumulated robustness [H, W] the reference frame's merge reads (merge.py:223-228) INSTEAD of this run's own
+    float64 sum — the implementation under test sums its maps in float32, and the denoiser's decisions
+    `acc_rob <= / < max_frame_count` compare that sum with an integer.
     ``reuse``: the ``capture`` of an earlier run on the same burst and config: its flow-independent intermediates
     (kernel covariances, reference statistics) are taken over instead of being recomputed."""
     if fast:
@@ -74,7 +77,8 @@ def main(ref_img, comp_imgs, config, capture=None, fast=False, flows=None, reuse
     covs = reuse["covs"][comp_imgs.shape[0]] if reuse else estimate_kernels(ref, config)
     if capture is not None:
         capture["covs"].append(covs)
-    merge_ref(ref, covs, num, den, cfa, config, acc_r if accumulate_r else None)
+    acc_in = np.asarray(acc_rob, dtype=np.float64) if (acc_rob is not None and accumulate_r) else acc_r
+    merge_ref(ref, covs, num, den, cfa, config, acc_in if accumulate_r else None)
     if capture is not None:
         capture["den"] = den.copy()  # accumulated weights before the normalisation (conditioning of num / den)
     divide(num, den)

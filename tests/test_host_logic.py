@@ -269,3 +269,7 @@ def test_fuzz_verdict_rules():
     finite = want.copy()
     finite[1, 1, 2] = 1.0
     assert run(oi=finite)[1]
+    # HIP's accumulated robustness must be the sum of its own maps (float32 accumulation noise only)
+    from helpers import side_failures, ACC_TOL
+    ok_side = dict(run()[0]["side_h"], acc=3e-7)
+    assert not side_failures("x", ok_side) and side_failures("x", dict(ok_side, acc=2 * ACC_TOL))

@@ -8,7 +8,7 @@ COMMIT=${1:-unknown}
 OUT=${2:-$PWD/gpurun_out/r05_fuzz_final.txt}
 shift 2
 NEW="$*"
-OLD="10 20 30 40 50 60 70 80 90 100 110 200 300 400 500 600 700 800 900 1000 1100 1200 1300 1400 1500 1600 1700 2000 2100 2200 2300 2400 2500 2600 2700"
+OLD="10 20 30 40 50 60 70 80 90 100 110 200 300 400 500 600 700 800 900 1000 1100 1200 1300 1400 1500 1600 1700 2000 2100 2200 2300 2400 2500 2600 2700 3000 3100 3200 3300 4000 4100 4200 4300 4400 4500 4600 4700"
 [ -n "$HHSR_FUZZ_OLD" ] && OLD="$HHSR_FUZZ_OLD"      # (a subset, for a trial run)
 mkdir -p "$(dirname "$OUT")"
 RULES=$(cat tests/helpers.py tests/test_fuzz_parity.py | sha256sum | cut -c1-16)
@@ -17,7 +17,7 @@ for g in $OLD $NEW; do B="$B,$g:22,$((g+1)):22,$((g+2)):20"; done
 {
   echo "# two-sided fuzz contract: commit $COMMIT, rules sha256[:16] (tests/helpers.py + tests/test_fuzz_parity.py) $RULES"
   echo "# sets: fixed 0-2 | run in earlier rounds: $OLD | NEW, never run before: ${NEW:-none}"
-  echo "# constants: $(grep -E '^(FLIP_PX|MAX_ICA_TILES|CLUSTER|MAX_FLIP_TILES) =' tests/helpers.py | sed 's/ *#.*//' | tr '\n' ';')"
+  echo "# constants: $(grep -E '^(FLIP_PX|MAX_ICA_TILES|CLUSTER|MAX_FLIP_TILES|ACC_TOL) =' tests/helpers.py | sed 's/ *#.*//' | tr '\n' ';')"
   echo "# per case: alignment (flows) | side H: HIP own flows vs ORACLE ON HIP'S FLOWS (whole chain; merge alone on HIP's flows + HIP's r) | side O: the same on the oracle's flows | informational"
 } > "$OUT"
 T0=$(date +%s)

@@ -4,7 +4,7 @@
 import re
 import sys
 
-SIDE = (r"\[nan (\d+), r (\S+), image max (\S+) \((\d+) > 1e-4, (\d+) outside rejecting regions, (\d+) not explained by r\); "
+SIDE = (r"\[nan (\d+), r (\S+), (?:acc \S+, )?image max (\S+) \((\d+) > 1e-4, (\d+) outside rejecting regions, (\d+) not explained by r\); "
         r"merge alone: nan (\d+), max (\S+) \((\d+) > 1e-4\)\]")
 RX = re.compile(r"case (\S+) \((.*?)\): flipped (\d+)( \(NOT one cluster\))?, ica (\d+), flow (\S+); HIP's flows " + SIDE +
                 r"; oracle's flows " + SIDE + r"; own vs own outside deviating tiles: (\d+) > 1e-4 \(max (\S+)\), oracle's own "
