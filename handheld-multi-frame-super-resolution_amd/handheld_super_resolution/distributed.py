@@ -360,11 +360,17 @@ class HipEngine:
             H, W = pipe.ref.shape
             sH, sW = pipe.output_size()
             acc = torch.zeros((world, 2, rows, sW, 3), dtype=torch.float32, device=self.device)
-            acc_r = torch.zeros((H, W), dtype=torch.float32, device=self.device) if self.accumulate_r else None
+            # (denoiser: the ranks' partial sums are float64 like the reference's sum — robustness.RobustnessSum; they are
+            # all-reduced in float64 and only then turned into the map the reference frame's merge decides on)
+            acc_r = (torch.zeros((H, W), dtype=torch.float64 if self.denoiser_on else torch.float32, device=self.device)
+                     if self.accumulate_r else None)
             if frames:
-                fuse_acc = acc_r is not None and can_fuse_acc_r(cfg)
+                fuse_acc = acc_r is not None and not self.denoiser_on and can_fuse_acc_r(cfg)
                 fuse_min = pipe.fuses_local_min() and (fuse_acc or acc_r is None)
-                fr = pipe.process_frames(list(frames), None if fuse_acc else acc_r, fuse_local_min=fuse_min)
+                fr = pipe.process_frames(list(frames), None if (fuse_acc or self.denoiser_on) else acc_r, fuse_local_min=fuse_min)
+                if self.denoiser_on:
+                    for f in fr:
+                        acc_r.add_(f[3])
                 for j in range(world):
                     b0, b1 = bounds[j], bounds[j + 1]
                     if b1 > b0:
@@ -407,7 +413,11 @@ class HipEngine:
                 den = torch.zeros_like(num)
                 num[row0:row0 + n] = acc[0, :n]
                 den[row0:row0 + n] = acc[1, :n]
-                merge_ref(ref[S0:S1], covs[S0 // q:S1 // q], num, den, self.pipe.cfa, cfg, rob[0][S0:S1])
+                from .robustness import RobustnessSum
+
+                merge_ref(ref[S0:S1], covs[S0 // q:S1 // q], num, den, self.pipe.cfa, cfg,
+                          RobustnessSum.decisions_of(rob[0][S0:S1].to(torch.float64),
+                                                     cfg.accumulated_robustness_denoiser.merge.max_frame_count))
                 divide(num, den)
                 return num[row0:row0 + n].contiguous()
             num, den = acc[0, :n], acc[1, :n]
@@ -434,6 +444,7 @@ class SlabWork:
     def __init__(self, eng, ref_dev, r0, r1, max_flow_y, ny_full, ref_wait=True):
         from .super_resolution import BurstPipeline
         from .merge import can_fuse_acc_r
+        from .robustness import RobustnessSum
 
         cfg = self.cfg = eng.config
         self.eng = eng
@@ -456,7 +467,9 @@ class SlabWork:
         # sub-image's first / last tile row is evaluated on the full field (module docstring)
         sub.flow_rows = (self.t0, int(ny_full) - self.t1)
         self.out = torch.empty((self.nrows, sW, 3), dtype=torch.float32, device=dev)
-        self.acc_r = torch.zeros((Hs, W), dtype=torch.float32, device=dev) if eng.accumulate_r else None
+        # (the denoiser decides on the sum: float64 like the reference's, robustness.RobustnessSum — as in main())
+        self.acc_sum = RobustnessSum((Hs, W), dev) if eng.denoiser_on else None
+        self.acc_r = torch.zeros((Hs, W), dtype=torch.float32, device=dev) if (eng.accumulate_r and not eng.denoiser_on) else None
         self.L0 = int(math.ceil(r0 / scale)) - S0
         self.L1 = min(Hs, int(math.ceil(r1 / scale)) - S0)
         self.frames = []
@@ -477,7 +490,8 @@ class SlabWork:
         sub_flows = [f[self.t0:self.t1] for f in flows]
         if self.eng.denoiser_on:
             for img, fl in zip(imgs, sub_flows):
-                raw, flow, covs, r = sub.process_frame(img[S0:S1], self.acc_r, flow=fl)
+                raw, flow, covs, r = sub.process_frame(img[S0:S1], None, flow=fl)
+                self.acc_sum.add(r)
                 merge(raw, flow, covs, r, self.num, self.den, sub.cfa, self.cfg)
         elif imgs:
             self.frames += sub.process_frames([img[S0:S1] for img in imgs], None if self.fuse_acc else self.acc_r,
@@ -489,9 +503,11 @@ class SlabWork:
 
         sub, cfg = self.sub, self.cfg
         if self.eng.denoiser_on:
-            merge_ref(sub.ref, sub.ref_covs, self.num, self.den, sub.cfa, cfg, self.acc_r)
+            merge_ref(sub.ref, sub.ref_covs, self.num, self.den, sub.cfa, cfg,
+                      self.acc_sum.for_decisions(cfg.accumulated_robustness_denoiser.merge.max_frame_count))
             divide(self.num, self.den)
             self.out.copy_(self.num[self.row0:self.row0 + self.nrows])
+            return self.out, self.acc_sum.mask((self.L0, self.L1))
         else:
             merge_burst(self.frames, sub.ref, sub.ref_covs, self.out, None, sub.cfa, cfg, do_ref=True, divide=True,
                         acc_r=self.acc_r if (self.fuse_acc and self.frames) else None, rows=(self.row0, self.nrows),
@@ -873,6 +889,8 @@ def main_sharded(ref_img, comp_imgs, config, group=None, engine=None, gather=Tru
                     else eng.finish_rows(red, r0, r1, ref_dev, ref_covs))
         if want_acc:
             a0, a1 = int(math.ceil(r0 / config.scale)), min(H, int(math.ceil(r1 / config.scale)))
+            if acc_full.dtype != torch.float32:  # (the denoiser's float64 sum: reported as the float32 map the API returns)
+                acc_full = acc_full.to(torch.float32)
             acc_r = acc_full[a0:a1] if r1 > r0 else None
         dev = acc.device
     else:

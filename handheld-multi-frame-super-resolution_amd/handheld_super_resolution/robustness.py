@@ -98,6 +98,43 @@ def compute_s(flows, M_th, s1, s2, flow_rows=(0, 0)):
     return S
 
 
+class RobustnessSum:
+    """The accumulated robustness the way the reference keeps it when something DECIDES on it: a float64 sum of the
+    per-frame maps (super_resolution.py:116-117, utils.py:93-120).  The accumulated-robustness denoiser compares the sum with
+    `max_frame_count` (merge.py:223-228: widen the reference splat / overwrite instead of add), and a sum such as
+    1 + 1 + 0.99999994 is 3 in float32 and not in float64 (found by the round-5 sweep: case 4300.15, 6 output values off by
+    0.038).  The kernels keep reading a float32 map: `for_decisions()` hands them one whose `<=` / `<` relations to the
+    threshold are those of the float64 sum.  (Where the sum is only reported — `robustness.save_mask` without the denoiser
+    — it stays the float32 sum of the fused kernels)"""
+
+    def __init__(self, shape, device):
+        self.sum = torch.zeros(tuple(shape), dtype=torch.float64, device=device)
+
+    def add(self, r):
+        self.sum.add_(r)  # float32 -> float64: exact
+        return self
+
+    def mask(self, rows=None):
+        """The sum as the float32 map the API returns (`debug_dict['accumulated robustness']`)."""
+        t = self.sum if rows is None else self.sum[rows[0]:rows[1]]
+        return t.to(torch.float32)
+
+    @staticmethod
+    def decisions_of(sum64, max_frame_count):
+        """float32 map a with  a <= mfc  <=>  sum <= mfc  and  a < mfc  <=>  sum < mfc  (the kernel compares (double) a)."""
+        mfc = float(max_frame_count)
+        m32 = np.float32(mfc)
+        below = m32 if float(m32) < mfc else np.nextafter(m32, np.float32(-np.inf))  # largest float32 below the threshold
+        above = m32 if float(m32) > mfc else np.nextafter(m32, np.float32(np.inf))   # smallest float32 above it
+        a = sum64.to(torch.float32)
+        a = torch.where((sum64 < mfc) & (a >= float(m32)), torch.full_like(a, float(below)), a)
+        a = torch.where((sum64 > mfc) & (a <= float(m32)), torch.full_like(a, float(above)), a)
+        return a
+
+    def for_decisions(self, max_frame_count, rows=None):
+        return self.decisions_of(self.sum if rows is None else self.sum[rows[0]:rows[1]], max_frame_count)
+
+
 def local_min(R, accumulate_into=None):
     """Alg. 9: 5x5 clamp-border minimum (robustness.py:641-686).  `accumulate_into` (float32 [H, W]) gets
     += r in the same pass (the reference's separate add() of super_resolution.py:158-159)."""

@@ -26,7 +26,7 @@ from .utils import divide, add, getTime, timer
 from .alignment import (align, init_alignment, build_gaussian_pyramid, build_gaussian_pyramids, align_batch,
                         can_align_batch)
 from .params import sanitize_config, update_snr_config
-from .robustness import (init_robustness, compute_robustness, compute_robustness_group, noise_curves_to_device,
+from .robustness import (init_robustness, compute_robustness, compute_robustness_group, noise_curves_to_device, RobustnessSum,
                          ref_planes, upscale_warp_stats, mono_sigma_sq)
 from .kernels import estimate_kernels, frame_stats, frame_stats_batch
 from .merge import merge, merge_ref, merge_burst, can_fuse_acc_r, can_fuse_local_min
@@ -520,7 +520,10 @@ def main(ref_img, comp_imgs, config, *, _no_runner=False):
     dev = pipe.device
     H, W = pipe.ref.shape
     sH, sW = pipe.output_size()
-    accumulated_r = torch.zeros((H, W), dtype=torch.float32, device=dev) if accumulate_r else None
+    # the denoiser DECIDES on the accumulated robustness: float64 sum like the reference's (robustness.RobustnessSum); a sum
+    # that is only reported (save_mask) stays the float32 sum of the kernels
+    acc_sum = RobustnessSum((H, W), dev) if denoiser_on else None
+    accumulated_r = torch.zeros((H, W), dtype=torch.float32, device=dev) if (accumulate_r and not denoiser_on) else None
     fuse_acc = accumulate_r and fused and can_fuse_acc_r(config) and n_images_of(comp_imgs) > 0
     num = torch.empty((sH, sW, 3), dtype=torch.float32, device=dev)
     den = None
@@ -548,6 +551,8 @@ def main(ref_img, comp_imgs, config, *, _no_runner=False):
             print("\nProcessing image {} ---------\n".format(im_id + 1))
             im_time = time.perf_counter()
         raw, flow, covs, r = pipe.process_frame(comp_imgs[im_id], None if fuse_acc else accumulated_r, index=im_id)
+        if acc_sum is not None:
+            acc_sum.add(r)
         if fused:
             frames.append((raw, flow, covs, r))
         else:
@@ -567,14 +572,15 @@ def main(ref_img, comp_imgs, config, *, _no_runner=False):
             acc_r=accumulated_r if fuse_acc else None, local_min=fuse_min)
     else:
         pipe._timed(merge_ref, 2, "\nAccumulating ref Img", "Ref Img accumulated (Total)")(
-            pipe.ref, ref_covs, num, den, pipe.cfa, config, accumulated_r if denoiser_on else None)
+            pipe.ref, ref_covs, num, den, pipe.cfa, config,
+            acc_sum.for_decisions(config.accumulated_robustness_denoiser.merge.max_frame_count) if denoiser_on else None)
         pipe._timed(divide, 2, end_s="\n------------------------\nImage normalized (Total)")(num, den)
     if verbose:
         torch.cuda.synchronize()
         s = "\nTotal ellapsed time : "
         print(s, " " * (50 - len(s)), ": ", round((time.perf_counter() - t1), 2), "seconds")
     if accumulate_r:
-        debug_dict["accumulated robustness"] = accumulated_r
+        debug_dict["accumulated robustness"] = acc_sum.mask() if denoiser_on else accumulated_r
     # host-buffer contract: main() returns when the caller's (page-locked) frames have been read — the uploads were
     # queued asynchronously (BurstPipeline.prefetch) and a serving loop refills its staging buffers right after the
     # call; the kernels keep running asynchronously on the current stream as before

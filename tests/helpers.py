@@ -165,7 +165,7 @@ FLIP_PX = 1e-3          # flow difference that marks a tile as following another
 MAX_ICA_TILES = 16      # tiles per case with a flow difference between 1e-4 and FLIP_PX (measured: <= 10, in 3 of 768 cases)
 CLUSTER = 8             # tiles per side of the finest-level tiles under one level-2 tile of the default pyramid
 MAX_FLIP_TILES = 16     # finest-level tiles per case under the ONE flipped decision (measured: 1, or a 2 x 2 block)
-ACC_TOL = 1e-6          # accumulated robustness of HIP (float32 sums) against the float64 sum of ITS OWN maps
+ACC_TOL = 1e-6          # the accumulated robustness HIP reports (a float32 map) against the float64 sum of ITS OWN maps
 # ---- Round 5: the contract is STAGE BY STAGE ON IDENTICAL INPUTS, in both directions.  Round 4's rules
 # compared HIP's own-flow image with the oracle's own-flow image and excused "flow-sensitive" values (agree once the oracle's
 # flows are injected into HIP) up to a cap, MAX_SENS = 0.15 — violated at 0.177, 0.187 and 0.671 on held-out seeds.  Now
@@ -174,11 +174,10 @@ ACC_TOL = 1e-6          # accumulated robustness of HIP (float32 sums, SURVEY.md
 #   merge         on IDENTICAL flows AND IDENTICAL robustness maps (HIP's r injected into the oracle, oracle.main(rob=...)):
 #                 image <= 1e-4 EVERYWHERE, identical NaN pattern                              (no region, count, size or
 #                 small-weight excuse: measured <= 3.4e-5 over 2560 cases incl. the value whose accumulated weight is 3.4e-7).
-#                 "Identical robustness" includes HIP's ACCUMULATED robustness (oracle.main(acc_rob=...)), which the reference
-#                 frame's merge reads: HIP sums its maps in float32 where the reference sums in float64, and
-#                 the denoiser compares the sum with an integer (`acc_rob < max_frame_count`: overwrite instead of add) — a sum
-#                 like 1 + 1 + 0.99999994 is 3 in float32 and not in float64 (case 4300.15: 6 values, 0.038).  The sum
-#                 itself is asserted: |acc_hip - sum of HIP's maps| <= ACC_TOL
+#                 The oracle sums HIP's maps in float64 like the reference (super_resolution.py:116-117) — and so does HIP
+#                 wherever the sum DECIDES something (robustness.RobustnessSum) since the sweep found case 4300.15: the
+#                 denoiser's `acc_rob < max_frame_count` at 1 + 1 + 0.99999994, which is 3 in float32 (6 values, 0.038).  The
+#                 map HIP reports is asserted against the float64 sum of its maps: <= ACC_TOL
 #   whole chain   on identical flows (o vs want_h, oi vs want): <= 1e-4 wherever every frame is accepted; where a frame is
 #                 being rejected a value may exceed 1e-4 only if the merge comparison above shows it to be the effect of the
 #                 <= 1e-4 by which r differs (it agrees once HIP's r is injected) — round 4's count / magnitude caps

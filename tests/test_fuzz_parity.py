@@ -23,10 +23,12 @@ MAX_FLIP_TILES):
         <= 3.4e-4 px, in 10 of 2304 cases);
   * robustness — on identical flows (HIP's: hr vs the oracle's r on HIP's flows; the oracle's: hr_i vs the oracle's own r):
     <= 1e-4 everywhere (measured <= 2.8e-5);
-  * accumulated robustness — HIP's float32 sum (SURVEY.md D15) against the float64 sum of its own maps: <= 1e-6;
-  * merge — on identical flows AND identical robustness maps — HIP's accumulated sum included, which the reference frame's
-    merge reads and the reference sums in float64: `acc_rob < max_frame_count` at 1 + 1 + 0.99999994 decides differently in
-    the two precisions (case 4300.15: 6 values, 0.038) — (o vs want_hm, oi vs want_om): identical NaN pattern (and equal
+  * accumulated robustness — the map HIP reports against the float64 sum of its own per-frame maps: <= 1e-6 (it is that sum
+    rounded to float32 when the denoiser is on, the kernels' float32 sum otherwise, SURVEY.md D15);
+  * merge — on identical flows AND identical robustness maps (o vs want_hm, oi vs want_om; the oracle sums HIP's maps in
+    float64 like the reference, and since the sweep found case 4300.15 — `acc_rob < max_frame_count` at 1 + 1 + 0.99999994
+    decides differently in float32: 6 values, 0.038 — so does HIP wherever the sum decides something,
+    robustness.RobustnessSum): identical NaN pattern (and equal
     infinities) everywhere; every value <= 1e-4 (measured <= 1.9e-5, also where the accumulated weight is 3.4e-7).  No
     region, count, magnitude or small-weight excuse;
   * the whole chain behind the alignment — on identical flows (o vs want_h, oi vs want): identical NaN pattern; <= 1e-4
@@ -143,8 +145,7 @@ def _stage1(c, ref, comp, gflow, o, hr, acc):
     rob = c["rob"]
     want_m, den_m = None, None
     if rob:
-        want_m, _ = oracle.main(ref, comp, config(c), capture=cap_m, fast=True, flows=list(gflow), rob=list(hr), reuse=cap,
-                                acc_rob=acc)
+        want_m, _ = oracle.main(ref, comp, config(c), capture=cap_m, fast=True, flows=list(gflow), rob=list(hr), reuse=cap)
         den_m = cap_m["den"]
     oflow = np.stack(cap["flow"])
     shape = (c["H"], c["W"])
@@ -172,7 +173,7 @@ def _stage2(c, path, oflow, oi, hr_i, acc_i):
     if c["rob"]:
         cap_m = {}
         want_m, _ = oracle.main(ref, comp, config(c), capture=cap_m, fast=True, flows=list(oflow), rob=list(hr_i),
-                                reuse={"covs": list(covs), "ref_stats": (None, None)}, acc_rob=acc_i)
+                                reuse={"covs": list(covs), "ref_stats": (None, None)})
         den_m = cap_m["den"]
     so = same_flow_side((c["H"], c["W"]), c["scale"], oi, want, hr_i, o_r, den, want_m, den_m)
     so["acc"] = _acc_err(acc_i, hr_i) if c["rob"] else 0.0

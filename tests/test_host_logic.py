@@ -273,3 +273,26 @@ def test_fuzz_verdict_rules():
     from helpers import side_failures, ACC_TOL
     ok_side = dict(run()[0]["side_h"], acc=3e-7)
     assert not side_failures("x", ok_side) and side_failures("x", dict(ok_side, acc=2 * ACC_TOL))
+
+
+def test_robustness_sum_keeps_float64_decisions():
+    """robustness.RobustnessSum: the accumulated-robustness denoiser's `<=` / `<` comparisons with max_frame_count are those
+    of the reference's float64 sum, although the kernel reads a float32 map (found by the round-5 sweep, case 4300.15)."""
+    import torch
+    from handheld_super_resolution.robustness import RobustnessSum
+
+    one_m = np.float32(1.0) - np.float32(2.0 ** -24)          # 0.99999994
+    r = [torch.tensor([[1.0, 1.0, 1.0, 0.5]], dtype=torch.float32), torch.tensor([[1.0, 1.0, 1.0, 0.5]], dtype=torch.float32),
+         torch.tensor([[float(one_m), 1.0, 0.25, 1.0]], dtype=torch.float32)]
+    acc = RobustnessSum((1, 4), "cpu")
+    f32 = torch.zeros((1, 4), dtype=torch.float32)
+    for t in r:
+        acc.add(t)
+        f32 += t
+    assert float(f32[0, 0]) == 3.0 and float(acc.sum[0, 0]) < 3.0    # the float32 sum has lost the decision
+    for mfc in (3, 3.0, 2.25, 8, 2.0000001):
+        a = acc.for_decisions(mfc).to(torch.float64)
+        assert torch.equal(a <= mfc, acc.sum <= mfc) and torch.equal(a < mfc, acc.sum < mfc), mfc
+    a = acc.for_decisions(3)
+    assert float(a[0, 0]) < 3.0 and float(a[0, 1]) == 3.0 and a.dtype == torch.float32
+    assert torch.equal(acc.mask(), acc.sum.to(torch.float32)) and acc.mask((0, 1)).shape == (1, 4)

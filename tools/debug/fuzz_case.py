@@ -21,7 +21,7 @@ dh = np.where(np.isnan(want_h), 0.0, np.abs(o_own.astype(np.float64) - want_h))
 print(f"side H (HIP's flows): max |o - want_h| = {dh.max():.3e} ({int((dh > 1e-4).sum())} > 1e-4); oracle's own move under HIP's "
       f"flows max |want_h - want| = {np.nanmax(np.abs(want_h.astype(np.float64) - want)):.3e}; max |flow diff| = {np.abs(gflow - oflow).max():.3e} px")
 if c["rob"]:
-    want_m, _ = oracle.main(ref, comp, fz.config(c), capture=cap_m, fast=True, flows=list(gflow), rob=list(hr_own), reuse=cap, acc_rob=acc_own)
+    want_m, _ = oracle.main(ref, comp, fz.config(c), capture=cap_m, fast=True, flows=list(gflow), rob=list(hr_own), reuse=cap)
     dm = np.where(np.isnan(want_m), 0.0, np.abs(o_own.astype(np.float64) - want_m))
     print(f"merge alone (HIP's flows and HIP's robustness): max |o - want_hm| = {dm.max():.3e} ({int((dm > 1e-4).sum())} > 1e-4); "
           f"max |r_hip - r_oracle(HIP's flows)| = {np.abs(hr_own - np.stack(cap_h['r'])).max():.3e}")
