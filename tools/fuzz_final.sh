@@ -8,7 +8,7 @@ COMMIT=${1:-unknown}
 OUT=${2:-$PWD/gpurun_out/r05_fuzz_final.txt}
 shift 2
 NEW="$*"
-OLD="10 20 30 40 50 60 70 80 90 100 110 200 300 400 500 600 700 800 900 1000 1100 1200 1300 1400 1500 1600 1700 2000 2100 2200 2300 2400 2500 2600 2700 3000 3100 3200 3300 4000 4100 4200 4300 4400 4500 4600 4700"
+OLD="10 20 30 40 50 60 70 80 90 100 110 200 300 400 500 600 700 800 900 1000 1100 1200 1300 1400 1500 1600 1700 2000 2100 2200 2300 2400 2500 2600 2700 3000 3100 3200 3300 4000 4100 4200 4300 4400 4500 4600 4700 5000 5100 5200 5300 6000 6100 6200 6300 6400 6500 6600 6700"
 [ -n "$HHSR_FUZZ_OLD" ] && OLD="$HHSR_FUZZ_OLD"      # (a subset, for a trial run)
 mkdir -p "$(dirname "$OUT")"
 RULES=$(cat tests/helpers.py tests/test_fuzz_parity.py | sha256sum | cut -c1-16)
