@@ -1,0 +1,51 @@
+"""The NAMED cases of the round-3..5 sweeps, kept in the default GPU suite: every burst that ever violated a rule of an
+earlier contract or led to a change of the contract or of the product runs here through the SAME two-sided contract as
+tests/test_fuzz_parity.py (its generator, its sweep, tests/helpers.py's rules — nothing of its own), so that what those
+cases taught stays tested when the generator seeds of the default sweep (0, 1, 2) do not reach them.
+
+    30.21, 1000.11, 1600.15   round 4's "flow-sensitive values" (0.19, 0.18, 0.67 on a [0, 1] image, above the old MAX_SENS cap):
+                              the reference algorithm's discontinuity in the flow — the ORACLE moves alike under HIP's flows
+    62.19                     one flipped border tile: 48 NaN-pattern mismatches under the one-sided rule, none on identical flows
+    101.9                     0.104 at an accumulated weight of 3.4e-7: explained by 5e-6 of robustness, merge alone 1.2e-6
+    302.9, 6502.17            the accumulated-robustness denoiser's `acc_rob < max_frame_count` decision (hsr/merge.py:223-228)
+                              flipped by <= 7e-6 of robustness: found by the first two-sided run
+    4300.15                   the same decision flipped by the PRECISION OF THE SUM (float32 in HIP, float64 in the reference):
+                              a deviation of the product, fixed (robustness.RobustnessSum); with HIP's own flows the whole chain
+                              now agrees everywhere, which is asserted here on top of the contract
+
+Report of all 4096 cases of one commit: profiles/r05_fuzz_final.txt; how to read it: PARITY.md."""
+import re
+
+import pytest
+
+import test_fuzz_parity as fz
+from test_fuzz_parity import oracle_pool  # noqa: F401  (the fork pool fixture)
+
+pytestmark = pytest.mark.gpu
+
+FINDINGS = ["30.21", "62.19", "101.9", "302.9", "1000.11", "1600.15", "4300.15", "6502.17"]
+
+
+def _case(cid):
+    gs, k = (int(v) for v in cid.split("."))
+    c = fz.cases(gs, k + 1)[k]
+    assert c["id"] == cid
+    return c
+
+
+@pytest.mark.timeout(900)
+def test_named_findings(oracle_pool):  # noqa: F811
+    lines = []
+    fz.sweep(oracle_pool, [_case(cid) for cid in FINDINGS], report=lines)
+    per_case = {m.group(1): ln for ln in lines if (m := re.match(r"case (\S+) ", ln))}
+    assert sorted(per_case) == sorted(FINDINGS)
+    failed = [ln[:900] for ln in per_case.values() if "ASSERTIONS FAILED" in ln]
+    assert not failed, "\n".join(failed)
+    # 4300.15 with HIP's own flows: the float64 robustness sum decides like the reference's — nothing above 1e-4 anywhere
+    m = re.search(r"HIP's flows \[nan 0, r \S+, acc \S+, image max (\S+) \((\d+) > 1e-4", per_case["4300.15"])
+    assert m and int(m.group(2)) == 0 and float(m.group(1)) <= 1e-4, per_case["4300.15"][:600]
+    # the flow-sensitive cases: what a one-sided comparison sees IS reproduced by the oracle on HIP's flows
+    for cid in ("30.21", "1000.11", "1600.15"):
+        m = re.search(r"own vs own outside deviating tiles: (\d+) > 1e-4 \(max \S+\), oracle's own move under HIP's flows: (\d+)",
+                      per_case[cid])
+        assert m and int(m.group(1)) > 0 and int(m.group(2)) >= int(m.group(1)) - 2, per_case[cid][-300:]
