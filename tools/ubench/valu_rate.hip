@@ -42,6 +42,12 @@
 #define A_CLAMPEXP "v_exp_f32_e64 %0, %0 clamp\n v_exp_f32_e64 %1, %1 clamp\n v_exp_f32_e64 %2, %2 clamp\n v_exp_f32_e64 %3, %3 clamp\n v_exp_f32_e64 %4, %4 clamp\n v_exp_f32_e64 %5, %5 clamp\n v_exp_f32_e64 %6, %6 clamp\n v_exp_f32_e64 %7, %7 clamp\n"
 #define A_FMACLAMP "v_fma_f32 %0, %0, %8, %9 clamp\n v_fma_f32 %1, %1, %8, %9 clamp\n v_fma_f32 %2, %2, %8, %9 clamp\n v_fma_f32 %3, %3, %8, %9 clamp\n v_fma_f32 %4, %4, %8, %9 clamp\n v_fma_f32 %5, %5, %8, %9 clamp\n v_fma_f32 %6, %6, %8, %9 clamp\n v_fma_f32 %7, %7, %8, %9 clamp\n"
 #define A_MULLO "v_mul_lo_u32 %0, %0, %8\n v_mul_lo_u32 %1, %1, %8\n v_mul_lo_u32 %2, %2, %8\n v_mul_lo_u32 %3, %3, %8\n v_mul_lo_u32 %4, %4, %8\n v_mul_lo_u32 %5, %5, %8\n v_mul_lo_u32 %6, %6, %8\n v_mul_lo_u32 %7, %7, %8\n"
+// the CLAMP form of the tap (2 fma + clamped exp + fmac + add), each instruction depending on the one before it ...
+#define A_TAP5 "v_fma_f32 %0, %0, %8, %9\n v_fma_f32 %0, %0, %8, %9\n v_exp_f32_e64 %1, %0 clamp\n v_fmac_f32 %2, %1, %8\n v_add_f32 %3, %3, %1\n v_fma_f32 %4, %4, %8, %9\n v_fma_f32 %4, %4, %8, %9\n v_exp_f32_e64 %5, %4 clamp\n v_fmac_f32 %6, %5, %8\n v_add_f32 %7, %7, %5\n"
+// ... and four taps batched by instruction class (8 fma, 4 exp, 4 fmac, 4 add): does the ORDER matter at 8 waves per SIMD?
+#define A_TAP5B "v_fma_f32 %0, %0, %8, %9\n v_fma_f32 %1, %1, %8, %9\n v_fma_f32 %2, %2, %8, %9\n v_fma_f32 %3, %3, %8, %9\n v_fma_f32 %0, %0, %8, %9\n v_fma_f32 %1, %1, %8, %9\n v_fma_f32 %2, %2, %8, %9\n v_fma_f32 %3, %3, %8, %9\n v_exp_f32_e64 %0, %0 clamp\n v_exp_f32_e64 %1, %1 clamp\n v_exp_f32_e64 %2, %2 clamp\n v_exp_f32_e64 %3, %3 clamp\n v_fmac_f32 %4, %0, %8\n v_fmac_f32 %5, %1, %8\n v_fmac_f32 %4, %2, %8\n v_fmac_f32 %5, %3, %8\n v_add_f32 %6, %6, %0\n v_add_f32 %7, %7, %1\n v_add_f32 %6, %6, %2\n v_add_f32 %7, %7, %3\n"
+KERNEL(k_tap5, A_TAP5)
+KERNEL(k_tap5b, A_TAP5B)
 KERNEL(k_cnd64, A_CND64)
 KERNEL(k_cmp, A_CMP)
 KERNEL(k_max, A_MAX)
@@ -154,6 +160,8 @@ int main() {
     run("iadd", k_iadd, 32, out);
     run("pk_fma", k_pkfma, 32, out);
     run("tap mix", k_tap, 48, out);
+    run("tap5 dependent order", k_tap5, 40, out);
+    run("tap5 batched by class", k_tap5b, 80, out);
     run("cnd e64", k_cnd64, 32, out);
     run("cmp", k_cmp, 32, out);
     run("max", k_max, 32, out);
