@@ -71,7 +71,7 @@ class OracleEngine:
         stats = oracle.init_robustness(ref_s, self.cfa, self.wb, cfg)
         num = np.zeros((round(s * Hs), round(s * W), 3), np.float32)
         den = np.zeros_like(num)
-        acc_r = np.zeros((Hs, W), np.float32)
+        acc_r = np.zeros((Hs, W), np.float64 if self.denoiser_on else np.float32)  # (the denoiser decides on a float64 sum)
         t = cfg.robustness.tuning
         for i, img in enumerate(comps):
             img_s = np.asarray(img, np.float32)[S0:S1]
@@ -81,11 +81,13 @@ class OracleEngine:
             r = oracle.compute_robustness(img_s, *stats, flow_s, self.cfa, self.wb, self.curves, cfg, S=S)
             acc_r += r
             oracle.merge(img_s, flow_s, oracle.estimate_kernels(img_s, cfg), r, num, den, self.cfa, cfg)
-        oracle.merge_ref(ref_s, oracle.estimate_kernels(ref_s, cfg), num, den, self.cfa, cfg)
+        oracle.merge_ref(ref_s, oracle.estimate_kernels(ref_s, cfg), num, den, self.cfa, cfg,
+                         acc_rob=acc_r if self.denoiser_on else None)
         oracle.divide(num, den)
         L0 = int(math.ceil(r0 / s)) - S0
         L1 = min(Hs, int(math.ceil(r1 / s)) - S0)
-        return torch.from_numpy(np.ascontiguousarray(num[row0:row0 + (r1 - r0)])), torch.from_numpy(acc_r[L0:L1].copy())
+        return (torch.from_numpy(np.ascontiguousarray(num[row0:row0 + (r1 - r0)])),
+                torch.from_numpy(acc_r[L0:L1].astype(np.float32)))
 
 
     # ---- strategy "reduce" --------------------------------------------------------------------------------------------
@@ -97,7 +99,7 @@ class OracleEngine:
         stats = oracle.init_robustness(self.ref, self.cfa, self.wb, cfg)
         num = np.zeros((sH, sW, 3), np.float32)
         den = np.zeros_like(num)
-        acc_r = np.zeros((H, W), np.float32)
+        acc_r = np.zeros((H, W), np.float64 if self.denoiser_on else np.float32)  # (HipEngine.partial: float64 partial sums)
         for img in my_frames:
             img = np.asarray(img, np.float32)
             flow = oracle.align(*self.al, oracle.compute_grey_images(img, "FFT"), cfg)
@@ -117,20 +119,30 @@ class OracleEngine:
         num = np.zeros((sH, sW, 3), np.float32)
         den = np.zeros_like(num)
         num[r0:r1], den[r0:r1] = acc_slab[0, : r1 - r0].numpy(), acc_slab[1, : r1 - r0].numpy()
-        oracle.merge_ref(ref, ref_covs, num, den, self.cfa, cfg)  # (whole image: only rows [r0, r1) are kept)
+        assert (acc_r is not None) == self.denoiser_on
+        oracle.merge_ref(ref, ref_covs, num, den, self.cfa, cfg,  # (whole image: only rows [r0, r1) are kept)
+                         acc_rob=acc_r.numpy() if self.denoiser_on else None)
         oracle.divide(num, den)
         return torch.from_numpy(np.ascontiguousarray(num[r0:r1]))
 
 
-def _burst(seam=False):
-    ref, comp, _ = synth.make_burst(128, 128, 4, seed=9, max_shift=0.0 if seam else 1.5)
+def _burst(seam=False, denoiser=False):
+    ref, comp, _ = synth.make_burst(128, 128, 4, seed=9, max_shift=0.0 if seam else 1.5, occluder=denoiser)
     if seam:  # frame 1 is brighter around raw rows 80-100: its robustness there sits in the band where S decides
         comp = comp.copy()
         yy = np.arange(128, dtype=np.float32)[:, None]
         comp[1] = np.clip(comp[1] + 0.06 * np.exp(-(((yy - 90) / 8.0) ** 2)), 0, 1).astype(np.float32)
     cfg = base_config(ts=16, scale=2)
     cfg.block_matching.tuning.factors = [1, 2, 2, 2]
+    if denoiser:  # merge.py:223-228 with both branches alive: 3 comp frames, "every frame fully accepted" adds, the rest overwrites
+        cfg.accumulated_robustness_denoiser.enabled = True
+        cfg.accumulated_robustness_denoiser.merge.enabled = True
+        cfg.accumulated_robustness_denoiser.merge.max_frame_count = 3
     return ref, comp, cfg
+
+
+class DenoiserEngine(OracleEngine):
+    denoiser_on = True
 
 
 class SeamEngine(OracleEngine):
@@ -148,16 +160,16 @@ class SeamEngine(OracleEngine):
         return torch.from_numpy(fl)
 
 
-def _worker(rank, world, port, out_path, strategy="rows", seam=False, n_comp=3, hip=None):
+def _worker(rank, world, port, out_path, strategy="rows", seam=False, n_comp=3, hip=None, denoiser=False):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
-        ref, comp, cfg = _burst(seam)
+        ref, comp, cfg = _burst(seam, denoiser)
         comp = comp[:n_comp]
         if hip:
             cfg.hip = hip
-        eng = OracleEngine(cfg)
+        eng = DenoiserEngine(cfg) if denoiser else OracleEngine(cfg)
         if seam:  # frame 1 of the burst is aligned by rank 1 % world as its (1 // world)-th frame
             eng = SeamEngine(cfg)
             eng._has_frame1, eng._frame1 = (1 % world == rank), 1 // world
@@ -307,6 +319,27 @@ def test_reduce_strategy_matches_sequential(tmp_path, world):
         d = np.abs(got["out"] - want)
     assert np.nanmax(d) < 2e-6  # measured 2.4e-7
     np.testing.assert_allclose(got["acc_r"], dbg["accumulated robustness"].astype(np.float32), rtol=0, atol=2e-6)
+
+
+@pytest.mark.timeout(300)
+@pytest.mark.parametrize("strategy", ["rows", "reduce"])
+def test_denoiser_sharded(tmp_path, strategy):
+    """The accumulated-robustness denoiser of the reference frame's merge (merge.py:223-228) across ranks: "rows" sums the
+    robustness of ALL frames on the rank's sub-image; "reduce" all-reduces the ranks' float64 partial sums before the slab is
+    finished (robustness.RobustnessSum: the decision `acc_rob < max_frame_count` is taken on the float64 sum).  Both
+    branches of the decision must occur in the burst."""
+    out_path = str(tmp_path / "out.npz")
+    mp.spawn(_worker, args=(2, _free_port(), out_path, strategy, False, 3, None, True), nprocs=2, join=True)
+    got = np.load(out_path)
+    ref, comp, cfg = _burst(denoiser=True)
+    want, dbg = oracle.main(ref, comp, cfg)
+    acc = dbg["accumulated robustness"]
+    assert 0.02 < float((acc < 3).mean()) < 0.98, "the burst does not exercise both branches of the decision"
+    assert (np.isnan(got["out"]) == np.isnan(want)).all()
+    with np.errstate(all="ignore"):
+        d = np.nanmax(np.abs(got["out"] - want))
+    assert d == 0.0 if strategy == "rows" else d < 2e-6
+    np.testing.assert_allclose(got["acc_r"], np.asarray(acc, np.float32), rtol=0, atol=0 if strategy == "rows" else 2e-6)
 
 
 @pytest.mark.timeout(300)
