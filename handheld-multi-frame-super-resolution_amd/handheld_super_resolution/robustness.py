@@ -121,7 +121,9 @@ class RobustnessSum:
 
     @staticmethod
     def decisions_of(sum64, max_frame_count):
-        """float32 map a with  a <= mfc  <=>  sum <= mfc  and  a < mfc  <=>  sum < mfc  (the kernel compares (double) a)."""
+        """float32 map a with  a <= mfc  <=>  sum <= mfc  and  a < mfc  <=>  sum < mfc  (the kernel compares (double) a).
+        Exact for every sum and every threshold float32 can hold (the reference's are frame counts); for a threshold it
+        cannot hold, a sum EQUAL to it (to the last float64 bit) lands on the side its float32 rounding lies on."""
         mfc = float(max_frame_count)
         m32 = np.float32(mfc)
         below = m32 if float(m32) < mfc else np.nextafter(m32, np.float32(-np.inf))  # largest float32 below the threshold

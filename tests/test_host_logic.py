@@ -296,3 +296,19 @@ def test_robustness_sum_keeps_float64_decisions():
     a = acc.for_decisions(3)
     assert float(a[0, 0]) < 3.0 and float(a[0, 1]) == 3.0 and a.dtype == torch.float32
     assert torch.equal(acc.mask(), acc.sum.to(torch.float32)) and acc.mask((0, 1)).shape == (1, 4)
+    # randomised: float64 sums of up to 20 float32 maps, dense around every threshold (also thresholds float32 cannot hold)
+    rng = np.random.default_rng(5)
+    for mfc in (1, 2, 3, 8, 19, 2.5, 2.1, 0.1, 16777217.0 / 8388608.0):
+        m32 = np.float32(mfc)
+        near = np.concatenate([np.float64(m32) + np.arange(-40, 41) * 2.0 ** -27,            # +- 5 float32 ulps of 2, float64 steps
+                               np.float64(mfc) + np.arange(-3, 4) * np.spacing(np.float64(mfc)),
+                               rng.uniform(0, 20, 256), [0.0, np.float64(mfc), np.float64(m32), 20.0]])
+        if float(m32) != float(mfc):  # no float32 EQUALS such a threshold: `sum == mfc` itself cannot be handed to the kernel
+            near = near[near != np.float64(mfc)]
+        s64 = torch.from_numpy(np.maximum(near, 0.0)[None])
+        a = RobustnessSum.decisions_of(s64, mfc)
+        assert a.dtype == torch.float32
+        a64 = a.to(torch.float64)
+        assert torch.equal(a64 <= mfc, s64 <= mfc) and torch.equal(a64 < mfc, s64 < mfc), mfc
+        far = (s64 - float(mfc)).abs() > 4 * float(np.spacing(m32))  # away from the threshold the map IS the rounded sum
+        assert torch.equal(a[far], s64.to(torch.float32)[far])
