@@ -96,6 +96,9 @@ def parse_args():
                     help="N > 1, rows: bound on |flow_y| in pixels for the sub-image halo (no host read in the step); "
                          "default: measured from the gathered flows (one scalar read per burst)")
     ap.add_argument("--cpu-cores", type=int, default=None, help="worker processes of the CPU baseline (default: all cores)")
+    ap.add_argument("--reps", type=int, default=5, help="repetitions of the timed block of --steps steps: ms_per_step is "
+                                                        "the MEDIAN block, ms_per_step_min / _max the spread")
+    ap.add_argument("--no-c5", action="store_true", help="skip the optional 48 MP x 20 x3 (C5 geometry) leg")
     args = ap.parse_args()
     if args.engine is not None and args.backend != "gloo":
         ap.error("--engine (a foreign per-rank engine: launch-plumbing tests) is only accepted with --backend gloo")
@@ -187,18 +190,91 @@ def main():
             e0.record()
             orig_call(name, *a)
             e1.record()
-            ev.append((e0, e1, a[4]))
+            timed_call.sink.append((e0, e1, a[4]))
         else:
             orig_call(name, *a)
 
     timed_call.on = False
+    timed_call.sink = ev
+    timed_call.steps = 0
     hmerge._lib.call = timed_call
+
+    # shader clock DURING a timed block: a one-wave probe (hhsr_clock_probe) sleeps on a side stream next to the block's
+    # kernels for ~60 % of its expected duration and reports shader cycles per 100 MHz tick
+    probe_stream = torch.cuda.Stream() if on_gpu else None
+
+    def probe_start(expect_ms):
+        if not on_gpu or expect_ms <= 0:
+            return None
+        buf = torch.zeros(4, dtype=torch.int64, device=dev)
+        with torch.cuda.stream(probe_stream):
+            hmerge._lib.call("hhsr_clock_probe", hmerge._lib.ptr(buf), int(0.6 * expect_ms * 1e5), hmerge._lib.stream())
+        return buf
+
+    def probe_mhz(buf):
+        if buf is None:
+            return None
+        probe_stream.synchronize()
+        c0, r0, c1, r1 = (int(v) for v in buf.cpu().tolist())
+        return (c1 - c0) / (r1 - r0) * 100.0 if r1 > r0 else None
+
+    def timed_reps(fn, steps, reps, warmup):
+        """`reps` timed blocks of `steps` steps (each bracketed like the contract says): per-block ms per step, and the
+        shader clock measured next to every block but the first (whose duration sizes the probes)."""
+        blocks, clocks = [], []
+        for rep in range(max(1, reps)):
+            pb = None
+            if blocks:
+                try:
+                    pb = probe_start(blocks[-1] * steps)
+                except Exception as e:  # noqa: BLE001
+                    errors.setdefault("clock_probe", f"{type(e).__name__}: {e}")
+            blocks.append(timed(fn, steps, warmup if rep == 0 else 0))
+            mhz = probe_mhz(pb)
+            if mhz:
+                clocks.append(mhz)
+        return blocks, clocks
+
+    def spread(blocks):
+        b = sorted(blocks)
+        return {"median": b[len(b) // 2] if len(b) % 2 else 0.5 * (b[len(b) // 2 - 1] + b[len(b) // 2]), "min": b[0], "max": b[-1]}
+
+    def pmc_lookup(scale_, H_, W_, NF_, launch_ms):
+        """HBM bytes / VALU instructions per launch of the merge kernel from the committed rocprofv3 --pmc passes of this
+        exact kernel source (newest profiles/rNN_pmc_merge*.json first); (None, None, why) when the record is stale."""
+        name = "pmc_merge_x3.json" if float(scale_) == 3.0 else "pmc_merge.json"
+        h = hashlib.sha256()
+        for src in MERGE_SRC.get(float(scale_), ("hhsr_merge.h", "hhsr_merge.hip")):
+            h.update(open(os.path.join(PKG_ROOT, "csrc", src), "rb").read())
+        sha = h.hexdigest()[:16]
+        note = "no PMC record in profiles/"
+        for fname in sorted((f for f in os.listdir(os.path.join(ROOT, "profiles")) if f.endswith("_" + name)), reverse=True):
+            try:
+                with open(os.path.join(ROOT, "profiles", fname)) as f:
+                    pm = json.load(f)
+            except Exception as e:  # noqa: BLE001
+                note = f"profiles/{fname}: {e}"
+                continue
+            if pm.get("workload") != f"{H_}x{W_}x{NF_} x{scale_}":
+                continue
+            if pm.get("source_sha16") != sha:
+                note = (f"profiles/{fname} was collected for kernel source {pm.get('source_sha16')}, the source is now "
+                        f"{sha}: counters not reported (re-run tools/pmc_merge.sh)")
+                continue
+            insts = pm["valu_wave_insts_per_launch"]
+            lane_ops = insts * 64 / (launch_ms * 1e-3)
+            return pm["traffic_bytes_per_launch"], {
+                "wave_insts_per_launch": insts, "achieved_Tlaneops": round(lane_ops / 1e12, 2),
+                "peak_Tlaneops": VALU_PEAK_TLANEOPS, "frac": round(lane_ops / 1e12 / VALU_PEAK_TLANEOPS, 3),
+                "source": f"profiles/{fname}"}, None
+        return None, None, note
 
     # one engine for all steps: with device-resident frames it captures the step in a HIP graph on its second call and
     # replays it afterwards (handheld_super_resolution/graph.py) — one launch per burst instead of ~280
     engine = engine_cls(cfg)
 
     def step(r=ref, c=comp):
+        timed_call.steps += int(timed_call.on)
         return hdist.main_sharded(r, c, cfg, engine=engine, gather=args.gather, strategy=args.strategy,
                                   max_flow=args.max_flow)[0]
 
@@ -224,12 +300,18 @@ def main():
             dt = float(t.item())
         return dt / steps * 1e3
 
+    errors = {}
+    t_region = time.perf_counter()
     for _ in range(args.warmup):
         step()
     barrier()
     timed_call.on = True
-    ms_per_step = timed(step, args.steps, 0)
+    # EXACTLY --steps steps per timed block, --reps blocks back to back: the headline is the median block
+    ms_blocks, sclk = timed_reps(step, args.steps, args.reps, 0)
     timed_call.on = False
+    timed_region_s = time.perf_counter() - t_region
+    sp = spread(ms_blocks)
+    ms_per_step = sp["median"]
     out_pix = round(scale * H) * round(scale * W)
     value = out_pix / (ms_per_step * 1e-3) / 1e6
     P, S = H * W, float(scale) ** 2
@@ -237,7 +319,6 @@ def main():
     # ---- the measurement exists from here on: the line is built NOW and printed exactly once — at the end of the optional
     # legs below (each guarded: a failing leg leaves its error string in line["errors"]), or by the exit hook if anything
     # else ends the process first.  N > 1 runs none of the host-resident / CPU legs (they are N = 1 figures).
-    errors = {}
     line = {
         "metric": "output Mpix/s for 12MP x 20-frame x2 SR burst; max-abs diff vs reference" if headline else
                   f"output Mpix/s for {H * W / 1e6:.0f}MP x {NF}-frame x{scale} SR burst; max-abs diff vs reference",
@@ -245,6 +326,12 @@ def main():
         "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "strong",
         "vs_baseline": round(value / 12.0, 2) if headline else None,
         "dtype": "f32", "data": "synthetic",
+        "reps": len(ms_blocks), "ms_per_step_min": round(sp["min"], 3), "ms_per_step_max": round(sp["max"], 3),
+        "ms_per_step_blocks": [round(b, 3) for b in ms_blocks],
+        "spread_pct": round(100.0 * (sp["max"] - sp["min"]) / sp["median"], 2),
+        "sclk_mhz": round(spread(sclk)["median"], 1) if sclk else None,
+        "sclk_mhz_blocks": [round(c, 1) for c in sclk] if sclk else None,
+        "timed_region_s": round(timed_region_s, 2),
     }
     printed = []
 
@@ -264,7 +351,7 @@ def main():
         g_any = torch.tensor([int(graphed)], dtype=torch.int32, device=dev)
         dist.all_reduce(g_any, op=dist.ReduceOp.MAX)
         graphed = bool(int(g_any.item()))
-    ms_eager, ev_steps = None, args.steps
+    ms_eager, ev_steps = None, timed_call.steps  # (not graphed: every step of the timed blocks launched the kernel itself)
     if graphed:
         # the timed steps were graph replays: no Python launch to bracket with events.  The dominant kernel's launch
         # duration comes from a few eager steps of the same workload right after (same kernel, same inputs)
@@ -426,7 +513,14 @@ def main():
     try:
         step_ms = [e0.elapsed_time(e1) for e0, e1, nfr in ev if nfr > 0]
         if step_ms:
-            avg_ms = float(np.sum(step_ms)) / ev_steps
+            per_step = len(step_ms) // ev_steps if ev_steps and len(step_ms) % ev_steps == 0 else 0
+            if per_step:  # launches of one step summed, then the MEDIAN over the steps
+                sums = [float(np.sum(step_ms[i * per_step:(i + 1) * per_step])) for i in range(ev_steps)]
+                avg_ms = float(np.median(sums))
+                launch_spread = (min(sums), max(sums))
+            else:
+                avg_ms = float(np.sum(step_ms)) / ev_steps
+                launch_spread = None
             # whole-image launch on one GPU; on N ranks each launch covers 1/N of the output rows (+ halo rows of input)
             nbytes = merge_burst_bytes(NF - 1, P, S) / world
             achieved = nbytes / (avg_ms * 1e-3) / 1e9
@@ -434,30 +528,12 @@ def main():
             # kernels, other integer scales the tile kernel, non-integer scales the generic one)
             kernel = ("k_merge_x2" if float(scale) == 2.0 else "k_merge_xs<3>" if float(scale) == 3.0 and W % 4 == 0
                       else "k_merge_burst_tile" if float(scale).is_integer() else "k_merge_burst")
-            traffic, valu, pmc_note = None, None, None
-            try:  # HBM bytes / VALU instructions per launch from the committed rocprofv3 --pmc passes of this exact kernel
-                pmc_file = "r05_pmc_merge_x3.json" if float(scale) == 3.0 else "r05_pmc_merge.json"
-                with open(os.path.join(ROOT, "profiles", pmc_file)) as f:
-                    pm = json.load(f)
-                h = hashlib.sha256()
-                for src in MERGE_SRC.get(float(scale), ("hhsr_merge.h", "hhsr_merge.hip")):
-                    h.update(open(os.path.join(PKG_ROOT, "csrc", src), "rb").read())
-                sha = h.hexdigest()[:16]
-                if pm.get("workload") == f"{H}x{W}x{NF} x{scale}" and world == 1:
-                    if pm.get("source_sha16") == sha:
-                        traffic = pm["traffic_bytes_per_launch"]
-                        insts = pm["valu_wave_insts_per_launch"]
-                        lane_ops = insts * 64 / (avg_ms * 1e-3)
-                        valu = {"wave_insts_per_launch": insts, "achieved_Tlaneops": round(lane_ops / 1e12, 2),
-                                "peak_Tlaneops": VALU_PEAK_TLANEOPS, "frac": round(lane_ops / 1e12 / VALU_PEAK_TLANEOPS, 3)}
-                    else:
-                        pmc_note = (f"profiles/{pmc_file} was collected for kernel source {pm.get('source_sha16')}, "
-                                    f"the source is now {sha}: counters not reported (re-run tools/pmc_merge.sh)")
-            except Exception as e:  # noqa: BLE001
-                pmc_note = f"no PMC record: {e}"
+            traffic, valu, pmc_note = pmc_lookup(scale, H, W, NF, avg_ms) if world == 1 else (None, None, None)
             roof = {"kernel": f"{kernel} (hhsr_merge_burst)", "bound": "valu", "achieved": round(achieved, 1),
                     "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
-                    "avg_launch_ms": round(avg_ms, 4), "bytes_per_launch": nbytes, "valu_issue": valu,
+                    "avg_launch_ms": round(avg_ms, 4), "avg_launch_ms_is": "median over the eager steps",
+                    "launch_ms_min_max": [round(v, 4) for v in launch_spread] if launch_spread else None,
+                    "bytes_per_launch": nbytes, "valu_issue": valu,
                     "frac_valu": valu["frac"] if valu else None, "frac_hbm": round(achieved / HBM_PEAK_GBS, 4),
                     "note": "the fused burst merge keeps the accumulators in registers: ~100 flop per byte, bound by VALU "
                             "issue (frac_valu), not by HBM; achieved / peak / frac are the HBM figures the contract asks for"
@@ -566,6 +642,62 @@ def main():
             del eng64
         except Exception as e:  # noqa: BLE001
             errors["weight_fp64_leg"] = f"{type(e).__name__}: {e}"
+
+    # ---- the C5 geometry on ONE GPU (48 MP x 20 frames x3 -> 432 MP; BASELINE.json configs[4] is this workload over 8 GPUs):
+    # the x3 merge kernel's numbers in the driver's own record.  Optional, guarded, N = 1, headline run only.
+    if on_gpu and world == 1 and headline and not args.no_c5 and not args.no_h2d:
+        import copy
+
+        try:
+            H5, W5, NF5, sc5 = 6000, 8000, 20, 3
+            ref5, comp5, _ = synth.make_burst_torch(H5, W5, NF5, dev, seed=4321)
+            cfg5 = hsr.default_config()
+            cfg5.verbose = 0
+            cfg5.scale = sc5
+            cfg5.hip = {"graph": not args.no_graph}
+            hsr.prepare_config(cfg5, np.full((H5, W5), float(ref5.mean()), np.float32), synth.ALPHA_ISO100, synth.BETA_ISO100,
+                               [[0, 1], [1, 2]], [1.0, 1.0, 1.0])
+            eng5 = engine_cls(cfg5)
+            fn5 = lambda: hdist.main_sharded(ref5, comp5, cfg5, engine=eng5)[0]  # noqa: E731
+            blocks5, clocks5 = timed_reps(fn5, 3, 3, 3)
+            sp5 = spread(blocks5)
+            del eng5
+            out5 = sc5 * H5 * sc5 * W5
+            c5 = {"workload": f"{H5}x{W5} Bayer burst, {NF5} frames, x{sc5} SR, frames resident in HBM, one GPU",
+                  "ms_per_step": round(sp5["median"], 3), "ms_per_step_min": round(sp5["min"], 3),
+                  "ms_per_step_max": round(sp5["max"], 3), "steps": 3, "reps": len(blocks5),
+                  "value": round(out5 / (sp5["median"] * 1e-3) / 1e6, 2), "unit": "Mpix/s",
+                  "sclk_mhz": round(spread(clocks5)["median"], 1) if clocks5 else None, "roofline": None}
+            line["c5_one_gpu"] = c5
+            # the x3 merge kernel's launch duration: HIP events around the launch in eager steps of the same workload
+            cfg5e = copy.deepcopy(cfg5)
+            cfg5e.hip = dict(cfg5e.hip, graph=False)
+            eng5e = engine_cls(cfg5e)
+            fn5e = lambda: hdist.main_sharded(ref5, comp5, cfg5e, engine=eng5e)[0]  # noqa: E731
+            for _ in range(2):
+                fn5e()
+            barrier()
+            ev5 = []
+            timed_call.sink, timed_call.on = ev5, True
+            timed(fn5e, 3, 0)
+            timed_call.on, timed_call.sink = False, ev
+            del eng5e
+            ms5 = [e0.elapsed_time(e1) for e0, e1, nfr in ev5 if nfr > 0]
+            if ms5 and len(ms5) % 3 == 0:
+                k5 = len(ms5) // 3
+                launch5 = float(np.median([float(np.sum(ms5[i * k5:(i + 1) * k5])) for i in range(3)]))
+                nb5 = merge_burst_bytes(NF5 - 1, H5 * W5, float(sc5) ** 2)
+                ach5 = nb5 / (launch5 * 1e-3) / 1e9
+                tr5, valu5, note5 = pmc_lookup(sc5, H5, W5, NF5, launch5)
+                c5["roofline"] = {"kernel": "k_merge_xs<3> (hhsr_merge_burst)", "bound": "valu", "achieved": round(ach5, 1),
+                                  "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach5 / HBM_PEAK_GBS, 4), "traffic": tr5,
+                                  "avg_launch_ms": round(launch5, 4), "bytes_per_launch": nb5, "valu_issue": valu5,
+                                  "frac_valu": valu5["frac"] if valu5 else None, "note": note5}
+            del ref5, comp5
+            torch.cuda.empty_cache()
+        except Exception as e:  # noqa: BLE001
+            timed_call.on, timed_call.sink = False, ev
+            errors["c5_leg"] = f"{type(e).__name__}: {e}"
 
     # ---- CPU baseline (all host cores) + parity with attribution, on a crop of the same burst ----------------------
     cpu, parity = None, None

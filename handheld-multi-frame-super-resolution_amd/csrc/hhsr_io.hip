@@ -63,3 +63,32 @@ extern "C" int hhsr_normalize_raw_u16(const uint16_t* raw, int n_frames, int H, 
                        (size_t)H * W, H, A);
     HHSR_LAUNCHED();
 }
+
+// ---- shader-clock probe (measurement support: bench.py's "sclk_mhz") --------------------------------------------
+// ONE wave reads the shader-cycle counter (s_memtime: one tick per shader clock, MI355X_MICROARCH.md "s_memtime tick")
+// and the constant 100 MHz counter (s_memrealtime) when it starts, sleeps until `ticks` of the constant counter have
+// passed (s_sleep: no issue slots taken from the kernels it runs next to) and reads both again.  Launched on a side
+// stream around a timed region it reports the clock the other kernels ACTUALLY ran at: out = {memtime0, realtime0,
+// memtime1, realtime1}; sclk = (out[2] - out[0]) / (out[3] - out[1]) x 100 MHz.
+__global__ void __launch_bounds__(64) k_clock_probe(unsigned long long* __restrict__ out, long long ticks) {
+    if (threadIdx.x != 0) return;
+    const unsigned long long c0 = __builtin_readcyclecounter(), r0 = wall_clock64();
+    unsigned long long r1 = r0;
+    while ((long long)(r1 - r0) < ticks) {
+        __builtin_amdgcn_s_sleep(127);
+        r1 = wall_clock64();
+    }
+    const unsigned long long c1 = __builtin_readcyclecounter();
+    out[0] = c0;
+    out[1] = r0;
+    out[2] = c1;
+    out[3] = r1;
+}
+
+extern "C" int hhsr_clock_probe(uint64_t* out4, int64_t ticks_100mhz, void* stream) {
+    HHSR_ARG(out4 != nullptr);
+    HHSR_ARG(ticks_100mhz >= 0 && ticks_100mhz <= 1000000000LL);  // at most 10 s
+    hipLaunchKernelGGL(k_clock_probe, dim3(1), dim3(64), 0, (hipStream_t)stream, (unsigned long long*)out4,
+                       (long long)ticks_100mhz);
+    HHSR_LAUNCHED();
+}

@@ -61,6 +61,7 @@ _SIGS = {
     "hhsr_postprocess": [P, P, P, I, I, FP, I, D, P, I, I, I, I, P],
     "hhsr_orient_plane": [P, P, I, I, I, P],
     "hhsr_merge_burst": [PP, PP, PP, PP, I, I, I, I, I, I, I, P, P, U8P, D, I, I, P, P, P, I, I, I, I, I, P],
+    "hhsr_clock_probe": [P, L, P],
     "hhsr_merge_burst_chain": [PP, PP, PP, PP, I, I, I, I, I, I, I, P, P, U8P, D, I, I, P, P, P, I, I, P, I, P],
 }
 

@@ -340,6 +340,13 @@ int hhsr_postprocess(const float* image, float* tmp, float* out, int H, int W, c
 /* float32 [H][W] plane (accumulated robustness) to its EXIF-oriented position (utils_image.py:12-55). */
 int hhsr_orient_plane(const float* in, float* out, int H, int W, int orientation, void* stream);
 
+/* ---- measurement support ------------------------------------------------------------------------------------------
+ * Shader-clock probe: one wave that sleeps for `ticks_100mhz` ticks of the constant 100 MHz counter and stores
+ * {shader cycles, 100 MHz ticks} at its start and end into out4 (DEVICE uint64[4]); launched on a side stream around a
+ * timed region, (out4[2] - out4[0]) / (out4[3] - out4[1]) x 100 MHz is the clock the kernels next to it ran at
+ * (bench.py's "sclk_mhz").  No counterpart in the reference. */
+int hhsr_clock_probe(uint64_t* out4, int64_t ticks_100mhz, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

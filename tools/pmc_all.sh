@@ -13,10 +13,10 @@ for C in "SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_
          "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR" \
          "FETCH_SIZE" "WRITE_SIZE"; do
   i=$((i+1))
-  rocprofv3 --pmc $C --kernel-include-regex "k_" --output-format csv -d $OUT/p$i -o p -- python $GRAFT_REPO_ROOT/bench.py $ARGS > $OUT/p$i.log 2>&1
+  rocprofv3 --pmc $C --kernel-include-regex "k_" --output-format csv -d $OUT/p$i -o p -- python $GRAFT_REPO_ROOT/bench.py --reps 1 $ARGS > $OUT/p$i.log 2>&1
 done
 rm -rf /tmp/pmc_all_kt
-rocprofv3 --kernel-trace -d /tmp/pmc_all_kt -o kt -- python $GRAFT_REPO_ROOT/bench.py $ARGS > /dev/null 2>&1
+rocprofv3 --kernel-trace -d /tmp/pmc_all_kt -o kt -- python $GRAFT_REPO_ROOT/bench.py --reps 1 $ARGS > /dev/null 2>&1
 cp $(find /tmp/pmc_all_kt -name "*results.db" | head -1) $OUT/kt.db
 python $GRAFT_REPO_ROOT/tools/pmc_all_report.py $OUT 2 > $OUT/table.md
 rm -f $OUT/kt.db

@@ -15,6 +15,6 @@ for C in "SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_
          "SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_MISC SQ_INST_LEVEL_LDS" \
          "FETCH_SIZE" "WRITE_SIZE"; do
   i=$((i+1))
-  rocprofv3 --pmc $C --kernel-include-regex "$RX" --output-format csv -d $OUT/p$i -o p$i -- python $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline --no-graph "$@" > $OUT/p$i.log 2>&1
+  rocprofv3 --pmc $C --kernel-include-regex "$RX" --output-format csv -d $OUT/p$i -o p$i -- python $GRAFT_REPO_ROOT/bench.py --reps 1 --no-cpu-baseline --no-graph "$@" > $OUT/p$i.log 2>&1
 done
 find $OUT -name "*counter_collection.csv" | head
