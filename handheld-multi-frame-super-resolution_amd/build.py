@@ -43,7 +43,7 @@ def _stale(target, deps):
 
 def build(force=False, verbose=True):
     os.makedirs(OBJ, exist_ok=True)
-    headers = [os.path.join(CSRC, "hhsr_common.h"), os.path.join(CSRC, "hhsr_fft.h"), os.path.join(CSRC, "hhsr_merge.h"), os.path.join(HERE, "..", "include", "hhsr.h"), __file__]
+    headers = [os.path.join(CSRC, "hhsr_common.h"), os.path.join(CSRC, "hhsr_fft.h"), os.path.join(CSRC, "hhsr_fft_bfly.h"), os.path.join(CSRC, "hhsr_merge.h"), os.path.join(HERE, "..", "include", "hhsr.h"), __file__]
     jobs = []
     objs = []
     for src, extra in SOURCES.items():

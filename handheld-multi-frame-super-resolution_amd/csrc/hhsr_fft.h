@@ -25,6 +25,8 @@ struct HhsrFft {
     int nc = 0;                     // kept columns per workgroup of the column kernel (2 or 1)
     int batch = 1;                  // frames one launch may carry: T holds this many spectra, tstride elements apart
     size_t tstride = 0;
+    int static_rows = 0, static_cols = 0;  // > 0: the row / column kernels run the passes of this compile-time plan
+                                           // (hhsr_fft.hip: HHSR_STATIC_ROWS / HHSR_STATIC_COLS)
 };
 
 bool hhsr_fft_create(HhsrFft& f, int H, int W, int batch);   // false: sizes unsupported (caller uses the library plans)

@@ -21,186 +21,10 @@
 #include "hhsr_common.h"
 #include "hhsr_fft.h"
 #include <math.h>
+#include <type_traits>
 #include <vector>
 
-#define HHSR_FFT_POW_RMAX 6  // radices up to this may take the power form (the schedule puts the small radices last)
-#ifndef HHSR_FFT_POW_MIN
-#define HHSR_FFT_POW_MIN 1024  // entries of one pass's twiddle table above which it is kept as w^k only (0: never)
-#endif
-
-// ---- complex helpers ------------------------------------------------------------------------------------
-__device__ __forceinline__ float2 cadd(float2 a, float2 b) { return make_float2(a.x + b.x, a.y + b.y); }
-__device__ __forceinline__ float2 csub(float2 a, float2 b) { return make_float2(a.x - b.x, a.y - b.y); }
-__device__ __forceinline__ float2 cmul(float2 a, float2 b) {
-    return make_float2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x);
-}
-__device__ __forceinline__ float2 cconj(float2 a) { return make_float2(a.x, -a.y); }
-__device__ __forceinline__ float2 cscale(float2 a, float s) { return make_float2(a.x * s, a.y * s); }
-__device__ __forceinline__ float2 mul_mi(float2 a) { return make_float2(a.y, -a.x); }  // a * (-i)
-__device__ __forceinline__ float2 mul_pi(float2 a) { return make_float2(-a.y, a.x); }  // a * (+i)
-
-// ---- forward R-point DFTs (w = exp(-2 pi i / R)) ------------------------------------------------------------
-__device__ __forceinline__ void dft2(float2* v) {
-    const float2 a = v[0], b = v[1];
-    v[0] = cadd(a, b);
-    v[1] = csub(a, b);
-}
-__device__ __forceinline__ void dft3(float2* v) {
-    const float s = 0.86602540378443864676f;
-    const float2 t1 = cadd(v[1], v[2]);
-    const float2 m1 = make_float2(v[0].x - 0.5f * t1.x, v[0].y - 0.5f * t1.y);
-    const float2 d = cscale(mul_mi(csub(v[1], v[2])), s);  // -i s (b - c)
-    v[0] = cadd(v[0], t1);
-    v[1] = cadd(m1, d);
-    v[2] = csub(m1, d);
-}
-__device__ __forceinline__ void dft4(float2* v) {
-    const float2 s02 = cadd(v[0], v[2]), d02 = csub(v[0], v[2]);
-    const float2 s13 = cadd(v[1], v[3]), d13 = mul_mi(csub(v[1], v[3]));  // -i (b - d)
-    v[0] = cadd(s02, s13);
-    v[2] = csub(s02, s13);
-    v[1] = cadd(d02, d13);
-    v[3] = csub(d02, d13);
-}
-__device__ __forceinline__ void dft5(float2* v) {
-    const float c1 = 0.30901699437494742410f, c2 = -0.80901699437494742410f;
-    const float s1 = 0.95105651629515357212f, s2 = 0.58778525229247312917f;
-    const float2 t1 = cadd(v[1], v[4]), t2 = cadd(v[2], v[3]);
-    const float2 t3 = csub(v[1], v[4]), t4 = csub(v[2], v[3]);
-    const float2 a = v[0];
-    const float2 m1 = make_float2(a.x + c1 * t1.x + c2 * t2.x, a.y + c1 * t1.y + c2 * t2.y);
-    const float2 m2 = make_float2(a.x + c2 * t1.x + c1 * t2.x, a.y + c2 * t1.y + c1 * t2.y);
-    const float2 n1 = mul_mi(make_float2(s1 * t3.x + s2 * t4.x, s1 * t3.y + s2 * t4.y));  // -i n1
-    const float2 n2 = mul_mi(make_float2(s2 * t3.x - s1 * t4.x, s2 * t3.y - s1 * t4.y));  // -i n2
-    v[0] = cadd(a, cadd(t1, t2));
-    v[1] = cadd(m1, n1);
-    v[4] = csub(m1, n1);
-    v[2] = cadd(m2, n2);
-    v[3] = csub(m2, n2);
-}
-
-// 7-point DFT: a_j = x_j + x_{7-j}, b_j = x_j - x_{7-j};  X_k = x_0 + sum_j a_j cos(2 pi j k / 7) -+ i sum_j b_j
-// sin(2 pi j k / 7) for k and 7 - k.  (4032 x 3024 sensors: 2016 = 2^5 3^2 7, 3024 = 2^4 3^3 7.)
-__device__ __forceinline__ void dft7(float2* v) {
-    const float c1 = 0.62348980185873353053f, c2 = -0.22252093395631440429f, c3 = -0.90096886790241912624f;
-    const float s1 = 0.78183148246802980871f, s2 = 0.97492791218182360702f, s3 = 0.43388373911755812048f;
-    const float2 x0 = v[0];
-    const float2 a1 = cadd(v[1], v[6]), a2 = cadd(v[2], v[5]), a3 = cadd(v[3], v[4]);
-    const float2 b1 = csub(v[1], v[6]), b2 = csub(v[2], v[5]), b3 = csub(v[3], v[4]);
-    // cos / sin of 2 pi j k / 7 for (j, k) in 1..3: index j*k mod 7 folded to 1..3 (sin changes sign past 3)
-    const float2 m1 = make_float2(x0.x + c1 * a1.x + c2 * a2.x + c3 * a3.x, x0.y + c1 * a1.y + c2 * a2.y + c3 * a3.y);
-    const float2 m2 = make_float2(x0.x + c2 * a1.x + c3 * a2.x + c1 * a3.x, x0.y + c2 * a1.y + c3 * a2.y + c1 * a3.y);
-    const float2 m3 = make_float2(x0.x + c3 * a1.x + c1 * a2.x + c2 * a3.x, x0.y + c3 * a1.y + c1 * a2.y + c2 * a3.y);
-    const float2 n1 = mul_mi(make_float2(s1 * b1.x + s2 * b2.x + s3 * b3.x, s1 * b1.y + s2 * b2.y + s3 * b3.y));
-    const float2 n2 = mul_mi(make_float2(s2 * b1.x - s3 * b2.x - s1 * b3.x, s2 * b1.y - s3 * b2.y - s1 * b3.y));
-    const float2 n3 = mul_mi(make_float2(s3 * b1.x - s1 * b2.x + s2 * b3.x, s3 * b1.y - s1 * b2.y + s2 * b3.y));
-    v[0] = cadd(x0, cadd(a1, cadd(a2, a3)));
-    v[1] = cadd(m1, n1);
-    v[6] = csub(m1, n1);
-    v[2] = cadd(m2, n2);
-    v[5] = csub(m2, n2);
-    v[3] = cadd(m3, n3);
-    v[4] = csub(m3, n3);
-}
-
-// ---- composite radices: R = A * B point DFTs in registers ----------------------------------------------------
-// Cooley-Tukey inside the butterfly: n = n1 B + n2, k = k1 + A k2:
-//   X[k1 + A k2] = sum_n2 w_B^(n2 k2) [ w_R^(n2 k1) sum_n1 v[n1 B + n2] w_A^(n1 k1) ].
-// The inner twiddles w_R^m are compile-time constants (float64 Taylor series, constexpr), trivial ones
-// (1, -i, -1, +i) cost no multiplication.  Three passes of radix 10-25 replace the five to six passes of radix
-// <= 5: half the LDS round trips and workgroup barriers of kernels that are bound by exactly those.
-constexpr double hhsr_pi = 3.14159265358979323846264338327950288;
-constexpr double c_sin_small(double x) {  // |x| <= pi/4
-    double term = x, sum = x;
-    for (int n = 1; n < 12; ++n) {
-        term *= -x * x / ((2.0 * n) * (2.0 * n + 1.0));
-        sum += term;
-    }
-    return sum;
-}
-constexpr double c_cos_small(double x) {
-    double term = 1.0, sum = 1.0;
-    for (int n = 1; n < 12; ++n) {
-        term *= -x * x / ((2.0 * n - 1.0) * (2.0 * n));
-        sum += term;
-    }
-    return sum;
-}
-// cos / sin of 2 pi m / R through octant reduction (exact on the axes)
-constexpr double c_cos2pi(int m, int R) {
-    m %= R;
-    if (8 * m <= R) return c_cos_small(2.0 * hhsr_pi * m / R);
-    if (8 * m <= 3 * R) return -c_sin_small(2.0 * hhsr_pi * (4 * m - R) / (4.0 * R));       // cos(pi/2 + d) = -sin d
-    if (8 * m <= 5 * R) return -c_cos_small(2.0 * hhsr_pi * (2 * m - R) / (2.0 * R));       // cos(pi + d) = -cos d
-    if (8 * m <= 7 * R) return c_sin_small(2.0 * hhsr_pi * (4 * m - 3 * R) / (4.0 * R));    // cos(3pi/2 + d) = sin d
-    return c_cos_small(2.0 * hhsr_pi * (m - R) / (double)R);
-}
-constexpr double c_sin2pi(int m, int R) {
-    m %= R;
-    if (8 * m <= R) return c_sin_small(2.0 * hhsr_pi * m / R);
-    if (8 * m <= 3 * R) return c_cos_small(2.0 * hhsr_pi * (4 * m - R) / (4.0 * R));
-    if (8 * m <= 5 * R) return -c_sin_small(2.0 * hhsr_pi * (2 * m - R) / (2.0 * R));
-    if (8 * m <= 7 * R) return -c_cos_small(2.0 * hhsr_pi * (4 * m - 3 * R) / (4.0 * R));
-    return c_sin_small(2.0 * hhsr_pi * (m - R) / (double)R);
-}
-template <int R>
-struct TwTab {  // w_R^m = exp(-2 pi i m / R)
-    float c[R], s[R];
-    constexpr TwTab() : c(), s() {
-        for (int m = 0; m < R; ++m) {
-            c[m] = (float)c_cos2pi(m, R);
-            s[m] = (float)(-c_sin2pi(m, R));
-        }
-    }
-};
-
-template <int R>
-__device__ __forceinline__ void dft_reg(float2* v);
-template <> __device__ __forceinline__ void dft_reg<2>(float2* v) { dft2(v); }
-template <> __device__ __forceinline__ void dft_reg<3>(float2* v) { dft3(v); }
-template <> __device__ __forceinline__ void dft_reg<4>(float2* v) { dft4(v); }
-template <> __device__ __forceinline__ void dft_reg<5>(float2* v) { dft5(v); }
-template <> __device__ __forceinline__ void dft_reg<7>(float2* v) { dft7(v); }
-
-template <int A, int B>
-__device__ __forceinline__ void dft_comp(float2* v) {
-    constexpr int R = A * B;
-    constexpr TwTab<R> tab{};
-    float2 y[B][A];
-#pragma unroll
-    for (int n2 = 0; n2 < B; ++n2) {
-        float2 t[A];
-#pragma unroll
-        for (int n1 = 0; n1 < A; ++n1) t[n1] = v[n1 * B + n2];
-        dft_reg<A>(t);
-#pragma unroll
-        for (int k1 = 0; k1 < A; ++k1) {
-            const int m = (n2 * k1) % R;
-            if (m == 0) y[n2][k1] = t[k1];
-            else if (4 * m == R) y[n2][k1] = mul_mi(t[k1]);
-            else if (2 * m == R) y[n2][k1] = make_float2(-t[k1].x, -t[k1].y);
-            else if (4 * m == 3 * R) y[n2][k1] = mul_pi(t[k1]);
-            else y[n2][k1] = cmul(t[k1], make_float2(tab.c[m], tab.s[m]));
-        }
-    }
-#pragma unroll
-    for (int k1 = 0; k1 < A; ++k1) {
-        float2 t[B];
-#pragma unroll
-        for (int n2 = 0; n2 < B; ++n2) t[n2] = y[n2][k1];
-        dft_reg<B>(t);
-#pragma unroll
-        for (int k2 = 0; k2 < B; ++k2) v[k1 + A * k2] = t[k2];
-    }
-}
-template <> __device__ __forceinline__ void dft_reg<6>(float2* v) { dft_comp<3, 2>(v); }
-template <> __device__ __forceinline__ void dft_reg<8>(float2* v) { dft_comp<4, 2>(v); }
-template <> __device__ __forceinline__ void dft_reg<9>(float2* v) { dft_comp<3, 3>(v); }
-template <> __device__ __forceinline__ void dft_reg<10>(float2* v) { dft_comp<5, 2>(v); }
-template <> __device__ __forceinline__ void dft_reg<12>(float2* v) { dft_comp<4, 3>(v); }
-template <> __device__ __forceinline__ void dft_reg<14>(float2* v) { dft_comp<7, 2>(v); }
-template <> __device__ __forceinline__ void dft_reg<15>(float2* v) { dft_comp<5, 3>(v); }
-template <> __device__ __forceinline__ void dft_reg<16>(float2* v) { dft_comp<4, 4>(v); }
+#include "hhsr_fft_bfly.h"
 
 // Butterflies one thread may hold between the read and the write phase of a pass (2 R VGPRs each)
 __host__ __device__ constexpr int fft_maxit(int R) { return R <= 3 ? 4 : R <= 5 ? 3 : R <= 12 ? 2 : 1; }
@@ -290,6 +114,109 @@ __device__ __forceinline__ void fft_lds(float2* buf, int bstride, int NB, const 
         Ns *= R;
     }
 }
+
+// ---- static plans: the same passes with N, the radices and every sub-transform length as template constants ------------
+// The run-time passes above compute every LDS address (input leg r at j + r L, output at q R Ns + k + r Ns, twiddle at
+// (r - 1) Ns + k: L, Ns in registers) and j / Ns by a float trick, per pass and per row; with constants the legs sit at
+// IMMEDIATE offsets of one base address per pass, and those bases depend on the thread id alone — the compiler keeps
+// them across the persistent row loop.  Same butterflies, same tables, same order of operations.
+template <int N_, int... RS>
+struct SPlan {
+    static constexpr int N = N_;
+    static constexpr int NP = (int)sizeof...(RS);
+    static constexpr int R[NP] = {RS...};
+    static constexpr int ns(int p) {  // sub-transform length before pass p
+        int s = 1;
+        for (int i = 0; i < p; ++i) s *= R[i];
+        return s;
+    }
+    static constexpr bool pw(int p) {  // (= pass_twiddles() with the default pow_min)
+        return HHSR_FFT_POW_MIN > 0 && R[p] <= HHSR_FFT_POW_RMAX && (R[p] - 1) * ns(p) > HHSR_FFT_POW_MIN;
+    }
+    static constexpr int toff(int p) {
+        int o = 0;
+        for (int i = 0; i < p; ++i) o += pw(i) ? ns(i) : (R[i] - 1) * ns(i);
+        return o;
+    }
+    static bool matches(int n, const HhsrRadices& rad) {
+        if (n != N || rad.n != NP || rad.pow_min != HHSR_FFT_POW_MIN) return false;
+        for (int i = 0; i < NP; ++i)
+            if (rad.r[i] != R[i]) return false;
+        return true;
+    }
+};
+struct NoPlan {
+    static constexpr int N = 0;
+};
+// the transform length as the kernel sees it: the plan's constant, or the run-time argument
+template <class SP>
+__device__ __forceinline__ int plan_len(int runtime) {
+    return std::is_same<SP, NoPlan>::value ? runtime : SP::N;
+}
+
+template <int N, int NB, int NT, int R, int Ns, bool PW>
+__device__ __forceinline__ void stockham_pass_s(float2* __restrict__ buf, const float2* __restrict__ twp, int tid) {
+    constexpr int MAXIT = fft_maxit(R), L = N / R, total = NB * L;
+    float2 v[MAXIT][R];
+    int dst[MAXIT];
+#pragma unroll
+    for (int it = 0; it < MAXIT; ++it) {
+        const int jj = tid + it * NT;
+        if (it * NT < total && jj < total) {
+            const int bidx = NB > 1 ? (int)((unsigned)jj / (unsigned)L) : 0;
+            const int j = jj - bidx * L;
+            const int q = (int)((unsigned)j / (unsigned)Ns), k = j - q * Ns;
+            const float2* ib = buf + bidx * N + j;
+#pragma unroll
+            for (int r = 0; r < R; ++r) v[it][r] = ib[r * L];
+            if (Ns > 1) {
+                if (R <= HHSR_FFT_POW_RMAX && PW) {
+                    float2 w[R];
+                    w[1] = twp[k];
+#pragma unroll
+                    for (int r = 2; r < R; ++r) w[r] = cmul(w[r >> 1], w[r - (r >> 1)]);
+#pragma unroll
+                    for (int r = 1; r < R; ++r) v[it][r] = cmul(v[it][r], w[r]);
+                } else {
+#pragma unroll
+                    for (int r = 1; r < R; ++r) v[it][r] = cmul(v[it][r], twp[(r - 1) * Ns + k]);
+                }
+            }
+            dft_reg<R>(v[it]);
+            dst[it] = bidx * N + q * (R * Ns) + k;
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int it = 0; it < MAXIT; ++it) {
+        const int jj = tid + it * NT;
+        if (it * NT < total && jj < total) {
+#pragma unroll
+            for (int r = 0; r < R; ++r) buf[dst[it] + r * Ns] = v[it][r];
+        }
+    }
+    __syncthreads();
+}
+
+template <class P, int NB, int NT, int PASS = 0>
+__device__ __forceinline__ void fft_lds_s(float2* buf, const float2* tw, int tid) {
+    if (PASS == 0) __syncthreads();
+    if constexpr (PASS < P::NP) {
+        stockham_pass_s<P::N, NB, NT, P::R[PASS], P::ns(PASS), P::pw(PASS)>(buf, tw + P::toff(PASS), tid);
+        fft_lds_s<P, NB, NT, PASS + 1>(buf, tw, tid);
+    }
+}
+
+// the lengths with a static plan (= what factorize() picks for them: hhsr_fft_create checks)
+// X(id, length, rows per workgroup / columns per workgroup, threads, radices...)
+#define HHSR_STATIC_ROWS(X)                                                                 \
+    X(1, 2000, 1, FFT_NT_SMALL, 10, 10, 10, 2) /* 4000-pixel rows (12 MP 4:3) */             \
+    X(2, 4000, 1, FFT_NT, 10, 10, 10, 4)       /* 8000-pixel rows (48 MP) */                 \
+    X(3, 2016, 1, FFT_NT_SMALL, 14, 12, 12)    /* 4032-pixel rows (the common 12 MP sensor) */
+#define HHSR_STATIC_COLS(X)                                                                 \
+    X(1, 3000, 2, FFT_NT, 3, 10, 10, 10)       /* 3000-pixel columns */                      \
+    X(2, 6000, 1, FFT_NT, 10, 10, 10, 6)       /* 6000-pixel columns */                      \
+    X(3, 3024, 2, FFT_NT, 9, 8, 7, 6)          /* 3024-pixel columns */
 
 __device__ __forceinline__ bool fft_kept(int u, int n) {
     int i = u + n / 2;
@@ -398,13 +325,14 @@ struct FftFrames {
     size_t tstride;  // float2 elements between the spectra of consecutive frames
 };
 
-template <int RB, int NT>
+template <int RB, int NT, class SP = NoPlan>
 __global__ void __launch_bounds__(NT, fft_rows_wpe(NT)) k_rows_fwd(FftFrames fr, int H, int W,
                                                                         float2* __restrict__ Tall, int Wk, HhsrRadices rad,
                                                                         const float2* __restrict__ twM, int twlen,
                                                                         const float2* __restrict__ twW) {
     extern __shared__ __attribute__((aligned(16))) float2 fl[];
-    const int M = W / 2, tid = threadIdx.x;
+    const int M = plan_len<SP>(W / 2), tid = threadIdx.x;
+    W = 2 * M;
 #if HHSR_FFT_TWG
     const float2* __restrict__ tw = twM;
     float2* buf = fl;
@@ -439,7 +367,8 @@ __global__ void __launch_bounds__(NT, fft_rows_wpe(NT)) k_rows_fwd(FftFrames fr,
             buf[rb * M + n] = reinterpret_cast<const float2*>(src + (size_t)(y0 + rb) * W)[n];
         }
     }
-    fft_lds(buf, M, nrows, tw, M, rad, tid, NT);
+    if constexpr (std::is_same<SP, NoPlan>::value) fft_lds(buf, M, nrows, tw, M, rad, tid, NT);
+    else fft_lds_s<SP, RB, NT>(buf, tw, tid);  // (RB = 1: nrows is always RB)
     // X[k] = 1/2 [(Z[k] + conj Z[M-k]) - i w_k (Z[k] - conj Z[M-k])],  w_k = exp(-2 pi i k / W); kept bins only,
     // straight from LDS to the blocked-transposed spectrum
     const int nblk = (Wk + TB - 1) / TB;
@@ -474,12 +403,13 @@ __global__ void __launch_bounds__(NT, fft_rows_wpe(NT)) k_rows_fwd(FftFrames fr,
 
 // Column kernel: TWO adjacent kept columns per workgroup (one 16-byte load per row serves both), transformed
 // simultaneously.  LDS: tw[twlen] | 2 x col[H]
-template <int NC>  // kept columns per workgroup: 2 (one 16-byte load per row serves both) or 1 (long columns)
+template <int NC, class SP = NoPlan>  // kept columns per workgroup: 2 (one 16-byte load per row serves both) or 1 (long columns)
 __global__ void __launch_bounds__(FFT_NT, FFT_COLS_WPE) k_cols(float2* __restrict__ Tall, size_t tstride, int H, int W, int Wk,
                                                                     HhsrRadices rad, const float2* __restrict__ twH,
                                                                     int twlen, float norm) {
     extern __shared__ __attribute__((aligned(16))) float2 fl[];
     const int tid = threadIdx.x;
+    H = plan_len<SP>(H);
     // workgroup b runs on XCD b % 8 (observed; locality only): give the 4 column pairs of one 64-byte block to
     // 4 consecutive workgroups of ONE XCD so that its L2 serves each cache line to all of them
     const int xcd = blockIdx.x & 7, loc = blockIdx.x >> 3;
@@ -501,7 +431,8 @@ __global__ void __launch_bounds__(FFT_NT, FFT_COLS_WPE) k_cols(float2* __restric
     } else {
         batched_for<float2>(H, tid, [&](int k) { return colb[(size_t)TB * k]; }, [&](int k, float2 v) { buf[k] = v; });
     }
-    fft_lds(buf, H, NC, tw, H, rad, tid, FFT_NT);
+    if constexpr (std::is_same<SP, NoPlan>::value) fft_lds(buf, H, NC, tw, H, rad, tid, FFT_NT);
+    else fft_lds_s<SP, NC, FFT_NT>(buf, tw, tid);
     {
         // fft_kept(u, H) with its constants hoisted: the shifted index of u lies in [lo, hi)
         const int hh = H / 2, lo = H / 4, hi = H - (H + 3) / 4;
@@ -522,7 +453,8 @@ __global__ void __launch_bounds__(FFT_NT, FFT_COLS_WPE) k_cols(float2* __restric
             }
         }
     }
-    fft_lds(buf, H, NC, tw, H, rad, tid, FFT_NT);
+    if constexpr (std::is_same<SP, NoPlan>::value) fft_lds(buf, H, NC, tw, H, rad, tid, FFT_NT);
+    else fft_lds_s<SP, NC, FFT_NT>(buf, tw, tid);
     for (int y = tid; y < H; y += FFT_NT) {
         if (NC == 2) {
             const float2 a = cconj(buf[y]), b2 = cconj(buf[H + y]);
@@ -533,13 +465,14 @@ __global__ void __launch_bounds__(FFT_NT, FFT_COLS_WPE) k_cols(float2* __restric
     }
 }
 
-template <int RB, int NT>
+template <int RB, int NT, class SP = NoPlan>
 __global__ void __launch_bounds__(NT, fft_rows_wpe(NT)) k_rows_inv(const float2* __restrict__ Tall, int H, int W, int Wk,
                                                                         FftFrames fr, HhsrRadices rad,
                                                                         const float2* __restrict__ twM, int twlen,
                                                                         const float2* __restrict__ twW) {
     extern __shared__ __attribute__((aligned(16))) float2 fl[];
-    const int M = W / 2, tid = threadIdx.x;
+    const int M = plan_len<SP>(W / 2), tid = threadIdx.x;
+    W = 2 * M;
 #if HHSR_FFT_TWG
     const float2* __restrict__ tw = twM;
     float2* buf = fl;
@@ -609,7 +542,8 @@ __global__ void __launch_bounds__(NT, fft_rows_wpe(NT)) k_rows_inv(const float2*
             buf[rb * M + mk] = cconj(cscale(cadd(s, d), 0.5f));
         }
     }
-    fft_lds(buf, M, nrows, tw, M, rad, tid, NT);
+    if constexpr (std::is_same<SP, NoPlan>::value) fft_lds(buf, M, nrows, tw, M, rad, tid, NT);
+    else fft_lds_s<SP, RB, NT>(buf, tw, tid);
     if ((M & 1) == 0 && (W & 3) == 0) {
         const int Mh = M / 2;
         const float rMh = 1.0f / (float)Mh;
@@ -801,6 +735,24 @@ bool hhsr_fft_create(HhsrFft& f, int H, int W, int batch) {
         hhsr_fft_destroy(f);
         return false;
     }
+    // static plans (HHSR_FFT_STATIC: bit 0 rows, bit 1 columns; 0: tests / A-B run the run-time passes)
+    const char* es = getenv("HHSR_FFT_STATIC");
+    const int allow = es ? atoi(es) : 3;
+    f.static_rows = f.static_cols = 0;
+#define HHSR_TRY_ROWS(ID, N, RB, NT, ...)                                                                                    \
+    if ((allow & 1) && !f.static_rows && f.rb == RB && f.nt_rows == NT && SPlan<N, __VA_ARGS__>::matches(M, f.radM) &&       \
+        hipFuncSetAttribute((const void*)k_rows_fwd<RB, NT, SPlan<N, __VA_ARGS__>>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)f.lds_rows) == hipSuccess && \
+        hipFuncSetAttribute((const void*)k_rows_inv<RB, NT, SPlan<N, __VA_ARGS__>>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)f.lds_rows) == hipSuccess)   \
+        f.static_rows = ID;
+    HHSR_STATIC_ROWS(HHSR_TRY_ROWS)
+#undef HHSR_TRY_ROWS
+#define HHSR_TRY_COLS(ID, N, NC, NT, ...)                                                                                    \
+    if ((allow & 2) && !f.static_cols && f.nc == NC && SPlan<N, __VA_ARGS__>::matches(H, f.radH) &&                          \
+        hipFuncSetAttribute((const void*)k_cols<NC, SPlan<N, __VA_ARGS__>>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)f.lds_cols) == hipSuccess) \
+        f.static_cols = ID;
+    HHSR_STATIC_COLS(HHSR_TRY_COLS)
+#undef HHSR_TRY_COLS
+    (void)hipGetLastError();
     f.ok = true;
     return true;
 }
@@ -835,14 +787,35 @@ int hhsr_fft_lowpass(const HhsrFft& f, const float* const* srcs, float* const* d
                                             f.radM, f.twM, f.twlenM, f.twW)
 #define ROWS_INV(RB, NT) hipLaunchKernelGGL((k_rows_inv<RB, NT>), dim3(nrb), dim3(NT), f.lds_rows, s, f.T, f.H, f.W, f.Wk, fr, \
                                             f.radM, f.twM, f.twlenM, f.twW)
+#define HHSR_RUN_ROWS_FWD(ID, N, RB, NT, ...)                                                                                \
+        if (f.static_rows == ID)                                                                                              \
+            hipLaunchKernelGGL((k_rows_fwd<RB, NT, SPlan<N, __VA_ARGS__>>), dim3(nrb), dim3(NT), f.lds_rows, s, fr, f.H, f.W, f.T, \
+                               f.Wk, f.radM, f.twM, f.twlenM, f.twW);                                                         \
+        else
+        HHSR_STATIC_ROWS(HHSR_RUN_ROWS_FWD)
+#undef HHSR_RUN_ROWS_FWD
         if (small) ROWS_FWD(1, FFT_NT_SMALL); else if (f.rb == 4) ROWS_FWD(4, FFT_NT); else if (f.rb == 2) ROWS_FWD(2, FFT_NT);
         else ROWS_FWD(1, FFT_NT);
+#define HHSR_RUN_COLS(ID, N, NC, NT, ...)                                                                                    \
+        if (f.static_cols == ID)                                                                                              \
+            hipLaunchKernelGGL((k_cols<NC, SPlan<N, __VA_ARGS__>>), dim3(((f.Wk + 63) / 64) * (64 / NC), fr.n), dim3(NT), f.lds_cols, \
+                               s, f.T, f.tstride, f.H, f.W, f.Wk, f.radH, f.twH, f.twlenH, norm);                             \
+        else
+        HHSR_STATIC_COLS(HHSR_RUN_COLS)
+#undef HHSR_RUN_COLS
         if (f.nc == 2)
             hipLaunchKernelGGL(k_cols<2>, dim3(((f.Wk + 63) / 64) * 32, fr.n), dim3(FFT_NT), f.lds_cols, s, f.T, f.tstride,
                                f.H, f.W, f.Wk, f.radH, f.twH, f.twlenH, norm);
         else
             hipLaunchKernelGGL(k_cols<1>, dim3(((f.Wk + 63) / 64) * 64, fr.n), dim3(FFT_NT), f.lds_cols, s, f.T, f.tstride,
                                f.H, f.W, f.Wk, f.radH, f.twH, f.twlenH, norm);
+#define HHSR_RUN_ROWS_INV(ID, N, RB, NT, ...)                                                                                \
+        if (f.static_rows == ID)                                                                                              \
+            hipLaunchKernelGGL((k_rows_inv<RB, NT, SPlan<N, __VA_ARGS__>>), dim3(nrb), dim3(NT), f.lds_rows, s, f.T, f.H, f.W, f.Wk, \
+                               fr, f.radM, f.twM, f.twlenM, f.twW);                                                           \
+        else
+        HHSR_STATIC_ROWS(HHSR_RUN_ROWS_INV)
+#undef HHSR_RUN_ROWS_INV
         if (small) ROWS_INV(1, FFT_NT_SMALL); else if (f.rb == 4) ROWS_INV(4, FFT_NT); else if (f.rb == 2) ROWS_INV(2, FFT_NT);
         else ROWS_INV(1, FFT_NT);
 #undef ROWS_FWD

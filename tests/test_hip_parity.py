@@ -123,6 +123,42 @@ def test_grey_fused_radix7_sensor_size(monkeypatch):
     utils_image._grey_plans.clear()
 
 
+def test_grey_static_plan_passes_equal_run_time_passes(monkeypatch):
+    """The FFT kernels' compile-time plans (csrc/hhsr_fft.hip: SPlan, HHSR_STATIC_ROWS / _COLS — every LDS offset an
+    immediate, index arithmetic hoisted out of the row loop) against the run-time passes (HHSR_FFT_STATIC=0) on the same
+    tables, for every size with a plan: rows only, columns only, both; single frame and batches; and against the float64
+    oracle at the bench's size."""
+    gen = torch.Generator(device=DEV).manual_seed(11)
+    worst = {}
+    for shape, batches in (((3000, 4000), (1, 3, 5)), ((3024, 4032), (1, 2)), ((6000, 8000), (1, 2))):
+        imgs = [torch.rand(shape, device=DEV, generator=gen) for _ in range(max(batches))]
+        imgs[-1][::2] *= 0.25  # (strong vertical frequencies: rows differ)
+
+        def run(mask, n):
+            monkeypatch.setenv("HHSR_FFT_STATIC", str(mask))
+            utils_image._grey_plans.clear()
+            if n == 1:
+                return [utils_image.compute_grey_images(imgs[0], "FFT").clone()]
+            return [o.clone() for o in utils_image.compute_grey_images_batch(imgs[:n], "FFT")]
+
+        for n in batches:
+            want = run(0, n)
+            for mask in (1, 2, 3):
+                got = run(mask, n)
+                for i in range(n):
+                    worst[shape] = max(worst.get(shape, 0.0), float((got[i] - want[i]).abs().max()))
+        if shape == (3000, 4000):
+            monkeypatch.delenv("HHSR_FFT_STATIC")
+            utils_image._grey_plans.clear()
+            for i in (0, 4):
+                assert_close(N(utils_image.compute_grey_images(imgs[i], "FFT")), oracle.grey_fft(N(imgs[i])), 0, 3e-6, f"static plans {i}")
+        del imgs
+    utils_image._grey_plans.clear()
+    print("static plans vs run-time passes, max abs difference:", worst)
+    # (the same operations on the same tables; hipcc contracts other multiply-add pairs: observed ~4e-7)
+    assert all(v < 2e-6 for v in worst.values()), worst
+
+
 def test_grey_golden(golden):
     g = golden("grey")
     for tag in "abc":
