@@ -2,6 +2,10 @@
 // the comment block above the HHSR_X2_* switches there for the design).
 #include "hhsr_merge.h"
 
+// Instruction budget (tools/isa_budget.py): the `//@ name` tags below open the source regions the script attributes the
+// kernel's instructions to (through the line table of a -gline-tables-only build).  -DHHSR_X2_BUDGET (analysis builds only)
+// leaves out the tap arm for non-finite coefficients, which ordinary data never executes.
+
 template <bool ISO, bool LMIN>
 __global__ void __launch_bounds__(256, HHSR_X2_OCC) k_merge_x2(BurstArgs a, Geo g, Cfa4 cfa, float* __restrict__ num,
                                                    float* __restrict__ den) {
@@ -55,7 +59,7 @@ __global__ void __launch_bounds__(256, HHSR_X2_OCC) k_merge_x2(BurstArgs a, Geo 
     // Per-frame geometry once per WORKGROUP: it only depends on the frame's flow vector and the parity class, so
     // evaluating it in every thread and frame (~50 instructions, ~40 % of them half-rate, identical in all lanes of a
     // wave) was 7 % of the kernel's VALU time.  Lane = frame here; the frame loop reads its entry back with four
-    // broadcast ds_read_b128.  (Visible to everybody after the first barrier of the frame loop.)
+    // broadcast ds_read_b128.  
     for (int n = tid; n < a.n + ((a.flags & HHSR_MERGE_DO_REF) ? 1 : 0); n += 256) {
         const bool isref = n >= a.n;
         float2 fl = make_float2(0.f, 0.f);
@@ -72,6 +76,7 @@ __global__ void __launch_bounds__(256, HHSR_X2_OCC) k_merge_x2(BurstArgs a, Geo 
             }
         }
     }
+    __syncthreads();  // (the first prefetch below reads the table)
 #endif
     const int py = wave >> 1, px = wave & 1;                        // this wave's parity class
     const int li = lane >> 3, lj = lane & 7;
@@ -116,36 +121,57 @@ __global__ void __launch_bounds__(256, HHSR_X2_OCC) k_merge_x2(BurstArgs a, Geo 
     float pr0 = 0.f, pr1 = 0.f, plr = 0.f, plr1 = 0.f;
     float4 pc = make_float4(0.f, 0.f, 0.f, 0.f);
     float2 pfl = make_float2(0.f, 0.f);
+    // Byte offsets of the staging slots that do not depend on the frame; the frame's window origin is wave-uniform (read
+    // back from the geometry table into SGPRs), so a load is ONE v_add_u32 + global_load ... s[base:base+1] — the first
+    // version recomputed floor / compare / convert of the flow vector per thread and frame behind a dependent global load of
+    // that vector, and every address in 64 bits (v_mad_i64_i32, v_lshl_add_u64): 39 VALU instructions per thread and frame.
+    const unsigned t0b = (unsigned)(e0y * g.pitch + e0x) * 4u, t1b = (unsigned)(e1y * g.pitch + e1x) * 4u;
+    const unsigned mb0 = (unsigned)moff0 * 4u, mb1 = (unsigned)moff1 * 4u, rb = (unsigned)ridx * 4u;
+    auto ldf = [](const float* base, unsigned byte_off) { return *reinterpret_cast<const float*>(reinterpret_cast<const char*>(base) + byte_off); };
     auto prefetch = [&](int n) {  // all windows are inside the image (checked above): no bounds tests
+        //@ prefetch
         const bool isref = n >= a.n;
         const float* __restrict__ raw = isref ? a.ref_raw : a.f[n].raw;
         const float4* __restrict__ cov = isref ? a.ref_cov : a.f[n].cov;
+#if HHSR_X2_GEO
+        // (the table's org of either parity: x2_comp_org of the frame's flow, l0 - 1 for the reference frame)
+        const int ox = __builtin_amdgcn_readfirstlane(reinterpret_cast<const int*>(s_geo)[(n * 8) * 4]);
+        const int oy = __builtin_amdgcn_readfirstlane(reinterpret_cast<const int*>(s_geo)[(n * 8 + 4) * 4]);
+#else
         int ox = lx0 - 1, oy = ly0 - 1;
         if (!isref) {
             pfl = a.f[n].flow[tile];
             ox = x2_comp_org(pfl.x, lx0);
             oy = x2_comp_org(pfl.y, ly0);
         }
-        pr0 = raw[(size_t)(oy + e0y) * g.pitch + ox + e0x];
-        if (has1) pr1 = raw[(size_t)(oy + e1y) * g.pitch + ox + e1x];
-        if (!ISO && hasc) pc = cov[(size_t)min((oy >> 1) + cey, g.gh - 1) * g.gw + min((ox >> 1) + cex, g.gw - 1)];
+#endif
+        const unsigned ob = (unsigned)(oy * g.pitch + ox) * 4u;  // (scalar)
+        pr0 = ldf(raw, ob + t0b);
+        if (has1) pr1 = ldf(raw, ob + t1b);
+        if (!ISO && hasc) {
+            const unsigned ci = (unsigned)(min((oy >> 1) + cey, g.gh - 1) * g.gw + min((ox >> 1) + cex, g.gw - 1));
+            pc = *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(cov) + ci * 16u);
+        }
         if (!isref) {
             if (LMIN) {
-                plr = a.f[n].r[moff0];
-                if (hasm1) plr1 = a.f[n].r[moff1];
+                plr = ldf(a.f[n].r, mb0);
+                if (hasm1) plr1 = ldf(a.f[n].r, mb1);
             } else {
-                plr = a.f[n].r[ridx];
+                plr = ldf(a.f[n].r, rb);
             }
         }
     };
 
+    //@ outside
     const float* __restrict__ rbase = s_R + ty * X2_RP + 2 * lj;
     const int cbase = li * X2_CP + lj;
 
     // write the prefetched registers of one frame into window buffer `bo`; returns that frame's flow / robustness
     float2 sfl = make_float2(0.f, 0.f);
     float sr = 0.f;
+    //@ outside
     auto stage = [&](int n, int bo) {
+        //@ staging
         const bool isref = n >= a.n;
         s_rawA[bo * RAWSZ + e0y * X2_RP + e0x] = pr0;
         if (e0x > 0) s_rawB[bo * RAWSZ + e0y * X2_RP + e0x - 1] = pr0;
@@ -165,8 +191,10 @@ __global__ void __launch_bounds__(256, HHSR_X2_OCC) k_merge_x2(BurstArgs a, Geo 
     // geometry, the identity fallback of the inverse and r = 1): as a run-time select it costs ~40 v_cndmask per frame,
     // and on gfx950 v_cndmask / v_min / v_cmp / v_floor / v_cvt issue at HALF the v_fma rate, v_exp / v_rcp at a quarter
     // (tools/ubench/valu_rate.hip) — the kernel is VALU-bound, so instruction classes are what to count.
+    //@ outside
     auto frame = [&](auto isref_c, const bool isref_rt, const float2 fl, float local_r, const int bo, const int n) {
         const bool isref = HHSR_X2_PEEL ? decltype(isref_c)::value : isref_rt;
+        //@ min5x5
         if (LMIN && !isref) {  // 5 x 5 minimum over rows ty .. ty + 4, columns tx .. tx + 4 of the R window
             // R is clamped to [0, 1] (never negative, never NaN): the order of its float32 bit patterns is the order of
             // the values, and v_min3_u32 needs no canonicalisation of its inputs (fminf costs a v_max per operand: 28
@@ -191,6 +219,7 @@ __global__ void __launch_bounds__(256, HHSR_X2_OCC) k_merge_x2(BurstArgs a, Geo 
             }
             local_r = __uint_as_float(m);
         }
+        //@ geometry
         if (!isref) racc += local_r;
         if (local_r == 0.f) return;
 #if HHSR_X2_GEO
@@ -213,6 +242,7 @@ __global__ void __launch_bounds__(256, HHSR_X2_OCC) k_merge_x2(BurstArgs a, Geo 
             for (int sb = 0; sb < 2; ++sb) {
                 float ixx = 2.f * X2_KEXP, ixy = 0.f, iyy = 2.f * X2_KEXP;
                 bool finite = true;
+                //@ cov_blend
                 if (!ISO) {
                     const int ca = cbase + ay.oc[sa] * X2_CP + ax.oc[sb];
                     const float4 c00 = lds_quad(s_cov + bo * COVSZ + ca), c01 = lds_quad(s_cov + bo * COVSZ + ca + 1);
@@ -222,6 +252,7 @@ __global__ void __launch_bounds__(256, HHSR_X2_OCC) k_merge_x2(BurstArgs a, Geo 
                     const float cxx = fmaf(w11, c11.x, fmaf(w10, c10.x, fmaf(w01, c01.x, w00 * c00.x)));
                     const float cxy = fmaf(w11, c11.y, fmaf(w10, c10.y, fmaf(w01, c01.y, w00 * c00.y)));
                     const float cyy = fmaf(w11, c11.w, fmaf(w10, c10.w, fmaf(w01, c01.w, w00 * c00.w)));
+                    //@ inverse
                     const float det = fmaf(cxx, cyy, -(cxy * cxy));
                     const float s1 = __builtin_amdgcn_rcpf(det) * X2_KEXP;
                     ixx = s1 * cyy;
@@ -240,6 +271,7 @@ __global__ void __launch_bounds__(256, HHSR_X2_OCC) k_merge_x2(BurstArgs a, Geo 
                 }
                 // the 3 x 3 taps: rows ty + e .. + 2, columns tx + e .. + 2 of the window, as aligned pairs from the
                 // copy whose shift makes column tx + e even
+                //@ tap_setup
                 const int mcol = px + ax.e[sb];  // 0, 1, 2
                 const float* __restrict__ rp = ((mcol & 1) ? s_rawB : s_rawA) + bo * RAWSZ + (ty + ay.e[sa]) * X2_RP + 2 * lj + (mcol & 2);
                 const float dx0 = ax.d0[sb], dy0 = ay.d0[sa];
@@ -250,6 +282,7 @@ __global__ void __launch_bounds__(256, HHSR_X2_OCC) k_merge_x2(BurstArgs a, Geo 
                 // z > 0 (non-positive-definite blends at the image border, D11).  Non-finite coefficients (NaN
                 // covariances of flat regions, D10; singular hand-made covariances) take the exact per-tap form.
                 auto taps = [&](auto exact_c) {
+                    //@ taps
                     constexpr bool EXACT = decltype(exact_c)::value;
 #pragma unroll
                     for (int di = 0; di < 3; ++di) {
@@ -273,9 +306,15 @@ __global__ void __launch_bounds__(256, HHSR_X2_OCC) k_merge_x2(BurstArgs a, Geo 
                         }
                     }
                 };
+                //@ tap_setup
                 if (!HHSR_X2_CLAMP) taps(std::true_type{});
+#ifdef HHSR_X2_BUDGET
+                else taps(std::false_type{});
+#else
                 else if (ISO || finite) taps(std::false_type{});
                 else taps(std::true_type{});
+#endif
+                //@ fold
                 // tap-offset parity -> absolute raw-coordinate parity (uniform): class (a, b) += r * sv[a ^ by][b ^ bx]
                 const int by = (ay.org + py + ay.e[sa]) & 1, bx = (ax.org + px + ax.e[sb]) & 1;
                 // (the empty asm statements keep the four arms real branches: if-converted, the permutation costs 16
@@ -319,6 +358,7 @@ __global__ void __launch_bounds__(256, HHSR_X2_OCC) k_merge_x2(BurstArgs a, Geo 
 #endif
             }
     };
+    //@ loop
     auto frame_n = [&](int n, const float2 fl, float lr, int bo) {
         if (!HHSR_X2_PEEL) frame(std::false_type{}, n >= a.n, fl, lr, bo, n);
         else if (n >= a.n) frame(std::true_type{}, true, fl, lr, bo, n);
@@ -334,6 +374,7 @@ __global__ void __launch_bounds__(256, HHSR_X2_OCC) k_merge_x2(BurstArgs a, Geo 
         if (n + 1 < nloop) prefetch(n + 1);  // in flight while this frame's taps are evaluated
         frame_n(n, fl, lr, 0);
     }
+    //@ outside
     if (chain_store) {  // park the accumulators for the final link
 #pragma unroll
         for (int k = 0; k < NA; ++k) {
