@@ -90,6 +90,7 @@ __global__ void __launch_bounds__(256, HHSR_XS_OCC) k_merge_xs(BurstArgs a, Geo 
     __shared__ __align__(16) float s_out[OROWS * OP];
     __shared__ __align__(16) float s_mskA[RAWSZ];  // EDGE frames: 1 where the window position lies inside the frame, else 0
     __shared__ __align__(16) float s_mskB[RAWSZ];  // (the same shifted by one column, like s_rawB)
+    __shared__ float4 s_frm[HHSR_MAX_FRAMES];      // per comp frame: window origin (x, y as int bits), flow vector
     const int tid = threadIdx.x;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
     const int nbx = gridDim.x, nblk = gridDim.x * gridDim.y;
@@ -119,8 +120,12 @@ __global__ void __launch_bounds__(256, HHSR_XS_OCC) k_merge_xs(BurstArgs a, Geo 
         if (ok) {
             const int ox = xs_comp_org<S>(fl.x, lx0), oy = xs_comp_org<S>(fl.y, ly0);
             edge_f = !(ox >= 0 && ox + X2_WIN <= g.W && oy >= 0 && oy + X2_WIN <= g.H);
+            // the frame loop's staging takes the origin from here (lane = frame; identical in the four waves) instead of
+            // re-deriving it per thread and frame behind a dependent load of the flow vector (k_merge_x2, round 6)
+            if (wave == 0) s_frm[lane] = make_float4(__int_as_float(ox), __int_as_float(oy), fl.x, fl.y);
         }
     }
+    __syncthreads();
 #if !HHSR_XS_EDGE  // A/B: round 3's rule — any window outside the image sends the tile down the per-pixel path
     if (edge_f || ((a.flags & HHSR_MERGE_DO_REF) && !(lx0 >= 1 && lx0 + QT + 2 <= g.W && ly0 >= 1 && ly0 + QT + 2 <= g.H))) ok = false;
     const unsigned long long edge_mask = 0ull;
@@ -175,18 +180,24 @@ __global__ void __launch_bounds__(256, HHSR_XS_OCC) k_merge_xs(BurstArgs a, Geo 
     const int nloop = a.n + ((a.flags & HHSR_MERGE_DO_REF) ? 1 : 0);
     float pr0 = 0.f, pr1 = 0.f, plr = 0.f, plr1 = 0.f;
     float4 pc = make_float4(0.f, 0.f, 0.f, 0.f);
-    float2 pfl = make_float2(0.f, 0.f);
     auto is_edge = [&](int n) { return n >= a.n ? edge_ref : (bool)((edge_mask >> n) & 1ull); };  // wave-uniform
+    // frame-independent byte offsets of the staging slots (32 bits: one v_add_u32 + a global_load ... s[base:base+1] per load)
+    const unsigned t0b = (unsigned)(e0y * g.pitch + e0x) * 4u, t1b = (unsigned)(e1y * g.pitch + e1x) * 4u;
+    const unsigned mb0 = (unsigned)moff0 * 4u, mb1 = (unsigned)moff1 * 4u, rb = (unsigned)ridx * 4u;
+    auto ldf = [](const float* base, unsigned byte_off) { return *reinterpret_cast<const float*>(reinterpret_cast<const char*>(base) + byte_off); };
+    auto frame_org = [&](int n, int& ox, int& oy) {  // wave-uniform, in SGPRs
+        ox = lx0 - 1, oy = ly0 - 1;
+        if (n < a.n) {
+            ox = __builtin_amdgcn_readfirstlane(reinterpret_cast<const int*>(s_frm)[n * 4]);
+            oy = __builtin_amdgcn_readfirstlane(reinterpret_cast<const int*>(s_frm)[n * 4 + 1]);
+        }
+    };
     auto prefetch = [&](int n, const bool edge_n) {
         const bool isref = n >= a.n;
         const float* __restrict__ raw = isref ? a.ref_raw : a.f[n].raw;
         const float4* __restrict__ cov = isref ? a.ref_cov : a.f[n].cov;
-        int ox = lx0 - 1, oy = ly0 - 1;
-        if (!isref) {
-            pfl = a.f[n].flow[tile];
-            ox = xs_comp_org<S>(pfl.x, lx0);
-            oy = xs_comp_org<S>(pfl.y, ly0);
-        }
+        int ox, oy;
+        frame_org(n, ox, oy);
         if (edge_n) {  // clamped coordinates; the mask says which window positions are real samples
             const int y0 = oy + e0y, x0 = ox + e0x, y1 = oy + e1y, x1 = ox + e1x;
             pr0 = raw[(size_t)clampi(y0, 0, g.H - 1) * g.pitch + clampi(x0, 0, g.W - 1)];
@@ -194,16 +205,20 @@ __global__ void __launch_bounds__(256, HHSR_XS_OCC) k_merge_xs(BurstArgs a, Geo 
             if (!ISO && hasc)
                 pc = cov[(size_t)clampi((oy >> 1) + cey, 0, g.gh - 1) * g.gw + clampi((ox >> 1) + cex, 0, g.gw - 1)];
         } else {
-        pr0 = raw[(size_t)(oy + e0y) * g.pitch + ox + e0x];
-        if (has1) pr1 = raw[(size_t)(oy + e1y) * g.pitch + ox + e1x];
-        if (!ISO && hasc) pc = cov[(size_t)min((oy >> 1) + cey, g.gh - 1) * g.gw + min((ox >> 1) + cex, g.gw - 1)];
+            const unsigned ob = (unsigned)(oy * g.pitch + ox) * 4u;  // (scalar)
+            pr0 = ldf(raw, ob + t0b);
+            if (has1) pr1 = ldf(raw, ob + t1b);
+            if (!ISO && hasc) {
+                const unsigned ci = (unsigned)(min((oy >> 1) + cey, g.gh - 1) * g.gw + min((ox >> 1) + cex, g.gw - 1));
+                pc = *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(cov) + ci * 16u);
+            }
         }
         if (!isref) {
             if (LMIN) {
-                plr = a.f[n].r[moff0];
-                if (hasm1) plr1 = a.f[n].r[moff1];
+                plr = ldf(a.f[n].r, mb0);
+                if (hasm1) plr1 = ldf(a.f[n].r, mb1);
             } else {
-                plr = a.f[n].r[ridx];
+                plr = ldf(a.f[n].r, rb);
             }
         }
     };
@@ -234,11 +249,8 @@ __global__ void __launch_bounds__(256, HHSR_XS_OCC) k_merge_xs(BurstArgs a, Geo 
         }
         const bool edge = EDGE_TILE && is_edge(n);
         if (edge) {
-            int ox = lx0 - 1, oy = ly0 - 1;
-            if (!isref) {
-                ox = xs_comp_org<S>(pfl.x, lx0);
-                oy = xs_comp_org<S>(pfl.y, ly0);
-            }
+            int ox, oy;
+            frame_org(n, ox, oy);
             const int y0 = oy + e0y, x0 = ox + e0x, y1 = oy + e1y, x1 = ox + e1x;
             const float pm0 = (y0 >= 0 && y0 < g.H && x0 >= 0 && x0 < g.W) ? 1.f : 0.f;
             const float pm1 = (y1 >= 0 && y1 < g.H && x1 >= 0 && x1 < g.W) ? 1.f : 0.f;
@@ -249,7 +261,8 @@ __global__ void __launch_bounds__(256, HHSR_XS_OCC) k_merge_xs(BurstArgs a, Geo 
                 if (e1x > 0) s_mskB[e1y * X2_RP + e1x - 1] = pm1;
             }
         }
-        const float2 fl = pfl;
+        float2 fl = make_float2(0.f, 0.f);  // (wave-uniform: a broadcast LDS read)
+        if (!isref) fl = *reinterpret_cast<const float2*>(reinterpret_cast<const float*>(s_frm) + n * 4 + 2);
         float local_r = isref ? 1.f : plr;
         __syncthreads();
         if (n + 1 < nloop) prefetch(n + 1, EDGE_TILE && is_edge(n + 1));
