@@ -19,27 +19,17 @@ import re
 import pytest
 
 import test_fuzz_parity as fz
-from test_fuzz_parity import oracle_pool  # noqa: F401  (the fork pool fixture)
+from test_fuzz_parity import oracle_pool, FINDINGS  # noqa: F401  (the fork pool fixture)
 
 pytestmark = pytest.mark.gpu
 
-FINDINGS = ["30.21", "62.19", "101.9", "302.9", "1000.11", "1600.15", "4300.15", "6502.17"]
 
-
-def _case(cid):
-    gs, k = (int(v) for v in cid.split("."))
-    c = fz.cases(gs, k + 1)[k]
-    assert c["id"] == cid
-    return c
-
-
-@pytest.mark.timeout(900)
+@pytest.mark.timeout(1800)
 def test_named_findings(oracle_pool):  # noqa: F811
-    lines = []
-    fz.sweep(oracle_pool, [_case(cid) for cid in FINDINGS], report=lines)
+    lines = fz.combined_sweep(oracle_pool)["lines"]  # (ONE sweep with the default batches, run once per session)
     per_case = {m.group(1): ln for ln in lines if (m := re.match(r"case (\S+) ", ln))}
-    assert sorted(per_case) == sorted(FINDINGS)
-    failed = [ln[:900] for ln in per_case.values() if "ASSERTIONS FAILED" in ln]
+    assert all(cid in per_case for cid in FINDINGS)
+    failed = [per_case[cid][:900] for cid in FINDINGS if "ASSERTIONS FAILED" in per_case[cid]]
     assert not failed, "\n".join(failed)
     # 4300.15 with HIP's own flows: the float64 robustness sum decides like the reference's — nothing above 1e-4 anywhere
     m = re.search(r"HIP's flows \[nan 0, r \S+, acc \S+, image max (\S+) \((\d+) > 1e-4", per_case["4300.15"])

@@ -66,7 +66,10 @@ import handheld_super_resolution as hsr
 pytestmark = pytest.mark.gpu
 
 CFAS = [((0, 1), (1, 2)), ((2, 1), (1, 0)), ((1, 0), (2, 1)), ((1, 2), (0, 1))]
-BATCHES = [(0, 22), (1, 22), (2, 20)]  # (generator seed, cases): the 64 cases
+# (generator seed, cases): the 64 cases of rounds 3-5 + two batches no round had run before they entered the suite (round 6)
+BATCHES = [(0, 22), (1, 22), (2, 20), (9000, 22), (9100, 22)]
+# every burst that ever violated a rule of an earlier contract or changed the contract / the product (test_fuzz_findings.py)
+FINDINGS = ["30.21", "62.19", "101.9", "302.9", "1000.11", "1600.15", "4300.15", "6502.17"]
 if os.environ.get("HHSR_FUZZ_BATCHES"):  # held-out batches, e.g. "10:22,11:22,12:20" (same assertions on other bursts)
     BATCHES = [tuple(int(v) for v in b.split(":")) for b in os.environ["HHSR_FUZZ_BATCHES"].split(",")]
 FLIPPED_PER_BATCH = 2   # flipped block-matching decisions (clusters of tiles) per batch  (measured: 0, 0, 1)
@@ -296,15 +299,44 @@ class _ReportFile(list):
 REPORT = bool(os.environ.get("HHSR_FUZZ_REPORT"))
 
 
+def named_case(cid):
+    gs, k = (int(v) for v in cid.split("."))
+    c = cases(gs, k + 1)[k]
+    assert c["id"] == cid
+    return c
+
+
+_COMBINED = {}
+
+
+def combined_sweep(pool):
+    """The default batches AND the named findings as ONE sweep, run once per session by whichever test asks first (a case
+    is ~100 s of dependent oracle runs on one core: 8 named cases alone took as long as the 64 of the sweep next to which
+    they cost a tenth).  Report mode inside: every case is judged, the tests assert on the lines."""
+    if not _COMBINED:
+        cs = [c for gs, n in BATCHES for c in cases(gs, n)]
+        have = {c["id"] for c in cs}
+        cs += [named_case(cid) for cid in FINDINGS if cid not in have]
+        lines, flips = [], {}
+        sweep(pool, cs, report=lines, flips=flips)
+        _COMBINED.update(lines=lines, flips=flips)
+    return _COMBINED
+
+
 @pytest.mark.timeout(1800)
 @pytest.mark.skipif(REPORT, reason="report mode: test_fuzz_report lists every case instead of stopping at the first")
 def test_fuzz_sweep(oracle_pool):
     """All batches as ONE sweep (draining the pipeline between batches cost a third of the test's time)."""
-    cs = [c for gs, n in BATCHES for c in cases(gs, n)]
-    flips = {}
-    sweep(oracle_pool, cs, flips=flips)
+    import re
+
+    res = combined_sweep(oracle_pool)
+    per_case = {m.group(1): ln for ln in res["lines"] if (m := re.match(r"case (\S+) ", ln))}
     for gs, n in BATCHES:
-        k = sum(flips.get(c["id"], 0) for c in cases(gs, n))
+        ids = [c["id"] for c in cases(gs, n)]
+        assert all(i in per_case for i in ids), f"batch {gs}: cases missing from the sweep"
+        failed = [per_case[i][:900] for i in ids if "ASSERTIONS FAILED" in per_case[i]]
+        assert not failed, "\n".join(failed)
+        k = sum(res["flips"].get(i, 0) for i in ids)
         assert k <= FLIPPED_PER_BATCH, f"batch {gs}: {k} flipped decisions"
 
 

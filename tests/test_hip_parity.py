@@ -1427,6 +1427,66 @@ def test_c2_full_size_against_oracle(metric0):
                    stray=(0, 0.0) if metric0 == "L1" else (4, 1e-3))
 
 
+@pytest.mark.timeout(1200)
+def test_c3_full_size_two_sided_four_frames():
+    """a FULL-SIZE comparison with the oracle in both directions inside the driver's suite (until now only in
+    profiles/r05_c3_full_oracle.txt, builder-run): the C3 geometry — 3000 x 4000, x2 -> 48 MP, default metrics
+    [L1, L2, L2, L2], robustness on — with 4 frames (one oracle worker per comp frame), through tools/full_size_oracle.py's
+    logic and the fuzz contract's rules (tests/test_fuzz_parity.py):
+      alignment   at most FLIP_BUDGET flipped block-matching tiles in one cluster, the others <= 1e-4 px;
+      side H      HIP vs the oracle's robustness + kernels + merge on HIP's flows: same NaN pattern, robustness <= 1e-4,
+                  every value <= 1e-4 where every frame is accepted, and where one is being rejected only what the
+                  oracle's merge ALONE on HIP's flows and HIP's robustness maps does not show;
+      side O      the same with the oracle's flows injected into HIP;
+      merge alone on identical flows and robustness maps: every one of the 144 M values <= 1e-4."""
+    import os
+    import sys
+
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    from full_size_oracle import chunked_side
+    from helpers import alignment_part, MAX_FLIP_TILES, MAX_ICA_TILES
+
+    H, W, NF, scale = 3000, 4000, 4, 2
+    ref, comp, _ = synth.make_burst(H, W, NF, seed=4242)
+
+    def cfg_fn(**hip):
+        cfg = base_config(ts=16, scale=scale, metrics=("L1", "L2", "L2", "L2"))
+        cfg.robustness.save_mask = True
+        if hip:
+            cfg.hip = hip
+        return cfg
+
+    def hip(cfg):
+        cfg.debug = True
+        out, dbg = hsr.main(ref, comp, cfg)
+        res = out.cpu().numpy(), np.stack(dbg["flow"]), np.stack(dbg["robustness"])
+        del out, dbg
+        torch.cuda.empty_cache()
+        return res
+
+    workers = NF - 1
+    o, gflow, hr = hip(cfg_fn())
+    cap, cap_h = {}, {}
+    want, _, _ = oracle.main_parallel(ref, comp, cfg_fn(), workers=workers, capture=cap, fast=True)
+    oflow, o_r = np.stack(cap["flow"]), np.stack(cap["r"])
+    al, _ = alignment_part(gflow, oflow)
+    print("alignment:", al)
+    assert al["nflip"] <= MAX_FLIP_TILES and al["one_cluster"] and al["n_ica"] <= MAX_ICA_TILES and al["dflow"] <= 1e-4, al
+    want_h, _, _ = oracle.main_parallel(ref, comp, cfg_fn(), workers=workers, capture=cap_h, fast=True, flows=list(gflow))
+    want_hm, _, _ = oracle.main_parallel(ref, comp, cfg_fn(), workers=workers, fast=True, flows=list(gflow), rob=list(hr))
+    side_h = chunked_side((H, W), scale, o, want_h, hr, np.stack(cap_h["r"]), want_hm)
+    del want_h, want_hm, o
+    oi, _, hr_i = hip(cfg_fn(inject_flows=[f for f in oflow]))
+    want_om, _, _ = oracle.main_parallel(ref, comp, cfg_fn(), workers=workers, fast=True, flows=list(oflow), rob=list(hr_i))
+    side_o = chunked_side((H, W), scale, oi, want, hr_i, o_r, want_om)
+    for tag, s in (("H", side_h), ("O", side_o)):
+        print(f"side {tag}: {s}")
+        assert s["nan_mis"] == 0 and s["m_nan"] == 0, (tag, s)
+        assert s["dr"] <= 1e-4, (tag, s)
+        assert s["m_max"] <= 1e-4 and s["m_n"] == 0, (tag, s)          # merge alone: everywhere
+        assert s["outside"] == 0 and s["unexplained"] == 0, (tag, s)   # whole chain: only what the robustness explains
+
+
 def test_c4_substitute_13_frames_sensor_size():
     """BASELINE config C4 (a real 13-frame DNG burst) cannot run: no DNG burst and no decoder exist offline.  Its stated
     substitute: 13 frames of 4032x3024, x2, robustness on, white balance != 1, BGGR — size-independent

@@ -52,8 +52,47 @@ def regions(src):
     return tags
 
 
+def by_line(path, rx, src, top):
+    """--lines N: the N source lines of `src` with the most VALU issue cycles attributed (static), with their text."""
+    base = src.split("/")[-1]
+    text = open(src).read().split("\n")
+    files, cur, lineno = {}, None, 0
+    counts = collections.defaultdict(collections.Counter)
+    for line in open(path):
+        t = line.strip()
+        m = re.match(r"\.file\s+(\d+)\s+(?:\"[^\"]*\"\s+)?\"([^\"]+)\"", t)
+        if m:
+            files[int(m.group(1))] = m.group(2)
+            continue
+        m = re.match(r"^(_Z\w+):", line)
+        if m:
+            cur = m.group(1) if rx.search(m.group(1)) else None
+            lineno = 0
+            continue
+        if line.startswith(".Lfunc_end"):
+            cur = None
+        if not cur:
+            continue
+        m = re.match(r"\.loc\s+(\d+)\s+(\d+)", t)
+        if m:
+            if files.get(int(m.group(1)), "").endswith(base):
+                lineno = int(m.group(2))
+            continue
+        if not t or t.startswith((";", ".", "//")) or t.endswith(":"):
+            continue
+        counts[lineno][rate(t.split()[0])] += 1
+    cyc = lambda c: 2.5 * c["full"] + 4.5 * c["half"] + 8.2 * c["quarter"]  # noqa: E731
+    total = sum(cyc(c) for c in counts.values())
+    print(f"total VALU issue cycles (static) {total:.0f}")
+    for ln, c in sorted(counts.items(), key=lambda kv: -cyc(kv[1]))[:top]:
+        print(f"{ln:5d} {cyc(c):7.0f} {100 * cyc(c) / total:5.1f}%  full {c['full']:4d} half {c['half']:4d} quarter {c['quarter']:3d} "
+              f"lds {c['lds_rd'] + c['lds_wr']:3d} vmem {c['vmem_rd'] + c['vmem_wr']:3d} | {text[ln - 1].strip()[:110] if 0 < ln <= len(text) else ''}")
+
+
 def main():
     path, rx, src = sys.argv[1], re.compile(sys.argv[2]), sys.argv[3]
+    if "--lines" in sys.argv:
+        return by_line(path, rx, src, int(sys.argv[sys.argv.index("--lines") + 1]))
     tags = regions(src)
     base = src.split("/")[-1]
     files, cur, fileno, region = {}, None, None, "outside"
