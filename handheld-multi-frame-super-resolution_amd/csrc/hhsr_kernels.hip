@@ -232,8 +232,10 @@ __global__ void __launch_bounds__(256) k_frame_stats(FrameStatsArgs A, FsFrames 
                 const double x2 = (double)v[2] * A.rwbk[2], x3 = (double)v[3] * A.rwbk[3];
                 if (A.unit_wb && A.pat >= 0) {
                     // white balance (1, 1, 1): raw / 1.0 is the raw value, and the float64 green mean ((0 + a) + b) / 2
-                    // rounded to float32 IS the float32 sum halved (a + b is exact in float64, halving is exact) — no
-                    // float64 instruction left in this block (11 per staged quad)
+                    // rounded to float32 IS the float32 sum halved — for operands whose exponents differ by at most 29 bits
+                    // (then a + b is exact in float64) and whose sum is a normal float32 (then halving is exact): normalised
+                    // sensor data in [0, 1] with values >= 2^-100 or exactly 0; beyond that the float64 route rounds twice
+                    // and may differ by one ulp.  No float64 instruction left in this block (11 per staged quad)
                     const float g01 = 0.5f * (v[1] + v[2]), g03 = 0.5f * (v[0] + v[3]);
                     ch[1] = A.pat <= 1 ? g01 : g03;
                     ch[0] = A.pat == 0 ? v[0] : A.pat == 1 ? v[3] : A.pat == 2 ? v[1] : v[2];
@@ -299,7 +301,9 @@ __global__ void __launch_bounds__(256) k_frame_stats(FrameStatsArgs A, FsFrames 
                 // mean = float32(float64(s0) / 9): the correctly rounded float32 quotient (a float32 over 9 never lies within
                 // 2^-28 relative of a float32 rounding boundary, so rounding through float64 changes nothing), which
                 // q = s0 r, q + (s0 - 9 q) r with r = RN(1 / 9) delivers in float32 — checked exhaustively over all 2^23
-                // mantissas (Markstein); the variance keeps the float64 mean
+                // mantissas (Markstein) at exponents where the residual s0 - 9 q is a normal number (|s0| >= 2^-100: sums of
+                // nine normalised samples, or exactly 0); a tinier sum may misround by one ulp.  The variance keeps the
+                // float64 mean
                 const float r9 = 1.0f / 9.0f, q9 = s0 * r9;
                 A.means[c * plane + o] = fmaf(fmaf(-9.0f, q9, s0), r9, q9);
                 if (A.vars) {

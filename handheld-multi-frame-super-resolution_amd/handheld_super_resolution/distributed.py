@@ -326,8 +326,16 @@ class HipEngine:
     def _mark_seen(self, key, tensors):
         """First sighting of an input set (or a fresh start after its plan was dropped): weak references to the tensors'
         storages-owning objects — a later call with the same address key counts as "the same inputs again" only while
-        they are alive (see rows_open)."""
+        they are alive (see rows_open).  The liveness is tied to the Python tensor OBJECTS (views of one base count as the
+        base): a caller that re-wraps the same storages in fresh tensor objects for every burst (.detach(), DLPack,
+        as_tensor of a pointer) is a first sighting every time — correct, ranks agree, but the rows plan is never captured
+        and every burst runs eagerly.  Pass the same tensors (or views of one base); `never_replayed` counts the sightings
+        that found their earlier wrappers dead, for whoever wonders why nothing is replayed."""
         import weakref
+
+        old = self._plan_seen.get(key)
+        if old is not None and any(r() is None for r in old["refs"]):
+            self.never_replayed = getattr(self, "never_replayed", 0) + 1
 
         self._plan_seen[key] = {"refs": tuple(weakref.ref(t._base if t._base is not None else t) for t in tensors),
                                 "state": "seen"}

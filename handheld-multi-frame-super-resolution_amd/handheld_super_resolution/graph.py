@@ -15,6 +15,7 @@ pool: valid until the next call with the same inputs.
 """
 import contextlib
 import gc
+import threading
 
 import torch
 
@@ -47,6 +48,9 @@ def _key(tensors):
     return tuple((t.data_ptr(), tuple(t.shape), t.dtype) for t in tensors)
 
 
+_gc_lock, _gc_depth, _gc_was = threading.Lock(), 0, False
+
+
 @contextlib.contextmanager
 def capture(graph, stream):
     """torch.cuda.graph(graph, stream=...) with the cyclic garbage collector held off while the stream is capturing.
@@ -55,14 +59,23 @@ def capture(graph, stream):
     permitted while a stream of the thread is capturing: the runtime aborts the process — seen as "Fatal Python error:
     Aborted ... Garbage-collecting" in the middle of a RowsPlan capture).  What became garbage meanwhile is collected
     after the capture."""
-    was = gc.isenabled()
-    gc.disable()
+    # main() may be called from several threads and capture_error_mode is thread-local, so two captures can overlap: the
+    # collector goes off with the FIRST and comes back with the LAST of them (a per-call flag let thread A switch it back
+    # on while thread B was still capturing — ADVICE r5)
+    global _gc_depth, _gc_was
+    with _gc_lock:
+        if _gc_depth == 0:
+            _gc_was = gc.isenabled()
+            gc.disable()
+        _gc_depth += 1
     try:
         with torch.cuda.graph(graph, stream=stream, capture_error_mode="thread_local"):
             yield
     finally:
-        if was:
-            gc.enable()
+        with _gc_lock:
+            _gc_depth -= 1
+            if _gc_depth == 0 and _gc_was:
+                gc.enable()
 
 
 class GraphRunner:

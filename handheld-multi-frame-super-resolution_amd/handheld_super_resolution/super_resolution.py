@@ -408,6 +408,11 @@ class BurstPipeline:
         # for `entry` below (the whole precompute and whatever else the caller's stream holds).  Until now the fork event
         # was recorded here, i.e. behind the ~0.5 ms of single-frame, latency-bound reference kernels — 6 % of the 12 MP
         # step, a sixth of a rank's step on 8 GPUs — and the _align_ready / _ref_ready waits had nothing left to wait for.
+        # CONTRACT of the early fork: the side streams are ordered behind the caller's stream as of the START of
+        # init_ref only.  Whatever the caller enqueues on its stream between init_ref() and this call — producing or
+        # normalising comp frames on the device, a flow field that needs a copy — is NOT ordered before the side streams'
+        # first reads; the in-repo callers hand over inputs that predate init_ref (or staged / host frames) and contiguous
+        # float32 flow views.  HHSR_LATE_FORK=1 restores the fork at this call for callers that cannot promise that.
         early = bool(self.ref_wait and getattr(self, "_entry_fresh", False) and n_streams > 1 and not serial and n >= 1
                      and not _LATE_FORK)
         self._entry_fresh = False

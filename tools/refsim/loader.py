@@ -54,9 +54,61 @@ def _is_cuda_call(node, name):
     )
 
 
+AUDIT = bool(os.environ.get("HHSR_REFSIM_AUDIT"))
+_BINOPS = {ast.Add: "add", ast.Sub: "sub", ast.Mult: "mul", ast.Div: "truediv", ast.FloorDiv: "floordiv", ast.Mod: "mod",
+           ast.Pow: "pow", ast.LShift: "lshift", ast.RShift: "rshift", ast.BitAnd: "and", ast.BitOr: "or", ast.BitXor: "xor"}
+
+
 class _KernelRewriter(ast.NodeTransformer):
+    """(HHSR_REFSIM_AUDIT=1 additionally routes every arithmetic operator, every max / min / abs call and every assignment
+    to a plain local name through tools.refsim.audit, which records the operand and result types and returns the value
+    unchanged: tests/test_refsim_typing.py checks the recorded classes against Numba's typing rules.)"""
+
+    def __init__(self, fname="?"):
+        self.fname = fname
+
+    def visit_BinOp(self, node):
+        self.generic_visit(node)
+        if AUDIT and type(node.op) in _BINOPS:
+            return ast.copy_location(ast.Call(func=ast.Name(id="__refsim_op", ctx=ast.Load()),
+                                              args=[ast.Constant(_BINOPS[type(node.op)]), node.left, node.right], keywords=[]), node)
+        return node
+
+    def visit_UnaryOp(self, node):
+        self.generic_visit(node)
+        if AUDIT and isinstance(node.op, ast.USub):
+            return ast.copy_location(ast.Call(func=ast.Name(id="__refsim_neg", ctx=ast.Load()), args=[node.operand], keywords=[]), node)
+        return node
+
+    def visit_AugAssign(self, node):
+        self.generic_visit(node)
+        if AUDIT and type(node.op) in _BINOPS:
+            import copy
+
+            load = copy.deepcopy(node.target)
+            for n in ast.walk(load):
+                if hasattr(n, "ctx"):
+                    n.ctx = ast.Load()
+            val = ast.Call(func=ast.Name(id="__refsim_op", ctx=ast.Load()),
+                           args=[ast.Constant("i" + _BINOPS[type(node.op)]), load, node.value], keywords=[])
+            if isinstance(node.target, ast.Name):
+                val = ast.Call(func=ast.Name(id="__refsim_assign", ctx=ast.Load()),
+                               args=[ast.Constant(self.fname), ast.Constant(node.target.id), val], keywords=[])
+            return ast.copy_location(ast.Assign(targets=[node.target], value=val), node)
+        return node
+
+    def visit_Assign(self, node):
+        self.generic_visit(node)
+        if AUDIT and len(node.targets) == 1 and isinstance(node.targets[0], ast.Name):
+            node.value = ast.Call(func=ast.Name(id="__refsim_assign", ctx=ast.Load()),
+                                  args=[ast.Constant(self.fname), ast.Constant(node.targets[0].id), node.value], keywords=[])
+        return node
+
     def visit_Call(self, node):
         self.generic_visit(node)
+        if AUDIT and isinstance(node.func, ast.Name) and node.func.id in ("max", "min", "abs") and not node.keywords:
+            return ast.copy_location(ast.Call(func=ast.Name(id="__refsim_call", ctx=ast.Load()),
+                                              args=[ast.Constant(node.func.id), *node.args], keywords=[]), node)
         if _is_cuda_call(node, "syncthreads"):
             return ast.Yield(value=ast.Tuple(elts=[ast.Constant("sync")], ctx=ast.Load()))
         if _is_cuda_call(node, "shfl_down_sync"):
@@ -85,7 +137,7 @@ class _ModuleRewriter(ast.NodeTransformer):
         if any(_is_cuda_jit(d) for d in node.decorator_list):
             decs = node.decorator_list
             node.decorator_list = []
-            node = _KernelRewriter().visit(node)
+            node = _KernelRewriter(node.name).visit(node)
             node.decorator_list = decs
         return node
 
@@ -180,6 +232,13 @@ class _RefLoader(importlib.abc.Loader):
         module.__dict__["__refsim_round"] = _k_round
         module.__dict__["__refsim_range"] = _k_range
         module.__dict__["__refsim_math"] = _KMath
+        if AUDIT:
+            from . import audit
+
+            module.__dict__["__refsim_op"] = audit.op
+            module.__dict__["__refsim_neg"] = audit.neg
+            module.__dict__["__refsim_call"] = audit.call
+            module.__dict__["__refsim_assign"] = audit.assign
         module.__dict__["__file__"] = self.path
         exec(compile(tree, self.path, "exec"), module.__dict__)
 

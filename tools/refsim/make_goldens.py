@@ -25,7 +25,10 @@ import torch
 
 from . import loader
 
-OUT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "..", "tests", "golden")
+GOLDEN = os.path.abspath(os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "..", "tests", "golden"))
+# HHSR_REFSIM_AUDIT=1 (tools/refsim/audit.py): the fixtures go to a scratch directory and are compared with the committed
+# ones — an audited run must reproduce them bit for bit —, the recorded type classes to tests/golden/typing_audit.json
+OUT = os.environ.get("HHSR_GOLDEN_OUT") or (os.path.join("/tmp", "hhsr_golden_audit") if loader.AUDIT else GOLDEN)
 OUT = os.path.abspath(OUT)
 
 cfgmod = loader.install()
@@ -35,7 +38,7 @@ from numba import cuda  # noqa: E402  (the fake one)
 def _load_synth():
     import importlib.util
 
-    p = os.path.join(os.path.dirname(OUT), "..", "handheld-multi-frame-super-resolution_amd",
+    p = os.path.join(os.path.dirname(GOLDEN), "..", "handheld-multi-frame-super-resolution_amd",
                      "handheld_super_resolution", "synthetic.py")
     spec = importlib.util.spec_from_file_location("_refsim_synth", os.path.abspath(p))
     m = importlib.util.module_from_spec(spec)
@@ -717,6 +720,24 @@ def main(argv):
         with np.errstate(all="ignore"):
             STAGES[n]()
         print(f"  done in {time.time() - t0:.1f}s")
+    if loader.AUDIT:
+        from . import audit
+
+        same = diff = 0
+        for n in names:
+            for f in sorted(os.listdir(OUT)):
+                if not f.endswith(".npz") or not os.path.exists(os.path.join(GOLDEN, f)):
+                    continue
+                with np.load(os.path.join(OUT, f)) as a, np.load(os.path.join(GOLDEN, f)) as b:
+                    for k in a.files:
+                        ok = k in b.files and a[k].dtype == b[k].dtype and a[k].shape == b[k].shape and \
+                            np.array_equal(a[k], b[k], equal_nan=a[k].dtype.kind == "f")
+                        same, diff = same + int(ok), diff + int(not ok)
+            break  # (every file once)
+        rec = audit.dump(os.path.join(GOLDEN, "typing_audit.json"))
+        print(f"[refsim] audit: {len(rec['ops'])} operator classes, {len(rec['calls'])} call classes, {len(rec['vars'])} local "
+              f"variables with more than one type ({rec['vars_single_type']} with one); fixtures of this audited run vs the "
+              f"committed ones: {same} arrays identical, {diff} different")
 
 
 if __name__ == "__main__":
