@@ -643,6 +643,24 @@ def main():
         except Exception as e:  # noqa: BLE001
             errors["weight_fp64_leg"] = f"{type(e).__name__}: {e}"
 
+    # ---- the accumulated-robustness merge denoiser on (merge.py:223-228; off in configs/default.yaml): the comp frames through
+    # the same fused merge, the float64 robustness sum in one pass (hhsr_rob_sum), then merge_ref with its overwrite / widen
+    # rules + divide.  N = 1, guarded.
+    if on_gpu and world == 1 and not args.no_h2d:
+        import copy
+
+        try:
+            cfgd = copy.deepcopy(cfg)
+            cfgd.accumulated_robustness_denoiser.enabled = True
+            cfgd.accumulated_robustness_denoiser.merge.enabled = True
+            engd = engine_cls(cfgd)
+            fnd = lambda: hdist.main_sharded(ref, comp, cfgd, engine=engd, gather=args.gather)[0]  # noqa: E731
+            msd = timed(fnd, max(3, args.steps // 2), 3)
+            line.update(ms_per_step_denoiser=round(msd, 3), value_denoiser=round(out_pix / (msd * 1e-3) / 1e6, 2))
+            del engd
+        except Exception as e:  # noqa: BLE001
+            errors["denoiser_leg"] = f"{type(e).__name__}: {e}"
+
     # ---- the C5 geometry on ONE GPU (48 MP x 20 frames x3 -> 432 MP; BASELINE.json configs[4] is this workload over 8 GPUs):
     # the x3 merge kernel's numbers in the driver's own record.  Optional, guarded, N = 1, headline run only.
     if on_gpu and world == 1 and headline and not args.no_c5 and not args.no_h2d:

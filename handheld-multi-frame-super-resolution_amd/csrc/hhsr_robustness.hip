@@ -936,6 +936,57 @@ extern "C" int hhsr_local_min5(const float* R, int H, int W, float* r, float* ac
     HHSR_LAUNCHED();
 }
 
+// ---- accumulated robustness as the reference keeps it where something decides on it (super_resolution.py:116-117,
+// 158-159; utils.py:93-120; merge.py:223-228): the float64 sum of the frames' maps, in frame order.  One pass over the n maps
+// instead of n read-modify-write passes of a float64 torch tensor between the frames (round 5: 4.6 GB of extra traffic per
+// 12 MP x 20 burst and five elementwise passes for the decision map).  Outputs, each optional: the float64 sum (kept for
+// bursts longer than one call: `load`), the sum rounded to float32 (the map the API reports), and the float32 DECISION map a
+// with  a <= mfc  <=>  sum <= mfc  and  a < mfc  <=>  sum < mfc  for the kernels that compare (double) a with
+// max_frame_count (robustness.RobustnessSum.decisions_of: exact for every threshold float32 can hold).
+struct RobSumFrames {
+    const float* r[HHSR_MAX_FRAMES];
+    int n;
+};
+
+__global__ void __launch_bounds__(256) k_rob_sum(RobSumFrames fr, size_t count, int load, double mfc, float m32, float below,
+                                                  float above, double* __restrict__ sum64, float* __restrict__ mask32,
+                                                  float* __restrict__ dec32) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= count) return;
+    double s = load ? sum64[i] : 0.0;
+    for (int n = 0; n < fr.n; ++n) s += (double)fr.r[n][i];  // float32 -> float64: exact; frame order like the reference
+    if (sum64) sum64[i] = s;
+    float a = (float)s;
+    if (mask32) mask32[i] = a;
+    if (dec32) {
+        if (s < mfc && a >= m32) a = below;
+        if (s > mfc && a <= m32) a = above;
+        dec32[i] = a;
+    }
+}
+
+extern "C" int hhsr_rob_sum(const float* const* rs, int n_frames, int H, int W, int load, double max_frame_count,
+                            double* sum64, float* mask32, float* decisions32, void* stream) {
+    HHSR_ARG(n_frames >= 0 && n_frames <= HHSR_MAX_FRAMES && H > 0 && W > 0);
+    HHSR_ARG(n_frames == 0 || rs != nullptr);
+    HHSR_ARG(!load || sum64 != nullptr);
+    HHSR_ARG(sum64 || mask32 || decisions32);
+    RobSumFrames fr;
+    fr.n = n_frames;
+    for (int k = 0; k < HHSR_MAX_FRAMES; ++k) {
+        fr.r[k] = k < n_frames ? rs[k] : nullptr;
+        HHSR_ARG(k >= n_frames || rs[k] != nullptr);
+    }
+    const float m32 = (float)max_frame_count;
+    // largest float32 below / smallest float32 above the threshold (the threshold itself where float32 cannot hold it)
+    const float below = (double)m32 < max_frame_count ? m32 : nextafterf(m32, -INFINITY);
+    const float above = (double)m32 > max_frame_count ? m32 : nextafterf(m32, INFINITY);
+    const size_t count = (size_t)H * W;
+    hipLaunchKernelGGL(k_rob_sum, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, (hipStream_t)stream, fr, count, load,
+                       max_frame_count, m32, below, above, sum64, mask32, decisions32);
+    HHSR_LAUNCHED();
+}
+
 // ---- monochrome sensors (`mode: grey`) ---------------------------------------------------------------------------
 // The frame itself is the one-channel guide image (robustness.py:62-66, 145-148); its 3x3 statistics come from
 // hhsr_mono_frame_stats.  The statistics map keeps its size in this mode (robustness.py:337-343) while the upscale

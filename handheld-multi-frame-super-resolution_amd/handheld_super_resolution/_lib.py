@@ -49,6 +49,7 @@ _SIGS = {
     "hhsr_rob_frame": [P, I, I, P, P, P, P, I, I, I, P, P, I, D, P, P],
     "hhsr_rob_frames": [PP, I, I, I, P, P, P, PP, I, I, I, PP, D, F, F, P, I, D, PP, I, I, P],
     "hhsr_local_min5": [P, I, I, P, P, P],
+    "hhsr_rob_sum": [PP, I, I, I, I, D, P, P, P, P],
     "hhsr_mono_frame_stats": [P, I, I, I, P, P, P, D, D, D, D, D, D, D, D, I, P],
     "hhsr_mono_rob_upscale": [P, I, I, P, I, I, I, P, P],
     "hhsr_mono_rob_sigma": [P, P, I, I, P, I, P, P],

@@ -112,6 +112,19 @@ class RobustnessSum:
 
     def add(self, r):
         self.sum.add_(r)  # float32 -> float64: exact
+        self._n = getattr(self, "_n", 0) + 1
+        return self
+
+    def add_many(self, rs):
+        """The maps of several frames in ONE pass (hhsr_rob_sum: the float64 sum in frame order, like add() frame by
+        frame — bit-identical —, without a read-modify-write of the float64 map per frame)."""
+        rs = [_lib.f32c(r) for r in rs]
+        H, W = self.sum.shape
+        for i in range(0, len(rs), _lib.MAX_FRAMES):
+            chunk = rs[i:i + _lib.MAX_FRAMES]
+            _lib.call("hhsr_rob_sum", _lib.ptr_array(chunk), len(chunk), int(H), int(W), 1 if getattr(self, "_n", 0) else 0, 0.0,
+                      _lib.ptr(self.sum), None, None, _lib.stream(self.sum.device))
+            self._n = getattr(self, "_n", 0) + len(chunk)
         return self
 
     def mask(self, rows=None):
@@ -134,7 +147,13 @@ class RobustnessSum:
         return a
 
     def for_decisions(self, max_frame_count, rows=None):
-        return self.decisions_of(self.sum if rows is None else self.sum[rows[0]:rows[1]], max_frame_count)
+        t = self.sum if rows is None else self.sum[rows[0]:rows[1]]
+        if t.is_cuda and t.is_contiguous():  # one kernel instead of five elementwise passes (= decisions_of, tested)
+            out = torch.empty(t.shape, dtype=torch.float32, device=t.device)
+            _lib.call("hhsr_rob_sum", _lib.ptr_array([]), 0, int(t.shape[0]), int(t.shape[1]), 1, float(max_frame_count),
+                      _lib.ptr(t), None, _lib.ptr(out), _lib.stream(t.device))
+            return out
+        return self.decisions_of(t, max_frame_count)
 
 
 def local_min(R, accumulate_into=None):

@@ -515,6 +515,13 @@ def main(ref_img, comp_imgs, config, *, _no_runner=False):
     accumulate_r = denoiser_on or bool(config.robustness.save_mask)
     hip_cfg = config.get("hip", None) if hasattr(config, "get") else None
     fused = True if hip_cfg is None else bool(hip_cfg.get("fused_merge", True))
+    # Denoiser on (round 6): the comp frames still go through the batched front end and ONE fused merge launch — without the
+    # reference frame and without normalising —, the float64 robustness sum is one pass over the frames' maps
+    # (hhsr_rob_sum), then the reference's sequential tail: merge_ref with the decision map (its overwrite / widen rules,
+    # merge.py:223-228) and divide.  Until now this configuration ran the per-frame operator path: a read-modify-write of
+    # the accumulators and of a float64 torch tensor per frame.
+    den_fused = fused and denoiser_on and can_fuse_acc_r(config) and n_images_of(comp_imgs) > 0 \
+        and not (config.verbose >= 1 or bool(config.debug))
     fused = fused and not denoiser_on
 
     if verbose:
@@ -532,7 +539,9 @@ def main(ref_img, comp_imgs, config, *, _no_runner=False):
     fuse_acc = accumulate_r and fused and can_fuse_acc_r(config) and n_images_of(comp_imgs) > 0
     num = torch.empty((sH, sW, 3), dtype=torch.float32, device=dev)
     den = None
-    if not fused:
+    if den_fused:
+        den = torch.empty_like(num)
+    elif not fused:
         num.zero_()
         den = torch.zeros_like(num)
     if verbose:
@@ -550,6 +559,10 @@ def main(ref_img, comp_imgs, config, *, _no_runner=False):
         frames = pipe.process_frames([comp_imgs[i] for i in range(n_images)], None if fuse_acc else accumulated_r,
                                      fuse_local_min=fuse_min)
         n_images = 0  # the per-frame loop below is the verbose / debug / sequential-merge path
+    elif den_fused:
+        frames = pipe.process_frames([comp_imgs[i] for i in range(n_images)], None, fuse_local_min=False)
+        acc_sum.add_many([f[3] for f in frames])
+        n_images = 0
     for im_id in range(n_images):
         if verbose:
             torch.cuda.synchronize()
@@ -576,6 +589,8 @@ def main(ref_img, comp_imgs, config, *, _no_runner=False):
             frames, pipe.ref, ref_covs, num, None, pipe.cfa, config, do_ref=True, divide=True,
             acc_r=accumulated_r if fuse_acc else None, local_min=fuse_min)
     else:
+        if den_fused:
+            merge_burst(frames, None, None, num, den, pipe.cfa, config, do_ref=False, divide=False, store_den=True)
         pipe._timed(merge_ref, 2, "\nAccumulating ref Img", "Ref Img accumulated (Total)")(
             pipe.ref, ref_covs, num, den, pipe.cfa, config,
             acc_sum.for_decisions(config.accumulated_robustness_denoiser.merge.max_frame_count) if denoiser_on else None)

@@ -201,6 +201,14 @@ int hhsr_rob_frames(const float* const* comp_means, int n_frames, int lh, int lw
 /* 5x5 clamp-border minimum (robustness.py:670-686).  acc_r != NULL additionally does acc_r += r
  * (the accumulated robustness of super_resolution.py:158-159, fused to save a pass). */
 int hhsr_local_min5(const float* R, int H, int W, float* r, float* acc_r, void* stream);
+/* Accumulated robustness the way the reference keeps it where something DECIDES on it (super_resolution.py:116-117,
+ * 158-159; utils.py:93-120; merge.py:223-228): the float64 sum of the n_frames (<= HHSR_MAX_FRAMES) maps rs[] (HOST array of
+ * device pointers, float32 [H][W]) in frame order, in one pass.  load != 0: start from sum64 (bursts longer than one
+ * call).  Outputs, each may be NULL (not all): sum64 double [H][W]; mask32 = the sum rounded to float32 (the map the API
+ * reports); decisions32 = float32 map a with (a <= mfc) == (sum <= mfc) and (a < mfc) == (sum < mfc) for
+ * mfc = max_frame_count — what hhsr_accumulate_ref compares as (double) a (exact for every mfc float32 can hold). */
+int hhsr_rob_sum(const float* const* rs, int n_frames, int H, int W, int load, double max_frame_count, double* sum64,
+                 float* mask32, float* decisions32, void* stream);
 
 /* ---- monochrome sensors, `mode: grey` (super_resolution.py:106-109, 144-147; kernels.py:83-87; robustness.py:62-66,
  * 145-148, 337-343; merge.py:131-137, 191-194, 349-354, 410): the frame is its own grey image (alignment unchanged), its

@@ -510,6 +510,57 @@ def test_merge_golden(golden, tag, scale, kern, do_ref, f64):
         assert_close(N(den), g[tag + "_denref"], 2e-5, 1e-6, tag + " denref")
 
 
+def test_rob_sum_kernel_and_fused_denoiser_path():
+    """hhsr_rob_sum (the float64 accumulated robustness of several frames in one pass, with the float32 decision map) against
+    torch's float64 sum and RobustnessSum.decisions_of, values on both sides of the threshold within float32 rounding; and
+    main() with the accumulated-robustness merge denoiser at x2 and x3 (the fused comp merge + merge_ref + divide path of
+    round 6) against the sequential operator path (config.hip.fused_merge = False: merge() frame by frame): identical images
+    and identical accumulated robustness."""
+    from handheld_super_resolution.robustness import RobustnessSum
+
+    gen = torch.Generator(device=DEV).manual_seed(3)
+    H, W, n = 96, 130, 5
+    rs = [torch.rand((H, W), device=DEV, generator=gen) for _ in range(n)]
+    rs[0][:8] = 1.0
+    rs[1][:8] = 1.0
+    rs[2][:8] = float(np.nextafter(np.float32(1.0), np.float32(0.0)))  # 1 + 1 + 0.99999994: 3 in float32, not in float64
+    rs[3][:8] = 0.0
+    rs[4][:8] = 0.0
+    acc = RobustnessSum((H, W), torch.device(DEV)).add_many(rs)
+    want = torch.zeros((H, W), dtype=torch.float64, device=DEV)
+    for r in rs:
+        want += r
+    assert torch.equal(acc.sum, want)
+    acc2 = RobustnessSum((H, W), torch.device(DEV)).add_many(rs[:2]).add_many(rs[2:])  # chained calls (load)
+    assert torch.equal(acc2.sum, want)
+    for mfc in (3.0, 2.0, 2.5, 3.0000001):
+        assert torch.equal(acc.for_decisions(mfc), RobustnessSum.decisions_of(want, mfc)), mfc
+        a = acc.for_decisions(mfc).double()
+        assert torch.equal(a <= mfc, want <= mfc) and torch.equal(a < mfc, want < mfc), mfc
+    assert float(want[0, 0]) < 3.0 and float(want[0, 0].float()) == 3.0  # the case the float32 sum decides differently
+
+    for scale, shape in ((2, (640, 704)), (3, (592, 640))):
+        ref, comp, _ = synth.make_burst(*shape, 4, seed=21 + scale, max_shift=2.0, occluder=True)
+
+        def cfg_fn(**hip):
+            cfg = base_config(ts=16, scale=scale)
+            cfg.robustness.save_mask = True
+            cfg.accumulated_robustness_denoiser.enabled = True
+            cfg.accumulated_robustness_denoiser.merge.enabled = True
+            if hip:
+                cfg.hip = hip
+            return cfg
+
+        out_f, dbg_f = hsr.main(ref, comp, cfg_fn())
+        out_s, dbg_s = hsr.main(ref, comp, cfg_fn(fused_merge=False))
+        assert torch.equal(dbg_f["accumulated robustness"], dbg_s["accumulated robustness"])
+        same = (out_f == out_s) | (out_f.isnan() & out_s.isnan())
+        worst = float(torch.nan_to_num(out_f - out_s, nan=0.0).abs().max())
+        # (the fused kernels sum the comp frames in the order merge() does; the float32-weight kernels differ from the per-frame
+        # operator kernels' float64 weight chain by rounding: 2e-5 relative like test_merge_golden)
+        assert bool(same.all()) or worst <= 2e-5, (scale, worst)
+
+
 def test_merge_ref_denoiser_golden(golden):
     g = golden("merge")
     H, W = g["ref"].shape
@@ -886,9 +937,16 @@ def test_e2e_golden_x1_denoiser(golden):
     assert_close(N(dbg["accumulated robustness"]), g["acc_r"], 0, 1e-4, "acc r")
     o = N(out)
     assert_close(o, g["out"], 0, 5e-5, "output")
-    cfg2 = x1_config(cfa, wb)  # non-debug (multi-stream) path
+    # non-debug path: the batched front end, the comp frames through ONE fused merge launch (float32 weight chain, like the
+    # headline path), hhsr_rob_sum, then merge_ref + divide (round 6; the debug path above is the per-frame operator path)
+    cfg2 = x1_config(cfa, wb)
     out2, _ = hsr.main(ref, comp, cfg2)
-    assert_close(N(out2), o, 0, 0, "debug path == fast path")
+    assert_close(N(out2), g["out"], 0, 5e-5, "fast path vs the reference's output")
+    assert_close(N(out2), o, 0, 2e-6, "fast path vs debug path")
+    cfg3 = x1_config(cfa, wb)  # ... and the per-frame path without the debug copies: bit-identical to the debug path
+    cfg3.hip = {"fused_merge": False}
+    out3, _ = hsr.main(ref, comp, cfg3)
+    assert_close(N(out3), o, 0, 0, "debug path == sequential fast path")
 
 
 @pytest.mark.parametrize("tag", ["s15", "s3", "s2iso", "ts32"])
