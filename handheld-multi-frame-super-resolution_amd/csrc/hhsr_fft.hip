@@ -234,10 +234,7 @@ __device__ __forceinline__ bool fft_kept(int u, int n) {
 // frame (rows fwd / cols / rows inv): 8: 39 / 57 / 39 = 135;  4: 40 / 43 / 44 = 127;  2: 43 / 35 / 59 = 137 — and with
 // the row kernels walking T in memory order and k_rows_inv reading every bin once (pairs Z[k], Z[M-k]):
 // 4: 40 / 44 / 40 = 124;  2: 42 / 35 / 44 = 121 (step 8.92 vs 8.99 ms).
-#ifndef HHSR_FFT_TB
-#define HHSR_FFT_TB 2
-#endif
-constexpr int TB = HHSR_FFT_TB;
+constexpr int TB = 2;
 __device__ __forceinline__ size_t t_index(int kx, int y, int H) { return ((size_t)(kx / TB) * H + y) * TB + (kx % TB); }
 
 constexpr int FFT_NT = 512;          // threads per workgroup: column kernel, and the row kernels' long rows
@@ -248,14 +245,11 @@ constexpr int FFT_NT = 512;          // threads per workgroup: column kernel, an
 // (four resident workgroups: 91.9 / 97.2; six — more than fit — 97.1 / 104.7).  The column kernel LOSES with 256 threads
 // (one column per workgroup: 90 -> 111 us) and keeps 512.
 constexpr int FFT_NT_SMALL = 256;
-#ifndef HHSR_FFT_TWG
-#define HHSR_FFT_TWG 0  // 1 (A/B, round 3): row kernels read their pass twiddles from global memory (L1 / L2) instead of an LDS
-                        // copy: 32 KB of LDS per workgroup -> four workgroups per CU (<= 64 VGPRs).  Measured: 248 / 221 us
-                        // per 3-4 frame launch instead of 118 / 116 — the twiddle loads sit on every pass's critical path
-#endif
+// (Round 3 A/B, removed: pass twiddles from global memory instead of the LDS copy — four workgroups per CU, 248 / 221 us per
+// 3-4 frame launch instead of 118 / 116: the twiddle loads sit on every pass's critical path.)
 // row kernels: 512 threads, 48 KB of LDS -> three workgroups per CU need <= 85 VGPRs (6 waves per SIMD);
 //              256 threads, 32 KB -> five workgroups per CU = 5 waves per SIMD (<= 102 VGPRs)
-__host__ __device__ constexpr int fft_rows_wpe(int nt) { return HHSR_FFT_TWG ? 8 : nt == FFT_NT ? 6 : 5; }
+__host__ __device__ constexpr int fft_rows_wpe(int nt) { return nt == FFT_NT ? 6 : 5; }
 constexpr int FFT_COLS_WPE = 4;     // column kernel: 72 KB of LDS -> two workgroups per CU (<= 128 VGPRs)
 
 // n elements global -> LDS (or any load / store pair) with the loads of a 4-iteration batch all in flight before the first
@@ -282,14 +276,11 @@ __device__ __forceinline__ void batched_for(int n, int tid, Load load, Store sto
 // holds one column block of 16 / TB consecutive rows, i.e. of G = 16 / (TB RB) consecutive row blocks: they go to
 // consecutive workgroups of ONE XCD (workgroup b runs on XCD b % 8 — observed; locality only), so that one L2 gathers /
 // serves the line instead of G of them (k_rows_inv fetched 4.6 x the spectrum's bytes with the plain round-robin walk).
-#ifndef HHSR_FFT_XCD
-#define HHSR_FFT_XCD 1
-#endif
 template <int RB>
 __device__ __forceinline__ int row_block(int it, int nblocks) {
     constexpr int G = (16 / (TB * RB)) > 0 ? 16 / (TB * RB) : 1;
     int blk;
-    if (HHSR_FFT_XCD && (gridDim.x & 7) == 0) {
+    if ((gridDim.x & 7) == 0) {
         const int v = (int)(blockIdx.x >> 3) + it * (int)(gridDim.x >> 3);
         blk = ((v / G) * 8 + (int)(blockIdx.x & 7)) * G + v % G;  // increasing in `it`
     } else {
@@ -333,14 +324,9 @@ __global__ void __launch_bounds__(NT, fft_rows_wpe(NT)) k_rows_fwd(FftFrames fr,
     extern __shared__ __attribute__((aligned(16))) float2 fl[];
     const int M = plan_len<SP>(W / 2), tid = threadIdx.x;
     W = 2 * M;
-#if HHSR_FFT_TWG
-    const float2* __restrict__ tw = twM;
-    float2* buf = fl;
-#else
     float2* tw = fl;
     float2* buf = tw + ((twlen + 1) & ~1);  // 16-byte aligned
     batched_for<float2, NT>(twlen, tid, [&](int k) { return twM[k]; }, [&](int k, float2 v) { tw[k] = v; });
-#endif
     // persistent workgroups: the grid is one resident round (HHSR_FFT_PERSIST), every workgroup walks the row blocks
     // (row_block): one twiddle copy and one dispatch per workgroup slot instead of per block
     const int nb = (H + RB - 1) / RB;
@@ -473,14 +459,9 @@ __global__ void __launch_bounds__(NT, fft_rows_wpe(NT)) k_rows_inv(const float2*
     extern __shared__ __attribute__((aligned(16))) float2 fl[];
     const int M = plan_len<SP>(W / 2), tid = threadIdx.x;
     W = 2 * M;
-#if HHSR_FFT_TWG
-    const float2* __restrict__ tw = twM;
-    float2* buf = fl;
-#else
     float2* tw = fl;
     float2* buf = tw + ((twlen + 1) & ~1);  // 16-byte aligned
     batched_for<float2, NT>(twlen, tid, [&](int k) { return twM[k]; }, [&](int k, float2 v) { tw[k] = v; });
-#endif
     const int nb = (H + RB - 1) / RB;
     for (int it = 0, vblk; (vblk = row_block<RB>(it, nb * fr.n)) >= 0; ++it) {  // persistent workgroups, see k_rows_fwd
     if (it) __syncthreads();
@@ -669,7 +650,7 @@ static int pick_rb(int M, HhsrRadices& rad, int& nt) {
     const int forced = e ? atoi(e) : 0;
     const char* ent = getenv("HHSR_FFT_NT_ROWS");
     const int forced_nt = ent ? atoi(ent) : 0;
-    if (!HHSR_FFT_TWG && (!forced || forced == 1) && forced_nt != FFT_NT && factorize(M, 1, rad, FFT_NT_SMALL) &&
+    if ((!forced || forced == 1) && forced_nt != FFT_NT && factorize(M, 1, rad, FFT_NT_SMALL) &&
         sizeof(float2) * (((pass_twiddles(rad).size() + 1) & ~(size_t)1) + (size_t)M) <= 32 * 1024) {
         nt = FFT_NT_SMALL;
         return 1;
@@ -710,7 +691,7 @@ bool hhsr_fft_create(HhsrFft& f, int H, int W, int batch) {
     const std::vector<float2> hM = pass_twiddles(f.radM), hH = pass_twiddles(f.radH);
     f.twlenM = (int)hM.size();
     f.twlenH = (int)hH.size();
-    f.lds_rows = sizeof(float2) * ((HHSR_FFT_TWG ? 0 : (size_t)((f.twlenM + 1) & ~1)) + (size_t)f.rb * M);
+    f.lds_rows = sizeof(float2) * ((size_t)((f.twlenM + 1) & ~1) + (size_t)f.rb * M);
     f.lds_cols = sizeof(float2) * ((size_t)((f.twlenH + 1) & ~1) + (size_t)f.nc * H);
     if (f.lds_cols > 150 * 1024 || f.lds_rows > 150 * 1024) return false;
     const bool small = f.nt_rows == FFT_NT_SMALL;  // (only with rb = 1)
@@ -770,7 +751,7 @@ int hhsr_fft_lowpass(const HhsrFft& f, const float* const* srcs, float* const* d
     // single-row workgroups with 32 kB), each walking several blocks
     static const int persist_env = getenv("HHSR_FFT_PERSIST") ? atoi(getenv("HHSR_FFT_PERSIST")) : -1;
     const bool small = f.nt_rows == FFT_NT_SMALL;
-    const int persist = persist_env >= 0 ? persist_env : HHSR_FFT_TWG ? 1024 : small ? 1280 : 768;
+    const int persist = persist_env >= 0 ? persist_env : small ? 1280 : 768;
     // unnormalised inverse transforms multiply by (W/2) and H
     const float norm = (float)(1.0 / ((double)(f.W / 2) * (double)f.H));
     for (int n0 = 0; n0 < n; n0 += f.batch) {  // the plan holds f.batch spectra: longer lists run in rounds

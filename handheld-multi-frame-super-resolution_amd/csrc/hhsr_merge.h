@@ -735,32 +735,16 @@ __device__ __forceinline__ void quad_tile_body(const BurstArgs& a, const Geo& g,
 //     class reads 8-byte aligned pairs (stride-2 dword reads would be 2-way bank conflicts);
 //   * the finished 32 x 32 x 3 tile goes through LDS and leaves as whole 16-byte vectors in 384-byte row segments
 //     (the per-thread dword stores of the first kernel wrote 1.42 x the output bytes).
-#ifndef HHSR_X2_CLAMP
-#define HHSR_X2_CLAMP 1  // 1: clamp(v_exp_f32) + exact path for non-finite coefficients (A/B: 3.54 ms); 0: min + v_exp_f32 per tap (3.63)
-#endif
-#ifndef HHSR_X2_PEEL
-#define HHSR_X2_PEEL 0   // 1: reference frame as a compile-time variant of the frame code (A/B: 160 VGPRs, 3.97 vs 3.54 ms); 0: run-time selects
-#endif
-#ifndef HHSR_X2_GEO
-#define HHSR_X2_GEO 1  // 1: per-frame geometry evaluated once per workgroup (lane = frame) and broadcast through LDS
-#endif
+// What the A/B builds of rounds 2-4 settled (the losing sides are gone from the source; numbers: DESIGN.md §4 / docs/history):
+// clamp(v_exp_f32) + an exact arm for non-finite coefficients instead of min + v_exp_f32 per tap (3.54 vs 3.63 ms); the
+// reference frame through run-time selects instead of a compile-time variant of the frame code (160 VGPRs: 3.97 vs 3.54
+// ms); per-frame geometry once per workgroup through LDS; 3 + 3 channel accumulators instead of 4 + 4 parity classes;
+// k_merge_xs: EDGE frames through the uniform code with masks, the LDS reads of sub-pixel q + 1 issued before the taps of q.
 #ifndef HHSR_XS_OCC
-#define HHSR_XS_OCC 2  // k_merge_xs<3>: 72 accumulators per thread; 3 waves per SIMD (168 VGPRs) spills 50 dwords
-#endif
-#ifndef HHSR_X2_RGB
-#define HHSR_X2_RGB 1  // k_merge_x2: 3 + 3 channel accumulators per sub-pixel (Bayer) instead of 4 + 4 parity classes
-#endif
-#ifndef HHSR_XS_EDGE
-#define HHSR_XS_EDGE 1  // k_merge_xs: frames whose window leaves the image run the uniform code with masks (0: per-pixel path)
-#endif
-#ifndef HHSR_XS_RGB
-#define HHSR_XS_RGB 1  // k_merge_xs: 3 + 3 channel accumulators per sub-pixel (Bayer) instead of 4 + 4 parity classes
-#endif
-#ifndef HHSR_XS_PIPE
-#define HHSR_XS_PIPE 1  // k_merge_xs: LDS reads of sub-pixel q + 1 issued before the taps of sub-pixel q
+#define HHSR_XS_OCC 2  // k_merge_xs<3>: 54 accumulators per thread; 3 waves per SIMD (168 VGPRs) spills 50 dwords
 #endif
 #ifndef HHSR_X2_OCC
-#define HHSR_X2_OCC 4  // waves per SIMD the register allocation of k_merge_x2 is held to (125 VGPRs; A/B: 3 = 4; 5 spills: 6.9 ms)
+#define HHSR_X2_OCC 4  // waves per SIMD the register allocation of k_merge_x2 is held to (122 VGPRs; A/B: 3 = 4; 5 spills: 6.9 ms)
 #endif
 constexpr int X2_RP = 24;   // raw / R window pitch in floats: rows are read with stride 2 -> 48 dwords = 16 (mod 32) banks
 constexpr int X2_CP = 24;   // covariance window pitch in float4: 96 dwords = 32 (mod 64) banks for ds_read_b128

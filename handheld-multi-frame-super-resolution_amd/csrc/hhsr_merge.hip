@@ -345,7 +345,7 @@ static int merge_burst_impl(const float* const* raws, const float* const* flows,
     const bool x3 = aligned16 && tiled && iscale == 3 && cfa_is_bayer(c) && ts % QT == 0 && sW == 3 * W && sH == 3 * H && row0 % (3 * QT) == 0 && nrows % 3 == 0 &&
                     W % 4 == 0 && !(force & HHSR_MERGE_FORCE_TILE);
     const bool chained = (flags & (HHSR_MERGE_STORE_CLASSES | HHSR_MERGE_LOAD_CLASSES)) != 0;
-    if (chained && !(quad && !x2_v1 && aligned16 && !mono && (cfa_is_bayer(c) || !HHSR_X2_RGB))) {
+    if (chained && !(quad && !x2_v1 && aligned16 && !mono && cfa_is_bayer(c))) {
         hhsr_set_error("hhsr_merge_burst_chain: needs the wave-per-class x2 kernel (scale 2, ts %% 16 == 0, sH = 2 H, "
                        "sW = 2 W, 16-byte aligned output, float32 weights, Bayer)");
         return -3;
@@ -368,7 +368,7 @@ static int merge_burst_impl(const float* const* raws, const float* const* flows,
 #undef HHSR_MB
     } else if (mono) {  // `mode: grey` at x2: the first-generation tile kernel with a per-pixel covariance window
         hhsr_launch_merge_quad(iso != 0, lmin, true, dim3(hhsr_cdiv(W, QT), hhsr_cdiv(nrows / 2, QT)), s, a, g, c, num, den);
-    } else if (quad && !x2_v1 && aligned16 && (cfa_is_bayer(c) || !HHSR_X2_RGB)) {  // x2: one wave per parity class
+    } else if (quad && !x2_v1 && aligned16 && cfa_is_bayer(c)) {  // x2: one wave per parity class
         hhsr_launch_merge_x2(iso != 0, lmin, dim3(hhsr_cdiv(W, QT), hhsr_cdiv(nrows / 2, QT)), s, a, g, c, num, den);
     } else if (quad) {  // x2, first generation (non-Bayer 2 x 2 colour layouts, unaligned outputs, HHSR_MERGE_FORCE_X2V1)
         hhsr_launch_merge_quad(iso != 0, lmin, false, dim3(hhsr_cdiv(W, QT), hhsr_cdiv(nrows / 2, QT)), s, a, g, c, num, den);

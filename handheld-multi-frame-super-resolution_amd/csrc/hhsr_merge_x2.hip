@@ -16,9 +16,7 @@ __global__ void __launch_bounds__(256, HHSR_X2_OCC) k_merge_x2(BurstArgs a, Geo 
     __shared__ float4 s_cov[NB * COVSZ];
     __shared__ __align__(16) float s_R[NB * RAWSZ];                 // LMIN: un-filtered robustness, tile + 2-pixel border
     __shared__ __align__(16) float s_out[32 * X2_OP];
-#if HHSR_X2_GEO
     __shared__ float4 s_geo[(HHSR_MAX_FRAMES + 1) * 8];             // per frame: [axis x, y][parity 0, 1] x 2 quads
-#endif
     const int tid = threadIdx.x;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;  // readfirstlane: known wave-uniform
     const int nbx = gridDim.x, nblk = gridDim.x * gridDim.y;
@@ -55,7 +53,6 @@ __global__ void __launch_bounds__(256, HHSR_X2_OCC) k_merge_x2(BurstArgs a, Geo 
     float* __restrict__ cls = a.cls ? a.cls + (size_t)bid * (33 * 256) + tid : nullptr;
     const int nfirst = chain_load ? a.first : 0;
 
-#if HHSR_X2_GEO
     // Per-frame geometry once per WORKGROUP: it only depends on the frame's flow vector and the parity class, so
     // evaluating it in every thread and frame (~50 instructions, ~40 % of them half-rate, identical in all lanes of a
     // wave) was 7 % of the kernel's VALU time.  Lane = frame here; the frame loop reads its entry back with four
@@ -77,15 +74,14 @@ __global__ void __launch_bounds__(256, HHSR_X2_OCC) k_merge_x2(BurstArgs a, Geo 
         }
     }
     __syncthreads();  // (the first prefetch below reads the table)
-#endif
     const int py = wave >> 1, px = wave & 1;                        // this wave's parity class
     const int li = lane >> 3, lj = lane & 7;
     const int ty = 2 * li + py, tx = 2 * lj + px;                   // LR pixel inside the tile
     const int ridx = (ly0 + ty) * g.W + lx0 + tx;
-    // HHSR_X2_RGB (round 4; Bayer layouts — the only ones this kernel is launched for): the two green parity classes are
-    // summed when a frame is folded: 3 + 3 accumulators per sub-pixel instead of 4 + 4 (24 instead of 32 per thread),
-    // and the epilogue has no class -> channel step (whose private arrays lived in scratch).  0: round 3's four classes.
-    constexpr int NC = HHSR_X2_RGB ? 3 : 4, NA = 4 * NC;
+    // Bayer layouts (the only ones this kernel is launched for): the two green parity classes are summed when a frame is
+    // folded: 3 + 3 accumulators per sub-pixel instead of 4 + 4 (24 instead of 32 per thread), and the epilogue has no
+    // class -> channel step (whose private arrays lived in scratch; round 4: 3.37 -> 3.24 ms).
+    constexpr int NC = 3, NA = 4 * NC;
     float nacc[2][2][NC], dacc[2][2][NC];
     const int rcl = cfa.c[0] == 0 ? 0 : cfa.c[1] == 0 ? 1 : cfa.c[2] == 0 ? 2 : 3;  // parity class of the red samples
     const int ri = rcl >> 1, rj = rcl & 1;
@@ -133,18 +129,9 @@ __global__ void __launch_bounds__(256, HHSR_X2_OCC) k_merge_x2(BurstArgs a, Geo 
         const bool isref = n >= a.n;
         const float* __restrict__ raw = isref ? a.ref_raw : a.f[n].raw;
         const float4* __restrict__ cov = isref ? a.ref_cov : a.f[n].cov;
-#if HHSR_X2_GEO
         // (the table's org of either parity: x2_comp_org of the frame's flow, l0 - 1 for the reference frame)
         const int ox = __builtin_amdgcn_readfirstlane(reinterpret_cast<const int*>(s_geo)[(n * 8) * 4]);
         const int oy = __builtin_amdgcn_readfirstlane(reinterpret_cast<const int*>(s_geo)[(n * 8 + 4) * 4]);
-#else
-        int ox = lx0 - 1, oy = ly0 - 1;
-        if (!isref) {
-            pfl = a.f[n].flow[tile];
-            ox = x2_comp_org(pfl.x, lx0);
-            oy = x2_comp_org(pfl.y, ly0);
-        }
-#endif
         const unsigned ob = (unsigned)(oy * g.pitch + ox) * 4u;  // (scalar)
         pr0 = ldf(raw, ob + t0b);
         if (has1) pr1 = ldf(raw, ob + t1b);
@@ -193,7 +180,7 @@ __global__ void __launch_bounds__(256, HHSR_X2_OCC) k_merge_x2(BurstArgs a, Geo 
     // (tools/ubench/valu_rate.hip) — the kernel is VALU-bound, so instruction classes are what to count.
     //@ outside
     auto frame = [&](auto isref_c, const bool isref_rt, const float2 fl, float local_r, const int bo, const int n) {
-        const bool isref = HHSR_X2_PEEL ? decltype(isref_c)::value : isref_rt;
+        const bool isref = isref_rt;  // (as a compile-time variant of the frame code: 160 VGPRs, 3.97 vs 3.54 ms — round 2)
         //@ min5x5
         if (LMIN && !isref) {  // 5 x 5 minimum over rows ty .. ty + 4, columns tx .. tx + 4 of the R window
             // R is clamped to [0, 1] (never negative, never NaN): the order of its float32 bit patterns is the order of
@@ -222,7 +209,6 @@ __global__ void __launch_bounds__(256, HHSR_X2_OCC) k_merge_x2(BurstArgs a, Geo 
         //@ geometry
         if (!isref) racc += local_r;
         if (local_r == 0.f) return;
-#if HHSR_X2_GEO
         X2Axis ax, ay;
         {
             const float4 xa = lds_quad(s_geo + n * 8 + px * 2), xb = lds_quad(s_geo + n * 8 + px * 2 + 1);
@@ -232,10 +218,6 @@ __global__ void __launch_bounds__(256, HHSR_X2_OCC) k_merge_x2(BurstArgs a, Geo 
             ay.org = __float_as_int(ya.x); ay.e[0] = 0; ay.e[1] = __float_as_int(ya.y); ay.d0[0] = ya.z; ay.d0[1] = ya.w;
             ay.oc[0] = __float_as_int(yb.x); ay.oc[1] = __float_as_int(yb.y); ay.f[0] = yb.z; ay.f[1] = yb.w;
         }
-#else
-        const X2Axis ax = isref ? x2_ref_axis(lx0, px) : x2_comp_axis(fl.x, lx0, px);
-        const X2Axis ay = isref ? x2_ref_axis(ly0, py) : x2_comp_axis(fl.y, ly0, py);
-#endif
 #pragma unroll
         for (int sa = 0; sa < 2; ++sa)
 #pragma unroll
@@ -264,10 +246,8 @@ __global__ void __launch_bounds__(256, HHSR_X2_OCC) k_merge_x2(BurstArgs a, Geo 
                         iyy = X2_KEXP;
                     }
                     // 0 * x is 0 for finite x and NaN for NaN / inf: one NaN test for the three coefficients
-                    if (HHSR_X2_CLAMP) {
-                        const float probe = fmaf(0.f, ixx, fmaf(0.f, ixy, 0.f * iyy));
-                        finite = probe == probe;
-                    }
+                    const float probe = fmaf(0.f, ixx, fmaf(0.f, ixy, 0.f * iyy));
+                    finite = probe == probe;
                 }
                 // the 3 x 3 taps: rows ty + e .. + 2, columns tx + e .. + 2 of the window, as aligned pairs from the
                 // copy whose shift makes column tx + e even
@@ -307,11 +287,10 @@ __global__ void __launch_bounds__(256, HHSR_X2_OCC) k_merge_x2(BurstArgs a, Geo 
                     }
                 };
                 //@ tap_setup
-                if (!HHSR_X2_CLAMP) taps(std::true_type{});
 #ifdef HHSR_X2_BUDGET
-                else taps(std::false_type{});
+                taps(std::false_type{});
 #else
-                else if (ISO || finite) taps(std::false_type{});
+                if (ISO || finite) taps(std::false_type{});
                 else taps(std::true_type{});
 #endif
                 //@ fold
@@ -320,7 +299,6 @@ __global__ void __launch_bounds__(256, HHSR_X2_OCC) k_merge_x2(BurstArgs a, Geo 
                 // (the empty asm statements keep the four arms real branches: if-converted, the permutation costs 16
                 // v_cndmask per sub-pixel, twice the FMAs it feeds;
                 // and distinct, so that the FMAs are not sunk below the arms leaving 8 permutation moves in each)
-#if HHSR_X2_RGB
                 // tap parity (a, b) is colour class (a ^ by, b ^ bx): red sits at parity (ri ^ by, rj ^ bx), blue diagonally
                 // opposite, the greens on the other diagonal — four wave-uniform arrangements
                 const int ra = ri ^ by, rb = rj ^ bx;
@@ -341,28 +319,11 @@ __global__ void __launch_bounds__(256, HHSR_X2_OCC) k_merge_x2(BurstArgs a, Geo 
                     else { asm volatile("; fold 00"); HHSR_FOLD3(0, 0) asm volatile("; end 00"); }
                 }
 #undef HHSR_FOLD3
-#else
-#define HHSR_FOLD(BY, BX)                                                                             \
-    _Pragma("unroll") for (int aa = 0; aa < 2; ++aa) _Pragma("unroll") for (int bb = 0; bb < 2; ++bb) { \
-        nacc[sa][sb][aa * 2 + bb] = fmaf(local_r, sv[aa ^ BY][bb ^ BX], nacc[sa][sb][aa * 2 + bb]);    \
-        dacc[sa][sb][aa * 2 + bb] = fmaf(local_r, sd[aa ^ BY][bb ^ BX], dacc[sa][sb][aa * 2 + bb]);    \
-    }
-                if (by) {
-                    if (bx) { asm volatile("; fold 11"); HHSR_FOLD(1, 1) asm volatile("; end 11"); }
-                    else { asm volatile("; fold 10"); HHSR_FOLD(1, 0) asm volatile("; end 10"); }
-                } else {
-                    if (bx) { asm volatile("; fold 01"); HHSR_FOLD(0, 1) asm volatile("; end 01"); }
-                    else { asm volatile("; fold 00"); HHSR_FOLD(0, 0) asm volatile("; end 00"); }
-                }
-#undef HHSR_FOLD
-#endif
             }
     };
     //@ loop
     auto frame_n = [&](int n, const float2 fl, float lr, int bo) {
-        if (!HHSR_X2_PEEL) frame(std::false_type{}, n >= a.n, fl, lr, bo, n);
-        else if (n >= a.n) frame(std::true_type{}, true, fl, lr, bo, n);
-        else frame(std::false_type{}, false, fl, lr, bo, n);
+        frame(std::false_type{}, n >= a.n, fl, lr, bo, n);
     };
     if (nloop > nfirst) prefetch(nfirst);
     for (int n = nfirst; n < nloop; ++n) {

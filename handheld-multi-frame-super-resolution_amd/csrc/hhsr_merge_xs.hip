@@ -126,14 +126,8 @@ __global__ void __launch_bounds__(256, HHSR_XS_OCC) k_merge_xs(BurstArgs a, Geo 
         }
     }
     __syncthreads();
-#if !HHSR_XS_EDGE  // A/B: round 3's rule — any window outside the image sends the tile down the per-pixel path
-    if (edge_f || ((a.flags & HHSR_MERGE_DO_REF) && !(lx0 >= 1 && lx0 + QT + 2 <= g.W && ly0 >= 1 && ly0 + QT + 2 <= g.H))) ok = false;
-    const unsigned long long edge_mask = 0ull;
-    const bool edge_ref = false;
-#else
     const unsigned long long edge_mask = __ballot(edge_f);  // bit n: frame n is an EDGE frame (identical in the four waves)
     const bool edge_ref = !(lx0 >= 1 && lx0 + QT + 2 <= g.W && ly0 >= 1 && ly0 + QT + 2 <= g.H);
-#endif
     if (!__all(ok)) {
         // generic per-pixel code from global memory for the S x S output pixels of this thread's LR pixel
         if (lx >= g.W || ly >= lrow1) return;
@@ -151,10 +145,9 @@ __global__ void __launch_bounds__(256, HHSR_XS_OCC) k_merge_xs(BurstArgs a, Geo 
     }
 
     const int ridx = ly * g.W + lx;
-    // HHSR_XS_RGB (Bayer sensors: the only layouts this kernel is launched for, cfa_is_bayer): the two green parity
-    // classes are summed when a frame is folded, so a sub-pixel has 3 + 3 accumulators instead of 4 + 4 (54 instead of 72
-    // per thread); 0: the four parity classes of round 3, mapped to channels in the epilogue (A/B)
-    constexpr int NC = HHSR_XS_RGB ? 3 : 4;
+    // Bayer sensors (the only layouts this kernel is launched for, cfa_is_bayer): the two green parity classes are summed
+    // when a frame is folded, so a sub-pixel has 3 + 3 accumulators instead of 4 + 4 (54 instead of 72 per thread)
+    constexpr int NC = 3;
     float nacc[S][S][NC], dacc[S][S][NC];
 #pragma unroll
     for (int k = 0; k < S * S * NC; ++k) {
@@ -311,7 +304,7 @@ __global__ void __launch_bounds__(256, HHSR_XS_OCC) k_merge_xs(BurstArgs a, Geo 
         for (int q = 0; q < S * S; ++q) {
             const int sa = q / S, sb = q % S;
             Sub nxt = cur;
-            if (HHSR_XS_PIPE && q + 1 < S * S) nxt = load_sub((q + 1) / S, (q + 1) % S);
+            if (q + 1 < S * S) nxt = load_sub((q + 1) / S, (q + 1) % S);
             float ixx = 2.f * X2_KEXP, ixy = 0.f, iyy = 2.f * X2_KEXP;
             bool finite = true;
             float r_eff = local_r;
@@ -391,7 +384,6 @@ __global__ void __launch_bounds__(256, HHSR_XS_OCC) k_merge_xs(BurstArgs a, Geo 
             else if (ISO || finite) taps(std::false_type{}, std::false_type{});
             else taps(std::true_type{}, std::false_type{});
             const int by = (ay.org + py + ay.e[sa]) & 1, bx = (ax.org + px + ax.e[sb]) & 1;
-#if HHSR_XS_RGB
             // tap parity (a, b) is colour class (a ^ by, b ^ bx): red sits at parity (ri ^ by, rj ^ bx), blue diagonally
             // opposite, the greens on the other diagonal — four wave-uniform arrangements
             const int ra = ri ^ by, rb = rj ^ bx;
@@ -412,23 +404,7 @@ __global__ void __launch_bounds__(256, HHSR_XS_OCC) k_merge_xs(BurstArgs a, Geo 
                 else { asm volatile("; xs fold 00"); HHSR_FOLD3(0, 0) asm volatile("; xs end 00"); }
             }
 #undef HHSR_FOLD3
-#else
-#define HHSR_FOLD(BY, BX)                                                                             \
-    _Pragma("unroll") for (int aa = 0; aa < 2; ++aa) _Pragma("unroll") for (int bb = 0; bb < 2; ++bb) { \
-        nacc[sa][sb][aa * 2 + bb] = fmaf(r_eff, sv[aa ^ BY][bb ^ BX], nacc[sa][sb][aa * 2 + bb]);      \
-        dacc[sa][sb][aa * 2 + bb] = fmaf(r_eff, sd[aa ^ BY][bb ^ BX], dacc[sa][sb][aa * 2 + bb]);      \
-    }
-            if (by) {
-                if (bx) { asm volatile("; xs fold 11"); HHSR_FOLD(1, 1) asm volatile("; xs end 11"); }
-                else { asm volatile("; xs fold 10"); HHSR_FOLD(1, 0) asm volatile("; xs end 10"); }
-            } else {
-                if (bx) { asm volatile("; xs fold 01"); HHSR_FOLD(0, 1) asm volatile("; xs end 01"); }
-                else { asm volatile("; xs fold 00"); HHSR_FOLD(0, 0) asm volatile("; xs end 00"); }
-            }
-#undef HHSR_FOLD
-#endif
-            if (HHSR_XS_PIPE) cur = nxt;
-            else if (q + 1 < S * S) cur = load_sub((q + 1) / S, (q + 1) % S);
+            cur = nxt;
         }
     }
     };  // run_frames
