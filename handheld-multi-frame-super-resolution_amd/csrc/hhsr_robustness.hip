@@ -784,6 +784,19 @@ __global__ void __launch_bounds__(256) k_rob_frames_row4(RobGroup gq, int lh, in
     // used to be issued at the top of their own iteration and waited for right away — 56 % of the wave time was parked;
     // 228 -> 222 us per 4-frame launch at 12 MP)
     float st[NST];
+    // slot p = tg + 64 u of the window is (channel c, row i, column j) for every frame: decomposed once; the address is
+    // 32-bit (the three guide planes are far below 4 GB) on the frame's plane pointer in SGPRs (round 6: the 64-bit form
+    // and the per-frame divisions were ~100 of the kernel's ~540 VALU instructions per thread and frame)
+    int fci[NST];  // c * plane + (i << 16 | j) does not fit one register: two small fields + the plane offset
+    unsigned fco[NST];
+#pragma unroll
+    for (int u = 0; u < NST; ++u) {
+        const int p = tg + 64 * u;
+        const int c = p / (RF_WN * RF_WN), q = p - c * (RF_WN * RF_WN);
+        const int i = q / RF_WN, j = q - i * RF_WN;
+        fci[u] = (i << 8) | j;
+        fco[u] = (unsigned)c * (unsigned)gplane;
+    }
     auto fetch = [&](int fr) {
         const float* __restrict__ cm = gq.cm[fr];
         const int wy0 = __float_as_int(s_tab[fr][v][grp][0].z), wx0 = __float_as_int(s_tab[fr][v][grp][1].z);
@@ -791,10 +804,9 @@ __global__ void __launch_bounds__(256) k_rob_frames_row4(RobGroup gq, int lh, in
         for (int u = 0; u < NST; ++u) {
             const int p = tg + 64 * u;
             if (p < WSZ) {
-                const int c = p / (RF_WN * RF_WN), q = p - c * (RF_WN * RF_WN);
-                const int i = q / RF_WN, j = q - i * RF_WN;
-                const int gy = clampi(wy0 + i, 0, lh - 1), gx = clampi(wx0 + j, 0, lw - 1);
-                st[u] = cm[c * gplane + (size_t)gy * lw + gx];
+                const int gy = clampi(wy0 + (fci[u] >> 8), 0, lh - 1), gx = clampi(wx0 + (fci[u] & 255), 0, lw - 1);
+                const unsigned off = (fco[u] + (unsigned)(__mul24(gy, lw) + gx)) * 4u;  // (gy, lw < 2^24)
+                st[u] = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(cm) + off);
             }
         }
     };
