@@ -655,12 +655,16 @@ __global__ void __launch_bounds__(256) k_align_wave(const float* __restrict__ re
         const int rx0 = tx * TS - 1, ry0 = ty * TS - 1;
         const bool ref_in = rx0 >= 0 && ry0 >= 0 && rx0 + RS <= rw && ry0 + RS <= rh;
         const bool win_in = ox >= 0 && oy >= 0 && ox + WS <= mw && oy + WS <= mh;
+        // (window origins are wave-uniform: the row base advances in SGPRs, every load of a window shares ONE 32-bit lane
+        // offset — `global_load ... v_off, s[base:base+1]` — instead of a 64-bit address per load; round 6)
         if (ref_in) {  // columns past the window re-read its last column (never stored)
-            const float* q = ref + (size_t)(ry0 + ir) * ref_pitch + rx0 + min(jr, RS - 1);
+            const char* qb = reinterpret_cast<const char*>(ref + (size_t)ry0 * ref_pitch + rx0);
+            const unsigned voff = (unsigned)(ir * ref_pitch + min(jr, RS - 1)) * 4u;
 #pragma unroll
             for (int k = 0; k < SR::NK; ++k) {
                 const bool tail = (k + 1) * SR::RPP > RS;  // compile time: this pass can run past the last row
-                vr[k] = (!tail || ir + k * SR::RPP < RS) ? q[(size_t)k * SR::RPP * ref_pitch] : 0.f;
+                vr[k] = (!tail || ir + k * SR::RPP < RS)
+                            ? *reinterpret_cast<const float*>(qb + (size_t)k * SR::RPP * ref_pitch * 4 + voff) : 0.f;
             }
         } else {
 #pragma unroll
@@ -671,11 +675,13 @@ __global__ void __launch_bounds__(256) k_align_wave(const float* __restrict__ re
             }
         }
         if (win_in) {
-            const float* q = mov + (size_t)(oy + iw) * mov_pitch + ox + min(jw, WS - 1);
+            const char* qb = reinterpret_cast<const char*>(mov + (size_t)oy * mov_pitch + ox);
+            const unsigned voff = (unsigned)(iw * mov_pitch + min(jw, WS - 1)) * 4u;
 #pragma unroll
             for (int k = 0; k < SW::NK; ++k) {
                 const bool tail = (k + 1) * SW::RPP > WS;
-                vw[k] = (!tail || iw + k * SW::RPP < WS) ? q[(size_t)k * SW::RPP * mov_pitch] : 0.f;
+                vw[k] = (!tail || iw + k * SW::RPP < WS)
+                            ? *reinterpret_cast<const float*>(qb + (size_t)k * SW::RPP * mov_pitch * 4 + voff) : 0.f;
             }
         } else {
 #pragma unroll
