@@ -99,6 +99,8 @@ def parse_args():
     ap.add_argument("--reps", type=int, default=5, help="repetitions of the timed block of --steps steps: ms_per_step is "
                                                         "the MEDIAN block, ms_per_step_min / _max the spread")
     ap.add_argument("--no-c5", action="store_true", help="skip the optional 48 MP x 20 x3 (C5 geometry) leg")
+    ap.add_argument("--weight-fp64", action="store_true", help="the main workload with config.hip.weight_fp64 (the reference's "
+                                                               "float64 weight chain on every pixel; kernel traces)")
     args = ap.parse_args()
     if args.engine is not None and args.backend != "gloo":
         ap.error("--engine (a foreign per-rank engine: launch-plumbing tests) is only accepted with --backend gloo")
@@ -172,6 +174,8 @@ def main():
     cfg.verbose = 0
     cfg.scale = scale
     cfg.hip = {"graph": not args.no_graph}
+    if args.weight_fp64:
+        cfg.hip["weight_fp64"] = True
     if args.streams is not None:
         cfg.hip["streams"] = args.streams
     if args.chunk is not None:
