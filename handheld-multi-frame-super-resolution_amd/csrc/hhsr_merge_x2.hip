@@ -181,6 +181,10 @@ __global__ void __launch_bounds__(256, HHSR_X2_OCC) k_merge_x2(BurstArgs a, Geo 
     //@ outside
     auto frame = [&](auto isref_c, const bool isref_rt, const float2 fl, float local_r, const int bo, const int n) {
         const bool isref = isref_rt;  // (as a compile-time variant of the frame code: 160 VGPRs, 3.97 vs 3.54 ms — round 2)
+        // the same flag as an opaque scalar INTEGER: as a bool the compiler carries it between blocks as a lane mask and
+        // rebuilds the branch condition with v_cndmask + v_cmp per use
+        int isref_s = __builtin_amdgcn_readfirstlane((int)isref_rt);
+        asm volatile("" : "+s"(isref_s));
         //@ min5x5
         if (LMIN && !isref) {  // 5 x 5 minimum over rows ty .. ty + 4, columns tx .. tx + 4 of the R window
             // R is clamped to [0, 1] (never negative, never NaN): the order of its float32 bit patterns is the order of
@@ -240,10 +244,14 @@ __global__ void __launch_bounds__(256, HHSR_X2_OCC) k_merge_x2(BurstArgs a, Geo 
                     ixx = s1 * cyy;
                     ixy = (-2.f * s1) * cxy;
                     iyy = s1 * cxx;
-                    if (isref && !(fabsf(det) > 1e-10f)) {  // linalg.py:53-64: identity (also for NaN, D10)
-                        ixx = X2_KEXP;
-                        ixy = 0.f;
-                        iyy = X2_KEXP;
+                    if (isref_s) {  // wave-uniform, and kept a real branch by the empty asm statement: if-converted, the reference
+                        // frame's rule costs a compare and three v_cndmask (half rate) per sub-pixel of EVERY frame
+                        asm volatile("; ref identity");
+                        if (!(fabsf(det) > 1e-10f)) {  // linalg.py:53-64: identity (also for NaN, D10)
+                            ixx = X2_KEXP;
+                            ixy = 0.f;
+                            iyy = X2_KEXP;
+                        }
                     }
                     // 0 * x is 0 for finite x and NaN for NaN / inf: one NaN test for the three coefficients
                     const float probe = fmaf(0.f, ixx, fmaf(0.f, ixy, 0.f * iyy));
@@ -268,7 +276,7 @@ __global__ void __launch_bounds__(256, HHSR_X2_OCC) k_merge_x2(BurstArgs a, Geo 
                     for (int di = 0; di < 3; ++di) {
                         const float2 v01 = lds_pair(rp + di * X2_RP), v23 = lds_pair(rp + di * X2_RP + 2);
                         const float c3[3] = {v01.x, v01.y, v23.x};
-                        const float dy = dy0 + (float)(di - 1);
+                        const float dy = di == 1 ? dy0 : dy0 + (float)(di - 1);  // (x + 0.f is an instruction: -0.f + 0.f = +0.f)
                         const float qa = iyy * dy * dy, qb = ixy * dy;
 #pragma unroll
                         for (int dj = 0; dj < 3; ++dj) {

@@ -228,6 +228,8 @@ __global__ void __launch_bounds__(256, HHSR_XS_OCC) k_merge_xs(BurstArgs a, Geo 
     if (nloop > 0) prefetch(0, EDGE_TILE && is_edge(0));
     for (int n = 0; n < nloop; ++n) {
         const bool isref = n >= a.n;
+        int isref_s = __builtin_amdgcn_readfirstlane((int)(n >= a.n));  // the flag as an opaque scalar integer (see k_merge_x2)
+        asm volatile("" : "+s"(isref_s));
         __syncthreads();
         s_rawA[e0y * X2_RP + e0x] = pr0;
         if (e0x > 0) s_rawB[e0y * X2_RP + e0x - 1] = pr0;
@@ -338,10 +340,13 @@ __global__ void __launch_bounds__(256, HHSR_XS_OCC) k_merge_xs(BurstArgs a, Geo 
                 ixx = s1 * cyy;
                 ixy = (-2.f * s1) * cxy;
                 iyy = s1 * cxx;
-                if (isref && !(fabsf(det) > 1e-10f)) {
-                    ixx = X2_KEXP;
-                    ixy = 0.f;
-                    iyy = X2_KEXP;
+                if (isref_s) {  // wave-uniform; a real branch (see k_merge_x2)
+                    asm volatile("; ref identity");
+                    if (!(fabsf(det) > 1e-10f)) {
+                        ixx = X2_KEXP;
+                        ixy = 0.f;
+                        iyy = X2_KEXP;
+                    }
                 }
                 const float probe = fmaf(0.f, ixx, fmaf(0.f, ixy, 0.f * iyy));
                 finite = probe == probe;
@@ -361,7 +366,7 @@ __global__ void __launch_bounds__(256, HHSR_XS_OCC) k_merge_xs(BurstArgs a, Geo 
                         const float2 ma = lds_pair(mp + di * X2_RP), mb = lds_pair(mp + di * X2_RP + 2);
                         m3[0] = ma.x; m3[1] = ma.y; m3[2] = mb.x;
                     }
-                    const float dy = dy0 + (float)(di - 1);
+                    const float dy = di == 1 ? dy0 : dy0 + (float)(di - 1);
                     const float qa = iyy * dy * dy, qb = ixy * dy;
 #pragma unroll
                     for (int dj = 0; dj < 3; ++dj) {
