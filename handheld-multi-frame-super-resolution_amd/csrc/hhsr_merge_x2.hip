@@ -69,7 +69,9 @@ __global__ void __launch_bounds__(256, HHSR_X2_OCC) k_merge_x2(BurstArgs a, Geo 
             for (int p = 0; p < 2; ++p) {
                 const X2Axis u = isref ? x2_ref_axis(l0, p) : x2_comp_axis(f, l0, p);
                 s_geo[n * 8 + axis * 4 + p * 2] = make_float4(__int_as_float(u.org), __int_as_float(u.e[1]), u.d0[0], u.d0[1]);
-                s_geo[n * 8 + axis * 4 + p * 2 + 1] = make_float4(__int_as_float(u.oc[0]), __int_as_float(u.oc[1]), u.f[0], u.f[1]);
+                // (the y axis' cell offsets are stored times the cell window's pitch: the frame loop adds them as they are)
+                const int ocs = axis ? X2_CP : 1;
+                s_geo[n * 8 + axis * 4 + p * 2 + 1] = make_float4(__int_as_float(u.oc[0] * ocs), __int_as_float(u.oc[1] * ocs), u.f[0], u.f[1]);
             }
         }
     }
@@ -121,6 +123,7 @@ __global__ void __launch_bounds__(256, HHSR_X2_OCC) k_merge_x2(BurstArgs a, Geo 
     // back from the geometry table into SGPRs), so a load is ONE v_add_u32 + global_load ... s[base:base+1] — the first
     // version recomputed floor / compare / convert of the flow vector per thread and frame behind a dependent global load of
     // that vector, and every address in 64 bits (v_mad_i64_i32, v_lshl_add_u64): 39 VALU instructions per thread and frame.
+    const unsigned cinv = (unsigned)(cey * g.gw + cex);
     const unsigned t0b = (unsigned)(e0y * g.pitch + e0x) * 4u, t1b = (unsigned)(e1y * g.pitch + e1x) * 4u;
     const unsigned mb0 = (unsigned)moff0 * 4u, mb1 = (unsigned)moff1 * 4u, rb = (unsigned)ridx * 4u;
     auto ldf = [](const float* base, unsigned byte_off) { return *reinterpret_cast<const float*>(reinterpret_cast<const char*>(base) + byte_off); };
@@ -136,7 +139,16 @@ __global__ void __launch_bounds__(256, HHSR_X2_OCC) k_merge_x2(BurstArgs a, Geo 
         pr0 = ldf(raw, ob + t0b);
         if (has1) pr1 = ldf(raw, ob + t1b);
         if (!ISO && hasc) {
-            const unsigned ci = (unsigned)(min((oy >> 1) + cey, g.gh - 1) * g.gw + min((ox >> 1) + cex, g.gw - 1));
+            // cell window origin (ox >> 1, oy >> 1); cells beyond the last row / column repeat it (the reference's clamp).
+            // Windows that stay inside the cell grid — all but the last tile row / column's — take ONE v_add per thread.
+            const int cx0 = ox >> 1, cy0 = oy >> 1;
+            unsigned ci;
+            if (cx0 + cwin <= g.gw && cy0 + cwin <= g.gh) {  // (scalar)
+                ci = (unsigned)(cy0 * g.gw + cx0) + cinv;
+            } else {
+                asm volatile("; clamped cells");  // (keeps the arm a branch)
+                ci = (unsigned)(min(cy0 + cey, g.gh - 1) * g.gw + min(cx0 + cex, g.gw - 1));
+            }
             pc = *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(cov) + ci * 16u);
         }
         if (!isref) {
@@ -152,6 +164,7 @@ __global__ void __launch_bounds__(256, HHSR_X2_OCC) k_merge_x2(BurstArgs a, Geo 
     //@ outside
     const float* __restrict__ rbase = s_R + ty * X2_RP + 2 * lj;
     const int cbase = li * X2_CP + lj;
+    const int tyrp = ty * X2_RP + 2 * lj;
 
     // write the prefetched registers of one frame into window buffer `bo`; returns that frame's flow / robustness
     float2 sfl = make_float2(0.f, 0.f);
@@ -183,29 +196,31 @@ __global__ void __launch_bounds__(256, HHSR_X2_OCC) k_merge_x2(BurstArgs a, Geo 
         const bool isref = isref_rt;  // (as a compile-time variant of the frame code: 160 VGPRs, 3.97 vs 3.54 ms — round 2)
         // the same flag as an opaque scalar INTEGER: as a bool the compiler carries it between blocks as a lane mask and
         // rebuilds the branch condition with v_cndmask + v_cmp per use
-        int isref_s = __builtin_amdgcn_readfirstlane((int)isref_rt);
+        int isref_s = __builtin_amdgcn_readfirstlane(n) - __builtin_amdgcn_readfirstlane(a.n);  // >= 0: the reference frame
         asm volatile("" : "+s"(isref_s));
         //@ min5x5
         if (LMIN && !isref) {  // 5 x 5 minimum over rows ty .. ty + 4, columns tx .. tx + 4 of the R window
             // R is clamped to [0, 1] (never negative, never NaN): the order of its float32 bit patterns is the order of
             // the values, and v_min3_u32 needs no canonicalisation of its inputs (fminf costs a v_max per operand: 28
             // half-rate instructions per thread and frame here)
-            unsigned m = 0x7f7fffffu;
+            unsigned m = 0u;  // (row 0 initialises it: a constant start value is one more v_min)
             if (px) {  // (uniform branch instead of a select per row)
 #pragma unroll
                 for (int r = 0; r < 5; ++r) {
                     const float2 v01 = lds_pair(rbase + bo * RAWSZ + r * X2_RP), v23 = lds_pair(rbase + bo * RAWSZ + r * X2_RP + 2);
                     const float2 v45 = lds_pair(rbase + bo * RAWSZ + r * X2_RP + 4);
-                    m = min(m, min(min(__float_as_uint(v01.y), __float_as_uint(v23.x)),
-                                   min(__float_as_uint(v23.y), min(__float_as_uint(v45.x), __float_as_uint(v45.y)))));
+                    const unsigned rm = min(min(__float_as_uint(v01.y), __float_as_uint(v23.x)),
+                                   min(__float_as_uint(v23.y), min(__float_as_uint(v45.x), __float_as_uint(v45.y))));
+                    m = r ? min(m, rm) : rm;
                 }
             } else {
 #pragma unroll
                 for (int r = 0; r < 5; ++r) {
                     const float2 v01 = lds_pair(rbase + bo * RAWSZ + r * X2_RP), v23 = lds_pair(rbase + bo * RAWSZ + r * X2_RP + 2);
                     const float2 v45 = lds_pair(rbase + bo * RAWSZ + r * X2_RP + 4);
-                    m = min(m, min(min(__float_as_uint(v01.y), __float_as_uint(v23.x)),
-                                   min(__float_as_uint(v23.y), min(__float_as_uint(v45.x), __float_as_uint(v01.x)))));
+                    const unsigned rm = min(min(__float_as_uint(v01.y), __float_as_uint(v23.x)),
+                                   min(__float_as_uint(v23.y), min(__float_as_uint(v45.x), __float_as_uint(v01.x))));
+                    m = r ? min(m, rm) : rm;
                 }
             }
             local_r = __uint_as_float(m);
@@ -230,7 +245,7 @@ __global__ void __launch_bounds__(256, HHSR_X2_OCC) k_merge_x2(BurstArgs a, Geo 
                 bool finite = true;
                 //@ cov_blend
                 if (!ISO) {
-                    const int ca = cbase + ay.oc[sa] * X2_CP + ax.oc[sb];
+                    const int ca = cbase + ay.oc[sa] + ax.oc[sb];  // (ay.oc: times X2_CP already)
                     const float4 c00 = lds_quad(s_cov + bo * COVSZ + ca), c01 = lds_quad(s_cov + bo * COVSZ + ca + 1);
                     const float4 c10 = lds_quad(s_cov + bo * COVSZ + ca + X2_CP), c11 = lds_quad(s_cov + bo * COVSZ + ca + X2_CP + 1);
                     const float gx = ax.f[sb], gy = ay.f[sa];
@@ -244,7 +259,7 @@ __global__ void __launch_bounds__(256, HHSR_X2_OCC) k_merge_x2(BurstArgs a, Geo 
                     ixx = s1 * cyy;
                     ixy = (-2.f * s1) * cxy;
                     iyy = s1 * cxx;
-                    if (isref_s) {  // wave-uniform, and kept a real branch by the empty asm statement: if-converted, the reference
+                    if (isref_s >= 0) {  // wave-uniform, and kept a real branch by the empty asm statement: if-converted, the reference
                         // frame's rule costs a compare and three v_cndmask (half rate) per sub-pixel of EVERY frame
                         asm volatile("; ref identity");
                         if (!(fabsf(det) > 1e-10f)) {  // linalg.py:53-64: identity (also for NaN, D10)
@@ -261,7 +276,7 @@ __global__ void __launch_bounds__(256, HHSR_X2_OCC) k_merge_x2(BurstArgs a, Geo 
                 // copy whose shift makes column tx + e even
                 //@ tap_setup
                 const int mcol = px + ax.e[sb];  // 0, 1, 2
-                const float* __restrict__ rp = ((mcol & 1) ? s_rawB : s_rawA) + bo * RAWSZ + (ty + ay.e[sa]) * X2_RP + 2 * lj + (mcol & 2);
+                const float* __restrict__ rp = ((mcol & 1) ? s_rawB : s_rawA) + bo * RAWSZ + tyrp + (ay.e[sa] * X2_RP + (mcol & 2));  // (scalar part apart)
                 const float dx0 = ax.d0[sb], dy0 = ay.d0[sa];
                 const float dxs[3] = {dx0 - 1.f, dx0, dx0 + 1.f};
                 float sv[2][2], sd[2][2];  // by parity of the tap offset (di + 1, dj + 1)
