@@ -99,6 +99,8 @@ def parse_args():
     ap.add_argument("--reps", type=int, default=5, help="repetitions of the timed block of --steps steps: ms_per_step is "
                                                         "the MEDIAN block, ms_per_step_min / _max the spread")
     ap.add_argument("--no-c5", action="store_true", help="skip the optional 48 MP x 20 x3 (C5 geometry) leg")
+    ap.add_argument("--denoiser", action="store_true", help="the main workload with the accumulated-robustness merge denoiser on "
+                    "(kernel traces of that path; the default run times it as the ms_per_step_denoiser leg)")
     ap.add_argument("--weight-fp64", action="store_true", help="the main workload with config.hip.weight_fp64 (the reference's "
                                                                "float64 weight chain on every pixel; kernel traces)")
     args = ap.parse_args()
@@ -176,6 +178,9 @@ def main():
     cfg.hip = {"graph": not args.no_graph}
     if args.weight_fp64:
         cfg.hip["weight_fp64"] = True
+    if args.denoiser:
+        cfg.accumulated_robustness_denoiser.enabled = True
+        cfg.accumulated_robustness_denoiser.merge.enabled = True
     if args.streams is not None:
         cfg.hip["streams"] = args.streams
     if args.chunk is not None:

@@ -42,12 +42,38 @@ __global__ void __launch_bounds__(256) k_accumulate_ref(const float* __restrict_
                                                          const float4* __restrict__ cov, Geo g, Cfa4 cfa,
                                                          const float* __restrict__ acc_rob, int rad_max,
                                                          double max_mult, double max_fc, float* __restrict__ num,
-                                                         float* __restrict__ den) {
+                                                         float* __restrict__ den, int divide, int fast) {
     const int oj = blockIdx.x * 64 + (threadIdx.x & 63), oi = blockIdx.y * 4 + (threadIdx.x >> 6);
     if (oj >= g.sW || oi >= g.sH) return;
     float val[3] = {0.f, 0.f, 0.f}, acc[3] = {0.f, 0.f, 0.f};
-    const bool over = ref_contrib<ISO>(raw, cov, g, cfa, oi, oj, acc_rob, rad_max, max_mult, max_fc, val, acc);
+    bool over = false, plain = fast && !border_pixel(g, oi, oj);
+    if (plain && acc_rob) {  // (ref_contrib's test: the denoiser widens / overwrites where few frames were merged)
+        const float pyf = (float)((double)(oi + g.off_hr) / g.scale) - (float)g.off_lr, pxf = (float)((double)oj / g.scale);
+        const int ry_i = min((int)rintf(pyf), g.H - 1), rx_i = min((int)rintf(pxf), g.W - 1);
+        plain = !((double)acc_rob[(size_t)ry_i * g.W + rx_i] <= max_fc);
+    }
+    if (plain) {
+        // HHSR_REF_FAST: float32 weights for the pixels the denoiser leaves alone, outside the border bands — the fused
+        // merge's reference frame (merge_pixel / k_merge_x2); the float64 chain below is 1.5 ms per 12 MP x2 pass
+        float n4[2][2] = {{0.f, 0.f}, {0.f, 0.f}}, d4[2][2] = {{0.f, 0.f}, {0.f, 0.f}};
+        ref_accum_fast<ISO>(raw, cov, g, oi, oj, n4, d4);
+        classes_to_rgb(cfa, n4, d4, val, acc);
+    } else {
+        over = ref_contrib<ISO>(raw, cov, g, cfa, oi, oj, acc_rob, rad_max, max_mult, max_fc, val, acc);
+    }
     const size_t o = ((size_t)oi * g.sW + oj) * 3;
+    if (divide) {  // HHSR_REF_DIVIDE: the normalisation (utils.py:62-90) in the same pass; den stays as it was
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            float nk = num[o + k], dk = den[o + k];
+            if (!(g.mono && k > 0)) {  // (one channel: the others are divided as they are)
+                nk = over ? val[k] : nk + val[k];
+                dk = over ? acc[k] : dk + acc[k];
+            }
+            num[o + k] = nk / dk;
+        }
+        return;
+    }
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
         if (g.mono && k > 0) break;  // one channel: the others are not even overwritten (merge.py:223-233)
@@ -235,10 +261,10 @@ extern "C" int hhsr_accumulate_ref(const float* raw, int H, int W, int pitch, co
     const float4* cv = reinterpret_cast<const float4*>(covs);
     if (iso)
         hipLaunchKernelGGL((k_accumulate_ref<true>), grid, block, 0, s, raw, cv, g, c, acc_rob, rad_max,
-                           max_multiplier, max_frame_count, num, den);
+                           max_multiplier, max_frame_count, num, den, kflags & HHSR_REF_DIVIDE, kflags & HHSR_REF_FAST);
     else
         hipLaunchKernelGGL((k_accumulate_ref<false>), grid, block, 0, s, raw, cv, g, c, acc_rob, rad_max,
-                           max_multiplier, max_frame_count, num, den);
+                           max_multiplier, max_frame_count, num, den, kflags & HHSR_REF_DIVIDE, kflags & HHSR_REF_FAST);
     HHSR_LAUNCHED();
 }
 

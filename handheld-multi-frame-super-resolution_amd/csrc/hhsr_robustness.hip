@@ -977,9 +977,87 @@ __global__ void __launch_bounds__(256) k_rob_sum(RobSumFrames fr, size_t count, 
     }
 }
 
-extern "C" int hhsr_rob_sum(const float* const* rs, int n_frames, int H, int W, int load, double max_frame_count,
+// The same over UN-filtered maps R: the 5 x 5 clamp-border minimum of every frame (robustness.py:641-686, k_local_min5's
+// two LDS passes) is taken here, on the way into the sum — for callers whose merge applies the minimum itself
+// (HHSR_MERGE_LOCAL_MIN) and that never materialise the filtered maps: one pass over the n maps instead of n launches of
+// k_local_min5 (a read and a write of every map) plus k_rob_sum's read.  The next frame's tile is fetched into registers
+// while the current one is reduced.
+__global__ void __launch_bounds__(256) k_rob_sum_min5(RobSumFrames fr, int H, int W, int load, double mfc, float m32,
+                                                       float below, float above, double* __restrict__ sum64,
+                                                       float* __restrict__ mask32, float* __restrict__ dec32) {
+    __shared__ float s[LM_TY + 4][LM_TX + 4 + 1];
+    __shared__ float s_row[LM_TY + 4][LM_TX + 1];
+    constexpr int NIN = ((LM_TY + 4) * (LM_TX + 4) + 255) / 256, NROW = (LM_TY + 4) * LM_TX / 256, NOUT = LM_TY * LM_TX / 256;
+    const int x0 = blockIdx.x * LM_TX, y0 = blockIdx.y * LM_TY, tid = threadIdx.x;
+    unsigned off[NIN];  // clamped source offsets of the thread's tile slots: the same for every frame
+#pragma unroll
+    for (int u = 0; u < NIN; ++u) {
+        const int p = tid + 256 * u, i = p / (LM_TX + 4), j = p - i * (LM_TX + 4);
+        off[u] = (unsigned)(clampi(y0 + i - 2, 0, H - 1) * W + clampi(x0 + j - 2, 0, W - 1));
+    }
+    double acc[NOUT];
+#pragma unroll
+    for (int u = 0; u < NOUT; ++u) {
+        const int p = tid + 256 * u, i = p / LM_TX, j = p - i * LM_TX;
+        const bool live = y0 + i < H && x0 + j < W;
+        acc[u] = (load && live) ? sum64[(size_t)(y0 + i) * W + x0 + j] : 0.0;
+    }
+    float pre[NIN];
+    auto fetch = [&](int n) {
+#pragma unroll
+        for (int u = 0; u < NIN; ++u)
+            if (tid + 256 * u < (LM_TY + 4) * (LM_TX + 4)) pre[u] = fr.r[n][off[u]];
+    };
+    if (fr.n > 0) fetch(0);
+    for (int n = 0; n < fr.n; ++n) {
+#pragma unroll
+        for (int u = 0; u < NIN; ++u) {
+            const int p = tid + 256 * u, i = p / (LM_TX + 4), j = p - i * (LM_TX + 4);
+            if (p < (LM_TY + 4) * (LM_TX + 4)) s[i][j] = pre[u];
+        }
+        __syncthreads();  // (also: the previous frame's column pass is done with s_row)
+        if (n + 1 < fr.n) fetch(n + 1);
+#pragma unroll
+        for (int u = 0; u < NROW; ++u) {
+            const int p = tid + 256 * u, i = p / LM_TX, j = p - i * LM_TX;
+            float m = s[i][j];
+#pragma unroll
+            for (int k = 1; k < 5; ++k) m = fminf(m, s[i][j + k]);
+            s_row[i][j] = m;
+        }
+        __syncthreads();  // (also: the row pass is done with s, which the next frame overwrites)
+#pragma unroll
+        for (int u = 0; u < NOUT; ++u) {
+            const int p = tid + 256 * u, i = p / LM_TX, j = p - i * LM_TX;
+            float m = s_row[i][j];
+#pragma unroll
+            for (int k = 1; k < 5; ++k) m = fminf(m, s_row[i + k][j]);
+            acc[u] += (double)m;  // float32 -> float64: exact; frame order like the reference
+        }
+    }
+#pragma unroll
+    for (int u = 0; u < NOUT; ++u) {
+        const int p = tid + 256 * u, i = p / LM_TX, j = p - i * LM_TX;
+        if (y0 + i >= H || x0 + j >= W) continue;
+        const size_t o = (size_t)(y0 + i) * W + x0 + j;
+        const double sv = acc[u];
+        if (sum64) sum64[o] = sv;
+        float a = (float)sv;
+        if (mask32) mask32[o] = a;
+        if (dec32) {
+            if (sv < mfc && a >= m32) a = below;
+            if (sv > mfc && a <= m32) a = above;
+            dec32[o] = a;
+        }
+    }
+}
+static_assert((LM_TY + 4) * LM_TX % 256 == 0 && LM_TY * LM_TX % 256 == 0, "k_rob_sum_min5: whole passes per thread");
+
+extern "C" int hhsr_rob_sum(const float* const* rs, int n_frames, int H, int W, int flags, double max_frame_count,
                             double* sum64, float* mask32, float* decisions32, void* stream) {
+    const int load = flags & HHSR_ROB_SUM_LOAD;
     HHSR_ARG(n_frames >= 0 && n_frames <= HHSR_MAX_FRAMES && H > 0 && W > 0);
+    HHSR_ARG(!(flags & ~(HHSR_ROB_SUM_LOAD | HHSR_ROB_SUM_MIN5)));
     HHSR_ARG(n_frames == 0 || rs != nullptr);
     HHSR_ARG(!load || sum64 != nullptr);
     HHSR_ARG(sum64 || mask32 || decisions32);
@@ -994,6 +1072,12 @@ extern "C" int hhsr_rob_sum(const float* const* rs, int n_frames, int H, int W, 
     const float below = (double)m32 < max_frame_count ? m32 : nextafterf(m32, -INFINITY);
     const float above = (double)m32 > max_frame_count ? m32 : nextafterf(m32, INFINITY);
     const size_t count = (size_t)H * W;
+    if ((flags & HHSR_ROB_SUM_MIN5) && n_frames > 0) {
+        HHSR_ARG(count < ((size_t)1 << 32));  // (32-bit element offsets)
+        hipLaunchKernelGGL(k_rob_sum_min5, dim3(hhsr_cdiv(W, LM_TX), hhsr_cdiv(H, LM_TY)), dim3(256), 0, (hipStream_t)stream,
+                           fr, H, W, load, max_frame_count, m32, below, above, sum64, mask32, decisions32);
+        HHSR_LAUNCHED();
+    }
     hipLaunchKernelGGL(k_rob_sum, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, (hipStream_t)stream, fr, count, load,
                        max_frame_count, m32, below, above, sum64, mask32, decisions32);
     HHSR_LAUNCHED();

@@ -8,6 +8,7 @@ from . import _lib
 
 # kflags of the C ABI (include/hhsr.h)
 KERNEL_ISO, WEIGHT_F64, FORCE_GENERIC, FORCE_TILE, FORCE_X2V1, SENSOR_MONO = 1, 2, 4, 8, 16, 32
+REF_DIVIDE, REF_FAST = 64, 128  # hhsr_accumulate_ref only (include/hhsr.h HHSR_REF_DIVIDE, HHSR_REF_FAST)
 _FORCE = {"auto": 0, "generic": FORCE_GENERIC, "tile": FORCE_TILE, "x2_v1": FORCE_X2V1}
 # process-wide A/B switches, read once like the library reads them
 _ENV_FORCE = ((FORCE_GENERIC if os.environ.get("HHSR_MERGE_NO_LDS") else 0) |
@@ -39,10 +40,18 @@ def merge(comp_img, alignments, covs, r, num, den, cfa_pattern, config):
               sH, sW, _lib.stream())
 
 
-def merge_ref(ref_img, kernels, num, den, cfa_pattern, config, acc_rob=None):
+def merge_ref(ref_img, kernels, num, den, cfa_pattern, config, acc_rob=None, divide=False, fast=False):
     """Accumulate the reference frame (merge.py:22-80); with the accumulated-robustness denoiser enabled
-    the window widens / the pixel is overwritten where few frames were merged."""
+    the window widens / the pixel is overwritten where few frames were merged.
+    divide=True (not in the reference's signature): the normalisation that follows in main() (super_resolution.py:187-190)
+    in the same pass — num = (num (+) ref) / (den (+) ref), `den` is left as it was; bit-identical to merge_ref + divide.
+    fast=True: float32 weights (the fused merge's reference-frame arithmetic) for the pixels the denoiser does not widen,
+    outside the border bands; the default is the reference's float64 chain on every pixel (<= 2e-5 relative apart)."""
     scale, kflags = _common(config)
+    if divide:
+        kflags |= REF_DIVIDE
+    if fast and not (kflags & WEIGHT_F64):
+        kflags |= REF_FAST
     H, W = ref_img.shape
     sH, sW, _ = num.shape
     den_cfg = config.accumulated_robustness_denoiser

@@ -115,14 +115,18 @@ class RobustnessSum:
         self._n = getattr(self, "_n", 0) + 1
         return self
 
-    def add_many(self, rs):
+    def add_many(self, rs, unfiltered=False):
         """The maps of several frames in ONE pass (hhsr_rob_sum: the float64 sum in frame order, like add() frame by
-        frame — bit-identical —, without a read-modify-write of the float64 map per frame)."""
+        frame — bit-identical —, without a read-modify-write of the float64 map per frame).
+        unfiltered=True: `rs` are the thresholded maps R BEFORE the 5x5 local minimum (the fused merge applies it itself:
+        merge_burst(local_min=True)); the minimum is taken on the way into the sum (HHSR_ROB_SUM_MIN5) = local_min() per
+        frame, then add(), without the filtered maps ever being written."""
         rs = [_lib.f32c(r) for r in rs]
         H, W = self.sum.shape
         for i in range(0, len(rs), _lib.MAX_FRAMES):
             chunk = rs[i:i + _lib.MAX_FRAMES]
-            _lib.call("hhsr_rob_sum", _lib.ptr_array(chunk), len(chunk), int(H), int(W), 1 if getattr(self, "_n", 0) else 0, 0.0,
+            flags = (1 if getattr(self, "_n", 0) else 0) | (2 if unfiltered else 0)  # HHSR_ROB_SUM_LOAD | _MIN5
+            _lib.call("hhsr_rob_sum", _lib.ptr_array(chunk), len(chunk), int(H), int(W), flags, 0.0,
                       _lib.ptr(self.sum), None, None, _lib.stream(self.sum.device))
             self._n = getattr(self, "_n", 0) + len(chunk)
         return self

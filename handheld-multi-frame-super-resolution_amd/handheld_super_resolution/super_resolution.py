@@ -560,8 +560,11 @@ def main(ref_img, comp_imgs, config, *, _no_runner=False):
                                      fuse_local_min=fuse_min)
         n_images = 0  # the per-frame loop below is the verbose / debug / sequential-merge path
     elif den_fused:
-        frames = pipe.process_frames([comp_imgs[i] for i in range(n_images)], None, fuse_local_min=False)
-        acc_sum.add_many([f[3] for f in frames])
+        # the merge kernel takes the 5x5 minimum itself where it can (x2 / x3 kernels); the float64 sum then takes it on
+        # the way in (HHSR_ROB_SUM_MIN5): the filtered maps are never written
+        fuse_min = pipe.fuses_local_min()
+        frames = pipe.process_frames([comp_imgs[i] for i in range(n_images)], None, fuse_local_min=fuse_min)
+        acc_sum.add_many([f[3] for f in frames], unfiltered=fuse_min)
         n_images = 0
     for im_id in range(n_images):
         if verbose:
@@ -590,11 +593,16 @@ def main(ref_img, comp_imgs, config, *, _no_runner=False):
             acc_r=accumulated_r if fuse_acc else None, local_min=fuse_min)
     else:
         if den_fused:
-            merge_burst(frames, None, None, num, den, pipe.cfa, config, do_ref=False, divide=False, store_den=True)
-        pipe._timed(merge_ref, 2, "\nAccumulating ref Img", "Ref Img accumulated (Total)")(
-            pipe.ref, ref_covs, num, den, pipe.cfa, config,
-            acc_sum.for_decisions(config.accumulated_robustness_denoiser.merge.max_frame_count) if denoiser_on else None)
-        pipe._timed(divide, 2, end_s="\n------------------------\nImage normalized (Total)")(num, den)
+            merge_burst(frames, None, None, num, den, pipe.cfa, config, do_ref=False, divide=False, store_den=True,
+                        local_min=fuse_min)
+        dec = acc_sum.for_decisions(config.accumulated_robustness_denoiser.merge.max_frame_count) if denoiser_on else None
+        if den_fused:  # reference frame + normalisation in ONE pass over the accumulators (HHSR_REF_DIVIDE), float32 weights
+            # where the denoiser does not widen (HHSR_REF_FAST: the arithmetic of the fused merge's reference frame)
+            merge_ref(pipe.ref, ref_covs, num, den, pipe.cfa, config, dec, divide=True, fast=True)
+        else:
+            pipe._timed(merge_ref, 2, "\nAccumulating ref Img", "Ref Img accumulated (Total)")(
+                pipe.ref, ref_covs, num, den, pipe.cfa, config, dec)
+            pipe._timed(divide, 2, end_s="\n------------------------\nImage normalized (Total)")(num, den)
     if verbose:
         torch.cuda.synchronize()
         s = "\nTotal ellapsed time : "

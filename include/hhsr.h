@@ -206,8 +206,13 @@ int hhsr_local_min5(const float* R, int H, int W, float* r, float* acc_r, void* 
  * device pointers, float32 [H][W]) in frame order, in one pass.  load != 0: start from sum64 (bursts longer than one
  * call).  Outputs, each may be NULL (not all): sum64 double [H][W]; mask32 = the sum rounded to float32 (the map the API
  * reports); decisions32 = float32 map a with (a <= mfc) == (sum <= mfc) and (a < mfc) == (sum < mfc) for
- * mfc = max_frame_count — what hhsr_accumulate_ref compares as (double) a (exact for every mfc float32 can hold). */
-int hhsr_rob_sum(const float* const* rs, int n_frames, int H, int W, int load, double max_frame_count, double* sum64,
+ * mfc = max_frame_count — what hhsr_accumulate_ref compares as (double) a (exact for every mfc float32 can hold).
+ * flags: HHSR_ROB_SUM_LOAD (= the former `load != 0`) | HHSR_ROB_SUM_MIN5: rs[] are the UN-filtered maps R and the sum is taken
+ * over their 5 x 5 clamp-border minima (robustness.py:641-686; = hhsr_local_min5 per frame, then the sum) — for callers whose
+ * merge applies the minimum itself (HHSR_MERGE_LOCAL_MIN) and never materialises the filtered maps. */
+#define HHSR_ROB_SUM_LOAD 1
+#define HHSR_ROB_SUM_MIN5 2
+int hhsr_rob_sum(const float* const* rs, int n_frames, int H, int W, int flags, double max_frame_count, double* sum64,
                  float* mask32, float* decisions32, void* stream);
 
 /* ---- monochrome sensors, `mode: grey` (super_resolution.py:106-109, 144-147; kernels.py:83-87; robustness.py:62-66,
@@ -240,6 +245,13 @@ int hhsr_mono_rob_frame(const float* comp_means, int H, int W, const float* ref_
 #define HHSR_MERGE_FORCE_GENERIC 4  /* no LDS staging: one thread per HR pixel, operands from global memory     */
 #define HHSR_MERGE_FORCE_TILE 8     /* no x2 kernel: the 16 x 16 HR tile kernel                                  */
 #define HHSR_MERGE_FORCE_X2V1 16    /* x2: first-generation kernel (per-pixel geometry) instead of k_merge_x2    */
+/* hhsr_accumulate_ref only: */
+#define HHSR_REF_DIVIDE 64   /* normalise in the same pass: num = (num (+) ref) / (den (+) ref), den is read and left as it is —
+                                accumulate_ref followed by divide (super_resolution.py:187-190) without a second pass over
+                                the accumulators; bit-identical to hhsr_accumulate_ref + hhsr_divide                    */
+#define HHSR_REF_FAST 128    /* float32 weight chain for the pixels the accumulated-robustness rule leaves alone, outside the
+                                border bands — what hhsr_merge_burst does for its reference frame; default: the reference's
+                                float64 chain on every pixel                                                            */
 /* all three merge entry points: */
 #define HHSR_SENSOR_MONO 32  /* `mode: grey`: every sample goes to channel 0; the per-frame entry points and the generic
                                 burst kernel leave channels 1, 2 of num / den as they are, the x2 tile kernel of

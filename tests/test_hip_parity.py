@@ -538,6 +538,18 @@ def test_rob_sum_kernel_and_fused_denoiser_path():
         a = acc.for_decisions(mfc).double()
         assert torch.equal(a <= mfc, want <= mfc) and torch.equal(a < mfc, want < mfc), mfc
     assert float(want[0, 0]) < 3.0 and float(want[0, 0].float()) == 3.0  # the case the float32 sum decides differently
+    # HHSR_ROB_SUM_MIN5: un-filtered maps in, the 5x5 clamp-border minimum taken on the way into the sum == local_min() per
+    # frame, then the sum — bit for bit, also chained (load) and on a map that is not a multiple of the kernel's 64 x 16 tiles
+    from handheld_super_resolution.robustness import local_min
+
+    want_min = torch.zeros((H, W), dtype=torch.float64, device=DEV)
+    for r in rs:
+        want_min += local_min(r)
+    acc3 = RobustnessSum((H, W), torch.device(DEV)).add_many(rs, unfiltered=True)
+    assert torch.equal(acc3.sum, want_min)
+    acc4 = RobustnessSum((H, W), torch.device(DEV)).add_many(rs[:3], unfiltered=True).add_many(rs[3:], unfiltered=True)
+    assert torch.equal(acc4.sum, want_min)
+    assert torch.equal(acc3.for_decisions(2.0), RobustnessSum.decisions_of(want_min, 2.0))
 
     for scale, shape in ((2, (640, 704)), (3, (592, 640))):
         ref, comp, _ = synth.make_burst(*shape, 4, seed=21 + scale, max_shift=2.0, occluder=True)
@@ -571,6 +583,23 @@ def test_merge_ref_denoiser_golden(golden):
     merge.merge_ref(T(g["ref"]), T(g["covs_ref"]), num, den, g["cfa"].tolist(), cfg, T(g["acc_rob"]))
     assert_close(N(num), g["den_numref"], 2e-5, 1e-6, "denoiser numref")
     assert_close(N(den), g["den_denref"], 2e-5, 1e-6, "denoiser denref")
+    # HHSR_REF_DIVIDE: reference frame + normalisation in one pass == merge_ref, then divide (bit for bit; den untouched)
+    for use_den in (True, False):
+        c2 = cfg if use_den else base_config(ts=16, scale=2)
+        acc = T(g["acc_rob"]) if use_den else None
+        n1, d1 = T(acc_pattern(2 * H, 2 * W, 0)), T(acc_pattern(2 * H, 2 * W, 5))
+        merge.merge_ref(T(g["ref"]), T(g["covs_ref"]), n1, d1, g["cfa"].tolist(), c2, acc)
+        utils.divide(n1, d1)
+        n2, d2 = T(acc_pattern(2 * H, 2 * W, 0)), T(acc_pattern(2 * H, 2 * W, 5))
+        merge.merge_ref(T(g["ref"]), T(g["covs_ref"]), n2, d2, g["cfa"].tolist(), c2, acc, divide=True)
+        assert torch.equal(n1.isnan(), n2.isnan()) and torch.equal(torch.nan_to_num(n1), torch.nan_to_num(n2)), use_den
+        assert torch.equal(d2, T(acc_pattern(2 * H, 2 * W, 5))), use_den
+        # HHSR_REF_FAST: float32 weights where the denoiser does not widen (the fused merge's reference-frame arithmetic)
+        n3, d3 = T(acc_pattern(2 * H, 2 * W, 0)), T(acc_pattern(2 * H, 2 * W, 5))
+        merge.merge_ref(T(g["ref"]), T(g["covs_ref"]), n3, d3, g["cfa"].tolist(), c2, acc, fast=True)
+        tag = "den_" if use_den else "s2_"
+        assert_close(N(n3), g[tag + "numref"], 2e-5, 1e-6, "fast numref")
+        assert_close(N(d3), g[tag + "denref"], 2e-5, 1e-6, "fast denref")
 
 
 def _frames(H, W, n, ts, seed, cfg):

@@ -46,7 +46,7 @@ for cfg in "$@"; do
   fi
   if [ -n "$KERNELS" ]; then
     rm -rf "/tmp/kt_$LABEL"
-    env $E rocprofv3 --kernel-trace --stats -d "/tmp/kt_$LABEL" -o kt -- python "$ROOT/bench.py --reps 1" --no-cpu-baseline --no-h2d --no-graph \
+    env $E rocprofv3 --kernel-trace --stats -d "/tmp/kt_$LABEL" -o kt -- python "$ROOT/bench.py" --reps 1 --no-cpu-baseline --no-h2d --no-graph \
       --steps "$STEPS" --warmup 2 --streams 1 $GEOM > "/tmp/kt_$LABEL.log" 2>&1
     echo "== kernels [$LABEL] ($E)"
     python "$ROOT/tools/rocprof_summary.py" "$(find "/tmp/kt_$LABEL" -name '*results.db' | head -1)" $((STEPS + 2)) | grep -E "$KERNELS|Total" | cut -c1-160
