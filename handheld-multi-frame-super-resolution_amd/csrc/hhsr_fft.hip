@@ -754,9 +754,18 @@ int hhsr_fft_lowpass(const HhsrFft& f, const float* const* srcs, float* const* d
     const int persist = persist_env >= 0 ? persist_env : small ? 1280 : 768;
     // unnormalised inverse transforms multiply by (W/2) and H
     const float norm = (float)(1.0 / ((double)(f.W / 2) * (double)f.H));
-    for (int n0 = 0; n0 < n; n0 += f.batch) {  // the plan holds f.batch spectra: longer lists run in rounds
+    // Frames per round: the kept spectra of a round's frames live between the three kernels, and they should live in the
+    // Infinity Cache (256 MB): 24 MB per 12 MP frame — four frames per round, the fewer launches win (57 us per frame against
+    // 62 / 70 with two / one) —, 96 MB per 48 MP frame — ONE frame per round: 253 us per frame against 271 / 285 with two /
+    // four, whose spectra go through HBM (tools/debug/fft_batch_probe.py).
+    const size_t spectrum = sizeof(float2) * f.tstride, budget = (size_t)112 << 20;
+    int per = (int)(budget / (spectrum ? spectrum : 1));
+    per = per < 1 ? 1 : per > f.batch ? f.batch : per;
+    static const int per_env = getenv("HHSR_FFT_ROUND") ? atoi(getenv("HHSR_FFT_ROUND")) : 0;  // (experiments)
+    if (per_env > 0) per = per_env > f.batch ? f.batch : per_env;
+    for (int n0 = 0; n0 < n; n0 += per) {  // (the plan holds f.batch spectra)
         FftFrames fr;
-        fr.n = n - n0 < f.batch ? n - n0 : f.batch;
+        fr.n = n - n0 < per ? n - n0 : per;
         fr.tstride = f.tstride;
         for (int k = 0; k < HHSR_MAX_BATCH; ++k) {
             fr.src[k] = srcs[n0 + (k < fr.n ? k : 0)];
