@@ -66,6 +66,10 @@ def _tensors(x):
 
 
 DEFAULT_STREAMS = 3  # measured at 12 MP x 20: 1 stream 15.3 ms, 2: 14.3, 3: 13.9, 4: 14.3
+LARGE_FRAME = 40_000_000  # raw pixels from which the frame pipeline runs on ONE stream: every kernel of a 48 MP frame fills the
+#                           GPU on its own and side streams only contend for the caches (round 6, one MI355X, 20 frames: 48 MP x3
+#                           51.9 ms on one stream / 52.5 on three, 48 MP x2 32.4 / 32.7; 30 MP x2 21.7 / 21.2, 24 MP 17.9 / 17.1,
+#                           12 MP 8.33 / 8.24: the smaller frames keep three)
 _stream_pool = {}  # device index -> side streams, shared by all pipelines of the process
 
 
@@ -397,7 +401,11 @@ class BurstPipeline:
     def _n_streams(self, n_streams):
         if n_streams is None:
             hip = self.config.get("hip", None) if hasattr(self.config, "get") else None
-            n_streams = int(hip.get("streams", DEFAULT_STREAMS)) if hip is not None else DEFAULT_STREAMS
+            default = DEFAULT_STREAMS
+            ref = getattr(self, "ref", None)
+            if ref is not None and ref.shape[0] * ref.shape[1] >= LARGE_FRAME:
+                default = 1
+            n_streams = int(hip.get("streams", default)) if hip is not None else default
         return max(1, int(n_streams))
 
     def _on_streams(self, n, n_streams, serial, work):
