@@ -81,7 +81,7 @@ def parse_args():
     ap.add_argument("--no-cpu-baseline", action="store_true", help="skip the CPU baseline and the parity leg")
     ap.add_argument("--no-h2d", action="store_true", help="skip the host-resident (H2D-inclusive) leg")
     ap.add_argument("--cpu-crop", type=int, default=1024, help="edge of the crop the CPU baseline / parity leg runs on")
-    ap.add_argument("--streams", type=int, default=None, help="HIP streams of the frame pipeline (default: config, 3)")
+    ap.add_argument("--streams", type=int, default=None, help="HIP streams of the frame pipeline (default: config, 2; 1 for frames of 40 MP and more)")
     ap.add_argument("--chunk", type=int, default=None, help="frames per front-end chunk = per batched launch (default 4)")
     ap.add_argument("--gather", action="store_true", help="N > 1: gather the finished row slabs to rank 0")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo for plumbing tests)")

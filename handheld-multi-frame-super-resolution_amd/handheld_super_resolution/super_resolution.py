@@ -9,7 +9,7 @@ MI355X design notes (vs the reference's per-frame Python loop):
     accumulators in registers (merge.merge_burst), instead of a read-modify-write of the 2x576 MB
     accumulators per frame;
   * the front end (grey FFT, pyramid, alignment levels, raw pass) runs one launch per STAGE AND CHUNK of frames, chunks
-    round-robin on three HIP streams; bursts that start in host memory run as eager uploads + per-chunk HIP graphs
+    round-robin on two HIP streams (one for frames of 40 MP and more); bursts that start in host memory run as eager uploads + per-chunk HIP graphs
     (graph.HostBurstRunner), device-resident bursts as one graph per burst (graph.GraphRunner);
   * multi-GPU (distributed.py): alignment frame-parallel, one all-gather of the flow fields, robustness / kernels /
     merge row-parallel (default), or frames one per GPU with one reduce-scatter of the num / den accumulators.
@@ -65,11 +65,13 @@ def _tensors(x):
             yield from _tensors(y)
 
 
-DEFAULT_STREAMS = 3  # measured at 12 MP x 20: 1 stream 15.3 ms, 2: 14.3, 3: 13.9, 4: 14.3
+DEFAULT_STREAMS = 2  # round 1, 12 MP x 20: 1 stream 15.3 ms, 2: 14.3, 3: 13.9, 4: 14.3 -> 3.  Round 6, with the batched front end and the
+#                      graph-replayed step (four alternating bench runs each, one MI355X): 2 streams 7.70 - 7.80 ms, 3: 7.76 - 7.88
+#                      (round 5's sweep had said the same: 8.21 against 8.36); eager, host-resident and denoiser legs the same or better
 LARGE_FRAME = 40_000_000  # raw pixels from which the frame pipeline runs on ONE stream: every kernel of a 48 MP frame fills the
 #                           GPU on its own and side streams only contend for the caches (round 6, one MI355X, 20 frames: 48 MP x3
 #                           51.9 ms on one stream / 52.5 on three, 48 MP x2 32.4 / 32.7; 30 MP x2 21.7 / 21.2, 24 MP 17.9 / 17.1,
-#                           12 MP 8.33 / 8.24: the smaller frames keep three)
+#                           12 MP 8.33 / 8.24: the smaller frames keep several)
 _stream_pool = {}  # device index -> side streams, shared by all pipelines of the process
 
 
@@ -361,7 +363,7 @@ class BurstPipeline:
 
     def process_frames(self, comp_imgs, accumulate_r=None, n_streams=None, fuse_local_min=False, flows=None):
         """process_frame() over a list of frames.  Frames are independent until the merge, so they are
-        issued round-robin on `n_streams` HIP streams (config.hip.streams, default 3): the launch-latency-
+        issued round-robin on `n_streams` HIP streams (config.hip.streams, default 2; 1 for frames >= LARGE_FRAME): the launch-latency-
         bound coarse pyramid levels of one frame overlap the bandwidth-bound kernels of another.  The caller's
         stream waits for all of them before returning.  A per-frame `accumulate_r` (read-modify-write of one
         map) forces a single stream.  `flows`: per-frame flow fields that replace the alignment."""
