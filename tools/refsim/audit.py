@@ -55,9 +55,14 @@ def neg(a):
     return r
 
 
-def call(name, *args):
+call_sites = collections.defaultdict(set)  # (name, (arg types...), result) -> {"kernel:line", ...}
+
+
+def call(name, site, *args):
     r = {"max": max, "min": min, "abs": abs}[name](*args)
-    calls[(name, tuple(tname(a) for a in args), tname(r))] += 1
+    k = (name, tuple(tname(a) for a in args), tname(r))
+    calls[k] += 1
+    call_sites[k].add(site)
     return r
 
 
@@ -69,7 +74,7 @@ def assign(kernel, var, value):
 def dump(path):
     rec = {
         "ops": sorted([list(k) + [n] for k, n in ops.items()]),
-        "calls": sorted([[k[0], list(k[1]), k[2], n] for k, n in calls.items()]),
+        "calls": sorted([[k[0], list(k[1]), k[2], n, sorted(call_sites[k])] for k, n in calls.items()]),
         "vars": sorted([[k[0], k[1], sorted(v)] for k, v in varts.items() if len(v) > 1]),
         "vars_single_type": sum(1 for v in varts.values() if len(v) == 1),
         "note": "classes of typed operations the reference's kernels executed while tools/refsim/make_goldens.py regenerated "

@@ -54,7 +54,8 @@ def _is_cuda_call(node, name):
     )
 
 
-AUDIT = bool(os.environ.get("HHSR_REFSIM_AUDIT"))
+AUDIT_CALLS = bool(os.environ.get("HHSR_REFSIM_AUDIT"))            # any value: max / min / abs calls, with their call sites
+AUDIT = AUDIT_CALLS and os.environ.get("HHSR_REFSIM_AUDIT") != "calls"  # "calls": ONLY those (minutes instead of hours)
 _BINOPS = {ast.Add: "add", ast.Sub: "sub", ast.Mult: "mul", ast.Div: "truediv", ast.FloorDiv: "floordiv", ast.Mod: "mod",
            ast.Pow: "pow", ast.LShift: "lshift", ast.RShift: "rshift", ast.BitAnd: "and", ast.BitOr: "or", ast.BitXor: "xor"}
 
@@ -106,9 +107,10 @@ class _KernelRewriter(ast.NodeTransformer):
 
     def visit_Call(self, node):
         self.generic_visit(node)
-        if AUDIT and isinstance(node.func, ast.Name) and node.func.id in ("max", "min", "abs") and not node.keywords:
+        if AUDIT_CALLS and isinstance(node.func, ast.Name) and node.func.id in ("max", "min", "abs") and not node.keywords:
+            site = f"{self.fname}:{getattr(node, 'lineno', 0)}"  # kernel (or device function) and source line of the call
             return ast.copy_location(ast.Call(func=ast.Name(id="__refsim_call", ctx=ast.Load()),
-                                              args=[ast.Constant(node.func.id), *node.args], keywords=[]), node)
+                                              args=[ast.Constant(node.func.id), ast.Constant(site), *node.args], keywords=[]), node)
         if _is_cuda_call(node, "syncthreads"):
             return ast.Yield(value=ast.Tuple(elts=[ast.Constant("sync")], ctx=ast.Load()))
         if _is_cuda_call(node, "shfl_down_sync"):
@@ -232,7 +234,7 @@ class _RefLoader(importlib.abc.Loader):
         module.__dict__["__refsim_round"] = _k_round
         module.__dict__["__refsim_range"] = _k_range
         module.__dict__["__refsim_math"] = _KMath
-        if AUDIT:
+        if AUDIT_CALLS:
             from . import audit
 
             module.__dict__["__refsim_op"] = audit.op

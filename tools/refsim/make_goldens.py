@@ -28,7 +28,7 @@ from . import loader
 GOLDEN = os.path.abspath(os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "..", "tests", "golden"))
 # HHSR_REFSIM_AUDIT=1 (tools/refsim/audit.py): the fixtures go to a scratch directory and are compared with the committed
 # ones — an audited run must reproduce them bit for bit —, the recorded type classes to tests/golden/typing_audit.json
-OUT = os.environ.get("HHSR_GOLDEN_OUT") or (os.path.join("/tmp", "hhsr_golden_audit") if loader.AUDIT else GOLDEN)
+OUT = os.environ.get("HHSR_GOLDEN_OUT") or (os.path.join("/tmp", "hhsr_golden_audit") if loader.AUDIT_CALLS else GOLDEN)
 OUT = os.path.abspath(OUT)
 
 cfgmod = loader.install()
@@ -720,7 +720,7 @@ def main(argv):
         with np.errstate(all="ignore"):
             STAGES[n]()
         print(f"  done in {time.time() - t0:.1f}s")
-    if loader.AUDIT:
+    if loader.AUDIT_CALLS:
         from . import audit
 
         same = diff = 0
@@ -734,7 +734,8 @@ def main(argv):
                             np.array_equal(a[k], b[k], equal_nan=a[k].dtype.kind == "f")
                         same, diff = same + int(ok), diff + int(not ok)
             break  # (every file once)
-        rec = audit.dump(os.path.join(GOLDEN, "typing_audit.json"))
+        # (HHSR_REFSIM_AUDIT=calls: only the max / min / abs calls, with their call sites — minutes instead of hours)
+        rec = audit.dump(os.path.join(GOLDEN, "typing_audit.json" if loader.AUDIT else "typing_audit_calls.json"))
         print(f"[refsim] audit: {len(rec['ops'])} operator classes, {len(rec['calls'])} call classes, {len(rec['vars'])} local "
               f"variables with more than one type ({rec['vars_single_type']} with one); fixtures of this audited run vs the "
               f"committed ones: {same} arrays identical, {diff} different")
